@@ -1,0 +1,168 @@
+/*
+ * tavb.h -- C ABI of libtavb.so, the MI355X (gfx950) engine behind typeagent's
+ * VectorBase nearest-neighbour lookup.
+ *
+ * The reference (microsoft/typeagent-py) has no FFI: the boundary it offers is the
+ * Python class `typeagent.aitools.vectorbase.VectorBase`
+ * (src/typeagent/aitools/vectorbase.py:82-287).  The entry points below are what a
+ * ctypes binding for that class's numeric methods binds; each one cites the
+ * reference lines whose arithmetic it replaces.  `typeagent_py_amd/_native.py` is
+ * that binding; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; no torch / HIP types in signatures (a `void* stream` is an
+ *    opaque hipStream_t, NULL = the context's own stream).
+ *  - every function returns TAVB_OK (0) or a negative TAVB_E_* code; the message for
+ *    the calling thread's last failure is `tavb_last_error()`.  The library never
+ *    calls abort()/exit().
+ *  - "dev" pointers are device memory owned by the caller (normally a torch tensor);
+ *    the library never frees them and keeps `tavb_set_corpus`'s pointer only until
+ *    the next tavb_set_corpus / tavb_destroy.  Host pointers are not retained after
+ *    a call returns; all outputs are caller-allocated.
+ *  - one in-flight call per context (the Python wrapper enforces this).
+ *  - results are ordered by (score descending, ordinal ascending); the reference's
+ *    order among exactly equal float32 scores is numpy-implementation-defined
+ *    (vectorbase.py:183-187), ours is deterministic.
+ *  - scores are the reference's public 0..1 scale: clip((cos + 1) / 2, 0, 1) evaluated
+ *    in float32 (vectorbase.py:44-47); `min_score` is compared as float32
+ *    (vectorbase.py:179 under NEP 50); NaN scores never pass (numpy `>=`).
+ */
+#ifndef TAVB_H
+#define TAVB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAVB_ABI_VERSION 1
+
+#define TAVB_OK 0
+#define TAVB_E_INVALID (-1)     /* bad argument */
+#define TAVB_E_HIP (-2)         /* a HIP runtime call failed; message has hipGetErrorString */
+#define TAVB_E_NO_CORPUS (-3)   /* search before tavb_set_corpus */
+#define TAVB_E_UNSUPPORTED (-4) /* shape outside what the kernels cover (see message) */
+#define TAVB_E_NOMEM (-5)
+
+#define TAVB_F32 0
+#define TAVB_F16 1
+
+/* Largest k served by the fused select-while-streaming kernels. */
+#define TAVB_MAX_FUSED_K 256
+/* Largest number of queries one streaming pass serves (bigger batches are split). */
+#define TAVB_MAX_STREAM_QUERIES 8
+
+typedef struct tavb_ctx tavb_ctx;
+
+/* ---- library ---------------------------------------------------------------- */
+int tavb_version(void);
+const char* tavb_last_error(void);
+int tavb_device_count(int* out_count);
+
+/* ---- context ---------------------------------------------------------------- */
+/* One context per (process, GPU).  `stream` = an existing hipStream_t to launch on
+ * (e.g. torch.cuda.current_stream().cuda_stream) or NULL to create a private one. */
+int tavb_create(int device, void* stream, tavb_ctx** out);
+int tavb_destroy(tavb_ctx* ctx);
+int tavb_synchronize(tavb_ctx* ctx);
+
+/* Tunables (launch geometry etc.); unknown names -> TAVB_E_INVALID.
+ *   "scan_blocks"   workgroups of the streaming scan (0 = auto: one per CU)
+ *   "scan_waves"    waves per workgroup, 1..16 (default 16)
+ *   "scan_unroll"   rows in flight per wave: 1, 2 or 4 (default 2)
+ *   "scan_nt"       1 = non-temporal corpus loads (default 1)
+ *   "scan_pipe"     1 = software-prefetch next rows before reducing current ones
+ *   "force_tier"    0 = auto, 1 = fixed-D kernel, 2 = vector kernel, 3 = scalar kernel
+ *   "mfma_min_batch" smallest batch routed to the MFMA kernel on f16 corpora
+ */
+int tavb_set_option(tavb_ctx* ctx, const char* name, int64_t value);
+int tavb_get_option(tavb_ctx* ctx, const char* name, int64_t* out_value);
+
+/* ---- corpus ----------------------------------------------------------------- */
+/* Borrow a row-major [rows, dim] matrix in device memory as the corpus
+ * (replaces the host ndarray `VectorBase._vectors`, vectorbase.py:84, 176).
+ * dtype TAVB_F32 (the reference's layout) or TAVB_F16 (our storage extension: the
+ * values the kernels see are the fp16 values widened to f32).  `ordinal_base` is
+ * added to every returned ordinal (row-sharded corpora: the shard's first row). */
+int tavb_set_corpus(tavb_ctx* ctx, const void* dev_rows, int64_t rows, int32_t dim, int32_t dtype,
+                    int64_t ordinal_base);
+
+/* K1: rows / ||row||_2 in float32, zero rows unchanged
+ * (model_adapters.py:181-183; tools/benchmark_vectorbase.py:85-86).  in == out allowed. */
+int tavb_normalize_rows_f32(tavb_ctx* ctx, const float* dev_in, float* dev_out, int64_t rows, int32_t dim);
+
+/* float32 -> float16 (round to nearest even), used to build f16 corpora on device. */
+int tavb_convert_f32_to_f16(tavb_ctx* ctx, const float* dev_in, void* dev_out, int64_t count);
+
+/* ---- synchronous lookups (host in, host out) ---------------------------------- */
+/* fuzzy_lookup_embedding without predicate (vectorbase.py:163-190):
+ * up to k best rows with score >= min_score.  out_* hold k entries; *out_count = M. */
+int tavb_search(tavb_ctx* ctx, const float* query_host, int32_t k, float min_score, int64_t* out_ordinals,
+                float* out_scores, int32_t* out_count);
+
+/* fuzzy_lookup_embedding_in_subset (vectorbase.py:203-230).  `rows_host[i]` is the
+ * (already wrapped, range-checked) corpus row of subset position i; the call returns
+ * POSITIONS into the subset list (the wrapper maps them back through the caller's
+ * list, reproducing `subset[indices[i]]`, :229).  Ties: ascending position. */
+int tavb_search_subset(tavb_ctx* ctx, const float* query_host, const int64_t* rows_host, int64_t n_subset,
+                       int32_t k, float min_score, int64_t* out_positions, float* out_scores,
+                       int32_t* out_count);
+
+/* Q independent lookups in one submission (the batching the reference leaves as a TODO,
+ * storage/sqlite/reltermsindex.py:259-271).  Semantics == Q calls of tavb_search.
+ * queries_host: float32 [nq, dim].  min_scores: nq thresholds.  Outputs [nq, k] / [nq]. */
+int tavb_search_batch(tavb_ctx* ctx, const float* queries_host, int32_t nq, int32_t k, const float* min_scores,
+                      int64_t* out_ordinals, float* out_scores, int32_t* out_counts);
+
+/* Continuation ("cursor") forms: the next k hits strictly AFTER the hit
+ * (after_score, after_ordinal) in the (score descending, ordinal ascending) order.
+ * Feeding the last hit of one page as the cursor of the next enumerates every row
+ * with score >= min_score, best first, k (<= TAVB_MAX_FUSED_K) at a time.  This is the
+ * candidate stream of the predicate path (vectorbase.py:191-201), of max_hits >
+ * TAVB_MAX_FUSED_K and of the max_hits == 0 quirk (all survivors, sorted).  For the
+ * subset form the cursor is a subset POSITION.  Each page is one corpus pass. */
+int tavb_search_after(tavb_ctx* ctx, const float* query_host, int32_t k, float min_score, float after_score,
+                      int64_t after_ordinal, int64_t* out_ordinals, float* out_scores, int32_t* out_count);
+int tavb_search_subset_after(tavb_ctx* ctx, const float* query_host, const int64_t* rows_host, int64_t n_subset,
+                             int32_t k, float min_score, float after_score, int64_t after_position,
+                             int64_t* out_positions, float* out_scores, int32_t* out_count);
+
+/* ---- asynchronous device-resident lookups (sharding, benchmarking) -------------- */
+/* A packed result key: (float32 score bits << 32) | (0xFFFFFFFF - ordinal); 0 = empty
+ * slot.  Bigger key = better hit, so per-shard lists merge with integer compares. */
+typedef uint64_t tavb_key;
+
+/* Queries already on the device (float32 [nq, dim]); writes nq sorted lists of k keys to
+ * dev_out_keys [nq, k] on the context's stream and returns without synchronising.
+ * Keys carry ordinal_base + row (must stay below 2^32 - 1). */
+int tavb_search_device(tavb_ctx* ctx, const float* dev_queries, int32_t nq, int32_t k, float min_score,
+                       tavb_key* dev_out_keys);
+
+/* Merge `n_lists` sorted key lists per query (dev_lists [n_lists, nq, k], e.g. the
+ * all-gathered per-shard results) into one list per query: dev_out_keys [nq, k]. */
+int tavb_merge_device(tavb_ctx* ctx, const tavb_key* dev_lists, int32_t n_lists, int32_t nq, int32_t k,
+                      tavb_key* dev_out_keys);
+
+/* Decode host copies of keys into ordinals/scores/counts (pure host helper). */
+int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* out_ordinals, float* out_scores,
+                     int32_t* out_counts);
+
+/* ---- measurement ------------------------------------------------------------ */
+/* HIP-event timing of the kernels this context launches, on the stream they run on.
+ * kernel ids: 0 = streaming scan (dot + score + select), 1 = list merge,
+ *             2 = MFMA batched scan, 3 = normalise, 4 = f32->f16 convert. */
+#define TAVB_KERNEL_SCAN 0
+#define TAVB_KERNEL_MERGE 1
+#define TAVB_KERNEL_MFMA 2
+#define TAVB_KERNEL_NORMALIZE 3
+#define TAVB_KERNEL_CONVERT 4
+#define TAVB_KERNEL_COUNT 5
+int tavb_profile_enable(tavb_ctx* ctx, int32_t on);
+int tavb_profile_reset(tavb_ctx* ctx);
+int tavb_profile_read(tavb_ctx* ctx, int32_t kernel_id, double* out_total_ms, int64_t* out_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAVB_H */

@@ -1,0 +1,386 @@
+"""ctypes binding of libtavb.so (C ABI in include/tavb.h) plus the device-side
+corpus holder.  PyTorch-ROCm is used only as the owner of device buffers and as
+the source of the HIP stream / torch.distributed; every computation on the
+lookup path is a hand-written gfx950 kernel reached through this binding.
+
+There is deliberately no CPU fallback here: if libtavb.so is missing or no
+MI355X is visible, lookups raise `RuntimeError`.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+import numpy as np
+
+TAVB_F32 = 0
+TAVB_F16 = 1
+MAX_FUSED_K = 256
+MAX_STREAM_QUERIES = 8
+
+KERNEL_SCAN, KERNEL_MERGE, KERNEL_MFMA, KERNEL_NORMALIZE, KERNEL_CONVERT = range(5)
+
+_LIB_NAME = "libtavb.so"
+_lib = None
+_lib_lock = threading.Lock()
+
+# (name, restype, argtypes) for every symbol declared in include/tavb.h
+_SIGNATURES = [
+    ("tavb_version", c_int, []),
+    ("tavb_last_error", c_char_p, []),
+    ("tavb_device_count", c_int, [POINTER(c_int)]),
+    ("tavb_create", c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    ("tavb_destroy", c_int, [c_void_p]),
+    ("tavb_synchronize", c_int, [c_void_p]),
+    ("tavb_set_option", c_int, [c_void_p, c_char_p, c_int64]),
+    ("tavb_get_option", c_int, [c_void_p, c_char_p, POINTER(c_int64)]),
+    ("tavb_set_corpus", c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64]),
+    ("tavb_normalize_rows_f32", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
+    ("tavb_convert_f32_to_f16", c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    ("tavb_search", c_int, [c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, POINTER(c_int32)]),
+    ("tavb_search_subset", c_int,
+     [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, POINTER(c_int32)]),
+    ("tavb_search_batch", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("tavb_search_after", c_int,
+     [c_void_p, c_void_p, c_int32, c_float, c_float, c_int64, c_void_p, c_void_p, POINTER(c_int32)]),
+    ("tavb_search_subset_after", c_int,
+     [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_int64, c_void_p, c_void_p, POINTER(c_int32)]),
+    ("tavb_search_device", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
+    ("tavb_merge_device", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    ("tavb_decode_keys", c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    ("tavb_profile_enable", c_int, [c_void_p, c_int32]),
+    ("tavb_profile_reset", c_int, [c_void_p]),
+    ("tavb_profile_read", c_int, [c_void_p, c_int32, POINTER(c_double), POINTER(c_int64)]),
+]
+
+ABI_SYMBOLS = [name for name, _, _ in _SIGNATURES]
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def load_library(preload_torch: bool = True):
+    """dlopen libtavb.so and declare its prototypes.
+
+    torch is imported first (when available) so that the process holds ONE HIP
+    runtime: torch's bundled libamdhip64.so has the same SONAME
+    (libamdhip64.so.7) as the ROCm one libtavb.so was linked against, so the
+    dynamic loader reuses the copy that is already mapped.
+    """
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.isfile(path):
+            raise RuntimeError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C typeagent_py_amd/csrc`). There is no CPU fallback."
+            )
+        if preload_torch:
+            try:
+                import torch  # noqa: F401
+            except Exception:  # pragma: no cover - torch is part of the image
+                pass
+        lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        for name, restype, argtypes in _SIGNATURES:
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+        return lib
+
+
+class TavbError(RuntimeError):
+    """A libtavb call failed (HIP/RCCL failures surface here, never as abort())."""
+
+
+def _check(lib, rc: int) -> None:
+    if rc != 0:
+        msg = lib.tavb_last_error()
+        text = msg.decode("utf-8", "replace") if msg else "unknown error"
+        if rc == -1:
+            raise ValueError(f"libtavb: {text}")
+        raise TavbError(f"libtavb error {rc}: {text}")
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = c_int(0)
+    rc = lib.tavb_device_count(byref(n))
+    if rc != 0:
+        return 0
+    return int(n.value)
+
+
+def f32_threshold(min_score) -> np.float32:
+    """The float32 `t` with (s >= t) == numpy's (s >= min_score) for float32 `s`.
+
+    vectorbase.py:179 compares a float32 array with the caller's scalar.  Under
+    NEP 50 a Python float/int is a weak scalar and is cast to float32 first
+    (0.85 -> 0.8500000238...); a numpy float64 scalar forces a float64 compare,
+    which equals comparing with the smallest float32 that is >= it.
+    """
+    if isinstance(min_score, np.floating) and not isinstance(min_score, np.float32):
+        wide = float(min_score)
+        if wide != wide:
+            return np.float32(np.nan)
+        narrow = np.float32(wide)
+        if float(narrow) < wide:
+            narrow = np.nextafter(narrow, np.float32(np.inf), dtype=np.float32)
+        return np.float32(narrow)
+    with np.errstate(over="ignore"):
+        return np.float32(min_score)
+
+
+class Engine:
+    """One libtavb context on one GPU + the torch tensors that hold the corpus."""
+
+    def __init__(self, device: int | None = None, use_torch_stream: bool = False):
+        import torch
+
+        self._torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "typeagent_py_amd: no HIP device visible (torch.cuda.is_available() is False); "
+                "the VectorBase engine runs on MI355X only and has no CPU fallback"
+            )
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = int(device)
+        stream_ptr = None
+        if use_torch_stream:
+            stream_ptr = c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        handle = c_void_p()
+        _check(self.lib, self.lib.tavb_create(self.device, stream_ptr, byref(handle)))
+        self._h = handle
+        self._lock = threading.Lock()
+        self.corpus = None  # torch tensor [capacity, dim]
+        self.rows = 0
+        self.dim = 0
+        self.dtype = TAVB_F32
+        self.ordinal_base = 0
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and self.lib is not None:
+            self.lib.tavb_destroy(h)
+        self.corpus = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- options / profiling ----------------------------------------------
+    def set_option(self, name: str, value: int) -> None:
+        _check(self.lib, self.lib.tavb_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        out = c_int64(0)
+        _check(self.lib, self.lib.tavb_get_option(self._h, name.encode(), byref(out)))
+        return int(out.value)
+
+    def profile_enable(self, on: bool = True) -> None:
+        _check(self.lib, self.lib.tavb_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self) -> None:
+        _check(self.lib, self.lib.tavb_profile_reset(self._h))
+
+    def profile_read(self, kernel_id: int) -> tuple[float, int]:
+        ms, n = c_double(0.0), c_int64(0)
+        _check(self.lib, self.lib.tavb_profile_read(self._h, kernel_id, byref(ms), byref(n)))
+        return float(ms.value), int(n.value)
+
+    def synchronize(self) -> None:
+        _check(self.lib, self.lib.tavb_synchronize(self._h))
+
+    # -- corpus ------------------------------------------------------------
+    def torch_dtype(self, dtype: int):
+        return self._torch.float16 if dtype == TAVB_F16 else self._torch.float32
+
+    def set_corpus_tensor(self, tensor, rows: int | None = None, ordinal_base: int = 0) -> None:
+        """Adopt a device tensor [>=rows, dim] (f32 or f16, contiguous) as the corpus."""
+        torch = self._torch
+        if tensor.dim() != 2 or not tensor.is_contiguous():
+            raise ValueError("corpus tensor must be a contiguous 2-D tensor")
+        if tensor.device.type != "cuda" or (tensor.device.index or 0) != self.device:
+            raise ValueError(f"corpus tensor must live on cuda:{self.device}")
+        if tensor.dtype == torch.float32:
+            dt = TAVB_F32
+        elif tensor.dtype == torch.float16:
+            dt = TAVB_F16
+        else:
+            raise ValueError("corpus tensor must be float32 or float16")
+        n = tensor.shape[0] if rows is None else int(rows)
+        if n > tensor.shape[0]:
+            raise ValueError("rows exceeds the tensor")
+        # make sure whatever produced the tensor on torch's stream has finished
+        torch.cuda.current_stream(self.device).synchronize()
+        _check(self.lib, self.lib.tavb_set_corpus(self._h, c_void_p(tensor.data_ptr()), n, tensor.shape[1], dt, int(ordinal_base)))
+        self.corpus, self.rows, self.dim, self.dtype, self.ordinal_base = tensor, n, int(tensor.shape[1]), dt, int(ordinal_base)
+
+    def upload_rows(self, host_rows: np.ndarray, start: int, dtype: int, capacity_hint: int = 0) -> None:
+        """Make device rows [start, start+len) equal to `host_rows` (f32), growing the
+        buffer geometrically; rows [0, start) are kept (vectorbase.py:128/145 re-copies
+        the whole matrix on every add; here an append moves only the new rows)."""
+        torch = self._torch
+        n_new = start + host_rows.shape[0]
+        dim = host_rows.shape[1]
+        tdt = self.torch_dtype(dtype)
+        dev = torch.device("cuda", self.device)
+        need_new = (
+            self.corpus is None or self.corpus.shape[1] != dim or self.corpus.dtype != tdt or self.corpus.shape[0] < n_new
+        )
+        if need_new:
+            cap = max(n_new, capacity_hint, 2 * (self.corpus.shape[0] if self.corpus is not None and start > 0 else 0), 16)
+            fresh = torch.empty((cap, dim), dtype=tdt, device=dev)
+            if start > 0:
+                if self.corpus is None or self.corpus.shape[1] != dim or self.corpus.dtype != tdt:
+                    raise RuntimeError("cannot keep old rows across a layout change")
+                fresh[:start].copy_(self.corpus[:start])
+            self.corpus = fresh
+        if host_rows.shape[0]:
+            src = np.ascontiguousarray(host_rows, dtype=np.float32)
+            if dtype == TAVB_F16:
+                src = src.astype(np.float16)  # round-to-nearest-even, same as v_cvt_f16_f32
+            self.corpus[start:n_new].copy_(torch.from_numpy(src))
+        self.set_corpus_tensor(self.corpus, rows=n_new, ordinal_base=self.ordinal_base)
+
+    def clear(self) -> None:
+        if self.corpus is not None:
+            self.set_corpus_tensor(self.corpus, rows=0, ordinal_base=self.ordinal_base)
+        self.rows = 0
+
+    # -- K1 / convert --------------------------------------------------------
+    def normalize_rows_(self, tensor) -> None:
+        torch = self._torch
+        assert tensor.dtype == torch.float32 and tensor.is_contiguous() and tensor.dim() == 2
+        torch.cuda.current_stream(self.device).synchronize()
+        _check(self.lib, self.lib.tavb_normalize_rows_f32(self._h, c_void_p(tensor.data_ptr()), c_void_p(tensor.data_ptr()),
+                                                          tensor.shape[0], tensor.shape[1]))
+        self.synchronize()
+
+    def normalize_rows(self, tensor):
+        out = self._torch.empty_like(tensor)
+        self._torch.cuda.current_stream(self.device).synchronize()
+        _check(self.lib, self.lib.tavb_normalize_rows_f32(self._h, c_void_p(tensor.data_ptr()), c_void_p(out.data_ptr()),
+                                                          tensor.shape[0], tensor.shape[1]))
+        self.synchronize()
+        return out
+
+    def to_f16(self, tensor):
+        torch = self._torch
+        assert tensor.dtype == torch.float32 and tensor.is_contiguous()
+        out = torch.empty(tensor.shape, dtype=torch.float16, device=tensor.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        _check(self.lib, self.lib.tavb_convert_f32_to_f16(self._h, c_void_p(tensor.data_ptr()), c_void_p(out.data_ptr()), tensor.numel()))
+        self.synchronize()
+        return out
+
+    # -- lookups -------------------------------------------------------------
+    def _query(self, q) -> np.ndarray:
+        a = np.ascontiguousarray(q, dtype=np.float32)
+        if a.ndim != 1 or a.shape[0] != self.dim:
+            raise ValueError(f"shapes ({self.rows},{self.dim}) and {tuple(np.shape(q))} not aligned: query must have {self.dim} elements")
+        return a
+
+    def search(self, q, k: int, thr: np.float32, after: tuple[float, int] | None = None):
+        """-> (ordinals int64[m], scores float32[m]) best first, m <= k <= MAX_FUSED_K."""
+        a = self._query(q)
+        ords = np.empty(k, dtype=np.int64)
+        scs = np.empty(k, dtype=np.float32)
+        cnt = c_int32(0)
+        with self._lock:
+            if after is None:
+                rc = self.lib.tavb_search(self._h, a.ctypes.data_as(c_void_p), k, c_float(float(thr)),
+                                          ords.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt))
+            else:
+                rc = self.lib.tavb_search_after(self._h, a.ctypes.data_as(c_void_p), k, c_float(float(thr)),
+                                                c_float(after[0]), int(after[1]),
+                                                ords.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt))
+        _check(self.lib, rc)
+        m = int(cnt.value)
+        return ords[:m], scs[:m]
+
+    def search_subset(self, q, rows: np.ndarray, k: int, thr: np.float32, after: tuple[float, int] | None = None):
+        """rows: int64 corpus rows per subset position -> (positions int64[m], scores float32[m])."""
+        a = self._query(q)
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        pos = np.empty(k, dtype=np.int64)
+        scs = np.empty(k, dtype=np.float32)
+        cnt = c_int32(0)
+        with self._lock:
+            if after is None:
+                rc = self.lib.tavb_search_subset(self._h, a.ctypes.data_as(c_void_p), r.ctypes.data_as(c_void_p), r.shape[0], k,
+                                                 c_float(float(thr)), pos.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt))
+            else:
+                rc = self.lib.tavb_search_subset_after(self._h, a.ctypes.data_as(c_void_p), r.ctypes.data_as(c_void_p), r.shape[0], k,
+                                                       c_float(float(thr)), c_float(after[0]), int(after[1]),
+                                                       pos.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt))
+        _check(self.lib, rc)
+        m = int(cnt.value)
+        return pos[:m], scs[:m]
+
+    def search_batch(self, queries, k: int, thrs):
+        """queries f32 [nq, dim]; thrs float32 [nq] -> (ordinals [nq,k], scores [nq,k], counts [nq])."""
+        a = np.ascontiguousarray(queries, dtype=np.float32)
+        if a.ndim != 2 or a.shape[1] != self.dim:
+            raise ValueError(f"queries must be [nq, {self.dim}]")
+        nq = a.shape[0]
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(thrs, dtype=np.float32), (nq,)))
+        ords = np.empty((nq, k), dtype=np.int64)
+        scs = np.empty((nq, k), dtype=np.float32)
+        cnts = np.zeros(nq, dtype=np.int32)
+        with self._lock:
+            rc = self.lib.tavb_search_batch(self._h, a.ctypes.data_as(c_void_p), nq, k, t.ctypes.data_as(c_void_p),
+                                            ords.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), cnts.ctypes.data_as(c_void_p))
+        _check(self.lib, rc)
+        return ords, scs, cnts
+
+    # device-resident forms ---------------------------------------------------
+    def search_device(self, dev_queries, k: int, thr: float, out_keys=None):
+        """dev_queries: torch f32 [nq, dim] on this device -> torch int64 [nq, k] of packed keys (async)."""
+        torch = self._torch
+        assert dev_queries.dtype == torch.float32 and dev_queries.is_contiguous() and dev_queries.shape[1] == self.dim
+        nq = dev_queries.shape[0]
+        if out_keys is None:
+            out_keys = torch.empty((nq, k), dtype=torch.int64, device=dev_queries.device)
+        with self._lock:
+            rc = self.lib.tavb_search_device(self._h, c_void_p(dev_queries.data_ptr()), nq, k, c_float(float(thr)), c_void_p(out_keys.data_ptr()))
+        _check(self.lib, rc)
+        return out_keys
+
+    def merge_device(self, dev_lists, out_keys=None):
+        """dev_lists: torch int64 [n_lists, nq, k] -> [nq, k] (async)."""
+        torch = self._torch
+        assert dev_lists.dtype == torch.int64 and dev_lists.is_contiguous() and dev_lists.dim() == 3
+        n_lists, nq, k = dev_lists.shape
+        if out_keys is None:
+            out_keys = torch.empty((nq, k), dtype=torch.int64, device=dev_lists.device)
+        with self._lock:
+            rc = self.lib.tavb_merge_device(self._h, c_void_p(dev_lists.data_ptr()), n_lists, nq, k, c_void_p(out_keys.data_ptr()))
+        _check(self.lib, rc)
+        return out_keys
+
+
+def decode_keys(keys: np.ndarray):
+    """Host int64/uint64 [nq, k] packed keys -> (ordinals [nq,k], scores [nq,k], counts [nq])."""
+    lib = load_library(preload_torch=False)
+    a = np.ascontiguousarray(keys).view(np.uint64)
+    if a.ndim != 2:
+        raise ValueError("keys must be 2-D")
+    nq, k = a.shape
+    ords = np.empty((nq, k), dtype=np.int64)
+    scs = np.empty((nq, k), dtype=np.float32)
+    cnts = np.zeros(nq, dtype=np.int32)
+    _check(lib, lib.tavb_decode_keys(a.ctypes.data_as(c_void_p), nq, k, ords.ctypes.data_as(c_void_p),
+                                     scs.ctypes.data_as(c_void_p), cnts.ctypes.data_as(c_void_p)))
+    return ords, scs, cnts

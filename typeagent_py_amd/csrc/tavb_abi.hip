@@ -1,0 +1,663 @@
+// C ABI of libtavb.so (declared in include/tavb.h): context, workspaces, the
+// host-synchronous lookups and the asynchronous device-resident ones.  Host code
+// only -- the kernels live in tavb_scan.hip / tavb_misc.hip / tavb_mfma.hip.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tavb_internal.h"
+
+typedef unsigned long long u64_t;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define TAVB_HIP(expr)                                                                                     \
+  do {                                                                                                     \
+    hipError_t e__ = (expr);                                                                               \
+    if (e__ != hipSuccess)                                                                                 \
+      return fail(TAVB_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+struct Buffer {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  bool pinned_host = false;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return TAVB_OK;
+    size_t want = std::max(bytes, cap * 2);
+    want = (want + 255) & ~(size_t)255;
+    if (ptr) {
+      hipError_t e = pinned_host ? hipHostFree(ptr) : hipFree(ptr);
+      ptr = nullptr;
+      cap = 0;
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "free of workspace failed: %s", hipGetErrorString(e));
+    }
+    hipError_t e = pinned_host ? hipHostMalloc(&ptr, want, hipHostMallocDefault) : hipMalloc(&ptr, want);
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      return fail(TAVB_E_NOMEM, "workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    return TAVB_OK;
+  }
+  void release() {
+    if (ptr) (void)(pinned_host ? hipHostFree(ptr) : hipFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+  }
+};
+
+struct PendingTiming {
+  int kernel;
+  hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct tavb_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cu = 256;
+
+  const void* corpus = nullptr;
+  int64_t rows = 0;
+  int32_t dim = 0;
+  int32_t dtype = TAVB_F32;
+  int64_t ordinal_base = 0;
+
+  tavb::ScanGeometry geom{0, 16, 2, 1, 0, 0};
+  int64_t mfma_min_batch = 32;
+  int64_t mfma_splits = 0;  // 0 = auto
+
+  Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows;
+  Buffer h_stage{nullptr, 0, true};
+
+  bool profiling = false;
+  double total_ms[TAVB_KERNEL_COUNT] = {0};
+  int64_t launches[TAVB_KERNEL_COUNT] = {0};
+  std::vector<PendingTiming> pending;
+  std::vector<hipEvent_t> free_events;
+
+  int last_tier = 0;
+};
+
+namespace {
+
+struct Timed {
+  tavb_ctx* c;
+  int kernel;
+  hipEvent_t a = nullptr, b = nullptr;
+  Timed(tavb_ctx* ctx, int k) : c(ctx), kernel(k) {
+    if (!c->profiling) return;
+    auto get = [&](hipEvent_t* ev) {
+      if (!c->free_events.empty()) {
+        *ev = c->free_events.back();
+        c->free_events.pop_back();
+        return true;
+      }
+      return hipEventCreate(ev) == hipSuccess;
+    };
+    if (get(&a) && get(&b)) {
+      (void)hipEventRecord(a, c->stream);
+    } else {
+      a = b = nullptr;
+    }
+  }
+  ~Timed() {
+    if (!a) return;
+    (void)hipEventRecord(b, c->stream);
+    c->pending.push_back({kernel, a, b});
+  }
+};
+
+int drain_timings(tavb_ctx* c) {
+  if (c->pending.empty()) return TAVB_OK;
+  TAVB_HIP(hipStreamSynchronize(c->stream));
+  for (auto& p : c->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+      c->total_ms[p.kernel] += ms;
+      c->launches[p.kernel] += 1;
+    }
+    c->free_events.push_back(p.start);
+    c->free_events.push_back(p.stop);
+  }
+  c->pending.clear();
+  return TAVB_OK;
+}
+
+int scan_blocks_for(const tavb_ctx* c, int64_t n_pos, int waves, int unroll) {
+  int blocks = c->geom.blocks > 0 ? c->geom.blocks : c->n_cu;
+  const int64_t per_block = (int64_t)waves * unroll;
+  const int64_t needed = (n_pos + per_block - 1) / per_block;
+  if (needed < blocks) blocks = (int)std::max<int64_t>(needed, 1);
+  return blocks;
+}
+
+// Core: queries on device (f32 [nq, dim]) -> sorted key lists d_out [nq, k] (async on the stream).
+int search_device_impl(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores /*host, nq*/,
+                       const int32_t* d_row_ids, int64_t n_pos, uint32_t index_base, u64_t* d_out,
+                       u64_t key_bound = ~0ull) {
+  if (n_pos <= 0) {
+    TAVB_HIP(hipMemsetAsync(d_out, 0, (size_t)nq * k * sizeof(u64_t), c->stream));
+    return TAVB_OK;
+  }
+  const int per_pass = (k > 64) ? 4 : TAVB_MAX_STREAM_QUERIES;
+  tavb::ScanGeometry g = c->geom;
+  if (g.waves < 1) g.waves = 1;
+  if (g.waves > 16) g.waves = 16;
+  g.blocks = scan_blocks_for(c, n_pos, g.waves, g.unroll);
+  const size_t list_bytes = (size_t)per_pass * g.blocks * k * sizeof(u64_t);
+  int rc = c->d_lists.reserve(list_bytes);
+  if (rc) return rc;
+  for (int q0 = 0; q0 < nq; q0 += per_pass) {
+    const int n = std::min(per_pass, nq - q0);
+    tavb::ScanParams p{};
+    p.corpus = c->corpus;
+    p.row_ids = d_row_ids;
+    p.queries = d_q + (size_t)q0 * c->dim;
+    p.lists = reinterpret_cast<u64_t*>(c->d_lists.ptr);
+    p.n_pos = n_pos;
+    p.dim = c->dim;
+    p.dtype = c->dtype;
+    p.nq = n;
+    p.k = k;
+    p.index_base = index_base;
+    p.key_bound = key_bound;
+    for (int i = 0; i < TAVB_MAX_STREAM_QUERIES; ++i) p.min_score[i] = (i < n) ? min_scores[q0 + i] : INFINITY;
+    {
+      Timed t(c, TAVB_KERNEL_SCAN);
+      hipError_t e = tavb::launch_scan(p, g, c->stream, &c->last_tier);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "scan kernel launch failed: %s", hipGetErrorString(e));
+    }
+    {
+      Timed t(c, TAVB_KERNEL_MERGE);
+      hipError_t e = tavb::launch_merge(p.lists, g.blocks, n, k, /*query_major=*/true, d_out + (size_t)q0 * k, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "merge kernel launch failed: %s", hipGetErrorString(e));
+    }
+  }
+  return TAVB_OK;
+}
+
+int check_ctx(tavb_ctx* c) {
+  if (!c) return fail(TAVB_E_INVALID, "null context");
+  return TAVB_OK;
+}
+
+int check_search_args(tavb_ctx* c, int k) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!c->corpus && c->rows != 0) return fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
+  if (c->dim <= 0) return fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
+  if (k < 1) return fail(TAVB_E_INVALID, "k must be >= 1 (got %d)", k);
+  if (k > TAVB_MAX_FUSED_K)
+    return fail(TAVB_E_UNSUPPORTED, "k=%d exceeds the fused-select limit %d; use tavb_search_thresholded_page", k,
+                TAVB_MAX_FUSED_K);
+  return TAVB_OK;
+}
+
+u64_t host_key(float score, uint32_t index) {
+  uint32_t bits;
+  memcpy(&bits, &score, sizeof bits);
+  return ((u64_t)bits << 32) | (u64_t)(0xFFFFFFFFu - index);
+}
+
+int cursor_key(float after_score, int64_t after_index, int64_t limit, u64_t* out) {
+  if (!(after_score >= 0.0f && after_score <= 1.0f)) return fail(TAVB_E_INVALID, "cursor score must be in [0, 1]");
+  if (after_index < 0 || after_index >= limit) return fail(TAVB_E_INVALID, "cursor index out of range");
+  *out = host_key(after_score, (uint32_t)after_index);
+  return TAVB_OK;
+}
+
+void decode(const u64_t* keys, int nq, int k, int64_t base, int64_t* ordinals, float* scores, int32_t* counts) {
+  for (int q = 0; q < nq; ++q) {
+    int m = 0;
+    for (int i = 0; i < k; ++i) {
+      const u64_t key = keys[(size_t)q * k + i];
+      if (key == 0) break;  // lists are sorted: the first empty slot ends the list
+      const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+      float s;
+      memcpy(&s, &hi, sizeof s);
+      ordinals[(size_t)q * k + i] = (int64_t)(0xFFFFFFFFu - lo) + base;
+      scores[(size_t)q * k + i] = s;
+      ++m;
+    }
+    counts[q] = m;
+  }
+}
+
+}  // namespace
+
+int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores,
+                                uint32_t index_base, u64_t* d_out);
+
+extern "C" {
+
+int tavb_version(void) { return TAVB_ABI_VERSION; }
+
+const char* tavb_last_error(void) { return g_last_error.c_str(); }
+
+int tavb_device_count(int* out_count) {
+  if (!out_count) return fail(TAVB_E_INVALID, "null out_count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *out_count = 0;
+    return fail(TAVB_E_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  *out_count = n;
+  return TAVB_OK;
+}
+
+int tavb_create(int device, void* stream, tavb_ctx** out) {
+  if (!out) return fail(TAVB_E_INVALID, "null out");
+  *out = nullptr;
+  int n = 0;
+  TAVB_HIP(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(TAVB_E_INVALID, "device %d out of range (have %d)", device, n);
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(TAVB_E_HIP, "hipSetDevice(%d) failed", device);
+  hipDeviceProp_t prop;
+  TAVB_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(TAVB_E_UNSUPPORTED, "device %d is %s; libtavb is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+  tavb_ctx* c = new (std::nothrow) tavb_ctx();
+  if (!c) return fail(TAVB_E_NOMEM, "out of host memory");
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (stream) {
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+    c->own_stream = false;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      return fail(TAVB_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    c->own_stream = true;
+  }
+  *out = c;
+  return TAVB_OK;
+}
+
+int tavb_destroy(tavb_ctx* c) {
+  if (!c) return TAVB_OK;
+  DeviceGuard guard(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& p : c->pending) {
+    (void)hipEventDestroy(p.start);
+    (void)hipEventDestroy(p.stop);
+  }
+  for (auto& e : c->free_events) (void)hipEventDestroy(e);
+  c->d_queries.release();
+  c->d_queries_f16.release();
+  c->d_lists.release();
+  c->d_out.release();
+  c->d_rows.release();
+  c->h_stage.release();
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return TAVB_OK;
+}
+
+int tavb_synchronize(tavb_ctx* c) {
+  if (int rc = check_ctx(c)) return rc;
+  DeviceGuard guard(c->device);
+  TAVB_HIP(hipStreamSynchronize(c->stream));
+  return TAVB_OK;
+}
+
+int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!name) return fail(TAVB_E_INVALID, "null option name");
+  std::string n(name);
+  if (n == "scan_blocks") {
+    if (v < 0 || v > 65535) return fail(TAVB_E_INVALID, "scan_blocks out of range");
+    c->geom.blocks = (int)v;
+  } else if (n == "scan_waves") {
+    if (v < 1 || v > 16) return fail(TAVB_E_INVALID, "scan_waves must be 1..16");
+    c->geom.waves = (int)v;
+  } else if (n == "scan_unroll") {
+    if (v != 1 && v != 2 && v != 4) return fail(TAVB_E_INVALID, "scan_unroll must be 1, 2 or 4");
+    c->geom.unroll = (int)v;
+  } else if (n == "scan_nt") {
+    c->geom.nt = v ? 1 : 0;
+  } else if (n == "scan_pipe") {
+    c->geom.pipe = v ? 1 : 0;
+  } else if (n == "force_tier") {
+    if (v < 0 || v > 3) return fail(TAVB_E_INVALID, "force_tier must be 0..3");
+    c->geom.tier = (int)v;
+  } else if (n == "mfma_min_batch") {
+    if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch must be >= 1");
+    c->mfma_min_batch = v;
+  } else if (n == "mfma_splits") {
+    if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");
+    c->mfma_splits = v;
+  } else {
+    return fail(TAVB_E_INVALID, "unknown option '%s'", name);
+  }
+  return TAVB_OK;
+}
+
+int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!name || !out) return fail(TAVB_E_INVALID, "null argument");
+  std::string n(name);
+  if (n == "scan_blocks") *out = c->geom.blocks;
+  else if (n == "scan_waves") *out = c->geom.waves;
+  else if (n == "scan_unroll") *out = c->geom.unroll;
+  else if (n == "scan_nt") *out = c->geom.nt;
+  else if (n == "scan_pipe") *out = c->geom.pipe;
+  else if (n == "force_tier") *out = c->geom.tier;
+  else if (n == "mfma_min_batch") *out = c->mfma_min_batch;
+  else if (n == "mfma_splits") *out = c->mfma_splits;
+  else if (n == "compute_units") *out = c->n_cu;
+  else if (n == "last_tier") *out = c->last_tier;
+  else return fail(TAVB_E_INVALID, "unknown option '%s'", name);
+  return TAVB_OK;
+}
+
+int tavb_set_corpus(tavb_ctx* c, const void* dev_rows, int64_t rows, int32_t dim, int32_t dtype, int64_t ordinal_base) {
+  if (int rc = check_ctx(c)) return rc;
+  if (rows < 0) return fail(TAVB_E_INVALID, "rows must be >= 0");
+  if (dim < 1) return fail(TAVB_E_INVALID, "dim must be >= 1");
+  if (dtype != TAVB_F32 && dtype != TAVB_F16) return fail(TAVB_E_INVALID, "dtype must be TAVB_F32 or TAVB_F16");
+  if (rows > 0 && !dev_rows) return fail(TAVB_E_INVALID, "null corpus pointer with rows > 0");
+  if (rows >= 0x7FFFFFFFll) return fail(TAVB_E_UNSUPPORTED, "at most 2^31-2 rows per device shard (got %lld)", (long long)rows);
+  if (ordinal_base < 0) return fail(TAVB_E_INVALID, "ordinal_base must be >= 0");
+  c->corpus = dev_rows;
+  c->rows = rows;
+  c->dim = dim;
+  c->dtype = dtype;
+  c->ordinal_base = ordinal_base;
+  return TAVB_OK;
+}
+
+int tavb_normalize_rows_f32(tavb_ctx* c, const float* dev_in, float* dev_out, int64_t rows, int32_t dim) {
+  if (int rc = check_ctx(c)) return rc;
+  if (rows < 0 || dim < 1) return fail(TAVB_E_INVALID, "bad shape");
+  if (rows == 0) return TAVB_OK;
+  if (!dev_in || !dev_out) return fail(TAVB_E_INVALID, "null pointer");
+  DeviceGuard guard(c->device);
+  Timed t(c, TAVB_KERNEL_NORMALIZE);
+  hipError_t e = tavb::launch_normalize_f32(dev_in, dev_out, rows, dim, c->stream);
+  if (e != hipSuccess) return fail(TAVB_E_HIP, "normalize launch failed: %s", hipGetErrorString(e));
+  return TAVB_OK;
+}
+
+int tavb_convert_f32_to_f16(tavb_ctx* c, const float* dev_in, void* dev_out, int64_t count) {
+  if (int rc = check_ctx(c)) return rc;
+  if (count < 0) return fail(TAVB_E_INVALID, "bad count");
+  if (count == 0) return TAVB_OK;
+  if (!dev_in || !dev_out) return fail(TAVB_E_INVALID, "null pointer");
+  DeviceGuard guard(c->device);
+  Timed t(c, TAVB_KERNEL_CONVERT);
+  hipError_t e = tavb::launch_f32_to_f16(dev_in, dev_out, count, c->stream);
+  if (e != hipSuccess) return fail(TAVB_E_HIP, "convert launch failed: %s", hipGetErrorString(e));
+  return TAVB_OK;
+}
+
+int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_t k, const float* min_scores,
+                      int64_t* out_ordinals, float* out_scores, int32_t* out_counts) {
+  if (int rc = check_search_args(c, k)) return rc;
+  if (nq < 0) return fail(TAVB_E_INVALID, "nq must be >= 0");
+  if (nq == 0) return TAVB_OK;
+  if (!queries_host || !min_scores || !out_ordinals || !out_scores || !out_counts)
+    return fail(TAVB_E_INVALID, "null argument");
+  if (c->rows == 0) {
+    for (int q = 0; q < nq; ++q) out_counts[q] = 0;
+    return TAVB_OK;
+  }
+  DeviceGuard guard(c->device);
+  const size_t qbytes = (size_t)nq * c->dim * sizeof(float);
+  const size_t obytes = (size_t)nq * k * sizeof(u64_t);
+  if (int rc = c->h_stage.reserve(std::max(qbytes, obytes))) return rc;
+  if (int rc = c->d_queries.reserve(qbytes)) return rc;
+  if (int rc = c->d_out.reserve(obytes)) return rc;
+  memcpy(c->h_stage.ptr, queries_host, qbytes);
+  TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
+  int rc = tavb_search_device_dispatch(c, reinterpret_cast<const float*>(c->d_queries.ptr), nq, k, min_scores, 0u,
+                                   reinterpret_cast<u64_t*>(c->d_out.ptr));
+  if (rc) return rc;
+  // the staging buffer is reused for the results: the H2D copy above is ordered before this D2H on the stream
+  TAVB_HIP(hipMemcpyAsync(c->h_stage.ptr, c->d_out.ptr, obytes, hipMemcpyDeviceToHost, c->stream));
+  TAVB_HIP(hipStreamSynchronize(c->stream));
+  decode(reinterpret_cast<const u64_t*>(c->h_stage.ptr), nq, k, c->ordinal_base, out_ordinals, out_scores, out_counts);
+  return TAVB_OK;
+}
+
+int tavb_search(tavb_ctx* c, const float* query_host, int32_t k, float min_score, int64_t* out_ordinals,
+                float* out_scores, int32_t* out_count) {
+  return tavb_search_batch(c, query_host, 1, k, &min_score, out_ordinals, out_scores, out_count);
+}
+
+static int search_subset_impl(tavb_ctx* c, const float* query_host, const int64_t* rows_host, int64_t n_subset, int32_t k,
+                              float min_score, bool has_cursor, float after_score, int64_t after_position,
+                              int64_t* out_positions, float* out_scores, int32_t* out_count) {
+  if (int rc = check_search_args(c, k)) return rc;
+  if (n_subset < 0) return fail(TAVB_E_INVALID, "n_subset must be >= 0");
+  if (!query_host || !out_positions || !out_scores || !out_count) return fail(TAVB_E_INVALID, "null argument");
+  if (n_subset == 0 || c->rows == 0) {
+    *out_count = 0;
+    return TAVB_OK;
+  }
+  if (!rows_host) return fail(TAVB_E_INVALID, "null rows_host");
+  if (n_subset >= 0x7FFFFFFFll) return fail(TAVB_E_UNSUPPORTED, "subset too long");
+  u64_t bound = ~0ull;
+  if (has_cursor) {
+    if (int rc = cursor_key(after_score, after_position, n_subset, &bound)) return rc;
+  }
+  DeviceGuard guard(c->device);
+  const size_t qbytes = (size_t)c->dim * sizeof(float);
+  const size_t rbytes = (size_t)n_subset * sizeof(int32_t);
+  const size_t obytes = (size_t)k * sizeof(u64_t);
+  const size_t qoff = (rbytes + 255) & ~(size_t)255;
+  if (int rc = c->h_stage.reserve(std::max(qoff + qbytes, obytes))) return rc;
+  if (int rc = c->d_queries.reserve(qbytes)) return rc;
+  if (int rc = c->d_rows.reserve(rbytes)) return rc;
+  if (int rc = c->d_out.reserve(obytes)) return rc;
+  int32_t* r32 = reinterpret_cast<int32_t*>(c->h_stage.ptr);
+  for (int64_t i = 0; i < n_subset; ++i) {
+    const int64_t r = rows_host[i];
+    if (r < 0 || r >= c->rows)
+      return fail(TAVB_E_INVALID, "subset row %lld out of range [0, %lld)", (long long)r, (long long)c->rows);
+    r32[i] = (int32_t)r;
+  }
+  memcpy(reinterpret_cast<char*>(c->h_stage.ptr) + qoff, query_host, qbytes);
+  TAVB_HIP(hipMemcpyAsync(c->d_rows.ptr, c->h_stage.ptr, rbytes, hipMemcpyHostToDevice, c->stream));
+  TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, reinterpret_cast<char*>(c->h_stage.ptr) + qoff, qbytes,
+                          hipMemcpyHostToDevice, c->stream));
+  int rc = search_device_impl(c, reinterpret_cast<const float*>(c->d_queries.ptr), 1, k, &min_score,
+                              reinterpret_cast<const int32_t*>(c->d_rows.ptr), n_subset, 0u,
+                              reinterpret_cast<u64_t*>(c->d_out.ptr), bound);
+  if (rc) return rc;
+  TAVB_HIP(hipMemcpyAsync(c->h_stage.ptr, c->d_out.ptr, obytes, hipMemcpyDeviceToHost, c->stream));
+  TAVB_HIP(hipStreamSynchronize(c->stream));
+  decode(reinterpret_cast<const u64_t*>(c->h_stage.ptr), 1, k, 0, out_positions, out_scores, out_count);
+  return TAVB_OK;
+}
+
+int tavb_search_subset(tavb_ctx* c, const float* query_host, const int64_t* rows_host, int64_t n_subset, int32_t k,
+                       float min_score, int64_t* out_positions, float* out_scores, int32_t* out_count) {
+  return search_subset_impl(c, query_host, rows_host, n_subset, k, min_score, false, 0.f, 0, out_positions, out_scores,
+                            out_count);
+}
+
+int tavb_search_subset_after(tavb_ctx* c, const float* query_host, const int64_t* rows_host, int64_t n_subset,
+                             int32_t k, float min_score, float after_score, int64_t after_position,
+                             int64_t* out_positions, float* out_scores, int32_t* out_count) {
+  return search_subset_impl(c, query_host, rows_host, n_subset, k, min_score, true, after_score, after_position,
+                            out_positions, out_scores, out_count);
+}
+
+int tavb_search_device(tavb_ctx* c, const float* dev_queries, int32_t nq, int32_t k, float min_score,
+                       tavb_key* dev_out_keys) {
+  if (int rc = check_search_args(c, k)) return rc;
+  if (nq < 1) return fail(TAVB_E_INVALID, "nq must be >= 1");
+  if (!dev_queries || !dev_out_keys) return fail(TAVB_E_INVALID, "null argument");
+  if (c->ordinal_base + c->rows >= 0xFFFFFFFFll)
+    return fail(TAVB_E_UNSUPPORTED, "device-resident keys hold 32-bit ordinals: ordinal_base + rows must be < 2^32 - 1");
+  DeviceGuard guard(c->device);
+  std::vector<float> ms((size_t)nq, min_score);
+  return tavb_search_device_dispatch(c, dev_queries, nq, k, ms.data(), (uint32_t)c->ordinal_base,
+                                     reinterpret_cast<u64_t*>(dev_out_keys));
+}
+
+int tavb_merge_device(tavb_ctx* c, const tavb_key* dev_lists, int32_t n_lists, int32_t nq, int32_t k,
+                      tavb_key* dev_out_keys) {
+  if (int rc = check_ctx(c)) return rc;
+  if (n_lists < 1 || nq < 1 || k < 1 || k > TAVB_MAX_FUSED_K) return fail(TAVB_E_INVALID, "bad merge shape");
+  if (!dev_lists || !dev_out_keys) return fail(TAVB_E_INVALID, "null argument");
+  DeviceGuard guard(c->device);
+  Timed t(c, TAVB_KERNEL_MERGE);
+  hipError_t e = tavb::launch_merge(reinterpret_cast<const u64_t*>(dev_lists), n_lists, nq, k, /*query_major=*/false,
+                                    reinterpret_cast<u64_t*>(dev_out_keys), c->stream);
+  if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
+  return TAVB_OK;
+}
+
+int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* out_ordinals, float* out_scores,
+                     int32_t* out_counts) {
+  if (nq < 0 || k < 1) return fail(TAVB_E_INVALID, "bad shape");
+  if (nq == 0) return TAVB_OK;
+  if (!keys_host || !out_ordinals || !out_scores || !out_counts) return fail(TAVB_E_INVALID, "null argument");
+  decode(reinterpret_cast<const u64_t*>(keys_host), nq, k, 0, out_ordinals, out_scores, out_counts);
+  return TAVB_OK;
+}
+
+int tavb_search_after(tavb_ctx* c, const float* query_host, int32_t k, float min_score, float after_score,
+                      int64_t after_ordinal, int64_t* out_ordinals, float* out_scores, int32_t* out_count) {
+  if (int rc = check_search_args(c, k)) return rc;
+  if (!query_host || !out_ordinals || !out_scores || !out_count) return fail(TAVB_E_INVALID, "null argument");
+  if (c->rows == 0) {
+    *out_count = 0;
+    return TAVB_OK;
+  }
+  u64_t bound;
+  if (int rc = cursor_key(after_score, after_ordinal - c->ordinal_base, c->rows, &bound)) return rc;
+  DeviceGuard guard(c->device);
+  const size_t qbytes = (size_t)c->dim * sizeof(float);
+  const size_t obytes = (size_t)k * sizeof(u64_t);
+  if (int rc = c->h_stage.reserve(std::max(qbytes, obytes))) return rc;
+  if (int rc = c->d_queries.reserve(qbytes)) return rc;
+  if (int rc = c->d_out.reserve(obytes)) return rc;
+  memcpy(c->h_stage.ptr, query_host, qbytes);
+  TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
+  int rc = search_device_impl(c, reinterpret_cast<const float*>(c->d_queries.ptr), 1, k, &min_score, nullptr, c->rows,
+                              0u, reinterpret_cast<u64_t*>(c->d_out.ptr), bound);
+  if (rc) return rc;
+  TAVB_HIP(hipMemcpyAsync(c->h_stage.ptr, c->d_out.ptr, obytes, hipMemcpyDeviceToHost, c->stream));
+  TAVB_HIP(hipStreamSynchronize(c->stream));
+  decode(reinterpret_cast<const u64_t*>(c->h_stage.ptr), 1, k, c->ordinal_base, out_ordinals, out_scores, out_count);
+  return TAVB_OK;
+}
+
+int tavb_profile_enable(tavb_ctx* c, int32_t on) {
+  if (int rc = check_ctx(c)) return rc;
+  DeviceGuard guard(c->device);
+  if (!on) {
+    if (int rc = drain_timings(c)) return rc;
+  }
+  c->profiling = on != 0;
+  return TAVB_OK;
+}
+
+int tavb_profile_reset(tavb_ctx* c) {
+  if (int rc = check_ctx(c)) return rc;
+  DeviceGuard guard(c->device);
+  if (int rc = drain_timings(c)) return rc;
+  for (int i = 0; i < TAVB_KERNEL_COUNT; ++i) {
+    c->total_ms[i] = 0;
+    c->launches[i] = 0;
+  }
+  return TAVB_OK;
+}
+
+int tavb_profile_read(tavb_ctx* c, int32_t kernel_id, double* out_total_ms, int64_t* out_launches) {
+  if (int rc = check_ctx(c)) return rc;
+  if (kernel_id < 0 || kernel_id >= TAVB_KERNEL_COUNT) return fail(TAVB_E_INVALID, "bad kernel id");
+  DeviceGuard guard(c->device);
+  if (int rc = drain_timings(c)) return rc;
+  if (out_total_ms) *out_total_ms = c->total_ms[kernel_id];
+  if (out_launches) *out_launches = c->launches[kernel_id];
+  return TAVB_OK;
+}
+
+}  // extern "C"
+
+// Routes a device-resident query batch to the streaming scan or (f16 corpus, large
+// batch) the MFMA kernel.  Not part of the public ABI.
+int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores,
+                                uint32_t index_base, u64_t* d_out) {
+  bool uniform_thr = true;
+  for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (min_scores[i] == min_scores[0]);
+  if (c->dtype == TAVB_F16 && nq >= c->mfma_min_batch && uniform_thr && tavb::mfma_supported(c->dim, k) && c->rows > 0) {
+    const int qt = tavb::mfma_query_tile();
+    const int nq_pad = ((nq + qt - 1) / qt) * qt;
+    const size_t q16 = (size_t)nq_pad * c->dim * 2;
+    if (int rc = c->d_queries_f16.reserve(q16)) return rc;
+    TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16, c->stream));
+    {
+      hipError_t e = tavb::launch_f32_to_f16(d_q, c->d_queries_f16.ptr, (int64_t)nq * c->dim, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "query convert launch failed: %s", hipGetErrorString(e));
+    }
+    const int splits = c->mfma_splits > 0 ? (int)c->mfma_splits : tavb::mfma_pick_splits(c->rows, nq_pad, c->n_cu);
+    if (int rc = c->d_lists.reserve((size_t)nq * splits * k * sizeof(u64_t))) return rc;
+    tavb::MfmaParams p{};
+    p.corpus = c->corpus;
+    p.queries = c->d_queries_f16.ptr;
+    p.lists = reinterpret_cast<u64_t*>(c->d_lists.ptr);
+    p.rows = c->rows;
+    p.dim = c->dim;
+    p.nq = nq;
+    p.nq_padded = nq_pad;
+    p.k = k;
+    p.index_base = index_base;
+    p.min_score = min_scores[0];
+    p.n_splits = splits;
+    {
+      Timed t(c, TAVB_KERNEL_MFMA);
+      hipError_t e = tavb::launch_mfma_scan(p, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "mfma scan launch failed: %s", hipGetErrorString(e));
+    }
+    {
+      Timed t(c, TAVB_KERNEL_MERGE);
+      hipError_t e = tavb::launch_merge(p.lists, splits, nq, k, /*query_major=*/true, d_out, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
+    }
+    return TAVB_OK;
+  }
+  return search_device_impl(c, d_q, nq, k, min_scores, nullptr, c->rows, index_base, d_out);
+}

@@ -1,0 +1,64 @@
+// Host-side declarations shared by the translation units of libtavb.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tavb.h"
+
+namespace tavb {
+
+struct ScanParams {
+  const void* corpus;      // [rows, dim] row-major, f32 or f16
+  const int32_t* row_ids;  // optional gather list (subset search): position -> row
+  const float* queries;    // device, f32 [nq, dim]
+  unsigned long long* lists;  // out: [nq, blocks, k] sorted keys, one list per workgroup
+  int64_t n_pos;           // number of candidate positions (rows, or subset length)
+  int32_t dim;
+  int32_t dtype;  // TAVB_F32 / TAVB_F16
+  int32_t nq;     // 1..TAVB_MAX_STREAM_QUERIES
+  int32_t k;      // 1..TAVB_MAX_FUSED_K
+  uint32_t index_base;  // added to the position before it is packed into the key
+  unsigned long long key_bound;  // exclusive upper bound on accepted keys (~0 = none): paging cursor
+  float min_score[TAVB_MAX_STREAM_QUERIES];
+};
+
+struct ScanGeometry {
+  int blocks;
+  int waves;   // per block
+  int unroll;  // rows in flight per wave
+  int nt;      // non-temporal loads
+  int pipe;    // software prefetch
+  int tier;    // 0 auto, 1 fixed, 2 vector, 3 scalar
+};
+
+// returns hipSuccess or the launch error; `*tier_used` reports the kernel family chosen
+hipError_t launch_scan(const ScanParams& p, const ScanGeometry& g, hipStream_t stream, int* tier_used);
+
+// lists: [n_lists, nq, k] (list-major) or [nq, n_lists, k] (query-major) sorted keys -> out [nq, k]
+hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, int k, bool query_major,
+                        unsigned long long* out, hipStream_t stream);
+
+hipError_t launch_normalize_f32(const float* in, float* out, int64_t rows, int dim, hipStream_t stream);
+hipError_t launch_f32_to_f16(const float* in, void* out, int64_t count, hipStream_t stream);
+
+// MFMA batched scan (f16 corpus, f16 queries staged by the launcher)
+struct MfmaParams {
+  const void* corpus;   // f16 [rows, dim]
+  const void* queries;  // f16 [nq_padded, dim] device
+  unsigned long long* lists;  // out [nq, n_splits, k]
+  int64_t rows;
+  int32_t dim;
+  int32_t nq;
+  int32_t nq_padded;
+  int32_t k;
+  uint32_t index_base;
+  float min_score;
+  int32_t n_splits;  // row ranges the corpus is cut into (one list per (query, split))
+};
+hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
+int mfma_query_tile();                    // queries per workgroup tile
+int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu);
+bool mfma_supported(int dim, int k);
+
+}  // namespace tavb

@@ -1,0 +1,146 @@
+// Small kernels around the scan: merging sorted key lists, L2 row normalisation
+// (model_adapters.py:181-183 of the reference) and f32 -> f16 conversion.
+
+#include <hip/hip_fp16.h>
+
+#include "tavb_device.h"
+#include "tavb_internal.h"
+
+namespace tavb {
+
+// ---------------------------------------------------------------------------
+// merge: n_lists sorted lists of k keys per query -> one sorted list of k keys.
+// One workgroup per query; each wave folds its share of the lists into a
+// register-resident list with bitonic merges, then the waves merge through LDS.
+// ---------------------------------------------------------------------------
+template <int KPL>
+__global__ void __launch_bounds__(1024) merge_kernel(const u64* __restrict__ lists, int n_lists, int nq, int k,
+                                                     int query_major, u64* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  u64* scratch = reinterpret_cast<u64*>(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_waves = blockDim.x >> 6;
+  const int q = blockIdx.x;
+  WaveTopK<KPL> mine;
+  mine.clear();
+  for (int m = wave; m < n_lists; m += n_waves) {
+    const u64* src = query_major ? lists + ((size_t)q * n_lists + m) * (size_t)k
+                                 : lists + ((size_t)m * nq + q) * (size_t)k;
+    WaveTopK<KPL> other;
+    other.load_reversed(src, k, lane);
+    mine.merge_reversed(other, lane);
+  }
+  block_merge<KPL>(mine, scratch, wave, n_waves, lane);
+  if (wave == 0) mine.store(out + (size_t)q * k, k, lane);
+}
+
+hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, int k, bool query_major,
+                        unsigned long long* out, hipStream_t stream) {
+  if (n_lists < 1 || nq < 1 || k < 1 || k > TAVB_MAX_FUSED_K) return hipErrorInvalidValue;
+  int waves = 16;
+  while (waves > 1 && waves / 2 >= n_lists) waves /= 2;  // no more waves than lists (rounded to a power of two)
+  const int kpl = k <= 64 ? 1 : 4;
+  const size_t lds = (size_t)((waves + 1) / 2) * 64 * kpl * sizeof(u64);
+  if (kpl == 1)
+    hipLaunchKernelGGL(merge_kernel<1>, dim3(nq), dim3(waves * 64), lds, stream, lists, n_lists, nq, k,
+                       query_major ? 1 : 0, out);
+  else
+    hipLaunchKernelGGL(merge_kernel<4>, dim3(nq), dim3(waves * 64), lds, stream, lists, n_lists, nq, k,
+                       query_major ? 1 : 0, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K1: y = x / ||x||_2 per row, float32, zero rows unchanged.  One wave per row;
+// HBM-bound (4 B read + 4 B written per element; the row is re-read from L2/L1
+// for the scaling pass, not from HBM, because a row is at most a few KiB).
+// The quotient is an IEEE float32 division so that it rounds like numpy's
+// `embeddings / norms` (no reciprocal-multiply).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) normalize_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int64_t rows, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const bool vec = (dim % 4 == 0) && (((uintptr_t)in | (uintptr_t)out) % 16 == 0);
+  for (int64_t r = wave; r < rows; r += n_waves) {
+    const float* x = in + r * (int64_t)dim;
+    float* y = out + r * (int64_t)dim;
+    float ss = 0.f;
+    if (vec) {
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+      for (int i = lane; i < dim / 4; i += 64) {
+        const f32x4 v = x4[i];
+        ss = fmaf(v.x, v.x, ss);
+        ss = fmaf(v.y, v.y, ss);
+        ss = fmaf(v.z, v.z, ss);
+        ss = fmaf(v.w, v.w, ss);
+      }
+    } else {
+      for (int i = lane; i < dim; i += 64) ss = fmaf(x[i], x[i], ss);
+    }
+    ss = wave_sum(ss);
+    float norm = sqrtf(ss);
+    if (!(norm > 0.f)) norm = 1.0f;  // np.where(norms > 0, norms, 1): zero (and NaN) norms divide by 1
+    if (vec) {
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+      f32x4* y4 = reinterpret_cast<f32x4*>(y);
+      for (int i = lane; i < dim / 4; i += 64) {
+        f32x4 v = x4[i];
+        v.x = v.x / norm;
+        v.y = v.y / norm;
+        v.z = v.z / norm;
+        v.w = v.w / norm;
+        y4[i] = v;
+      }
+    } else {
+      for (int i = lane; i < dim; i += 64) y[i] = x[i] / norm;
+    }
+  }
+}
+
+hipError_t launch_normalize_f32(const float* in, float* out, int64_t rows, int dim, hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, rows, dim);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// f32 -> f16, round to nearest even (v_cvt_f16_f32), 8 elements per lane per step
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) f32_to_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out,
+                                                         int64_t count) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n8 = count / 8;
+  const bool vec = (((uintptr_t)in) % 16 == 0) && (((uintptr_t)out) % 16 == 0);
+  if (vec) {
+    const f32x4* in4 = reinterpret_cast<const f32x4*>(in);
+    f16x8* out8 = reinterpret_cast<f16x8*>(out);
+    for (int64_t i = tid; i < n8; i += nthreads) {
+      const f32x4 a = in4[2 * i], b = in4[2 * i + 1];
+      f16x8 h;
+      h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+      h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+      out8[i] = h;
+    }
+    for (int64_t i = n8 * 8 + tid; i < count; i += nthreads) out[i] = (_Float16)in[i];
+  } else {
+    for (int64_t i = tid; i < count; i += nthreads) out[i] = (_Float16)in[i];
+  }
+}
+
+hipError_t launch_f32_to_f16(const float* in, void* out, int64_t count, hipStream_t stream) {
+  if (count <= 0) return hipSuccess;
+  int64_t blocks = (count / 8 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in,
+                     reinterpret_cast<_Float16*>(out), count);
+  return hipGetLastError();
+}
+
+}  // namespace tavb

@@ -1,0 +1,131 @@
+"""Row-sharded lookup across the GPUs of one node: one process per GPU
+(`torch.distributed`, backend "nccl" == RCCL over xGMI), each rank owning a
+contiguous range of corpus rows.
+
+Why this shards: a row's score depends only on that row
+and the query (vectorbase.py:176 of the reference), so the global top-k is the
+top-k of the union of the per-shard top-k lists.  The only exchange step is an
+all-gather of the per-rank packed result keys -- `nq * k * 8` bytes per rank
+(256 KiB at nq=1024, k=32), latency-bound, far below xGMI link bandwidth --
+followed by a local k-way merge kernel on every rank.  No all-reduce, no
+tensor/pipeline parallelism: there is nothing else to exchange on this path.
+
+Result keys are `(score bits << 32) | (0xFFFFFFFF - global_ordinal)`, so the
+merge is a pure integer max-merge and ties resolve to the smaller global
+ordinal on every rank identically (all ranks return the same answer).
+
+The compute backend is injected so that the communication pattern can be tested
+on CPU with `gloo` (tests/test_sharded_gloo.py supplies a host backend); the
+product backend below is the only one this package ships and it runs the HIP
+kernels.  There is no CPU fallback in the product path.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Protocol
+
+import numpy as np
+
+from . import _native
+
+
+def shard_range(total_rows: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous row range [lo, hi) of `rank`: the first (total % world) ranks get one extra row."""
+    base, extra = divmod(total_rows, world_size)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+class ShardBackend(Protocol):
+    def local_search(self, queries, k: int, thr: float):  # -> tensor int64 [nq, k] packed keys (global ordinals)
+        ...
+
+    def merge(self, gathered):  # tensor int64 [world, nq, k] -> tensor int64 [nq, k]
+        ...
+
+    def to_host(self, keys) -> np.ndarray:  # -> int64 [nq, k]
+        ...
+
+    def empty_gather(self, world: int, nq: int, k: int):  # tensor int64 [world, nq, k] on the backend's device
+        ...
+
+
+class DeviceShardBackend:
+    """HIP kernels on this rank's GPU, launched on a dedicated torch stream so that
+    RCCL collectives issued by torch.distributed order correctly with them."""
+
+    def __init__(self, device: int):
+        import torch
+
+        self.torch = torch
+        self.device = int(device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(self.stream):
+            self.engine = _native.Engine(self.device, use_torch_stream=True)
+
+    def set_shard(self, tensor, row_offset: int, rows: int | None = None) -> None:
+        self.engine.set_corpus_tensor(tensor, rows=rows, ordinal_base=row_offset)
+
+    def local_search(self, queries, k: int, thr: float):
+        with self.torch.cuda.stream(self.stream):
+            return self.engine.search_device(queries, k, thr)
+
+    def merge(self, gathered):
+        with self.torch.cuda.stream(self.stream):
+            return self.engine.merge_device(gathered)
+
+    def to_host(self, keys) -> np.ndarray:
+        with self.torch.cuda.stream(self.stream):
+            host = keys.cpu()
+        return host.numpy()
+
+    def empty_gather(self, world: int, nq: int, k: int):
+        return self.torch.empty((world, nq, k), dtype=self.torch.int64, device=self.torch.device("cuda", self.device))
+
+
+@dataclass
+class ShardedResult:
+    ordinals: np.ndarray  # int64 [nq, k] global row ordinals
+    scores: np.ndarray  # float32 [nq, k]
+    counts: np.ndarray  # int32 [nq]
+
+
+class ShardedSearcher:
+    """Collective top-k over a row-sharded corpus.  Every rank calls `search` with the
+    same queries (they are tiny next to the corpus: <= 3 MiB for 1024 x 1536 fp16, so the
+    caller broadcasts/duplicates them) and every rank gets the same global result."""
+
+    def __init__(self, backend: ShardBackend, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.backend = backend
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def search_keys(self, queries, k: int, min_score: float = 0.0):
+        """-> backend tensor int64 [nq, k] of merged keys (still on the device, async)."""
+        if not (1 <= k <= _native.MAX_FUSED_K):
+            raise ValueError(f"k must be in 1..{_native.MAX_FUSED_K}")
+        thr = float(_native.f32_threshold(min_score))
+        local = self.backend.local_search(queries, k, thr)
+        if self.world == 1:
+            return local
+        nq = local.shape[0]
+        gathered = self.backend.empty_gather(self.world, nq, k)
+        stream = getattr(self.backend, "stream", None)
+        if stream is not None:
+            with self.backend.torch.cuda.stream(stream):
+                self.dist.all_gather_into_tensor(gathered.view(-1), local.view(-1), group=self.group)
+        else:
+            self.dist.all_gather_into_tensor(gathered.view(-1), local.view(-1), group=self.group)
+        return self.backend.merge(gathered)
+
+    def search(self, queries, k: int, min_score: float = 0.0) -> ShardedResult:
+        keys = self.backend.to_host(self.search_keys(queries, k, min_score))
+        ords, scs, cnts = _native.decode_keys(keys)
+        return ShardedResult(ords, scs, cnts)

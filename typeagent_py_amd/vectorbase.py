@@ -1,0 +1,443 @@
+"""Drop-in for `typeagent.aitools.vectorbase` with the nearest-neighbour search
+running on MI355X (gfx950) through libtavb.so.
+
+API mirror of the reference's `src/typeagent/aitools/vectorbase.py`
+(/root/reference; line numbers below refer to it):
+
+  DEFAULT_MIN_SCORE, MODEL_DEFAULT_MIN_SCORES, get_default_min_score   :16-41
+  cosine_to_score                                                      :44-47
+  ScoredInt                                                            :50-55
+  TextEmbeddingIndexSettings                                           :58-79
+  VectorBase                                                           :82-287
+
+Same names, arguments, defaults, return types and exceptions.  What differs is
+where the arithmetic runs: `fuzzy_lookup_embedding*` launch HIP kernels (fused
+dot + score + threshold + top-k) instead of np.dot/argpartition, and there is
+one additive method, `fuzzy_lookup_embeddings` (a batch of queries in one
+submission).  The host ndarray `_vectors` stays the authoritative copy for
+serialize()/deserialize(); the device buffer mirrors it and is synced lazily,
+appends moving only the new rows.
+
+There is no CPU fallback: a lookup on a non-empty index without libtavb.so or
+without a visible MI355X raises RuntimeError.
+
+Documented deviations from the reference (none is exercised by its callers):
+  * equal float32 scores are ordered by ascending ordinal (the reference's order
+    among ties is whatever numpy's introselect leaves, :183-187);
+  * a query is converted to float32 (np.dot would promote a float64 query);
+  * `predicate` is called lazily, best score first, until `max_hits` rows are
+    accepted (the reference calls it for every survivor in ordinal order, :195-199);
+  * negative `max_hits` raises ValueError (the reference returns slicing artefacts).
+"""
+
+from __future__ import annotations
+
+import os
+from collections.abc import Callable
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native
+from .embeddings import IEmbeddingModel, NormalizedEmbedding, NormalizedEmbeddings
+
+DEFAULT_MIN_SCORE = 0.85
+
+# Per-model score cut-offs the reference ships for the built-in OpenAI models (:31-35).
+MODEL_DEFAULT_MIN_SCORES: dict[str, float] = {
+    "text-embedding-3-large": 0.74,
+    "text-embedding-3-small": 0.73,
+    "text-embedding-ada-002": 0.93,
+}
+
+_PAGE = _native.MAX_FUSED_K  # rows fetched per device pass on the paged paths
+
+
+def get_default_min_score(model_name: str) -> float:
+    return MODEL_DEFAULT_MIN_SCORES.get(model_name, DEFAULT_MIN_SCORE)
+
+
+def cosine_to_score(cosine_similarity: np.ndarray) -> np.ndarray:
+    """Host-side statement of the score map the kernels apply per row: cosine in
+    [-1, 1] -> public score in [0, 1]."""
+    return np.clip((cosine_similarity + 1.0) / 2.0, 0.0, 1.0)
+
+
+@dataclass
+class ScoredInt:
+    item: int
+    score: float
+
+
+def _default_embedding_model() -> IEmbeddingModel:
+    # The reference builds its default provider model here (:74, model_adapters
+    # .create_embedding_model).  That is LLM/HTTP plumbing outside this package: use the
+    # reference's factory when typeagent is importable, otherwise insist on an explicit model.
+    try:
+        from typeagent.aitools.model_adapters import create_embedding_model  # type: ignore
+    except Exception as exc:  # pragma: no cover - depends on the host environment
+        raise RuntimeError(
+            "TextEmbeddingIndexSettings needs an explicit embedding_model when typeagent's "
+            "model_adapters is not importable"
+        ) from exc
+    return create_embedding_model()
+
+
+@dataclass
+class TextEmbeddingIndexSettings:
+    embedding_model: IEmbeddingModel
+    min_score: float  # 0..1
+    max_matches: int | None  # >= 1, None = no limit
+    batch_size: int  # >= 1
+
+    def __init__(
+        self,
+        embedding_model: IEmbeddingModel | None = None,
+        min_score: float | None = None,
+        max_matches: int | None = None,
+        batch_size: int | None = None,
+    ):
+        self.embedding_model = embedding_model or _default_embedding_model()
+        name = getattr(self.embedding_model, "model_name", "")
+        self.min_score = get_default_min_score(name) if min_score is None else min_score
+        self.max_matches = max_matches if (max_matches and max_matches >= 1) else None
+        self.batch_size = batch_size if (batch_size and batch_size >= 1) else 8
+
+
+def _env_dtype() -> int:
+    v = os.environ.get("TYPEAGENT_VB_DTYPE", "fp32").lower()
+    if v in ("fp16", "f16", "half"):
+        return _native.TAVB_F16
+    return _native.TAVB_F32
+
+
+class VectorBase:
+    settings: TextEmbeddingIndexSettings
+    _model: IEmbeddingModel
+    _embedding_size: int
+
+    def __init__(
+        self,
+        settings: TextEmbeddingIndexSettings,
+        *,
+        device: int | None = None,
+        corpus_dtype: str | None = None,
+    ):
+        self.settings = settings
+        self._model = settings.embedding_model
+        self._embedding_size = 0
+        self._device_index = device if device is not None else (int(os.environ["TYPEAGENT_VB_DEVICE"]) if "TYPEAGENT_VB_DEVICE" in os.environ else None)
+        if corpus_dtype is None:
+            self._dtype = _env_dtype()
+        else:
+            self._dtype = _native.TAVB_F16 if corpus_dtype.lower() in ("fp16", "f16", "half", "float16") else _native.TAVB_F32
+        self._engine: _native.Engine | None = None
+        self._host = np.zeros((0,), dtype=np.float32)  # backing store; _vectors is a view of its first _count rows
+        self._count = 0
+        self._dev_rows = 0  # rows of the host matrix already mirrored on the device
+        self._dev_valid = True  # False => the device copy must be rebuilt from row 0
+        self._device_only = None  # torch tensor when the corpus lives only on the device
+        self.clear()
+
+    # ------------------------------------------------------------------ storage
+    @property
+    def _vectors(self) -> NormalizedEmbeddings:
+        if self._device_only is not None:
+            self._materialize_host()
+        if self._embedding_size > 0 and self._host.ndim == 2 and self._count != self._host.shape[0]:
+            return self._host[: self._count]  # the filled part of the growth buffer
+        return self._host  # exactly the adopted / full matrix (same object every time)
+
+    @_vectors.setter
+    def _vectors(self, value: NormalizedEmbeddings) -> None:
+        self._adopt_host(value)
+
+    def _adopt_host(self, matrix: np.ndarray) -> None:
+        self._device_only = None
+        self._host = matrix
+        self._count = len(matrix)
+        self._dev_rows = 0
+        self._dev_valid = False
+
+    def _materialize_host(self) -> None:
+        t, n = self._device_only, self._count
+        self._device_only = None
+        host = t[:n].float().cpu().numpy()
+        self._host, self._count = host, n  # device copy stays valid: same rows
+        if self._dtype == _native.TAVB_F16:
+            pass  # host copy holds the fp16 values widened to f32
+
+    def _reserve(self, extra: int) -> None:
+        need = self._count + extra
+        if self._host.ndim != 2 or self._host.shape[1] != self._embedding_size:
+            self._host = np.zeros((max(need, 4), self._embedding_size), dtype=np.float32)
+            return
+        if need > self._host.shape[0]:
+            grown = np.empty((max(need, 2 * self._host.shape[0], 4), self._embedding_size), dtype=np.float32)
+            grown[: self._count] = self._host[: self._count]
+            self._host = grown
+
+    async def get_embedding(self, key: str, cache: bool = True) -> NormalizedEmbedding:
+        if cache:
+            return await self._model.get_embedding(key)
+        return await self._model.get_embedding_nocache(key)
+
+    async def get_embeddings(self, keys: list[str], cache: bool = True) -> NormalizedEmbeddings:
+        if cache:
+            return await self._model.get_embeddings(keys)
+        return await self._model.get_embeddings_nocache(keys)
+
+    def __len__(self) -> int:
+        return self._count
+
+    def __bool__(self) -> bool:  # an empty index is still truthy (:111-113)
+        return True
+
+    def add_embedding(self, key: str | None, embedding: NormalizedEmbedding | list[float]) -> None:
+        row = np.asarray(embedding, dtype=np.float32)
+        if self._embedding_size == 0:
+            self._set_embedding_size(len(row))
+        if len(row) != self._embedding_size:
+            raise ValueError(f"Embedding size mismatch: expected {self._embedding_size}, got {len(row)}")
+        if self._device_only is not None:
+            self._materialize_host()
+        self._reserve(1)
+        self._host[self._count] = row.reshape(-1)
+        self._count += 1
+        if key is not None:
+            self._model.add_embedding(key, row)
+
+    def add_embeddings(self, keys: None | list[str], embeddings: NormalizedEmbeddings) -> None:
+        if embeddings.ndim != 2:
+            raise ValueError(f"Expected 2D embeddings array, got {embeddings.ndim}D")
+        if self._embedding_size == 0:
+            self._set_embedding_size(embeddings.shape[1])
+        if embeddings.shape[1] != self._embedding_size:
+            raise ValueError(f"Embedding size mismatch: expected {self._embedding_size}, got {embeddings.shape[1]}")
+        if self._device_only is not None:
+            self._materialize_host()
+        n = embeddings.shape[0]
+        self._reserve(n)
+        self._host[self._count : self._count + n] = embeddings
+        self._count += n
+        if keys is not None:
+            for key, row in zip(keys, embeddings):
+                self._model.add_embedding(key, row)
+
+    async def add_key(self, key: str, cache: bool = True) -> None:
+        embedding = await self.get_embedding(key, cache=cache)
+        self.add_embedding(key if cache else None, embedding)
+
+    async def add_keys(self, keys: list[str], cache: bool = True) -> NormalizedEmbeddings | None:
+        if not keys:
+            return None
+        embeddings = await self.get_embeddings(keys, cache=cache)
+        self.add_embeddings(keys if cache else None, embeddings)
+        return embeddings
+
+    # ------------------------------------------------------------------ device mirror
+    def _ensure_engine(self) -> _native.Engine:
+        if self._engine is None:
+            self._engine = _native.Engine(self._device_index)
+        return self._engine
+
+    def _sync_device(self) -> _native.Engine:
+        eng = self._ensure_engine()
+        if self._device_only is not None:
+            return eng
+        n = self._count
+        if not self._dev_valid:
+            self._dev_rows = 0
+            self._dev_valid = True
+        if self._dev_rows > n:
+            self._dev_rows = 0
+        if self._dev_rows < n or eng.rows != n or eng.dim != self._embedding_size:
+            start = self._dev_rows if (eng.corpus is not None and eng.dim == self._embedding_size and eng.dtype == self._dtype) else 0
+            eng.upload_rows(self._host[start:n], start, self._dtype, capacity_hint=self._host.shape[0] if start == 0 else 0)
+            self._dev_rows = n
+        return eng
+
+    def mark_dirty(self) -> None:
+        """Call after mutating the array returned by serialize()/_vectors in place:
+        the device mirror is rebuilt on the next lookup."""
+        self._dev_valid = False
+
+    def adopt_device_corpus(self, tensor, rows: int | None = None, ordinal_base: int = 0) -> None:
+        """Use a float32/float16 torch tensor [N, D] already on the GPU as the corpus
+        without a host copy (corpora larger than host RAM).  serialize() will copy
+        it back on demand."""
+        eng = self._ensure_engine()
+        eng.ordinal_base = ordinal_base
+        eng.set_corpus_tensor(tensor, rows=rows, ordinal_base=ordinal_base)
+        self._set_embedding_size(int(tensor.shape[1]))
+        self._device_only = tensor
+        self._count = eng.rows
+        self._dtype = eng.dtype
+        self._dev_rows, self._dev_valid = eng.rows, True
+        self._host = np.zeros((0, self._embedding_size), dtype=np.float32)
+
+    @property
+    def engine(self) -> _native.Engine:
+        """The device engine with the corpus synced (tuning knobs, profiling, device-resident calls)."""
+        return self._sync_device()
+
+    # ------------------------------------------------------------------ lookups
+    @staticmethod
+    def _limits(max_hits: int | None, min_score: float | None) -> tuple[int, np.float32]:
+        if max_hits is None:
+            max_hits = 10
+        if min_score is None:
+            min_score = 0.0
+        if max_hits < 0:
+            raise ValueError("max_hits must be >= 0")
+        return max_hits, _native.f32_threshold(min_score)
+
+    def _paged(self, fetch: Callable[[int, tuple[float, int] | None], tuple[np.ndarray, np.ndarray]], want: int | None,
+               accept: Callable[[int], bool] | None) -> tuple[list[int], list[float]]:
+        """Walk the best-first candidate stream `fetch(k, cursor)` page by page until `want`
+        rows are taken (None = all) or the stream ends."""
+        items: list[int] = []
+        scores: list[float] = []
+        cursor: tuple[float, int] | None = None
+        while want is None or len(items) < want:
+            k = _PAGE if (want is None or accept is not None) else min(_PAGE, want - len(items))
+            ids, scs = fetch(k, cursor)
+            for i, s in zip(ids.tolist(), scs.tolist()):
+                if accept is None or accept(i):
+                    items.append(i)
+                    scores.append(s)
+                    if want is not None and len(items) >= want:
+                        break
+            if len(ids) < k:
+                break
+            cursor = (float(scs[-1]), int(ids[-1]))
+        return items, scores
+
+    def fuzzy_lookup_embedding(
+        self,
+        embedding: NormalizedEmbedding,
+        max_hits: int | None = None,
+        min_score: float | None = None,
+        predicate: Callable[[int], bool] | None = None,
+    ) -> list[ScoredInt]:
+        max_hits, thr = self._limits(max_hits, min_score)
+        if self._count == 0:
+            return []
+        eng = self._sync_device()
+        if predicate is None and 1 <= max_hits <= _PAGE:
+            ids, scs = eng.search(embedding, max_hits, thr)
+            return [ScoredInt(int(i), float(s)) for i, s in zip(ids.tolist(), scs.tolist())]
+        if predicate is not None and max_hits == 0:
+            return []  # scored_ordinals[:0] (:201)
+        # max_hits == 0 without predicate: every survivor, sorted (the [-0:] quirk, :186-187)
+        want = None if (predicate is None and max_hits == 0) else max_hits
+        items, scores = self._paged(lambda k, cur: eng.search(embedding, k, thr, after=cur), want,
+                                    (lambda i: bool(predicate(int(i)))) if predicate is not None else None)
+        return [ScoredInt(i, s) for i, s in zip(items, scores)]
+
+    def fuzzy_lookup_embedding_in_subset(
+        self,
+        embedding: NormalizedEmbedding,
+        ordinals_of_subset: list[int],
+        max_hits: int | None = None,
+        min_score: float | None = None,
+    ) -> list[ScoredInt]:
+        max_hits, thr = self._limits(max_hits, min_score)
+        if len(ordinals_of_subset) == 0 or self._count == 0:
+            return []
+        subset = np.asarray(ordinals_of_subset)
+        if subset.dtype.kind not in "iu":
+            raise IndexError("arrays used as indices must be of integer (or boolean) type")
+        subset = subset.astype(np.int64, copy=False).reshape(-1)
+        n = self._count
+        rows = np.where(subset < 0, subset + n, subset)  # numpy index wrap (:218)
+        bad = (rows < 0) | (rows >= n)
+        if bad.any():
+            first = int(subset[np.argmax(bad)])
+            raise IndexError(f"index {first} is out of bounds for axis 0 with size {n}")
+        eng = self._sync_device()
+        if 1 <= max_hits <= _PAGE:
+            pos, scs = eng.search_subset(embedding, rows, max_hits, thr)
+            return [ScoredInt(int(subset[p]), float(s)) for p, s in zip(pos.tolist(), scs.tolist())]
+        want = None if max_hits == 0 else max_hits
+        positions, scores = self._paged(lambda k, cur: eng.search_subset(embedding, rows, k, thr, after=cur), want, None)
+        return [ScoredInt(int(subset[p]), s) for p, s in zip(positions, scores)]
+
+    def fuzzy_lookup_embeddings(
+        self,
+        embeddings: NormalizedEmbeddings,
+        max_hits: int | None = None,
+        min_score: float | None = None,
+    ) -> list[list[ScoredInt]]:
+        """Batch form: equals [fuzzy_lookup_embedding(e, max_hits, min_score) for e in embeddings],
+        served by one device submission (the reference loops, storage/memory/reltermsindex.py:320-332)."""
+        queries = np.asarray(embeddings, dtype=np.float32)
+        if queries.ndim != 2:
+            raise ValueError(f"Expected 2D embeddings array, got {queries.ndim}D")
+        max_hits, thr = self._limits(max_hits, min_score)
+        if self._count == 0 or len(queries) == 0:
+            return [[] for _ in range(len(queries))]
+        if not (1 <= max_hits <= _PAGE):
+            return [self.fuzzy_lookup_embedding(q, max_hits, min_score) for q in queries]
+        eng = self._sync_device()
+        ords, scs, cnts = eng.search_batch(queries, max_hits, thr)
+        out: list[list[ScoredInt]] = []
+        for qi in range(len(queries)):
+            m = int(cnts[qi])
+            out.append([ScoredInt(int(i), float(s)) for i, s in zip(ords[qi, :m].tolist(), scs[qi, :m].tolist())])
+        return out
+
+    async def fuzzy_lookup(
+        self,
+        key: str,
+        max_hits: int | None = None,
+        min_score: float | None = None,
+        predicate: Callable[[int], bool] | None = None,
+    ) -> list[ScoredInt]:
+        if max_hits is None:
+            max_hits = self.settings.max_matches
+        if min_score is None:
+            min_score = self.settings.min_score
+        embedding = await self.get_embedding(key)
+        return self.fuzzy_lookup_embedding(embedding, max_hits=max_hits, min_score=min_score, predicate=predicate)
+
+    # ------------------------------------------------------------------ bookkeeping
+    def _set_embedding_size(self, size: int) -> None:
+        assert size > 0
+        self._embedding_size = size
+
+    def clear(self) -> None:
+        self._device_only = None
+        self._count = 0
+        self._dev_rows = 0
+        self._dev_valid = False
+        if self._embedding_size > 0:
+            self._host = np.zeros((0, self._embedding_size), dtype=np.float32)
+        else:
+            self._host = np.array([], dtype=np.float32)
+
+    def get_embedding_at(self, pos: int) -> NormalizedEmbedding:
+        if 0 <= pos < self._count:
+            return self._vectors[pos]
+        raise IndexError(f"Index {pos} out of bounds for embedding index of size {len(self)}")
+
+    def serialize_embedding_at(self, pos: int) -> NormalizedEmbedding | None:
+        return self._vectors[pos] if 0 <= pos < self._count else None
+
+    def serialize(self) -> NormalizedEmbeddings:
+        vectors = self._vectors
+        if self._embedding_size > 0:
+            assert vectors.shape == (len(vectors), self._embedding_size)
+        return vectors  # the live matrix, like the reference (:271)
+
+    def deserialize(self, data: NormalizedEmbeddings | None) -> None:
+        if data is None:
+            self.clear()
+            return
+        if self._embedding_size == 0:
+            if data.ndim < 2 or data.shape[0] == 0:
+                self.clear()  # nothing to learn the width from
+                return
+            self._set_embedding_size(data.shape[1])
+        assert data.shape == (len(data), self._embedding_size), [data.shape, self._embedding_size]
+        self._adopt_host(data)  # kept by reference, like the reference (:287)
