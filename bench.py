@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Benchmark of the VectorBase kNN hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg2_f16]
+
+Contract (one JSON line on stdout from rank 0):
+  * a "step" is one lookup pass of the hot path over the resident corpus:
+      cfg2 (default, BASELINE.json configs[1]): 1M x 1536 fp32 corpus, ONE query, top-32,
+           through the synchronous C-ABI call `tavb_search` (query H2D + scan + merge +
+           result D2H + sync) -- what a `VectorBase.fuzzy_lookup_embedding` caller sees;
+      cfg3 (configs[2]): 10M x 1536 fp16 corpus, a 1024-query batch, top-32 (MFMA path).
+  * value = queries/sec over the timed K steps (wall clock, barrier + synchronize on both
+    sides, max over ranks).  With --gpus N the corpus is row-sharded, 1M (cfg2) / 10M (cfg3)
+    rows PER GPU (weak scaling: total rows = N x that), per-shard top-k lists are
+    all-gathered over RCCL and merged on every rank; `value` then counts shard-scans,
+    i.e. queries/s x N (rows scanned per second / rows per shard), and the plain
+    end-to-end rate is reported beside it as `queries_per_sec`.
+  * roofline: algorithmic bytes (cfg2: N*D*4 per query) or flops (cfg3: 2*Q*N*D per batch)
+    divided by the scan kernel's mean duration measured with HIP events on the stream the
+    kernel runs on (libtavb's profile API), against 8 TB/s HBM / 2.5 PFLOP/s dense fp16 MFMA.
+  * cpu_baseline: the numpy oracle (a restatement of the reference's VectorBase arithmetic,
+    oracle/vectorbase_oracle.py) timed on this box's host cores on the same corpus.
+Synthetic data: gaussian rows, L2-normalised on the device (no dataset exists for this path).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
+
+WORKLOADS = {
+    #            rows/GPU    dim   dtype   queries/step  k
+    "cfg2": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1, k=32, bound="hbm"),
+    "cfg2_f16": dict(rows=1_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm"),
+    "cfg3": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma"),
+    "cfg1": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="hbm"),
+}
+
+
+def make_device_corpus(eng, rows: int, dim: int, seed: int, dtype: str, chunk: int = 262_144):
+    """Gaussian rows generated on the device, normalised by our K1 kernel (and rounded to
+    fp16 by our convert kernel).  The host never holds more than it asks for."""
+    import torch
+
+    dev = torch.device("cuda", eng.device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    out = torch.empty((rows, dim), dtype=torch.float16 if dtype == "fp16" else torch.float32, device=dev)
+    for lo in range(0, rows, chunk):
+        hi = min(rows, lo + chunk)
+        if dtype == "fp16":
+            tmp = torch.empty((hi - lo, dim), dtype=torch.float32, device=dev)
+            tmp.normal_(generator=gen)
+            eng.normalize_rows_(tmp)
+            out[lo:hi].copy_(eng.to_f16(tmp))
+            del tmp
+        else:
+            view = out[lo:hi]
+            view.normal_(generator=gen)
+            eng.normalize_rows_(view)
+    torch.cuda.synchronize(dev)
+    return out
+
+
+def host_queries(count: int, dim: int, seed: int) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((count, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q
+
+
+def cpu_baseline(corpus_host: np.ndarray, queries: np.ndarray, k: int, budget_s: float = 15.0) -> dict:
+    from oracle import vectorbase_oracle as vo
+
+    cores = len(os.sched_getaffinity(0))
+    vo.lookup(corpus_host, queries[0], k, 0.0)  # warm-up (BLAS thread pool, page-in)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    i = 0
+    while (time.perf_counter() < t_end and i < 400) or i < 3:
+        q = queries[i % len(queries)]
+        t0 = time.perf_counter_ns()
+        vo.lookup(corpus_host, q, k, 0.0)
+        times.append((time.perf_counter_ns() - t0) / 1e9)
+        i += 1
+    med = float(np.median(times))
+    return {
+        "value": 1.0 / med,
+        "unit": "queries/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{len(times)} sequential single-query lookups on the same {corpus_host.shape[0]}x{corpus_host.shape[1]} fp32 corpus "
+                  f"(numpy {np.__version__} / OpenBLAS sgemv, default threads), median {med * 1e3:.2f} ms, min {min(times) * 1e3:.2f} ms",
+        "p50_ms": med * 1e3,
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=None, help="override rows per GPU (debugging)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (e.g. scan_unroll=4)")
+    args = ap.parse_args()
+
+    import torch
+
+    from typeagent_py_amd import _native
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.rows:
+        wl["rows"] = args.rows
+    steps = args.steps if args.steps is not None else (200 if wl["nq"] == 1 else 10)
+    warmup = args.warmup if args.warmup is not None else (20 if wl["nq"] == 1 else 2)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and args.gpus > 1:
+        sys.stderr.write(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run\n")
+    dev = local_rank if distributed else 0
+    torch.cuda.set_device(dev)
+
+    rows, dim, k, nq = wl["rows"], wl["dim"], wl["k"], wl["nq"]
+    thr = float(_native.f32_threshold(0.0))
+    queries = host_queries(max(64, nq), dim, 4242)  # identical on every rank
+
+    if distributed:
+        from typeagent_py_amd.sharded import DeviceShardBackend, ShardedSearcher
+
+        backend = DeviceShardBackend(dev)
+        eng = backend.engine
+        with torch.cuda.stream(backend.stream):
+            corpus = make_device_corpus(eng, rows, dim, 100_043 + rank, wl["dtype"])
+        backend.set_shard(corpus, row_offset=rank * rows)
+        searcher = ShardedSearcher(backend)
+    else:
+        eng = _native.Engine(dev)
+        corpus = make_device_corpus(eng, rows, dim, 1043, wl["dtype"])
+        eng.set_corpus_tensor(corpus)
+        searcher = None
+    for item in args.opt:
+        name, val = item.split("=")
+        eng.set_option(name, int(val))
+
+    dq_all = torch.from_numpy(queries).to(torch.device("cuda", dev))
+    torch.cuda.synchronize(dev)
+
+    def one_step(i: int):
+        if nq == 1:
+            qi = i % len(queries)
+            if searcher is None:
+                return eng.search(queries[qi], k, np.float32(thr))
+            return searcher.search(dq_all[qi:qi + 1], k, 0.0)
+        if searcher is None:
+            return eng.search_batch(queries[:nq], k, np.float32(thr))
+        return searcher.search(dq_all[:nq], k, 0.0)
+
+    for i in range(warmup):
+        one_step(i)
+    eng.profile_enable(True)
+    eng.profile_reset()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        s0 = time.perf_counter_ns()
+        one_step(warmup + i)
+        lat.append((time.perf_counter_ns() - s0) / 1e3)
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", dev))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kid = _native.KERNEL_MFMA if (wl["bound"] == "mfma") else _native.KERNEL_SCAN
+    kern_ms, kern_n = eng.profile_read(kid)
+    if kern_n == 0 and kid == _native.KERNEL_MFMA:  # batch fell back to the streaming kernel
+        kid = _native.KERNEL_SCAN
+        kern_ms, kern_n = eng.profile_read(kid)
+    merge_ms, merge_n = eng.profile_read(_native.KERNEL_MERGE)
+    eng.profile_enable(False)
+
+    if rank == 0:
+        qps = steps * nq / elapsed
+        esize = 2 if wl["dtype"] == "fp16" else 4
+        avg_kernel_s = (kern_ms / max(kern_n, 1)) * 1e-3
+        launches_per_step = kern_n / steps
+        if wl["bound"] == "hbm":
+            alg = rows * dim * esize  # bytes one launch must read: the shard once
+            achieved = alg / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None}
+        else:
+            nq_per_launch = nq / max(launches_per_step, 1e-9)
+            alg = 2.0 * nq_per_launch * rows * dim
+            achieved = alg / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
+            peak = MFMA_F16_PEAK_TFLOPS if kid == _native.KERNEL_MFMA else HBM_PEAK_GBS
+            roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS,
+                    "traffic": None}
+        roof["kernel"] = {0: "scan (tavb::scan_*_kernel)", 2: "mfma (tavb::mfma_scan_kernel)"}.get(kid, str(kid))
+        roof["kernel_avg_ms"] = avg_kernel_s * 1e3
+        roof["kernel_launches"] = kern_n
+        roof["algorithmic_per_launch"] = alg
+        roof["merge_avg_us"] = (merge_ms / max(merge_n, 1)) * 1e3
+
+        out = {
+            "metric": "queries/sec + p50 lookup latency, 1536-d top-32 kNN",
+            "value": qps * world,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if wl["dtype"] == "fp32" else "f16 storage, f32 accumulate",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {rows}x{dim} {wl['dtype']} rows per GPU, {nq} quer{'y' if nq == 1 else 'ies'}/step, top-{k}, min_score 0.0",
+                "rows_per_gpu": rows,
+                "total_rows": rows * world,
+                "queries_per_step": nq,
+                "k": k,
+                "parallelism": f"row-sharded x{world}, RCCL all-gather of per-shard top-k + merge" if world > 1 else "single GPU",
+                "value_counts": "queries/s x n_gpus (shard scans per second)" if world > 1 else "queries/s",
+            },
+            "queries_per_sec": qps,
+            "p50_latency_us": float(np.percentile(lat, 50)),
+            "p99_latency_us": float(np.percentile(lat, 99)),
+            "min_latency_us": float(np.min(lat)),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and not distributed:
+            n_host = min(rows, 1_000_000)
+            host = corpus[:n_host].float().cpu().numpy()
+            # the GPU answer for query 0 must be the oracle's answer on the same bytes
+            from oracle import vectorbase_oracle as vo
+
+            o, s = eng.search(queries[0], k, np.float32(thr)) if n_host == rows else (None, None)
+            if o is not None:
+                vo.check_topk_parity(vo.scores_full(host, queries[0]), o.tolist(), s.tolist(), k, 0.0)
+                out["parity_check"] = "query 0: top-k ordinals/scores match the oracle on the same corpus bytes"
+            base = cpu_baseline(host, queries, k, args.cpu_seconds)
+            if n_host != rows:
+                base["sample"] += f"; first {n_host} of {rows} rows only"
+            out["cpu_baseline"] = base
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

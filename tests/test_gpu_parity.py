@@ -1,0 +1,506 @@
+"""GPU suite (`-m gpu`, runs on the MI355X box): the HIP path, reached through the
+drop-in VectorBase class and through the ctypes C ABI, against
+  * the committed golden vectors (answers of the VERBATIM reference class),
+  * the numpy oracle on seeded random inputs (differential, modulo fp32 near-ties:
+    ordinals must be the reference's wherever its scores are separated by more than
+    4 * 2^-24; scores within 1e-5 -- `oracle.vectorbase_oracle.check_topk_parity`),
+  * size-independent properties at BASELINE.json's full size (1M x 1536).
+Nothing here reads /root/reference."""
+
+import asyncio
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import vectorbase_oracle as vo
+from tests.fakes import NullModel, create_test_embedding_model
+from tests.synth import explicit_case_arrays, make_corpus, make_queries, subset_choice
+from typeagent_py_amd import ScoredInt, TextEmbeddingIndexSettings, VectorBase, _native
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-5  # north_star: cosine scores within 1e-5 fp32
+
+
+def new_vb(vectors=None, dtype="fp32") -> VectorBase:
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), corpus_dtype=dtype)
+    if vectors is not None and len(vectors):
+        vb.add_embeddings(None, np.ascontiguousarray(vectors, dtype=np.float32))
+    return vb
+
+
+def items_scores(res):
+    assert all(isinstance(r, ScoredInt) for r in res)
+    return [r.item for r in res], [r.score for r in res]
+
+
+def assert_matches_expect(res, expect, ref_scores=None, k=None, min_score=0.0):
+    """Exact item sequence + scores within tolerance; if the exact sequence differs, fall back to the
+    near-tie-aware checker (needs ref_scores) so that only genuine fp32 ties are forgiven."""
+    items, scores = items_scores(res)
+    if items == expect["items"]:
+        np.testing.assert_allclose(scores, expect["scores"], atol=SCORE_TOL, rtol=0)
+        return True
+    assert ref_scores is not None, f"items differ: {items[:8]}... vs {expect['items'][:8]}..."
+    rep = vo.check_topk_parity(ref_scores, items, scores, k, min_score)
+    assert rep.tie_permuted_positions > 0
+    return False
+
+
+# --------------------------------------------------------------------------------------
+# the library really is the thing that runs
+# --------------------------------------------------------------------------------------
+def test_native_library_loaded_and_device_is_gfx950():
+    import torch
+
+    assert torch.cuda.is_available()
+    lib = _native.load_library()
+    assert lib.tavb_version() == 1
+    assert _native.device_count() >= 1
+    eng = _native.Engine(0)
+    assert eng.get_option("compute_units") >= 64
+    eng.close()
+    with open("/proc/self/maps") as f:
+        assert "libtavb.so" in f.read()
+
+
+# --------------------------------------------------------------------------------------
+# golden vectors
+# --------------------------------------------------------------------------------------
+def test_golden_explicit_cases(golden):
+    for case in golden["explicit"]:
+        v, q = explicit_case_arrays(case)
+        kw = dict(case["args"])
+        vb = new_vb(v)
+        if v.shape[0] == 0:
+            vb._set_embedding_size(len(q))
+        name = case["name"]
+        if "subset" in case:
+            if case.get("raises") == "IndexError":
+                with pytest.raises(IndexError):
+                    vb.fuzzy_lookup_embedding_in_subset(q, case["subset"], **kw)
+                continue
+            res = vb.fuzzy_lookup_embedding_in_subset(q, case["subset"], **kw)
+        elif "predicate_mod" in case:
+            m, r = case["predicate_mod"]
+            res = vb.fuzzy_lookup_embedding(q, predicate=lambda i: i % m == r, **kw)
+        else:
+            res = vb.fuzzy_lookup_embedding(q, **kw)
+        items, scores = items_scores(res)
+        exp = case["expect"]
+        assert len(items) == len(exp["items"]), name
+        np.testing.assert_allclose(scores, exp["scores"], atol=SCORE_TOL, rtol=0, err_msg=name)
+        if items != exp["items"]:
+            # only exactly-equal scores may be ordered differently (ours: ascending ordinal / position)
+            for a, b, sa in zip(items, exp["items"], exp["scores"]):
+                if a != b:
+                    assert exp["scores"].count(sa) > 1, f"{name}: {items} vs {exp['items']}"
+            assert sorted(items) == sorted(exp["items"]), name
+
+
+def test_reference_known_answer_exact(golden):
+    # reference tests/test_vectorbase.py:239-252: items [0,1,2], scores exactly [1.0, 0.5, 0.0]
+    vb = new_vb(np.array([[1, 0], [0, 1], [-1, 0]], dtype=np.float32))
+    res = vb.fuzzy_lookup_embedding(np.array([1.0, 0.0], dtype=np.float32), max_hits=3, min_score=0.0)
+    assert [r.item for r in res] == [0, 1, 2]
+    assert [r.score for r in res] == [1.0, 0.5, 0.0]
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_golden_seeded_cases(golden, idx):
+    entry = golden["seeded"][idx]
+    v, q = make_corpus(entry["n"], entry["d"], entry["seed"])
+    assert _sha(v) == entry["corpus_sha256"]
+    vb = new_vb(v)
+    ref_scores = vo.scores_full(v, q)
+    exact = 0
+    for run in entry["runs"]:
+        kw = dict(run["args"])
+        k = 10 if kw["max_hits"] is None else kw["max_hits"]
+        ms = 0.0 if kw["min_score"] is None else kw["min_score"]
+        if run["kind"] == "full":
+            res = vb.fuzzy_lookup_embedding(q, **kw)
+            exact += assert_matches_expect(res, run["expect"], ref_scores, k, ms)
+        elif run["kind"] == "subset":
+            sub = subset_choice(entry["n"], run["subset_args"]["size"], run["subset_args"]["seed"])
+            res = vb.fuzzy_lookup_embedding_in_subset(q, sub, **kw)
+            exact += assert_matches_expect(res, run["expect"])
+        elif run["kind"] == "full_f16_corpus_f32_query":
+            vb16 = new_vb(v, dtype="fp16")
+            res = vb16.fuzzy_lookup_embedding(q, **kw)
+            v16 = v.astype(np.float16).astype(np.float32)
+            exact += assert_matches_expect(res, run["expect"], vo.scores_full(v16, q), k, ms)
+        elif run["kind"] == "full_f16_corpus_f16_query":
+            vb16 = new_vb(v, dtype="fp16")
+            q16 = q.astype(np.float16).astype(np.float32)
+            res = vb16.fuzzy_lookup_embedding(q16, **kw)
+            v16 = v.astype(np.float16).astype(np.float32)
+            exact += assert_matches_expect(res, run["expect"], vo.scores_full(v16, q16), k, ms)
+    assert exact >= 1
+
+
+@pytest.mark.slow
+def test_golden_cfg2_one_million_rows(golden):
+    """BASELINE config 2 at full size: 1M x 1536 fp32, single query, top-32 -- against the
+    answer of the verbatim reference recorded in the goldens."""
+    entry = next(e for e in golden["seeded"] if e["name"].startswith("cfg2_1m"))
+    v, q = make_corpus(entry["n"], entry["d"], entry["seed"])
+    assert _sha(q) == entry["query_sha256"]
+    vb = new_vb()
+    vb.deserialize(v)  # adopt by reference: no second 6 GB host copy
+    for run in entry["runs"]:
+        kw = dict(run["args"])
+        res = vb.fuzzy_lookup_embedding(q, **kw)
+        items, scores = items_scores(res)
+        assert items == run["expect"]["items"]  # smallest top-33 gap 8.9e-7 >> fp32 noise
+        np.testing.assert_allclose(scores, run["expect"]["scores"], atol=SCORE_TOL, rtol=0)
+    # size-independent properties on the same corpus
+    planted = vb.fuzzy_lookup_embedding(v[777_777], max_hits=1, min_score=0.0)
+    assert planted[0].item == 777_777 and abs(planted[0].score - 1.0) <= 1e-6
+    top64 = vb.fuzzy_lookup_embedding(q, max_hits=64, min_score=0.0)
+    top32 = vb.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
+    assert [r.item for r in top64[:32]] == [r.item for r in top32]  # prefix property
+    s = [r.score for r in top64]
+    assert s == sorted(s, reverse=True)
+    thr = top32[-1].score
+    cut = vb.fuzzy_lookup_embedding(q, max_hits=64, min_score=thr)
+    assert [r.item for r in cut] == [r.item for r in top64 if r.score >= np.float32(thr)]
+
+
+# --------------------------------------------------------------------------------------
+# differential vs the oracle
+# --------------------------------------------------------------------------------------
+def _diff_one(v, q, k, min_score, vb, ref_scores=None):
+    if ref_scores is None:
+        ref_scores = vo.scores_full(v, q)
+    res = vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=min_score)
+    items, scores = items_scores(res)
+    kk = 10 if k is None else k
+    ms = 0.0 if min_score is None else min_score
+    return vo.check_topk_parity(ref_scores, items, scores, kk, ms)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 17, 64, 100, 384, 768, 1024, 1536, 1540, 3072])
+def test_differential_dims(d):
+    n = 3000 if d <= 1536 else 1200
+    v, q = make_corpus(n, d, 1000 + d)
+    vb = new_vb(v)
+    sc = vo.scores_full(v, q)
+    exact = total = 0
+    for k, ms in [(None, None), (1, 0.0), (10, 0.0), (32, 0.0), (50, 0.5), (64, 0.0), (65, 0.0), (200, 0.0), (256, 0.3), (32, 0.53), (32, 0.99), (10, 1.5)]:
+        rep = _diff_one(v, q, k, ms, vb, sc)
+        exact += rep.exact_positions
+        total += rep.k_returned
+    if d >= 17:
+        assert exact == total, "no near-ties expected in gaussian data at this size"
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 127, 129, 511, 1000, 4097, 20000])
+def test_differential_row_counts(n):
+    v, q = make_corpus(n, 1536, 2000 + n)
+    vb = new_vb(v)
+    sc = vo.scores_full(v, q)
+    for k in (1, 10, 32, n, n + 1):
+        if k <= 256:
+            _diff_one(v, q, k, 0.0, vb, sc)
+
+
+def test_large_k_paging_and_zero_quirk():
+    v, q = make_corpus(1500, 96, 77)
+    vb = new_vb(v)
+    sc = vo.scores_full(v, q)
+    for k in (257, 300, 700, 1500, 1501, 5000):
+        res = vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=0.45)
+        items, scores = items_scores(res)
+        vo.check_topk_parity(sc, items, scores, k, 0.45)
+    everything = vb.fuzzy_lookup_embedding(q, max_hits=0, min_score=0.5)  # [-0:] quirk: all survivors, sorted
+    ref = vo.lookup(v, q, 0, 0.5)
+    assert len(everything) == len(ref) > 256
+    vo.check_topk_parity(sc, *items_scores(everything), 0, 0.5)
+
+
+def test_predicate_path():
+    v, q = make_corpus(2500, 64, 78)
+    vb = new_vb(v)
+    for pred in (lambda i: i % 7 == 3, lambda i: i > 2400, lambda i: False, lambda i: True):
+        ref = vo.lookup(v, q, 12, 0.4, pred)
+        res = vb.fuzzy_lookup_embedding(q, max_hits=12, min_score=0.4, predicate=pred)
+        items, scores = items_scores(res)
+        assert items == [i for i, _ in ref]
+        np.testing.assert_allclose(scores, [s for _, s in ref], atol=SCORE_TOL, rtol=0)
+    assert vb.fuzzy_lookup_embedding(q, max_hits=0, min_score=0.0, predicate=lambda i: True) == []
+
+
+def test_subset_search_differential():
+    v, q = make_corpus(5000, 1536, 79)
+    vb = new_vb(v)
+    rng = np.random.default_rng(5)
+    for size, k, ms in [(1, 10, 0.0), (20, 32, 0.0), (1000, 10, 0.0), (3000, 50, 0.5), (700, 300, 0.0)]:
+        sub = rng.choice(5000, size=size, replace=False).tolist()
+        res = vb.fuzzy_lookup_embedding_in_subset(q, sub, max_hits=k, min_score=ms)
+        items, scores = items_scores(res)
+        sc = vo.cosine_to_score(np.dot(v[np.asarray(sub)], q))
+        vo.check_topk_parity(sc, items, scores, k, ms, candidate_ordinals=np.asarray(sub))
+    # duplicates and negative ordinals (numpy fancy-index semantics, vectorbase.py:217-229)
+    sub = [4999, 17, 17, -1, 3, -5000]
+    res = vb.fuzzy_lookup_embedding_in_subset(q, sub, max_hits=10, min_score=0.0)
+    ref = vo.lookup_in_subset(v, q, sub, 10, 0.0)
+    assert sorted(r.item for r in res) == sorted(i for i, _ in ref)
+    np.testing.assert_allclose(sorted(r.score for r in res), sorted(s for _, s in ref), atol=SCORE_TOL, rtol=0)
+    with pytest.raises(IndexError):
+        vb.fuzzy_lookup_embedding_in_subset(q, [0, 5000])
+    with pytest.raises(IndexError):
+        vb.fuzzy_lookup_embedding_in_subset(q, [-5001])
+
+
+@pytest.mark.parametrize("nq", [1, 2, 3, 5, 8, 9, 20])
+@pytest.mark.parametrize("d,k", [(1536, 32), (384, 50), (1536, 200), (10, 7)])
+def test_batch_equals_sequential(nq, d, k):
+    v, _ = make_corpus(4000, d, 300 + d)
+    qs = make_queries(nq, d, 400 + nq)
+    vb = new_vb(v)
+    batch = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.3)
+    assert len(batch) == nq
+    for qi in range(nq):
+        single = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=0.3)
+        bi, bs = items_scores(batch[qi])
+        si, ss = items_scores(single)
+        sc = vo.scores_full(v, qs[qi])
+        vo.check_topk_parity(sc, bi, bs, k, 0.3)
+        vo.check_topk_parity(sc, si, ss, k, 0.3)
+        assert bi == si
+        np.testing.assert_allclose(bs, ss, atol=2e-7, rtol=0)
+
+
+@pytest.mark.parametrize("d", [8, 384, 1536, 2048])
+def test_f16_corpus_differential(d):
+    v, q = make_corpus(6000, d, 500 + d)
+    vb = new_vb(v, dtype="fp16")
+    v16 = v.astype(np.float16).astype(np.float32)  # what the device holds, widened
+    sc = vo.scores_full(v16, q)
+    for k, ms in [(10, 0.0), (32, 0.0), (200, 0.4)]:
+        res = vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=ms)
+        vo.check_topk_parity(sc, *items_scores(res), k, ms)
+
+
+@pytest.mark.parametrize("tier", [1, 2, 3])
+def test_kernel_tiers_agree(tier):
+    v, q = make_corpus(8192, 1536, 600)
+    sc = vo.scores_full(v, q)
+    vb = new_vb(v)
+    vb.engine.set_option("force_tier", tier)
+    res = vb.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
+    assert vb.engine.get_option("last_tier") == tier
+    rep = vo.check_topk_parity(sc, *items_scores(res), 32, 0.0)
+    assert rep.ordinals_bit_exact
+    res = vb.fuzzy_lookup_embedding(q, max_hits=130, min_score=0.0)
+    vo.check_topk_parity(sc, *items_scores(res), 130, 0.0)
+
+
+@pytest.mark.parametrize("opts", [dict(scan_unroll=1), dict(scan_unroll=4), dict(scan_nt=0), dict(scan_pipe=1),
+                                  dict(scan_pipe=1, scan_unroll=1), dict(scan_waves=4, scan_blocks=1024),
+                                  dict(scan_waves=8, scan_blocks=512), dict(scan_waves=1, scan_blocks=7)])
+def test_launch_geometry_variants_agree(opts):
+    v, q = make_corpus(30000, 1536, 601)
+    sc = vo.scores_full(v, q)
+    vb = new_vb(v)
+    for name, val in opts.items():
+        vb.engine.set_option(name, val)
+    res = vb.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
+    rep = vo.check_topk_parity(sc, *items_scores(res), 32, 0.0)
+    assert rep.ordinals_bit_exact
+
+
+def test_ties_resolve_to_ascending_ordinal():
+    row = np.zeros(64, dtype=np.float32)
+    row[3] = 1.0
+    v = np.tile(row, (1000, 1))
+    vb = new_vb(v)
+    res = vb.fuzzy_lookup_embedding(row, max_hits=10, min_score=0.0)
+    assert [r.item for r in res] == list(range(10)) and all(r.score == 1.0 for r in res)
+    res = vb.fuzzy_lookup_embedding(row, max_hits=300, min_score=0.0)
+    assert [r.item for r in res] == list(range(300))
+
+
+def test_nan_zero_and_clip_rows():
+    v = np.array([[0, 0], [np.nan, 1], [3, 0], [-3, 0], [0.5, 0], [np.inf, 0], [-np.inf, 0]], dtype=np.float32)
+    vb = new_vb(v)
+    with np.errstate(invalid="ignore"):
+        ref = vo.lookup(v, np.array([1, 0], dtype=np.float32), 10, 0.0)
+    res = vb.fuzzy_lookup_embedding(np.array([1.0, 0.0], dtype=np.float32), max_hits=10, min_score=0.0)
+    got = sorted((r.item, r.score) for r in res)
+    assert got == sorted(ref)  # NaN row dropped, +-inf clipped to 1/0, zero row scores exactly 0.5
+
+
+def test_float32_threshold_rule():
+    c = float(np.float32(0.85)) * 2 - 1
+    v = np.array([[c, 0], [np.nextafter(np.float32(c), np.float32(-1)), 0]], dtype=np.float32)
+    vb = new_vb(v)
+    q = np.array([1.0, 0.0], dtype=np.float32)
+    ref = vo.lookup(v, q, 10, 0.85)
+    res = vb.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.85)
+    assert [r.item for r in res] == [i for i, _ in ref]
+    ref64 = vo.lookup(v, q, 10, np.float64(0.85))
+    res64 = vb.fuzzy_lookup_embedding(q, max_hits=10, min_score=np.float64(0.85))
+    assert [r.item for r in res64] == [i for i, _ in ref64]
+
+
+# --------------------------------------------------------------------------------------
+# API behaviour that needs the device (reference tests/test_vectorbase.py:148-159, 209-236)
+# --------------------------------------------------------------------------------------
+def test_fuzzy_lookup_by_text_with_fake_model():
+    vb = VectorBase(TextEmbeddingIndexSettings(create_test_embedding_model()))
+
+    async def go():
+        for key in ("word1", "word2", "word3"):
+            await vb.add_key(key)
+        return await vb.fuzzy_lookup("word1", max_hits=2, min_score=0.0)
+
+    results = asyncio.run(go())
+    assert 1 <= len(results) <= 2
+    assert results[0].item == 0
+    assert results[0].score > 0.9
+
+
+def test_subset_semantics_from_reference_tests():
+    vb = VectorBase(TextEmbeddingIndexSettings(create_test_embedding_model()))
+    samples = [np.array(x, dtype=np.float32) for x in ([0.1, 0.2, 0.3], [0.4, 0.5, 0.6], [0.7, 0.8, 0.9])]
+    for s in samples:
+        vb.add_embedding(None, s)
+    result = vb.fuzzy_lookup_embedding_in_subset(samples[0], [0, 1, 2])
+    assert len(result) > 0 and 0 in [r.item for r in result]
+    result = vb.fuzzy_lookup_embedding_in_subset(samples[0], [1])
+    assert len(result) == 1 and result[0].item == 1
+    assert vb.fuzzy_lookup_embedding_in_subset(samples[0], []) == []
+
+
+def test_appends_between_lookups_keep_device_in_sync():
+    v, q = make_corpus(5000, 384, 900)
+    vb = new_vb(v[:10])
+    for upto in (10, 11, 100, 1000, 5000):
+        if len(vb) < upto:
+            if upto - len(vb) == 1:
+                vb.add_embedding(None, v[len(vb)])
+            else:
+                vb.add_embeddings(None, v[len(vb):upto])
+        res = vb.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.0)
+        vo.check_topk_parity(vo.scores_full(v[:upto], q), *items_scores(res), 10, 0.0)
+    vb.clear()
+    assert vb.fuzzy_lookup_embedding(q) == []
+    vb.add_embeddings(None, v[100:200])
+    res = vb.fuzzy_lookup_embedding(q, max_hits=5, min_score=0.0)
+    vo.check_topk_parity(vo.scores_full(v[100:200], q), *items_scores(res), 5, 0.0)
+    other = np.ascontiguousarray(v[300:400])
+    vb.deserialize(other)
+    res = vb.fuzzy_lookup_embedding(q, max_hits=5, min_score=0.0)
+    vo.check_topk_parity(vo.scores_full(other, q), *items_scores(res), 5, 0.0)
+
+
+def test_wrong_query_size_raises_value_error():
+    vb = new_vb(np.ones((4, 8), dtype=np.float32))
+    with pytest.raises(ValueError):
+        vb.fuzzy_lookup_embedding(np.ones(7, dtype=np.float32))
+
+
+# --------------------------------------------------------------------------------------
+# K1 normalise / convert kernels
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 1), (7, 3), (100, 33), (1000, 384), (5000, 1536), (64, 4097)])
+def test_normalize_rows_kernel(shape):
+    import torch
+
+    rng = np.random.default_rng(shape[0] + shape[1])
+    x = (rng.standard_normal(shape) * 3).astype(np.float32)
+    x[0] = 0  # zero row must stay zero (model_adapters.py:182)
+    eng = _native.Engine(0)
+    t = torch.from_numpy(x).cuda()
+    y = eng.normalize_rows(t).cpu().numpy()
+    ref = vo.l2_normalize_rows(x)
+    assert np.all(y[0] == 0)
+    np.testing.assert_allclose(y, ref, atol=2e-7, rtol=2e-7)  # fp32 summation-order noise only
+    if shape[0] > 1:
+        n = np.linalg.norm(y[1:].astype(np.float64), axis=1)
+        assert np.all(np.abs(n - 1) < 1e-6)  # reference tests/test_embeddings.py:112-120
+    eng.normalize_rows_(t)
+    np.testing.assert_array_equal(t.cpu().numpy(), y)
+    eng.close()
+
+
+def test_f32_to_f16_is_round_to_nearest_even():
+    import torch
+
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.standard_normal(100_003).astype(np.float32), np.array([0, -0.0, 65504, 1e-8, 6.1e-5, 1 + 2**-11, 1 + 3 * 2**-11], dtype=np.float32)])
+    eng = _native.Engine(0)
+    y = eng.to_f16(torch.from_numpy(x).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(y.view(np.uint16), x.astype(np.float16).view(np.uint16))
+    eng.close()
+
+
+# --------------------------------------------------------------------------------------
+# the C ABI's device-resident calls: per-shard search + merge == whole-corpus search
+# --------------------------------------------------------------------------------------
+def test_shard_search_plus_merge_equals_whole():
+    import torch
+
+    v, _ = make_corpus(9001, 1536, 1234)
+    qs = make_queries(5, 1536, 1235)
+    k = 32
+    whole = _native.Engine(0)
+    whole.upload_rows(v, 0, _native.TAVB_F32)
+    dq = torch.from_numpy(qs).cuda()
+    kw = whole.search_device(dq, k, 0.0)
+    whole.synchronize()
+    want = kw.cpu().numpy()
+    parts = []
+    bounds = [0, 1, 2500, 2501, 9001]
+    engines = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        e = _native.Engine(0)
+        e.ordinal_base = lo
+        e.upload_rows(v[lo:hi], 0, _native.TAVB_F32)
+        keys = e.search_device(dq, k, 0.0)
+        e.synchronize()
+        parts.append(keys)
+        engines.append(e)
+    gathered = torch.stack(parts).contiguous()
+    merged = whole.merge_device(gathered)
+    whole.synchronize()
+    np.testing.assert_array_equal(merged.cpu().numpy(), want)
+    ords, scs, cnts = _native.decode_keys(want)
+    for qi in range(5):
+        vo.check_topk_parity(vo.scores_full(v, qs[qi]), ords[qi, : cnts[qi]], scs[qi, : cnts[qi]], k, 0.0)
+    for e in engines + [whole]:
+        e.close()
+
+
+def test_device_only_corpus_and_lazy_host_copy():
+    import torch
+
+    v, q = make_corpus(3000, 1536, 4321)
+    vb = new_vb()
+    vb.adopt_device_corpus(torch.from_numpy(v).cuda())
+    assert len(vb) == 3000 and vb._embedding_size == 1536
+    res = vb.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
+    vo.check_topk_parity(vo.scores_full(v, q), *items_scores(res), 32, 0.0)
+    np.testing.assert_array_equal(vb.serialize(), v)  # copied back on demand
+
+
+def test_profile_counters_count_launches():
+    v, q = make_corpus(20000, 1536, 55)
+    vb = new_vb(v)
+    eng = vb.engine
+    eng.profile_enable(True)
+    eng.profile_reset()
+    for _ in range(3):
+        vb.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
+    ms, n = eng.profile_read(_native.KERNEL_SCAN)
+    assert n == 3 and ms > 0
+    ms2, n2 = eng.profile_read(_native.KERNEL_MERGE)
+    assert n2 == 3 and ms2 > 0
+    eng.profile_enable(False)
