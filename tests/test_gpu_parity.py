@@ -417,6 +417,61 @@ def test_wrong_query_size_raises_value_error():
 
 
 # --------------------------------------------------------------------------------------
+# MFMA batched path (fp16 corpus, fp16-rounded queries, fp32 accumulate)
+# --------------------------------------------------------------------------------------
+def _f16(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,nq,k,ms,splits", [
+    (20_000, 40, 32, 0.0, 0),
+    (20_000, 300, 10, 0.52, 0),
+    (5_000, 64, 64, 0.0, 3),
+    (100, 33, 32, 0.0, 0),
+    (70_001, 256, 32, 0.0, 17),
+    (33_000, 1024, 32, 0.0, 0),
+    (9_000, 50, 5, 0.9, 8),
+])
+def test_mfma_batch_against_oracle(n, nq, k, ms, splits):
+    v, _ = make_corpus(n, 1536, 7000 + n % 97)
+    qs = make_queries(nq, 1536, 7100 + nq)
+    qs[0] = v[n // 2]  # plant an exact match
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    eng.set_option("mfma_min_batch", 32)
+    eng.set_option("mfma_splits", splits)
+    eng.profile_enable(True)
+    eng.profile_reset()
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
+    ms_mfma, n_mfma = eng.profile_read(_native.KERNEL_MFMA)
+    assert n_mfma == 1, "the MFMA kernel must be the one that ran"
+    v16, q16 = _f16(v), _f16(qs)  # the values the device multiplies
+    exact = total = 0
+    check = range(nq) if nq <= 64 else list(range(0, nq, max(1, nq // 48))) + [nq - 1]
+    for qi in check:
+        sc = vo.scores_full(v16, q16[qi])
+        items, scores = items_scores(out[qi])
+        rep = vo.check_topk_parity(sc, items, scores, k, ms)
+        exact += rep.exact_positions
+        total += rep.k_returned
+    assert out[0][0].item == n // 2 and abs(out[0][0].score - 1.0) < 2e-3
+    assert exact >= total - 2  # gaussian data: (near-)ties are vanishingly rare
+
+
+def test_mfma_batch_equals_streaming_path_on_f16_representable_queries():
+    v, _ = make_corpus(12_345, 1536, 7200)
+    qs = _f16(make_queries(48, 1536, 7201))
+    vb = new_vb(v, dtype="fp16")
+    vb.engine.set_option("mfma_min_batch", 32)
+    batch = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    vb.engine.set_option("mfma_min_batch", 1 << 30)  # force the streaming kernels
+    stream = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    for a, b in zip(batch, stream):
+        assert [r.item for r in a] == [r.item for r in b]
+        np.testing.assert_allclose([r.score for r in a], [r.score for r in b], atol=3e-7, rtol=0)
+
+
+# --------------------------------------------------------------------------------------
 # K1 normalise / convert kernels
 # --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(1, 1), (7, 3), (100, 33), (1000, 384), (5000, 1536), (64, 4097)])

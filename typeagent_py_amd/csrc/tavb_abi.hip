@@ -102,7 +102,7 @@ struct tavb_ctx {
   int64_t mfma_min_batch = 32;
   int64_t mfma_splits = 0;  // 0 = auto
 
-  Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows;
+  Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand;
   Buffer h_stage{nullptr, 0, true};
 
   bool profiling = false;
@@ -326,6 +326,7 @@ int tavb_destroy(tavb_ctx* c) {
   c->d_lists.release();
   c->d_out.release();
   c->d_rows.release();
+  c->d_cand.release();
   c->h_stage.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -635,10 +636,12 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     }
     const int splits = c->mfma_splits > 0 ? (int)c->mfma_splits : tavb::mfma_pick_splits(c->rows, nq_pad, c->n_cu);
     if (int rc = c->d_lists.reserve((size_t)nq * splits * k * sizeof(u64_t))) return rc;
+    if (int rc = c->d_cand.reserve(tavb::mfma_workspace_bytes(splits, nq_pad))) return rc;
     tavb::MfmaParams p{};
     p.corpus = c->corpus;
     p.queries = c->d_queries_f16.ptr;
     p.lists = reinterpret_cast<u64_t*>(c->d_lists.ptr);
+    p.workspace = reinterpret_cast<u64_t*>(c->d_cand.ptr);
     p.rows = c->rows;
     p.dim = c->dim;
     p.nq = nq;

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/tavb.h"
@@ -47,6 +48,7 @@ struct MfmaParams {
   const void* corpus;   // f16 [rows, dim]
   const void* queries;  // f16 [nq_padded, dim] device
   unsigned long long* lists;  // out [nq, n_splits, k]
+  unsigned long long* workspace;  // candidate buffers, mfma_workspace_bytes() bytes
   int64_t rows;
   int32_t dim;
   int32_t nq;
@@ -60,5 +62,6 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
 int mfma_query_tile();                    // queries per workgroup tile
 int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu);
 bool mfma_supported(int dim, int k);
+size_t mfma_workspace_bytes(int n_splits, int nq_padded);
 
 }  // namespace tavb
