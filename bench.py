@@ -132,7 +132,7 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("TAVB_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank dry run of the N>1 code
     if distributed:
         import torch.distributed as dist
 
@@ -156,7 +156,7 @@ def main() -> None:
         with torch.cuda.stream(backend.stream):
             corpus = make_device_corpus(eng, rows, dim, 100_043 + rank, wl["dtype"])
         backend.set_shard(corpus, row_offset=rank * rows)
-        searcher = ShardedSearcher(backend)
+        searcher = ShardedSearcher(backend, always_collective=True)
     else:
         eng = _native.Engine(dev)
         corpus = make_device_corpus(eng, rows, dim, 1043, wl["dtype"])

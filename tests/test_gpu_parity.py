@@ -543,6 +543,42 @@ def test_shard_search_plus_merge_equals_whole():
         e.close()
 
 
+def test_sharded_searcher_on_one_rank_rccl():
+    """The product's N > 1 code path (DeviceShardBackend + RCCL all-gather + merge kernel) on a
+    one-rank process group: same answer as the plain engine."""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from typeagent_py_amd.sharded import DeviceShardBackend, ShardedSearcher
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        v, _ = make_corpus(10_000, 1536, 8100)
+        qs = make_queries(6, 1536, 8101)
+        backend = DeviceShardBackend(0)
+        with torch.cuda.stream(backend.stream):
+            shard = torch.from_numpy(v).cuda()
+        backend.set_shard(shard, row_offset=5_000_000)
+        searcher = ShardedSearcher(backend, always_collective=True)
+        dq = torch.from_numpy(qs).cuda()
+        res = searcher.search(dq, 32, 0.0)
+        for qi in range(6):
+            m = int(res.counts[qi])
+            assert m == 32
+            vo.check_topk_parity(vo.scores_full(v, qs[qi]), (res.ordinals[qi, :m] - 5_000_000).tolist(), res.scores[qi, :m].tolist(), 32, 0.0)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_device_only_corpus_and_lazy_host_copy():
     import torch
 

@@ -98,12 +98,13 @@ class ShardedSearcher:
     same queries (they are tiny next to the corpus: <= 3 MiB for 1024 x 1536 fp16, so the
     caller broadcasts/duplicates them) and every rank gets the same global result."""
 
-    def __init__(self, backend: ShardBackend, group=None):
+    def __init__(self, backend: ShardBackend, group=None, always_collective: bool = False):
         import torch.distributed as dist
 
         self.dist = dist
         self.backend = backend
         self.group = group
+        self.always_collective = always_collective  # run the all-gather even for one rank (tests)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -113,7 +114,7 @@ class ShardedSearcher:
             raise ValueError(f"k must be in 1..{_native.MAX_FUSED_K}")
         thr = float(_native.f32_threshold(min_score))
         local = self.backend.local_search(queries, k, thr)
-        if self.world == 1:
+        if self.world == 1 and not (self.always_collective and self.dist.is_initialized()):
             return local
         nq = local.shape[0]
         gathered = self.backend.empty_gather(self.world, nq, k)
