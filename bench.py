@@ -225,6 +225,15 @@ def main() -> None:
             peak = MFMA_F16_PEAK_TFLOPS if kid == _native.KERNEL_MFMA else HBM_PEAK_GBS
             roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS,
                     "traffic": None}
+        try:  # HBM traffic comes from a separate rocprofv3 --pmc pass (bench.py cannot count it itself)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f).get(args.workload)
+            if pmc and pmc.get("traffic_bytes_per_launch") and not args.rows:
+                roof["traffic"] = pmc["traffic_bytes_per_launch"] / (1e9 if wl["bound"] == "hbm" else 1.0)
+                roof["traffic_unit"] = "GB per launch" if wl["bound"] == "hbm" else "B per launch"
+                roof["traffic_source"] = pmc["source"]
+        except Exception:
+            pass
         roof["kernel"] = {0: "scan (tavb::scan_*_kernel)", 2: "mfma (tavb::mfma_scan_kernel)"}.get(kid, str(kid))
         roof["kernel_avg_ms"] = avg_kernel_s * 1e3
         roof["kernel_launches"] = kern_n
