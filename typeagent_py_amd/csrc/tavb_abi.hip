@@ -101,6 +101,7 @@ struct tavb_ctx {
   tavb::ScanGeometry geom{0, 16, 2, 1, 0, 0};
   int64_t mfma_min_batch = 32;
   int64_t mfma_splits = 0;  // 0 = auto
+  int64_t mfma_variant = 2;
 
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand;
   Buffer h_stage{nullptr, 0, true};
@@ -363,6 +364,9 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_min_batch") {
     if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch must be >= 1");
     c->mfma_min_batch = v;
+  } else if (n == "mfma_variant") {
+    if (v != 1 && v != 2) return fail(TAVB_E_INVALID, "mfma_variant must be 1 or 2");
+    c->mfma_variant = v;
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");
     c->mfma_splits = v;
@@ -384,6 +388,7 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "force_tier") *out = c->geom.tier;
   else if (n == "mfma_min_batch") *out = c->mfma_min_batch;
   else if (n == "mfma_splits") *out = c->mfma_splits;
+  else if (n == "mfma_variant") *out = c->mfma_variant;
   else if (n == "compute_units") *out = c->n_cu;
   else if (n == "last_tier") *out = c->last_tier;
   else return fail(TAVB_E_INVALID, "unknown option '%s'", name);
@@ -650,6 +655,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     p.index_base = index_base;
     p.min_score = min_scores[0];
     p.n_splits = splits;
+    p.variant = (int)c->mfma_variant;
     {
       Timed t(c, TAVB_KERNEL_MFMA);
       hipError_t e = tavb::launch_mfma_scan(p, c->stream);

@@ -57,6 +57,7 @@ struct MfmaParams {
   uint32_t index_base;
   float min_score;
   int32_t n_splits;  // row ranges the corpus is cut into (one list per (query, split))
+  int32_t variant;   // 1 = lock-step K loop, 2 = ping-pong wave groups
 };
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
 int mfma_query_tile();                    // queries per workgroup tile

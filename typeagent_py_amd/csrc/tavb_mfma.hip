@@ -75,6 +75,16 @@ struct MfmaDeviceParams {
   float min_score;
 };
 
+// Pin a wave-uniform pointer into SGPRs.  Without this the compiler strength-reduces the eight
+// LDS-DMA source addresses of a K step into eight 64-bit VGPR induction variables (16 VGPRs, spilled
+// in this kernel); with it each address is "SGPR base + 32-bit VGPR offset" (the saddr form).
+__device__ __forceinline__ const char* sgpr_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
 // ascending bitonic sort of one key per lane (lane 63 ends up with the largest)
 __device__ __forceinline__ u64 sort64_ascending(u64 key, int lane) {
 #pragma unroll
@@ -106,6 +116,20 @@ __device__ __forceinline__ WaveTopK<1> best_of_buffer(const u64* buf, int n, int
   return best;
 }
 
+// VARIANT 1: every wave alternates {read fragments, 8 MFMAs} in lock step, one barrier per K step.
+// VARIANT 2: the two wave groups (rows 0-127 / 128-255 of the tile = waves 0-3 / 4-7, one wave of
+//            each group per SIMD) run half a phase apart: while one group issues its 16 MFMAs of a
+//            half K step, the other group reads its next fragments from LDS and issues the LDS-DMA
+//            for the next slab.  Raw s_barrier (no implied vmcnt drain), counted waits placed by hand.
+#define TAVB_SB() __builtin_amdgcn_sched_barrier(0)
+#define TAVB_BARRIER()            \
+  do {                            \
+    TAVB_SB();                    \
+    __builtin_amdgcn_s_barrier(); \
+    TAVB_SB();                    \
+  } while (0)
+
+template <int VARIANT>
 __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel(const MfmaDeviceParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   float* thr_lds = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);      // [BN] admission threshold (exclusive)
@@ -143,44 +167,47 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel(const MfmaDevicePar
   const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * BN * row_bytes;
 
   // --- staging: each wave issues 4 LDS-DMA instructions per operand per K step; instruction i
-  //     covers tile rows 8i .. 8i+7 (8 lanes x 16 B per 128-byte row)
+  //     covers tile rows 8i .. 8i+7 (8 lanes x 16 B per 128-byte row).  Addresses are a wave-uniform
+  //     base (SGPRs) plus a 32-bit per-lane offset that is loop invariant.
   const int st_row_in_inst = lane >> 3;
   const int st_slot = lane & 7;
+  uint32_t st_off_b[4];  // query operand: constant for the whole kernel
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + st_row_in_inst;
+    st_off_b[j] = (uint32_t)row * (uint32_t)row_bytes + (uint32_t)((st_slot ^ ((row >> 1) & 7)) * 16);
+  }
+  uint32_t st_off_a[4];  // corpus operand: per tile (rows past the corpus end are clamped)
 
-  auto stage = [&](int buf, int64_t row0, int kt) {
-    unsigned char* abase = smem + buf * STAGE_BYTES;
-    unsigned char* bbase = abase + A_BYTES;
+  auto set_tile_offsets = [&](int64_t row0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int inst = wave * 4 + j;
-      const int row = inst * 8 + st_row_in_inst;
-      const int gslot = st_slot ^ ((row >> 1) & 7);
+      const int row = (wave * 4 + j) * 8 + st_row_in_inst;
       int64_t grow = row0 + row;
       if (grow >= p.rows) grow = p.rows - 1;  // stay in bounds; masked in the epilogue
-      const char* ga = corpus + (size_t)grow * row_bytes + (size_t)kt * (BK * 2) + gslot * 16;
-      __builtin_amdgcn_global_load_lds((global_void*)ga, (lds_void*)(abase + inst * 1024), 16, 0, 0);
-      const char* gb = qbase + (size_t)row * row_bytes + (size_t)kt * (BK * 2) + gslot * 16;
-      __builtin_amdgcn_global_load_lds((global_void*)gb, (lds_void*)(bbase + inst * 1024), 16, 0, 0);
+      st_off_a[j] = (uint32_t)(grow - row0) * (uint32_t)row_bytes + (uint32_t)((st_slot ^ ((row >> 1) & 7)) * 16);
     }
   };
 
-  // fragment read offsets (bytes within an operand slab) for this lane
+  auto stage = [&](int buf, int64_t row0, int kt) {
+    unsigned char* abase = smem + buf * STAGE_BYTES + wave * 4096;
+    unsigned char* bbase = abase + A_BYTES;
+    const char* ga = sgpr_ptr(corpus + (size_t)row0 * row_bytes + (size_t)kt * (BK * 2));  // wave-uniform
+    const char* gb = sgpr_ptr(qbase + (size_t)kt * (BK * 2));                               // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((global_void*)(ga + (size_t)st_off_a[j]), (lds_void*)(abase + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((global_void*)(gb + (size_t)st_off_b[j]), (lds_void*)(bbase + j * 1024), 16, 0, 0);
+    }
+  };
+
+  // fragment reads: lane l reads row (l & 31) of a 32-row block at logical 16-byte slot
+  // 2*k16 + (l >> 5); the physical slot is that XOR ((row >> 1) & 7), and because the block bases
+  // are multiples of 16 rows the XOR term depends on the lane only: offset = (k16 << 5) ^ frag_x.
   const int frag_row = lane & 31;
-  const int frag_khalf = lane >> 5;
-  int a_off[4], b_off[2];
-  int a_sw[4], b_sw[2];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int row = wm * 128 + mi * 32 + frag_row;
-    a_off[mi] = row * 128;
-    a_sw[mi] = (row >> 1) & 7;
-  }
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int row = wn * 64 + ni * 32 + frag_row;
-    b_off[ni] = row * 128;
-    b_sw[ni] = (row >> 1) & 7;
-  }
+  const uint32_t frag_x = (uint32_t)(((lane >> 5) ^ ((frag_row >> 1) & 7)) << 4);
+  const uint32_t a_lane = (uint32_t)((wm * 128 + frag_row) * 128);            // + mi * 4096
+  const uint32_t b_lane = (uint32_t)(A_BYTES + (wn * 64 + frag_row) * 128);   // + ni * 4096
 
   __syncthreads();  // thresholds / counters initialised
 
@@ -193,33 +220,86 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel(const MfmaDevicePar
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    stage(0, row0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < n_ksteps; ++kt) {
-      if (kt + 1 < n_ksteps) stage(cur ^ 1, row0, kt + 1);
-      const unsigned char* abase = smem + cur * STAGE_BYTES;
-      const unsigned char* bbase = abase + A_BYTES;
+    if constexpr (VARIANT == 1) {
+      set_tile_offsets(row0);
+      stage(0, row0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int cur = 0;
+      for (int kt = 0; kt < n_ksteps; ++kt) {
+        if (kt + 1 < n_ksteps) stage(cur ^ 1, row0, kt + 1);
+        const unsigned char* sbase = smem + cur * STAGE_BYTES;
 #pragma unroll
-      for (int k16 = 0; k16 < 4; ++k16) {
-        const int slot = k16 * 2 + frag_khalf;
-        f16x8 af[4], bf[2];
+        for (int k16 = 0; k16 < 4; ++k16) {
+          const uint32_t kx = (uint32_t)(k16 << 5) ^ frag_x;
+          f16x8 af[4], bf[2];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          af[mi] = *reinterpret_cast<const f16x8*>(abase + a_off[mi] + ((slot ^ a_sw[mi]) << 4));
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          bf[ni] = *reinterpret_cast<const f16x8*>(bbase + b_off[ni] + ((slot ^ b_sw[ni]) << 4));
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+          for (int mi = 0; mi < 4; ++mi)
+            af[mi] = *reinterpret_cast<const f16x8*>(sbase + (a_lane + kx) + mi * 4096);
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            bf[ni] = *reinterpret_cast<const f16x8*>(sbase + (b_lane + kx) + ni * 4096);
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+      }
+    } else {
+      // slab 0 of this tile: issued here for the first tile, under the previous epilogue otherwise
+      if (row0 == r_begin) {
+        set_tile_offsets(row0);
+        stage(0, row0, 0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      cur ^= 1;
+      const int group = wm;  // wave-uniform
+      if (group == 1) TAVB_BARRIER();  // group 1 runs one barrier interval behind group 0
+      for (int kt = 0; kt < n_ksteps; ++kt) {
+        const unsigned char* sbase = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          // ---- LOAD phase: fragments of two k16 sub-steps, next slab's LDS-DMA
+          f16x8 af[2][4], bf[2][2];
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const uint32_t kx = (uint32_t)((half * 2 + kk) << 5) ^ frag_x;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+              af[kk][mi] = *reinterpret_cast<const f16x8*>(sbase + (a_lane + kx) + mi * 4096);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              bf[kk][ni] = *reinterpret_cast<const f16x8*>(sbase + (b_lane + kx) + ni * 4096);
+          }
+          if (half == 0 && kt + 1 < n_ksteps) stage((kt + 1) & 1, row0, kt + 1);
+          // the slab issued during this K step must have landed before the barrier that precedes group
+          // 0's first read of it (group 1 waits here, group 0 after its MFMAs below)
+          if (half == 1 && group == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the buffer can be restaged
+          TAVB_BARRIER();
+          // ---- MFMA phase
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          if (half == 1 && group == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          TAVB_BARRIER();
+        }
+      }
+      if (group == 0) TAVB_BARRIER();  // re-align the groups
+      if (row0 + BM < r_end) {  // next tile's first slab flies under the epilogue
+        set_tile_offsets(row0 + BM);
+        stage(0, row0 + BM, 0);
+      }
     }
 
     // ---- epilogue: score, admission test, append ------------------------------------
@@ -330,15 +410,21 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.cand = p.workspace;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_scan_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_scan_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_scan_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   // grid: groups of 8 consecutive block ids = 8 different row ranges (one per XCD)
   const int groups = (p.n_splits + 7) / 8;
   const int grid = groups * d.n_qtiles * 8;
-  hipLaunchKernelGGL(mfma_scan_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, stream, d);
+  if (p.variant == 1)
+    hipLaunchKernelGGL(mfma_scan_kernel<1>, dim3(grid), dim3(NTHREADS), LDS_BYTES, stream, d);
+  else
+    hipLaunchKernelGGL(mfma_scan_kernel<2>, dim3(grid), dim3(NTHREADS), LDS_BYTES, stream, d);
   return hipGetLastError();
 }
 
