@@ -432,7 +432,8 @@ def _f16(a):
     (33_000, 1024, 32, 0.0, 0),
     (9_000, 50, 5, 0.9, 8),
 ])
-def test_mfma_batch_against_oracle(n, nq, k, ms, splits):
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_mfma_batch_against_oracle(n, nq, k, ms, splits, variant):
     v, _ = make_corpus(n, 1536, 7000 + n % 97)
     qs = make_queries(nq, 1536, 7100 + nq)
     qs[0] = v[n // 2]  # plant an exact match
@@ -440,6 +441,7 @@ def test_mfma_batch_against_oracle(n, nq, k, ms, splits):
     eng = vb.engine
     eng.set_option("mfma_min_batch", 32)
     eng.set_option("mfma_splits", splits)
+    eng.set_option("mfma_variant", variant)
     eng.profile_enable(True)
     eng.profile_reset()
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)

@@ -102,6 +102,9 @@ struct tavb_ctx {
   int64_t mfma_min_batch = 32;
   int64_t mfma_splits = 0;  // 0 = auto
   int64_t mfma_variant = 2;
+  int64_t mfma_ablate = 0;
+  int64_t mfma_prio = 1;
+  int64_t mfma_group = 0;
 
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand;
   Buffer h_stage{nullptr, 0, true};
@@ -365,8 +368,17 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch must be >= 1");
     c->mfma_min_batch = v;
   } else if (n == "mfma_variant") {
-    if (v != 1 && v != 2) return fail(TAVB_E_INVALID, "mfma_variant must be 1 or 2");
+    if (v < 1 || v > 3) return fail(TAVB_E_INVALID, "mfma_variant must be 1, 2 or 3");
     c->mfma_variant = v;
+  } else if (n == "mfma_group") {
+    if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_group must be 0..2");
+    c->mfma_group = v;
+  } else if (n == "mfma_prio") {
+    if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_prio must be 0..2");
+    c->mfma_prio = v;
+  } else if (n == "mfma_ablate") {
+    if (v < 0 || v > 3) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..3");
+    c->mfma_ablate = v;
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");
     c->mfma_splits = v;
@@ -656,6 +668,9 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     p.min_score = min_scores[0];
     p.n_splits = splits;
     p.variant = (int)c->mfma_variant;
+    p.ablate = (int)c->mfma_ablate;
+    p.prio = (int)c->mfma_prio;
+    p.group_sel = (int)c->mfma_group;
     {
       Timed t(c, TAVB_KERNEL_MFMA);
       hipError_t e = tavb::launch_mfma_scan(p, c->stream);

@@ -58,6 +58,9 @@ struct MfmaParams {
   float min_score;
   int32_t n_splits;  // row ranges the corpus is cut into (one list per (query, split))
   int32_t variant;   // 1 = lock-step K loop, 2 = ping-pong wave groups
+  int32_t group_sel; // ping-pong grouping: 0 = wave>>2, 1 = wave&1, 2 = (wave>>1)&1
+  int32_t prio;      // s_setprio placement: 0 none, 1 MFMA phase, 2 LOAD phase
+  int32_t ablate;    // measurement only: bit 0 = drop MFMAs, bit 1 = drop LDS-DMA (garbage results)
 };
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
 int mfma_query_tile();                    // queries per workgroup tile

@@ -73,6 +73,7 @@ struct MfmaDeviceParams {
   int32_t k;
   uint32_t index_base;
   float min_score;
+  int32_t group_sel;
 };
 
 // Pin a wave-uniform pointer into SGPRs.  Without this the compiler strength-reduces the eight
@@ -129,7 +130,10 @@ __device__ __forceinline__ WaveTopK<1> best_of_buffer(const u64* buf, int n, int
     TAVB_SB();                    \
   } while (0)
 
-template <int VARIANT>
+// ABLATE (measurement only, results are garbage): 1 = no MFMAs, 2 = no LDS-DMA after the first slab,
+// 3 = neither (barriers + fragment reads only).
+// PRIO: 0 = no s_setprio, 1 = MFMA phase at priority 1, 2 = LOAD phase at priority 1.
+template <int VARIANT, int ABLATE, int PRIO>
 __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel(const MfmaDeviceParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   float* thr_lds = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);      // [BN] admission threshold (exclusive)
@@ -257,13 +261,15 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel(const MfmaDevicePar
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      const int group = wm;  // wave-uniform
+      // which waves form a ping-pong group: the two groups must hold one wave per SIMD each
+      const int group = (p.group_sel == 0) ? (wave >> 2) : (p.group_sel == 1) ? (wave & 1) : ((wave >> 1) & 1);  // wave-uniform
       if (group == 1) TAVB_BARRIER();  // group 1 runs one barrier interval behind group 0
       for (int kt = 0; kt < n_ksteps; ++kt) {
         const unsigned char* sbase = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           // ---- LOAD phase: fragments of two k16 sub-steps, next slab's LDS-DMA
+          if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
           f16x8 af[2][4], bf[2][2];
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
@@ -275,28 +281,33 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel(const MfmaDevicePar
             for (int ni = 0; ni < 2; ++ni)
               bf[kk][ni] = *reinterpret_cast<const f16x8*>(sbase + (b_lane + kx) + ni * 4096);
           }
-          if (half == 0 && kt + 1 < n_ksteps) stage((kt + 1) & 1, row0, kt + 1);
+          if ((ABLATE & 2) == 0 && half == 0 && kt + 1 < n_ksteps) stage((kt + 1) & 1, row0, kt + 1);
           // the slab issued during this K step must have landed before the barrier that precedes group
           // 0's first read of it (group 1 waits here, group 0 after its MFMAs below)
           if (half == 1 && group == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the buffer can be restaged
+          if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
           TAVB_BARRIER();
           // ---- MFMA phase
-          __builtin_amdgcn_s_setprio(1);
+          if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-              for (int ni = 0; ni < 2; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
-          __builtin_amdgcn_s_setprio(0);
+              for (int ni = 0; ni < 2; ++ni) {
+                if constexpr ((ABLATE & 1) == 0)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
+                else
+                  asm volatile("" ::"v"(af[kk][mi]), "v"(bf[kk][ni]));
+              }
+          if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
           if (half == 1 && group == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           TAVB_BARRIER();
         }
       }
       if (group == 0) TAVB_BARRIER();  // re-align the groups
-      if (row0 + BM < r_end) {  // next tile's first slab flies under the epilogue
+      if ((ABLATE & 2) == 0 && row0 + BM < r_end) {  // next tile's first slab flies under the epilogue
         set_tile_offsets(row0 + BM);
         stage(0, row0 + BM, 0);
       }
@@ -371,6 +382,262 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel(const MfmaDevicePar
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// VARIANT 3: same tile shape and ping-pong wave groups as variant 2, but the operand stream is
+// decoupled from the tile loop:
+//   * K advances in steps of 32 halves (64 bytes per row, 16 KiB per operand per step);
+//   * the corpus operand (A) and the query operand (B) have separate LDS rings -- NA slots for A
+//     (long latency: HBM / Infinity Cache), NB slots for B (short latency: the query tile stays in
+//     L2) -- and separate stagers: the four waves of group 0 issue A's LDS-DMA, the four waves of
+//     group 1 issue B's, so each wave's vmcnt queue holds one operand's loads only and a counted
+//     `s_waitcnt vmcnt(4 * (depth - 1))` retires exactly the step that is needed next while
+//     depth - 1 steps stay in flight;
+//   * the step stream runs straight across tile boundaries (the loads for the next tile's first
+//     steps are already in flight while the current tile's epilogue runs);
+//   * 16-byte slots of the 64-byte LDS rows are XOR-swizzled with (row >> 2) & 3.
+// Everything else (admission / append / compaction, result lists) is as in variants 1 and 2.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NA, int NB>
+__global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDeviceParams p) {
+  constexpr int KS = 32;                 // halves per step
+  constexpr int SLOT = 256 * KS * 2;     // 16 KiB: one operand, one step
+  constexpr int DA = NA - 1, DB = NB - 1;  // steps in flight
+  constexpr int B_RING = NA * SLOT;
+  constexpr int CTRL = (NA + NB) * SLOT;
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* thr_lds = reinterpret_cast<float*>(smem + CTRL);
+  int* cnt_lds = reinterpret_cast<int*>(smem + CTRL + BN * 4);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2;
+  const int wn = wave & 3;
+  const int group = wm;  // group 0 = waves 0-3 (tile rows 0-127, stages A); group 1 = waves 4-7 (stages B)
+  const int lw = wave & 3;
+
+  const int b = blockIdx.x;
+  const int xcd = b & 7;
+  const int t = b >> 3;
+  const int qtile = t % p.n_qtiles;
+  const int split = (t / p.n_qtiles) * 8 + xcd;
+  if (split >= p.n_splits) return;
+  const int64_t r_begin = (int64_t)split * p.rows_per_split;
+  const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
+  const int logical_block = split * p.n_qtiles + qtile;
+  u64* my_cand = p.cand + (size_t)logical_block * BN * CAP;
+
+  const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
+  for (int i = tid; i < BN; i += NTHREADS) {
+    thr_lds[i] = (p.min_score != p.min_score) ? __builtin_inff() : thr0;
+    cnt_lds[i] = 0;
+  }
+
+  const int D = p.dim;
+  const int steps_per_tile = D / KS;
+  const size_t row_bytes = (size_t)D * 2;
+  const char* corpus = reinterpret_cast<const char*>(p.corpus);
+  const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * BN * row_bytes;
+  const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BM - 1) / BM) : 0;
+  if (n_tiles == 0) {
+    // empty row range: emit empty lists
+    for (int q = wave; q < BN; q += NTHREADS / 64) {
+      const int qg = qtile * BN + q;
+      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.n_splits + split) * (size_t)p.k + lane] = 0ull;
+    }
+    return;
+  }
+
+  // ---- stager state: instruction j of this wave covers operand rows (lw*4 + j)*16 .. +15, four
+  //      lanes (16-byte slots) per 64-byte row
+  const int st_row_in_inst = lane >> 2;
+  const int st_slot = lane & 3;
+  uint32_t st_off[4];
+  auto set_offsets = [&](int64_t row0, bool clamp) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (lw * 4 + j) * 16 + st_row_in_inst;
+      int64_t r = row;
+      if (clamp && row0 + r >= p.rows) r = p.rows - 1 - row0;  // stay in bounds; masked in the epilogue
+      st_off[j] = (uint32_t)r * (uint32_t)row_bytes + (uint32_t)((st_slot ^ ((row >> 2) & 3)) * 16);
+    }
+  };
+  int st_tile = 0;   // tile of the next step this wave stages (group 0 only; group 1's operand has no tiles)
+  int st_kt = 0;     // K step within the tile
+  int st_slot_idx = 0;  // ring slot it goes to
+  set_offsets(r_begin, group == 0);
+
+  auto stage_next = [&]() {
+    if (group == 0) {
+      const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
+      const char* g = sgpr_ptr(corpus + (size_t)(r_begin + (int64_t)tile * BM) * row_bytes + (size_t)st_kt * (KS * 2));
+      unsigned char* l = smem + st_slot_idx * SLOT + lw * 4096;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((global_void*)(g + (size_t)st_off[j]), (lds_void*)(l + j * 1024), 16, 0, 0);
+      if (++st_slot_idx == NA) st_slot_idx = 0;
+      if (++st_kt == steps_per_tile) {
+        st_kt = 0;
+        ++st_tile;
+        if (st_tile < n_tiles) set_offsets(r_begin + (int64_t)st_tile * BM, true);
+      }
+    } else {
+      const char* g = sgpr_ptr(qbase + (size_t)st_kt * (KS * 2));
+      unsigned char* l = smem + B_RING + st_slot_idx * SLOT + lw * 4096;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((global_void*)(g + (size_t)st_off[j]), (lds_void*)(l + j * 1024), 16, 0, 0);
+      if (++st_slot_idx == NB) st_slot_idx = 0;
+      if (++st_kt == steps_per_tile) st_kt = 0;
+    }
+  };
+
+  // ---- fragment read addresses: row (lane & 31) of a 32-row block, logical slot 2*k16 + (lane >> 5),
+  //      physical slot = logical ^ ((row >> 2) & 3)  ->  byte (k16 << 5) ^ frag_x within the 64-byte row
+  const int frag_row = lane & 31;
+  const uint32_t frag_x = (uint32_t)(((lane >> 5) ^ ((frag_row >> 2) & 3)) << 4);
+  const uint32_t a_lane = (uint32_t)((wm * 128 + frag_row) * 64);           // + mi * 2048
+  const uint32_t b_lane = (uint32_t)(B_RING + (wn * 64 + frag_row) * 64);   // + ni * 2048
+
+  // ---- prologue: fill the pipelines, wait for step 0
+  if (group == 0) {
+#pragma unroll 1
+    for (int i = 0; i < DA; ++i) stage_next();
+    wait_vmcnt<4 * (DA - 1)>();
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < DB; ++i) stage_next();
+    wait_vmcnt<4 * (DB - 1)>();
+  }
+  __syncthreads();  // ring step 0 landed, thresholds initialised (no LDS-DMA is drained: the waits above are counted)
+  if (group == 1) TAVB_BARRIER();  // group 1 runs one barrier interval behind group 0
+
+  int rd_a = 0, rd_b = 0;  // ring slots of the step being consumed
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const int64_t row0 = r_begin + (int64_t)tile * BM;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+#pragma unroll 1
+    for (int kt = 0; kt < steps_per_tile; ++kt) {
+      // ---- LOAD phase
+      const unsigned char* abase = smem + rd_a * SLOT;
+      const unsigned char* bbase = smem + rd_b * SLOT;
+      f16x8 af[2][4], bf[2][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint32_t kx = (uint32_t)(kk << 5) ^ frag_x;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[kk][mi] = *reinterpret_cast<const f16x8*>(abase + (a_lane + kx) + mi * 2048);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bf[kk][ni] = *reinterpret_cast<const f16x8*>(bbase + (b_lane + kx) + ni * 2048);
+      }
+      stage_next();  // the slot being refilled was last read one step ago (two barriers back)
+      if (group == 1) wait_vmcnt<4 * (DB - 1)>();  // B of the next step has landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TAVB_BARRIER();
+      // ---- MFMA phase
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (group == 0) wait_vmcnt<4 * (DA - 1)>();  // A of the next step has landed
+      TAVB_BARRIER();
+      if (++rd_a == NA) rd_a = 0;
+      if (++rd_b == NB) rd_b = 0;
+    }
+    if (group == 0) TAVB_BARRIER();  // re-align the groups for the epilogue
+
+    // ---- epilogue: score, admission test, append
+    bool stored = false;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int ql = wn * 64 + ni * 32 + (lane & 31);
+      const float thr = thr_lds[ql];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        bool any = false;
+        float sc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
+          any = any || (sc[r] > thr);
+        }
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+          if (any) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (sc[r] > thr) {
+                const int64_t row = row0 + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float s = sc[r];
+                s = (s > 0.0f) ? s : 0.0f;
+                s = (s > 1.0f) ? 1.0f : s;
+                if (row < r_end && s >= p.min_score) {
+                  const int pos = atomicAdd(&cnt_lds[ql], 1);
+                  if (pos < CAP) my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)row + p.index_base);
+                  stored = true;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    // appended keys must be in memory before another wave compacts the buffer; only a wave that
+    // stored pays the drain of its (otherwise still flying) LDS-DMA queue
+    if (__builtin_amdgcn_ballot_w64(stored) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TAVB_BARRIER();
+    for (int q = wave; q < BN; q += NTHREADS / 64) {
+      const int n = cnt_lds[q];
+      if (n > CAP - BM) {
+        u64* buf = my_cand + (size_t)q * CAP;
+        const WaveTopK<1> best = best_of_buffer(buf, n < CAP ? n : CAP, lane);
+        if (lane < p.k) buf[lane] = best.key[0];
+        const int kept = __popcll(__ballot(best.key[0] != 0ull && lane < p.k));
+        const u64 kth = best.at(p.k - 1);
+        if (lane == 0) {
+          cnt_lds[q] = kept;
+          const float kth_score = __uint_as_float((uint32_t)(kth >> 32));
+          if (kth != 0ull && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TAVB_BARRIER();
+    if (group == 1) TAVB_BARRIER();  // stagger again
+  }
+  if (group == 0) TAVB_BARRIER();  // pairs with group 1's last stagger barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead loads before the block retires
+  __syncthreads();
+
+  for (int q = wave; q < BN; q += NTHREADS / 64) {
+    const int qg = qtile * BN + q;
+    if (qg >= p.nq) continue;
+    const int n = cnt_lds[q];
+    const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane);
+    u64* out = p.lists + ((size_t)qg * p.n_splits + split) * (size_t)p.k;
+    if (lane < p.k) out[lane] = best.key[0];
+  }
+}
+
 }  // namespace
 
 int mfma_query_tile() { return BN; }
@@ -404,28 +671,42 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.k = p.k;
   d.index_base = p.index_base;
   d.min_score = p.min_score;
+  d.group_sel = p.group_sel;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
   d.rows_per_split = ((per + BM - 1) / BM) * BM;
   if (!p.workspace) return hipErrorInvalidValue;
   d.cand = p.workspace;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_scan_kernel<1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_scan_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  // grid: groups of 8 consecutive block ids = 8 different row ranges (one per XCD)
   const int groups = (p.n_splits + 7) / 8;
   const int grid = groups * d.n_qtiles * 8;
-  if (p.variant == 1)
-    hipLaunchKernelGGL(mfma_scan_kernel<1>, dim3(grid), dim3(NTHREADS), LDS_BYTES, stream, d);
-  else
-    hipLaunchKernelGGL(mfma_scan_kernel<2>, dim3(grid), dim3(NTHREADS), LDS_BYTES, stream, d);
-  return hipGetLastError();
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS_BYTES, stream, d);
+    return hipGetLastError();
+  };
+  // grid: groups of 8 consecutive block ids = 8 different row ranges (one per XCD)
+  if (p.variant == 3) {
+    constexpr int NA3 = 6, NB3 = 3;
+    constexpr int LDS3 = (NA3 + NB3) * 16384 + BN * 8;
+    auto kern = mfma_scan_kernel_v3<NA3, NB3>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS3, stream, d);
+    return hipGetLastError();
+  }
+  if (p.variant == 1) return go(mfma_scan_kernel<1, 0, 0>);
+  const int sel = p.ablate * 4 + p.prio;
+  switch (sel) {
+    case 0 * 4 + 0: return go(mfma_scan_kernel<2, 0, 0>);
+    case 0 * 4 + 1: return go(mfma_scan_kernel<2, 0, 1>);
+    case 0 * 4 + 2: return go(mfma_scan_kernel<2, 0, 2>);
+    case 1 * 4 + 0: return go(mfma_scan_kernel<2, 1, 0>);
+    case 2 * 4 + 0: return go(mfma_scan_kernel<2, 2, 0>);
+    case 2 * 4 + 1: return go(mfma_scan_kernel<2, 2, 1>);
+    case 2 * 4 + 2: return go(mfma_scan_kernel<2, 2, 2>);
+    case 3 * 4 + 0: return go(mfma_scan_kernel<2, 3, 0>);
+    default: return go(mfma_scan_kernel<2, 0, 0>);
+  }
 }
 
 }  // namespace tavb
