@@ -4,10 +4,9 @@ export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
 echo "== $(date -u +%FT%TZ)" | tee $OUT/round.log
-for CFG in "2 0" "2 1" "2 2" "0 0" "0 1" "0 2"; do
-  set -- $CFG
-  timeout 900 python bench.py --workload cfg3 --rows 4000000 --steps 4 --warmup 1 --no-cpu-baseline --opt mfma_variant=2 --opt mfma_ablate=$1 --opt mfma_group=$2 > $OUT/ab_$1_$2.json 2> $OUT/ab_$1_$2.err
+for A in 0 1 2 3 4 5; do
+  timeout 900 python bench.py --workload cfg3 --rows 4000000 --steps 4 --warmup 1 --no-cpu-baseline --opt mfma_variant=3 --opt mfma_ablate=$A > $OUT/ab3_$A.json 2> $OUT/ab3_$A.err
   python -c "
-import json;d=json.load(open('$OUT/ab_$1_$2.json'));print('ablate $1 group $2 kernel_ms', round(d['roofline']['kernel_avg_ms'],3), 'TF-eq', round(d['roofline']['achieved'],1))" | tee -a $OUT/round.log
+import json;d=json.load(open('$OUT/ab3_$A.json'));print('v3 ablate $A kernel_ms', round(d['roofline']['kernel_avg_ms'],3), 'TF-eq', round(d['roofline']['achieved'],1))" | tee -a $OUT/round.log
 done
 echo "== done" | tee -a $OUT/round.log

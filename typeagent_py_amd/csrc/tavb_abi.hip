@@ -368,7 +368,7 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch must be >= 1");
     c->mfma_min_batch = v;
   } else if (n == "mfma_variant") {
-    if (v < 1 || v > 3) return fail(TAVB_E_INVALID, "mfma_variant must be 1, 2 or 3");
+    if (v < 1 || v > 4) return fail(TAVB_E_INVALID, "mfma_variant must be 1..4");
     c->mfma_variant = v;
   } else if (n == "mfma_group") {
     if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_group must be 0..2");
@@ -377,7 +377,7 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_prio must be 0..2");
     c->mfma_prio = v;
   } else if (n == "mfma_ablate") {
-    if (v < 0 || v > 3) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..3");
+    if (v < 0 || v > 7) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..7");
     c->mfma_ablate = v;
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");

@@ -403,7 +403,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int NA, int NB>
+template <int NA, int NB, int ABL>
 __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDeviceParams p) {
   constexpr int KS = 32;                 // halves per step
   constexpr int SLOT = 256 * KS * 2;     // 16 KiB: one operand, one step
@@ -476,7 +476,8 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
   auto stage_next = [&]() {
     if (group == 0) {
       const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
-      const char* g = sgpr_ptr(corpus + (size_t)(r_begin + (int64_t)tile * BM) * row_bytes + (size_t)st_kt * (KS * 2));
+      const int64_t src_row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM;  // ablation: every block re-reads tile 0 (L2 resident)
+      const char* g = sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * (KS * 2));
       unsigned char* l = smem + st_slot_idx * SLOT + lw * 4096;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -543,8 +544,10 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) bf[kk][ni] = *reinterpret_cast<const f16x8*>(bbase + (b_lane + kx) + ni * 2048);
       }
-      stage_next();  // the slot being refilled was last read one step ago (two barriers back)
-      if (group == 1) wait_vmcnt<4 * (DB - 1)>();  // B of the next step has landed
+      if constexpr ((ABL & 2) == 0) {
+        stage_next();  // the slot being refilled was last read one step ago (two barriers back)
+        if (group == 1) wait_vmcnt<4 * (DB - 1)>();  // B of the next step has landed
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       TAVB_BARRIER();
       // ---- MFMA phase
@@ -554,10 +557,16 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < 2; ++ni) {
+            if constexpr ((ABL & 1) == 0)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
+            else
+              asm volatile("" ::"v"(af[kk][mi]), "v"(bf[kk][ni]));
+          }
       __builtin_amdgcn_s_setprio(0);
-      if (group == 0) wait_vmcnt<4 * (DA - 1)>();  // A of the next step has landed
+      if constexpr ((ABL & 2) == 0) {
+        if (group == 0) wait_vmcnt<4 * (DA - 1)>();  // A of the next step has landed
+      }
       TAVB_BARRIER();
       if (++rd_a == NA) rd_a = 0;
       if (++rd_b == NB) rd_b = 0;
@@ -577,7 +586,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
-          any = any || (sc[r] > thr);
+          any = any || (ABL == 0 && sc[r] > thr);
         }
         if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
           if (any) {
@@ -638,6 +647,266 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// VARIANT 4: no ping-pong.  Every wave software-pipelines itself: while its 16 MFMAs of step S
+// issue (one every 32 cycles), the 12 fragment reads of step S+1 (second register set) and its 4
+// LDS-DMA instructions for step S+N are slotted into the gaps between them
+// (sched_group_barrier: 1 MFMA : 1 DS read / 1 VMEM).  One barrier per K step.  Rings, swizzle,
+// decoupled stagers (waves 0-3 stage A, waves 4-7 stage B) and counted vmcnt waits as in variant 3.
+//   step S:  [stager: vmcnt(4*(N-2)) -> step S+1 landed]  lgkmcnt(0)  s_barrier
+//            { MFMAs(S) on frag set S&1 | ds_reads of ring slot S+1 into frag set (S+1)&1 |
+//              LDS-DMA of step S+N into ring slot S (everyone finished reading it before the barrier) }
+// ---------------------------------------------------------------------------------------------
+template <int NA, int NB, int ABL>
+__global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDeviceParams p) {
+  constexpr int KS = 32;
+  constexpr int SLOT = 256 * KS * 2;
+  constexpr int B_RING = NA * SLOT;
+  constexpr int CTRL = (NA + NB) * SLOT;
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* thr_lds = reinterpret_cast<float*>(smem + CTRL);
+  int* cnt_lds = reinterpret_cast<int*>(smem + CTRL + BN * 4);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2;
+  const int wn = wave & 3;
+  const bool is_a = wave < 4;  // waves 0-3 stage the corpus operand, waves 4-7 the query operand
+  const int lw = wave & 3;
+
+  const int b = blockIdx.x;
+  const int xcd = b & 7;
+  const int t = b >> 3;
+  const int qtile = t % p.n_qtiles;
+  const int split = (t / p.n_qtiles) * 8 + xcd;
+  if (split >= p.n_splits) return;
+  const int64_t r_begin = (int64_t)split * p.rows_per_split;
+  const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
+  const int logical_block = split * p.n_qtiles + qtile;
+  u64* my_cand = p.cand + (size_t)logical_block * BN * CAP;
+
+  const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
+  for (int i = tid; i < BN; i += NTHREADS) {
+    thr_lds[i] = (p.min_score != p.min_score) ? __builtin_inff() : thr0;
+    cnt_lds[i] = 0;
+  }
+
+  const int D = p.dim;
+  const int steps_per_tile = D / KS;  // even: D is a multiple of 64
+  const uint32_t row_bytes = (uint32_t)D * 2u;
+  const char* corpus = reinterpret_cast<const char*>(p.corpus);
+  const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * BN * row_bytes;
+  const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BM - 1) / BM) : 0;
+  if (n_tiles == 0) {
+    for (int q = wave; q < BN; q += NTHREADS / 64) {
+      const int qg = qtile * BN + q;
+      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.n_splits + split) * (size_t)p.k + lane] = 0ull;
+    }
+    return;
+  }
+
+  // ---- stager: instruction j covers operand rows (lw*4 + j)*16 .. +15, four 16-byte slots per row.
+  //      Branch-free: everything that differs between the A and B stagers is a scalar select.
+  uint32_t st_rowoff[4], st_slotoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (lw * 4 + j) * 16 + (lane >> 2);
+    st_rowoff[j] = (uint32_t)row * row_bytes;
+    st_slotoff[j] = (uint32_t)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
+  }
+  const int ring_n = is_a ? NA : NB;
+  const uint32_t ring_base = (is_a ? 0u : (uint32_t)B_RING) + (uint32_t)lw * 4096u;
+  // running, wave-uniform source pointer of the next step to stage: +64 bytes per K step; at the end of
+  // a tile's K range the A stager jumps to the next tile (or, past the last tile, back to the start of
+  // the last one: harmless reloads that keep the vmcnt bookkeeping uniform), the B stager back to k = 0.
+  const int64_t k_rewind = -(int64_t)(steps_per_tile - 1) * (KS * 2);
+  const int64_t tile_jump = is_a ? k_rewind + (int64_t)BM * row_bytes : k_rewind;
+  const char* st_ptr = is_a ? corpus + (size_t)((ABL & 4) ? 0 : r_begin) * row_bytes : qbase;
+  int64_t st_last_row = is_a ? (p.rows - 1 - r_begin) : 255;  // last valid row of the staged tile, relative to its row 0
+  int st_tiles_left = is_a ? n_tiles - 1 : 0;
+  int st_kt = 0, st_slot = 0;
+
+  auto stage_next = [&]() {
+    const char* g = sgpr_ptr(st_ptr);
+    // rows past the end of the corpus are clamped to its last row (they are masked in the epilogue)
+    const uint32_t max_rowoff = (uint32_t)(st_last_row < 255 ? st_last_row : 255) * row_bytes;
+    unsigned char* l = smem + ring_base + (uint32_t)st_slot * SLOT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t off = (st_rowoff[j] < max_rowoff ? st_rowoff[j] : max_rowoff) + st_slotoff[j];
+      __builtin_amdgcn_global_load_lds((global_void*)(g + (size_t)off), (lds_void*)(l + j * 1024), 16, 0, 0);
+    }
+    st_slot = (st_slot + 1 == ring_n) ? 0 : st_slot + 1;
+    const bool wrap = (st_kt + 1 == steps_per_tile);
+    const bool advance = wrap && st_tiles_left > 0 && (ABL & 4) == 0;
+    st_kt = wrap ? 0 : st_kt + 1;
+    st_ptr += wrap ? (advance ? tile_jump : k_rewind) : (int64_t)(KS * 2);
+    st_last_row -= advance ? BM : 0;
+    st_tiles_left -= advance ? 1 : 0;
+  };
+
+  const int frag_row = lane & 31;
+  const uint32_t frag_x = (uint32_t)(((lane >> 5) ^ ((frag_row >> 2) & 3)) << 4);
+  const uint32_t a_lane = (uint32_t)((wm * 128 + frag_row) * 64);
+  const uint32_t b_lane = (uint32_t)(B_RING + (wn * 64 + frag_row) * 64);
+
+  auto read_frags = [&](f16x8(&af)[2][4], f16x8(&bf)[2][2], int slot_a, int slot_b) {
+    const unsigned char* abase = smem + slot_a * SLOT;
+    const unsigned char* bbase = smem + slot_b * SLOT;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint32_t kx = (uint32_t)(kk << 5) ^ frag_x;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) af[kk][mi] = *reinterpret_cast<const f16x8*>(abase + (a_lane + kx) + mi * 2048);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) bf[kk][ni] = *reinterpret_cast<const f16x8*>(bbase + (b_lane + kx) + ni * 2048);
+    }
+  };
+
+  // ---- prologue: fill both rings completely, wait for step 0, read its fragments
+  if (is_a) {
+#pragma unroll 1
+    for (int i = 0; i < NA; ++i) stage_next();
+    wait_vmcnt<4 * (NA - 1)>();
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < NB; ++i) stage_next();
+    wait_vmcnt<4 * (NB - 1)>();
+  }
+  TAVB_BARRIER();
+  f16x8 af0[2][4], bf0[2][2], af1[2][4], bf1[2][2];
+  read_frags(af0, bf0, 0, 0);
+  int rd_a = 1, rd_b = 1;  // ring slots of the step whose fragments are read next
+
+  f32x16 acc[4][2];
+
+  // one K step: MFMAs on (fu_a, fu_b), prefetch the next step's fragments into (fl_a, fl_b)
+  auto step = [&](f16x8(&fu_a)[2][4], f16x8(&fu_b)[2][2], f16x8(&fl_a)[2][4], f16x8(&fl_b)[2][2]) {
+    if (is_a)
+      wait_vmcnt<4 * (NA - 2)>();  // the next step's A slab has landed
+    else
+      wait_vmcnt<4 * (NB - 2)>();  // the next step's B slab has landed
+    // this step's fragments are in registers, so its ring slot is free.  The builtin (not inline asm) so
+    // that the compiler's own wait-count bookkeeping sees it and does not put a second lgkmcnt(0) -- one
+    // that would also drain the reads issued below -- in front of the first MFMA.
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt/expcnt untouched
+    TAVB_BARRIER();
+    read_frags(fl_a, fl_b, rd_a, rd_b);
+    if constexpr ((ABL & 2) == 0) stage_next();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          if constexpr ((ABL & 1) == 0)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fu_a[kk][mi], fu_b[kk][ni], acc[mi][ni], 0, 0, 0);
+          else
+            asm volatile("" ::"v"(fu_a[kk][mi]), "v"(fu_b[kk][ni]));
+        }
+    // interleave: one LDS read after each of the first 12 MFMAs, one LDS-DMA after each of the last 4
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    rd_a = (rd_a + 1 == NA) ? 0 : rd_a + 1;
+    rd_b = (rd_b + 1 == NB) ? 0 : rd_b + 1;
+  };
+
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const int64_t row0 = r_begin + (int64_t)tile * BM;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+#pragma unroll 1
+    for (int kt = 0; kt < steps_per_tile; kt += 2) {
+      step(af0, bf0, af1, bf1);
+      step(af1, bf1, af0, bf0);
+    }
+
+    // ---- epilogue: score, admission test, append
+    bool stored = false;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int ql = wn * 64 + ni * 32 + (lane & 31);
+      const float thr = thr_lds[ql];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        bool any = false;
+        float sc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
+          any = any || (ABL == 0 && sc[r] > thr);
+        }
+        if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi][ni]));
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+          if (any) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (sc[r] > thr) {
+                const int64_t row = row0 + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float s = sc[r];
+                s = (s > 0.0f) ? s : 0.0f;
+                s = (s > 1.0f) ? 1.0f : s;
+                if (row < r_end && s >= p.min_score) {
+                  const int pos = atomicAdd(&cnt_lds[ql], 1);
+                  if (pos < CAP) my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)row + p.index_base);
+                  stored = true;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(stored) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TAVB_BARRIER();
+    for (int q = wave; q < BN; q += NTHREADS / 64) {
+      const int n = cnt_lds[q];
+      if (n > CAP - BM) {
+        u64* buf = my_cand + (size_t)q * CAP;
+        const WaveTopK<1> best = best_of_buffer(buf, n < CAP ? n : CAP, lane);
+        if (lane < p.k) buf[lane] = best.key[0];
+        const int kept = __popcll(__ballot(best.key[0] != 0ull && lane < p.k));
+        const u64 kth = best.at(p.k - 1);
+        if (lane == 0) {
+          cnt_lds[q] = kept;
+          const float kth_score = __uint_as_float((uint32_t)(kth >> 32));
+          if (kth != 0ull && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TAVB_BARRIER();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead LDS-DMA before the block retires
+  __syncthreads();
+
+  for (int q = wave; q < BN; q += NTHREADS / 64) {
+    const int qg = qtile * BN + q;
+    if (qg >= p.nq) continue;
+    const int n = cnt_lds[q];
+    const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane);
+    u64* out = p.lists + ((size_t)qg * p.n_splits + split) * (size_t)p.k;
+    if (lane < p.k) out[lane] = best.key[0];
+  }
+}
+
 }  // namespace
 
 int mfma_query_tile() { return BN; }
@@ -685,14 +954,40 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
     return hipGetLastError();
   };
   // grid: groups of 8 consecutive block ids = 8 different row ranges (one per XCD)
+  if (p.variant == 4) {
+    constexpr int NA4 = 6, NB4 = 3;
+    constexpr int LDS4 = (NA4 + NB4) * 16384 + BN * 8;
+    auto go4 = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS4, stream, d);
+      return hipGetLastError();
+    };
+    switch (p.ablate) {
+      case 1: return go4(mfma_scan_kernel_v4<NA4, NB4, 1>);
+      case 2: return go4(mfma_scan_kernel_v4<NA4, NB4, 2>);
+      case 3: return go4(mfma_scan_kernel_v4<NA4, NB4, 3>);
+      case 4: return go4(mfma_scan_kernel_v4<NA4, NB4, 4>);
+      default: return go4(mfma_scan_kernel_v4<NA4, NB4, 0>);
+    }
+  }
   if (p.variant == 3) {
     constexpr int NA3 = 6, NB3 = 3;
     constexpr int LDS3 = (NA3 + NB3) * 16384 + BN * 8;
-    auto kern = mfma_scan_kernel_v3<NA3, NB3>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS3, stream, d);
-    return hipGetLastError();
+    auto go3 = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS3, stream, d);
+      return hipGetLastError();
+    };
+    switch (p.ablate) {
+      case 1: return go3(mfma_scan_kernel_v3<NA3, NB3, 1>);
+      case 4: return go3(mfma_scan_kernel_v3<NA3, NB3, 4>);
+      case 5: return go3(mfma_scan_kernel_v3<NA3, NB3, 5>);
+      case 2: return go3(mfma_scan_kernel_v3<NA3, NB3, 2>);
+      case 3: return go3(mfma_scan_kernel_v3<NA3, NB3, 3>);
+      default: return go3(mfma_scan_kernel_v3<NA3, NB3, 0>);
+    }
   }
   if (p.variant == 1) return go(mfma_scan_kernel<1, 0, 0>);
   const int sel = p.ablate * 4 + p.prio;
