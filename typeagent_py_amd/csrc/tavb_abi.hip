@@ -101,7 +101,7 @@ struct tavb_ctx {
   tavb::ScanGeometry geom{0, 16, 2, 1, 0, 0};
   int64_t mfma_min_batch = 32;
   int64_t mfma_splits = 0;  // 0 = auto
-  int64_t mfma_variant = 2;
+  int64_t mfma_variant = 3;
   int64_t mfma_ablate = 0;
   int64_t mfma_prio = 1;
   int64_t mfma_group = 0;
@@ -377,7 +377,7 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_prio must be 0..2");
     c->mfma_prio = v;
   } else if (n == "mfma_ablate") {
-    if (v < 0 || v > 7) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..7");
+    if (v < 0 || v > 63) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..63");
     c->mfma_ablate = v;
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");

@@ -783,7 +783,8 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
   f32x16 acc[4][2];
 
   // one K step: MFMAs on (fu_a, fu_b), prefetch the next step's fragments into (fl_a, fl_b)
-  auto step = [&](f16x8(&fu_a)[2][4], f16x8(&fu_b)[2][2], f16x8(&fl_a)[2][4], f16x8(&fl_b)[2][2]) {
+  auto step = [&](f16x8(&fu_a)[2][4], f16x8(&fu_b)[2][2], f16x8(&fl_a)[2][4], f16x8(&fl_b)[2][2], bool sync) {
+    if (sync) {
     if (is_a)
       wait_vmcnt<4 * (NA - 2)>();  // the next step's A slab has landed
     else
@@ -793,7 +794,8 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
     // that would also drain the reads issued below -- in front of the first MFMA.
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt/expcnt untouched
     TAVB_BARRIER();
-    read_frags(fl_a, fl_b, rd_a, rd_b);
+    }
+    if constexpr ((ABL & 32) == 0) read_frags(fl_a, fl_b, rd_a, rd_b);
     if constexpr ((ABL & 2) == 0) stage_next();
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -832,8 +834,8 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
 
 #pragma unroll 1
     for (int kt = 0; kt < steps_per_tile; kt += 2) {
-      step(af0, bf0, af1, bf1);
-      step(af1, bf1, af0, bf0);
+      step(af0, bf0, af1, bf1, (ABL & 16) ? (kt & 3) == 0 : true);
+      step(af1, bf1, af0, bf0, (ABL & 24) ? false : true);
     }
 
     // ---- epilogue: score, admission test, append
@@ -968,6 +970,9 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 2: return go4(mfma_scan_kernel_v4<NA4, NB4, 2>);
       case 3: return go4(mfma_scan_kernel_v4<NA4, NB4, 3>);
       case 4: return go4(mfma_scan_kernel_v4<NA4, NB4, 4>);
+      case 34: return go4(mfma_scan_kernel_v4<NA4, NB4, 34>);  // MFMAs + barriers only
+      case 10: return go4(mfma_scan_kernel_v4<NA4, NB4, 10>);  // no LDS-DMA, barrier every 2nd step
+      case 18: return go4(mfma_scan_kernel_v4<NA4, NB4, 18>);  // no LDS-DMA, barrier every 4th step
       default: return go4(mfma_scan_kernel_v4<NA4, NB4, 0>);
     }
   }
