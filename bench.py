@@ -46,6 +46,9 @@ WORKLOADS = {
     "cfg2_f16": dict(rows=1_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm"),
     "cfg3": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma"),
     "cfg1": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="hbm"),
+    # fused multi-index user query: 4 term lookups k=50@0.85 on a 10M-row terms corpus + 1 message
+    # re-rank k=25@0.7 on a 10M-row message corpus (full scan, or --cfg5-subset 1000) + 1 thread lookup k=10@0.7 on 1k rows
+    "cfg5": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=6, k=50, bound="hbm"),
 }
 
 
@@ -107,6 +110,99 @@ def cpu_baseline(corpus_host: np.ndarray, queries: np.ndarray, k: int, budget_s:
     }
 
 
+def run_cfg5(args, wl) -> None:
+    """BASELINE config 5: user queries/s of the fused multi-index submission (typeagent_py_amd/fused.py)."""
+    import torch
+
+    from typeagent_py_amd import TextEmbeddingIndexSettings, VectorBase, _native
+    from typeagent_py_amd.fused import FusedIndexQuery
+
+    rows, dim = wl["rows"], wl["dim"]
+    steps = args.steps if args.steps is not None else 30
+    warmup = args.warmup if args.warmup is not None else 3
+    fq = FusedIndexQuery(0)
+    eng = fq.engine
+    with torch.cuda.stream(fq.stream):
+        terms = make_device_corpus(eng, rows, dim, 50_043, wl["dtype"])
+        msgs = make_device_corpus(eng, rows, dim, 50_044, wl["dtype"])
+        threads = make_device_corpus(eng, 1000, dim, 50_045, wl["dtype"])
+    fq.set_corpus("terms", terms)
+    fq.set_corpus("messages", msgs)
+    fq.set_corpus("threads", threads)
+    for item in args.opt:
+        name, val = item.split("=")
+        eng.set_option(name, int(val))
+    rng = np.random.default_rng(5)
+    # queries near real rows so that the thresholds keep a few hits (gaussian data is otherwise all below 0.7)
+    def near(t, r, eps):
+        v = t[r].float().cpu().numpy() + eps * rng.standard_normal(dim).astype(np.float32) / np.sqrt(dim)
+        return (v / np.linalg.norm(v)).astype(np.float32)
+    user_queries = []
+    for u in range(8):
+        tq = np.stack([near(terms, int(rng.integers(rows)), 0.3) for _ in range(4)])
+        user_queries.append((tq, near(msgs, int(rng.integers(rows)), 0.6), near(threads, int(rng.integers(1000)), 0.6)))
+    subset = np.random.default_rng(99).choice(rows, size=args.cfg5_subset, replace=False).tolist() if args.cfg5_subset else None
+
+    if args.cfg5_separate:
+        class _Null:
+            model_name = "bench"
+        vbs = []
+        for t in (terms, msgs, threads):
+            vb = VectorBase(TextEmbeddingIndexSettings(_Null()), device=0)
+            vb.adopt_device_corpus(t)
+            vbs.append(vb)
+
+        def one(i):
+            tq, mq, hq = user_queries[i % len(user_queries)]
+            out = [vbs[0].fuzzy_lookup_embedding(q, max_hits=50, min_score=0.85) for q in tq]
+            if subset is None:
+                out.append(vbs[1].fuzzy_lookup_embedding(mq, max_hits=25, min_score=0.7))
+            else:
+                out.append(vbs[1].fuzzy_lookup_embedding_in_subset(mq, subset, max_hits=25, min_score=0.7))
+            out.append(vbs[2].fuzzy_lookup_embedding(hq, max_hits=10, min_score=0.7))
+            return out
+    else:
+        def one(i):
+            tq, mq, hq = user_queries[i % len(user_queries)]
+            return fq.run(tq, mq, hq, message_subset=subset)
+
+    for i in range(warmup):
+        one(i)
+    if not args.cfg5_separate:
+        eng.profile_enable(True)
+        eng.profile_reset()
+    torch.cuda.synchronize()
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        s0 = time.perf_counter_ns()
+        one(warmup + i)
+        lat.append((time.perf_counter_ns() - s0) / 1e3)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    esize = 2 if wl["dtype"] == "fp16" else 4
+    alg = rows * dim * esize + (len(subset) if subset else rows) * dim * esize + 1000 * dim * esize
+    out = {
+        "metric": "user queries/sec + p50 latency, fused multi-index VectorBase lookups (cfg5)",
+        "value": steps / elapsed, "unit": "user-queries/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 storage, f32 accumulate", "data": "synthetic",
+        "config": {"workload": f"cfg5: 4 term lookups k=50@0.85 on {rows}x{dim} + message re-rank k=25@0.7 "
+                               f"({'subset of ' + str(len(subset)) if subset else 'full scan'}) on {rows}x{dim} + thread lookup k=10@0.7 on 1000x{dim}; "
+                               f"{'six separate synchronous calls' if args.cfg5_separate else 'one fused submission'}"},
+        "p50_latency_us": float(np.percentile(lat, 50)), "p99_latency_us": float(np.percentile(lat, 99)),
+        "roofline": {"bound": "hbm", "achieved": alg / (elapsed / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "note": "whole user query (all kernels + copies + one sync) against the bytes the three corpora passes must read"},
+        "cpu_baseline": None,
+    }
+    if not args.cfg5_separate:
+        ms, n = eng.profile_read(_native.KERNEL_SCAN)
+        out["roofline"]["scan_kernel_ms_per_user_query"] = ms / steps
+        out["roofline"]["scan_launches_per_user_query"] = n / steps
+    print(json.dumps(out))
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +212,8 @@ def main() -> None:
     ap.add_argument("--rows", type=int, default=None, help="override rows per GPU (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cfg5-subset", type=int, default=0, help="cfg5: message re-rank over a subset of this many ordinals (0 = full scan)")
+    ap.add_argument("--cfg5-separate", action="store_true", help="cfg5: issue the six lookups as separate synchronous calls")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (e.g. scan_unroll=4)")
     args = ap.parse_args()
 
@@ -126,6 +224,9 @@ def main() -> None:
     wl = dict(WORKLOADS[args.workload])
     if args.rows:
         wl["rows"] = args.rows
+    if args.workload == "cfg5":
+        run_cfg5(args, wl)
+        return
     steps = args.steps if args.steps is not None else (200 if wl["nq"] == 1 else 10)
     warmup = args.warmup if args.warmup is not None else (20 if wl["nq"] == 1 else 2)
 

@@ -139,6 +139,12 @@ typedef uint64_t tavb_key;
 int tavb_search_device(tavb_ctx* ctx, const float* dev_queries, int32_t nq, int32_t k, float min_score,
                        tavb_key* dev_out_keys);
 
+/* Subset form of the above: one query (device, float32 [dim]) against the rows listed in
+ * dev_rows (device int32 [n_subset], already wrapped / range-checked by the caller); keys carry
+ * subset POSITIONS.  Asynchronous.  Used by the fused multi-index submission. */
+int tavb_search_subset_device(tavb_ctx* ctx, const float* dev_query, const int32_t* dev_rows, int64_t n_subset,
+                              int32_t k, float min_score, tavb_key* dev_out_keys);
+
 /* Merge `n_lists` sorted key lists per query (dev_lists [n_lists, nq, k], e.g. the
  * all-gathered per-shard results) into one list per query: dev_out_keys [nq, k]. */
 int tavb_merge_device(tavb_ctx* ctx, const tavb_key* dev_lists, int32_t n_lists, int32_t nq, int32_t k,

@@ -581,6 +581,103 @@ def test_sharded_searcher_on_one_rank_rccl():
         dist.destroy_process_group()
 
 
+def test_fused_multi_index_query_equals_separate_calls():
+    """cfg5: T term lookups (k=50 @0.85) + message re-rank (k=25 @0.7, full scan and subset) + thread lookup
+    (k=10 @0.7) in one submission == the same lookups issued one by one == the oracle."""
+    import torch
+
+    from typeagent_py_amd.fused import FusedIndexQuery
+
+    dim = 1536
+    terms, _ = make_corpus(30_000, dim, 9100)
+    msgs, _ = make_corpus(20_000, dim, 9101)
+    thr, _ = make_corpus(1_000, dim, 9102)
+    rng = np.random.default_rng(9103)
+    # term queries close to existing rows so that min_score 0.85 keeps something
+    tq = np.stack([terms[i] + 0.25 * rng.standard_normal(dim).astype(np.float32) / np.sqrt(dim) for i in (5, 777, 12_345, 29_999)])
+    tq /= np.linalg.norm(tq, axis=1, keepdims=True)
+    mq = msgs[4242] + 0.6 * rng.standard_normal(dim).astype(np.float32) / np.sqrt(dim)
+    mq /= np.linalg.norm(mq)
+    hq = thr[17] + 0.6 * rng.standard_normal(dim).astype(np.float32) / np.sqrt(dim)
+    hq /= np.linalg.norm(hq)
+    subset = subset_choice(20_000, 1000, 99) + [4242]
+
+    fq = FusedIndexQuery(0)
+    fq.set_corpus("terms", torch.from_numpy(terms).cuda())
+    fq.set_corpus("messages", torch.from_numpy(msgs).cuda())
+    fq.set_corpus("threads", torch.from_numpy(thr).cuda())
+    torch.cuda.synchronize()
+    full = fq.run(tq, mq, hq)
+    sub = fq.run(tq, mq, hq, message_subset=subset)
+
+    vt, vm, vh = new_vb(terms), new_vb(msgs), new_vb(thr)
+    for i in range(4):
+        single = vt.fuzzy_lookup_embedding(tq[i], max_hits=50, min_score=0.85)
+        assert [r.item for r in full.terms[i]] == [r.item for r in single] and len(single) >= 1
+        np.testing.assert_allclose([r.score for r in full.terms[i]], [r.score for r in single], atol=2e-7, rtol=0)
+        vo.check_topk_parity(vo.scores_full(terms, tq[i]), *items_scores(full.terms[i]), 50, 0.85)
+        assert [r.item for r in sub.terms[i]] == [r.item for r in single]
+    single = vm.fuzzy_lookup_embedding(mq, max_hits=25, min_score=0.7)
+    assert [r.item for r in full.messages] == [r.item for r in single] and single[0].item == 4242
+    vo.check_topk_parity(vo.scores_full(msgs, mq), *items_scores(full.messages), 25, 0.7)
+    single = vm.fuzzy_lookup_embedding_in_subset(mq, subset, max_hits=25, min_score=0.7)
+    assert [r.item for r in sub.messages] == [r.item for r in single] and 4242 in [r.item for r in sub.messages]
+    single = vh.fuzzy_lookup_embedding(hq, max_hits=10, min_score=0.7)
+    assert [r.item for r in full.threads] == [r.item for r in single] and single[0].item == 17
+    # missing pieces are simply skipped
+    only_terms = fq.run(tq[:2])
+    assert len(only_terms.terms) == 2 and only_terms.messages == [] and only_terms.threads == []
+
+
+@pytest.mark.slow
+def test_cfg3_full_size_batch_against_chunked_oracle():
+    """BASELINE config 3 at full size (10M x 1536 fp16, 1024-query batch, top-32, MFMA kernel): a sample of
+    the queries is checked against the chunked oracle (per-1M-row reference-sized lookups over device chunks
+    copied back and widened to fp32, merged) plus size-independent properties on all 1024 answers."""
+    import torch
+
+    from bench import host_queries, make_device_corpus
+
+    rows, dim, nq, k = 10_000_000, 1536, 1024, 32
+    eng = _native.Engine(0)
+    corpus = make_device_corpus(eng, rows, dim, 10_043, "fp16")
+    eng.set_corpus_tensor(corpus)
+    eng.profile_enable(True)
+    eng.profile_reset()
+    qs = host_queries(nq, dim, 4242)
+    planted = {0: 123_456, 7: 9_999_999, 1000: 5_000_000}  # query index -> row whose (fp16) values become the query
+    for qi, r in planted.items():
+        qs[qi] = corpus[r].float().cpu().numpy()
+    ords, scs, cnts = eng.search_batch(qs, k, np.float32(0.0))
+    assert eng.profile_read(_native.KERNEL_MFMA)[1] >= 1
+    assert np.all(cnts == k)
+    assert np.all(np.diff(scs, axis=1) <= 0)  # sorted best first
+    assert np.all((ords >= 0) & (ords < rows))
+    assert all(len(set(ords[i].tolist())) == k for i in range(nq))  # no duplicates
+    for qi, r in planted.items():
+        assert ords[qi, 0] == r and abs(scs[qi, 0] - 1.0) < 2e-3
+    # the same queries through the streaming kernels (independent code path, fp16-representable queries)
+    sample = [0, 7, 333, 1000, 1023]
+    q16 = qs[sample].astype(np.float16).astype(np.float32)
+    eng.set_option("mfma_min_batch", 1 << 30)
+    o2, s2, c2 = eng.search_batch(q16, k, np.float32(0.0))
+    np.testing.assert_array_equal(o2, ords[sample])
+    np.testing.assert_allclose(s2, scs[sample], atol=3e-7, rtol=0)
+    # chunked oracle on three of them
+    chunk = 1_000_000
+    best = {qi: [] for qi in sample[:3]}
+    for lo in range(0, rows, chunk):
+        host = corpus[lo : lo + chunk].float().cpu().numpy()
+        for j, qi in enumerate(sample[:3]):
+            part = vo.lookup(host, q16[j], k, 0.0)
+            best[qi].extend((lo + i, s) for i, s in part)
+    for j, qi in enumerate(sample[:3]):
+        ref = sorted(best[qi], key=lambda t: (-t[1], t[0]))[:k]
+        assert [i for i, _ in ref] == ords[qi].tolist()
+        np.testing.assert_allclose([s for _, s in ref], scs[qi], atol=SCORE_TOL, rtol=0)
+    eng.close()
+
+
 def test_device_only_corpus_and_lazy_host_copy():
     import torch
 

@@ -49,6 +49,7 @@ _SIGNATURES = [
     ("tavb_search_subset_after", c_int,
      [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_int64, c_void_p, c_void_p, POINTER(c_int32)]),
     ("tavb_search_device", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
+    ("tavb_search_subset_device", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     ("tavb_merge_device", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     ("tavb_decode_keys", c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     ("tavb_profile_enable", c_int, [c_void_p, c_int32]),
@@ -206,7 +207,7 @@ class Engine:
     def torch_dtype(self, dtype: int):
         return self._torch.float16 if dtype == TAVB_F16 else self._torch.float32
 
-    def set_corpus_tensor(self, tensor, rows: int | None = None, ordinal_base: int = 0) -> None:
+    def set_corpus_tensor(self, tensor, rows: int | None = None, ordinal_base: int = 0, sync_torch: bool = True) -> None:
         """Adopt a device tensor [>=rows, dim] (f32 or f16, contiguous) as the corpus."""
         torch = self._torch
         if tensor.dim() != 2 or not tensor.is_contiguous():
@@ -223,7 +224,8 @@ class Engine:
         if n > tensor.shape[0]:
             raise ValueError("rows exceeds the tensor")
         # make sure whatever produced the tensor on torch's stream has finished
-        torch.cuda.current_stream(self.device).synchronize()
+        if sync_torch:
+            torch.cuda.current_stream(self.device).synchronize()
         _check(self.lib, self.lib.tavb_set_corpus(self._h, c_void_p(tensor.data_ptr()), n, tensor.shape[1], dt, int(ordinal_base)))
         self.corpus, self.rows, self.dim, self.dtype, self.ordinal_base = tensor, n, int(tensor.shape[1]), dt, int(ordinal_base)
 
@@ -355,6 +357,20 @@ class Engine:
             out_keys = torch.empty((nq, k), dtype=torch.int64, device=dev_queries.device)
         with self._lock:
             rc = self.lib.tavb_search_device(self._h, c_void_p(dev_queries.data_ptr()), nq, k, c_float(float(thr)), c_void_p(out_keys.data_ptr()))
+        _check(self.lib, rc)
+        return out_keys
+
+    def search_subset_device(self, dev_query, dev_rows, k: int, thr: float, out_keys=None):
+        """dev_query: torch f32 [1, dim] or [dim]; dev_rows: torch int32 [S] (valid corpus rows) ->
+        torch int64 [1, k] packed keys carrying subset positions (async)."""
+        torch = self._torch
+        assert dev_query.dtype == torch.float32 and dev_query.is_contiguous() and dev_query.numel() == self.dim
+        assert dev_rows.dtype == torch.int32 and dev_rows.is_contiguous() and dev_rows.dim() == 1
+        if out_keys is None:
+            out_keys = torch.empty((1, k), dtype=torch.int64, device=dev_query.device)
+        with self._lock:
+            rc = self.lib.tavb_search_subset_device(self._h, c_void_p(dev_query.data_ptr()), c_void_p(dev_rows.data_ptr()),
+                                                    dev_rows.shape[0], k, c_float(float(thr)), c_void_p(out_keys.data_ptr()))
         _check(self.lib, rc)
         return out_keys
 

@@ -553,6 +553,17 @@ int tavb_search_device(tavb_ctx* c, const float* dev_queries, int32_t nq, int32_
                                      reinterpret_cast<u64_t*>(dev_out_keys));
 }
 
+int tavb_search_subset_device(tavb_ctx* c, const float* dev_query, const int32_t* dev_rows, int64_t n_subset, int32_t k,
+                              float min_score, tavb_key* dev_out_keys) {
+  if (int rc = check_search_args(c, k)) return rc;
+  if (!dev_query || !dev_out_keys) return fail(TAVB_E_INVALID, "null argument");
+  if (n_subset < 0 || n_subset >= 0x7FFFFFFFll) return fail(TAVB_E_INVALID, "bad subset length");
+  if (n_subset > 0 && !dev_rows) return fail(TAVB_E_INVALID, "null dev_rows");
+  DeviceGuard guard(c->device);
+  return search_device_impl(c, dev_query, 1, k, &min_score, dev_rows, c->rows == 0 ? 0 : n_subset, 0u,
+                            reinterpret_cast<u64_t*>(dev_out_keys));
+}
+
 int tavb_merge_device(tavb_ctx* c, const tavb_key* dev_lists, int32_t n_lists, int32_t nq, int32_t k,
                       tavb_key* dev_out_keys) {
   if (int rc = check_ctx(c)) return rc;
