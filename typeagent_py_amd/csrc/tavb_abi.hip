@@ -108,6 +108,7 @@ struct tavb_ctx {
 
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand;
   Buffer h_stage{nullptr, 0, true};
+  Buffer h_out{nullptr, 0, true};  // pinned + device-visible: the last kernel of a synchronous lookup writes its keys straight here
 
   bool profiling = false;
   double total_ms[TAVB_KERNEL_COUNT] = {0};
@@ -332,6 +333,7 @@ int tavb_destroy(tavb_ctx* c) {
   c->d_rows.release();
   c->d_cand.release();
   c->h_stage.release();
+  c->h_out.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return TAVB_OK;
@@ -461,18 +463,17 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
   DeviceGuard guard(c->device);
   const size_t qbytes = (size_t)nq * c->dim * sizeof(float);
   const size_t obytes = (size_t)nq * k * sizeof(u64_t);
-  if (int rc = c->h_stage.reserve(std::max(qbytes, obytes))) return rc;
+  if (int rc = c->h_stage.reserve(qbytes)) return rc;
+  if (int rc = c->h_out.reserve(obytes)) return rc;
   if (int rc = c->d_queries.reserve(qbytes)) return rc;
-  if (int rc = c->d_out.reserve(obytes)) return rc;
   memcpy(c->h_stage.ptr, queries_host, qbytes);
   TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
   int rc = tavb_search_device_dispatch(c, reinterpret_cast<const float*>(c->d_queries.ptr), nq, k, min_scores, 0u,
-                                   reinterpret_cast<u64_t*>(c->d_out.ptr));
+                                   reinterpret_cast<u64_t*>(c->h_out.ptr));
   if (rc) return rc;
-  // the staging buffer is reused for the results: the H2D copy above is ordered before this D2H on the stream
-  TAVB_HIP(hipMemcpyAsync(c->h_stage.ptr, c->d_out.ptr, obytes, hipMemcpyDeviceToHost, c->stream));
+  // no D2H copy: the merge kernel wrote the keys into pinned host memory
   TAVB_HIP(hipStreamSynchronize(c->stream));
-  decode(reinterpret_cast<const u64_t*>(c->h_stage.ptr), nq, k, c->ordinal_base, out_ordinals, out_scores, out_counts);
+  decode(reinterpret_cast<const u64_t*>(c->h_out.ptr), nq, k, c->ordinal_base, out_ordinals, out_scores, out_counts);
   return TAVB_OK;
 }
 
@@ -502,10 +503,10 @@ static int search_subset_impl(tavb_ctx* c, const float* query_host, const int64_
   const size_t rbytes = (size_t)n_subset * sizeof(int32_t);
   const size_t obytes = (size_t)k * sizeof(u64_t);
   const size_t qoff = (rbytes + 255) & ~(size_t)255;
-  if (int rc = c->h_stage.reserve(std::max(qoff + qbytes, obytes))) return rc;
+  if (int rc = c->h_stage.reserve(qoff + qbytes)) return rc;
+  if (int rc = c->h_out.reserve(obytes)) return rc;
   if (int rc = c->d_queries.reserve(qbytes)) return rc;
   if (int rc = c->d_rows.reserve(rbytes)) return rc;
-  if (int rc = c->d_out.reserve(obytes)) return rc;
   int32_t* r32 = reinterpret_cast<int32_t*>(c->h_stage.ptr);
   for (int64_t i = 0; i < n_subset; ++i) {
     const int64_t r = rows_host[i];
@@ -519,11 +520,10 @@ static int search_subset_impl(tavb_ctx* c, const float* query_host, const int64_
                           hipMemcpyHostToDevice, c->stream));
   int rc = search_device_impl(c, reinterpret_cast<const float*>(c->d_queries.ptr), 1, k, &min_score,
                               reinterpret_cast<const int32_t*>(c->d_rows.ptr), n_subset, 0u,
-                              reinterpret_cast<u64_t*>(c->d_out.ptr), bound);
+                              reinterpret_cast<u64_t*>(c->h_out.ptr), bound);
   if (rc) return rc;
-  TAVB_HIP(hipMemcpyAsync(c->h_stage.ptr, c->d_out.ptr, obytes, hipMemcpyDeviceToHost, c->stream));
   TAVB_HIP(hipStreamSynchronize(c->stream));
-  decode(reinterpret_cast<const u64_t*>(c->h_stage.ptr), 1, k, 0, out_positions, out_scores, out_count);
+  decode(reinterpret_cast<const u64_t*>(c->h_out.ptr), 1, k, 0, out_positions, out_scores, out_count);
   return TAVB_OK;
 }
 
@@ -599,17 +599,16 @@ int tavb_search_after(tavb_ctx* c, const float* query_host, int32_t k, float min
   DeviceGuard guard(c->device);
   const size_t qbytes = (size_t)c->dim * sizeof(float);
   const size_t obytes = (size_t)k * sizeof(u64_t);
-  if (int rc = c->h_stage.reserve(std::max(qbytes, obytes))) return rc;
+  if (int rc = c->h_stage.reserve(qbytes)) return rc;
+  if (int rc = c->h_out.reserve(obytes)) return rc;
   if (int rc = c->d_queries.reserve(qbytes)) return rc;
-  if (int rc = c->d_out.reserve(obytes)) return rc;
   memcpy(c->h_stage.ptr, query_host, qbytes);
   TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
   int rc = search_device_impl(c, reinterpret_cast<const float*>(c->d_queries.ptr), 1, k, &min_score, nullptr, c->rows,
-                              0u, reinterpret_cast<u64_t*>(c->d_out.ptr), bound);
+                              0u, reinterpret_cast<u64_t*>(c->h_out.ptr), bound);
   if (rc) return rc;
-  TAVB_HIP(hipMemcpyAsync(c->h_stage.ptr, c->d_out.ptr, obytes, hipMemcpyDeviceToHost, c->stream));
   TAVB_HIP(hipStreamSynchronize(c->stream));
-  decode(reinterpret_cast<const u64_t*>(c->h_stage.ptr), 1, k, c->ordinal_base, out_ordinals, out_scores, out_count);
+  decode(reinterpret_cast<const u64_t*>(c->h_out.ptr), 1, k, c->ordinal_base, out_ordinals, out_scores, out_count);
   return TAVB_OK;
 }
 

@@ -24,11 +24,23 @@ __global__ void __launch_bounds__(1024) merge_kernel(const u64* __restrict__ lis
   const int q = blockIdx.x;
   WaveTopK<KPL> mine;
   mine.clear();
-  for (int m = wave; m < n_lists; m += n_waves) {
-    const u64* src = query_major ? lists + ((size_t)q * n_lists + m) * (size_t)k
-                                 : lists + ((size_t)m * nq + q) * (size_t)k;
+  auto list_ptr = [&](int m) {
+    return query_major ? lists + ((size_t)q * n_lists + m) * (size_t)k : lists + ((size_t)m * nq + q) * (size_t)k;
+  };
+  // four lists per round: all their loads are issued before the first merge, so the (dependent,
+  // latency-bound) merges of one round overlap the memory latency of the next
+  constexpr int G = (KPL == 1) ? 4 : 1;
+  int m = wave;
+  for (; m + (G - 1) * n_waves < n_lists; m += G * n_waves) {
+    WaveTopK<KPL> other[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) other[g].load_reversed(list_ptr(m + g * n_waves), k, lane);
+#pragma unroll
+    for (int g = 0; g < G; ++g) mine.merge_reversed(other[g], lane);
+  }
+  for (; m < n_lists; m += n_waves) {
     WaveTopK<KPL> other;
-    other.load_reversed(src, k, lane);
+    other.load_reversed(list_ptr(m), k, lane);
     mine.merge_reversed(other, lane);
   }
   block_merge<KPL>(mine, scratch, wave, n_waves, lane);

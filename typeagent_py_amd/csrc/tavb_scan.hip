@@ -357,7 +357,7 @@ constexpr size_t scratch_bytes(int kpl, int waves) { return (size_t)((waves + 1)
 template <typename T, int CH, int NQ, int KPL, int U, bool NT, bool PIPE>
 hipError_t go_fixed(const ScanParams& p, const ScanGeometry& g, hipStream_t s) {
   constexpr int regs_est = U * CH * 4 * (PIPE ? 2 : 1) + (NQ == 1 ? CH * Elem<T>::EPL : 8) + U * NQ + NQ * KPL * 2 + 24;
-  constexpr int MAXT = (regs_est > 120) ? 512 : 1024;
+  constexpr int MAXT = (regs_est > 120 || NQ > 1) ? 512 : 1024;  // multi-query: the compiler keeps many LDS query slices live
   constexpr int D = CH * 64 * Elem<T>::EPL;
   int waves = g.waves;
   if (waves * 64 > MAXT) waves = MAXT / 64;
@@ -413,9 +413,14 @@ hipError_t go_fixed_q1_variants(const ScanParams& p, const ScanGeometry& g, hipS
 
 template <typename T, int CH>
 hipError_t dispatch_fixed(const ScanParams& p, const ScanGeometry& g, hipStream_t s, int nqt, int kpl) {
-  if (nqt != 1) return hipErrorInvalidValue;  // multi-query passes use the vector tier (queries in LDS)
-  if (kpl == 1) return go_fixed_q1_variants<T, CH>(p, g, s);
-  return go_fixed<T, CH, 1, 4, 2, true, false>(p, g, s);
+  if (nqt == 1) {
+    if (kpl == 1) return go_fixed_q1_variants<T, CH>(p, g, s);
+    return go_fixed<T, CH, 1, 4, 2, true, false>(p, g, s);
+  }
+  if (kpl != 1) return hipErrorInvalidValue;  // 256-deep lists with several queries: vector tier
+  if (nqt == 2) return go_fixed<T, CH, 2, 1, 2, true, false>(p, g, s);
+  if (nqt == 4) return go_fixed<T, CH, 4, 1, 2, true, false>(p, g, s);
+  return hipErrorInvalidValue;  // 8 queries do not fit the register file unrolled: vector tier
 }
 
 template <typename T>
@@ -452,14 +457,14 @@ hipError_t launch_scan(const ScanParams& p, const ScanGeometry& g, hipStream_t s
   const size_t vec_lds = (size_t)nqt * p.dim * 4 + 16 + scratch_bytes(kpl, g.waves);
   int tier = g.tier;
   if (tier == 0) {
-    if (aligned && p.dim == 1536 && nqt == 1)
+    if (aligned && p.dim == 1536 && (nqt == 1 || (kpl == 1 && nqt <= 4)))
       tier = 1;
     else if (aligned && vec_lds <= 150 * 1024)
       tier = 2;
     else
       tier = 3;
   }
-  if (tier == 1 && !(aligned && p.dim == 1536 && nqt == 1)) return hipErrorInvalidValue;
+  if (tier == 1 && !(aligned && p.dim == 1536 && (nqt == 1 || (kpl == 1 && nqt <= 4)))) return hipErrorInvalidValue;
   if (tier == 2 && !(aligned && vec_lds <= 150 * 1024)) return hipErrorInvalidValue;
   if (tier_used) *tier_used = tier;
   if (tier == 1) return f16 ? dispatch_fixed<_Float16, 3>(p, g, stream, nqt, kpl) : dispatch_fixed<float, 6>(p, g, stream, nqt, kpl);
