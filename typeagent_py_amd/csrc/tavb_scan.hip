@@ -457,7 +457,9 @@ hipError_t launch_scan(const ScanParams& p, const ScanGeometry& g, hipStream_t s
   const size_t vec_lds = (size_t)nqt * p.dim * 4 + 16 + scratch_bytes(kpl, g.waves);
   int tier = g.tier;
   if (tier == 0) {
-    if (aligned && p.dim == 1536 && (nqt == 1 || (kpl == 1 && nqt <= 4)))
+    // several queries per pass: the unrolled tier-1 form needs ~170 VGPRs (8 waves/CU) and measured slower
+    // than the LDS-query vector tier at 16 waves/CU (cfg5 terms pass 8.1 ms vs 6.6 ms), so auto picks tier 2 there
+    if (aligned && p.dim == 1536 && nqt == 1)
       tier = 1;
     else if (aligned && vec_lds <= 150 * 1024)
       tier = 2;
