@@ -376,6 +376,30 @@ def test_fuzzy_lookup_by_text_with_fake_model():
     assert results[0].score > 0.9
 
 
+def test_lookup_texts_batched_equals_sequential_fuzzy_lookup():
+    """the batched form of TermEmbeddingIndex.lookup_terms (reference
+    storage/memory/reltermsindex.py:320-332) == the sequential fuzzy_lookup loop."""
+    from typeagent_py_amd.adapters import lookup_texts_batched
+
+    vb = VectorBase(TextEmbeddingIndexSettings(create_test_embedding_model(embedding_size=48), min_score=0.3, max_matches=7))
+    words = [f"term number {i} about {'cats' if i % 3 else 'dogs'}" for i in range(200)]
+
+    async def go():
+        await vb.add_keys(words)
+        queries = ["term number 17 about cats", "dogs", "something else entirely", words[150]]
+        batched = await lookup_texts_batched(vb, queries)
+        sequential = [await vb.fuzzy_lookup(q) for q in queries]
+        return batched, sequential
+
+    batched, sequential = asyncio.run(go())
+    assert len(batched) == 4
+    for b, s in zip(batched, sequential):
+        assert [r.item for r in b] == [r.item for r in s] and len(b) <= 7
+        np.testing.assert_allclose([r.score for r in b], [r.score for r in s], atol=2e-7, rtol=0)
+    assert batched[0][0].item == 17 and batched[3][0].item == 150
+    assert asyncio.run(lookup_texts_batched(vb, [])) == []
+
+
 def test_subset_semantics_from_reference_tests():
     vb = VectorBase(TextEmbeddingIndexSettings(create_test_embedding_model()))
     samples = [np.array(x, dtype=np.float32) for x in ([0.1, 0.2, 0.3], [0.4, 0.5, 0.6], [0.7, 0.8, 0.9])]

@@ -1,0 +1,126 @@
+"""Callers on either side of the VectorBase hot path (the "next" rows),
+restated so that they use the device path in one submission instead of a Python loop.
+
+Reference lines (/root/reference):
+  * `TermEmbeddingIndex.lookup_terms`            storage/memory/reltermsindex.py:320-332
+  * `SqliteRelatedTermsFuzzy.lookup_terms`       storage/sqlite/reltermsindex.py:259-271
+      ("TODO: Some kind of batching?") -- both are `[await fuzzy_lookup(text, ...) for text in texts]`
+  * message-ordinal aggregation                  storage/sqlite/messageindex.py:228-257,
+                                                 storage/memory/messageindex.py:185-207
+      (best score per message over its chunks, sorted by score, cut at max_matches)
+  * raw little-endian float32 embedding files    knowpro/serialization.py:84-98, 114-136
+      (`<name>_embeddings.bin`: related-term rows first, then message rows)
+"""
+
+from __future__ import annotations
+
+import os
+from collections.abc import Callable, Sequence
+
+import numpy as np
+
+from .vectorbase import ScoredInt, VectorBase
+
+
+async def lookup_texts_batched(
+    vector_base: VectorBase,
+    texts: Sequence[str],
+    max_hits: int | None = None,
+    min_score: float | None = None,
+) -> list[list[ScoredInt]]:
+    """== [await vector_base.fuzzy_lookup(t, max_hits, min_score) for t in texts], as ONE device
+    submission: the texts are embedded in one (cache-aware) call and looked up by
+    `fuzzy_lookup_embeddings`.  Defaults resolve like `fuzzy_lookup` (vectorbase.py:239-242):
+    max_hits <- settings.max_matches (None -> 10), min_score <- settings.min_score."""
+    texts = list(texts)
+    if not texts:
+        return []
+    if max_hits is None:
+        max_hits = vector_base.settings.max_matches
+    if min_score is None:
+        min_score = vector_base.settings.min_score
+    embeddings = await vector_base.get_embeddings(texts)
+    return vector_base.fuzzy_lookup_embeddings(np.asarray(embeddings, dtype=np.float32), max_hits=max_hits, min_score=min_score)
+
+
+def install_batched_lookup_terms() -> list[str]:
+    """When typeagent is importable, replace the two sequential `lookup_terms` bodies by the batched
+    form above.  Returns the names of the classes that were patched (empty here: typeagent needs
+    Python >= 3.12 and its provider dependencies)."""
+    patched: list[str] = []
+    try:
+        from typeagent.storage.memory import reltermsindex as mem  # type: ignore
+
+        async def lookup_terms(self, texts, max_hits=None, min_score=None):
+            matches = await lookup_texts_batched(self._vectorbase, texts, max_hits, min_score)
+            return [self.matches_to_terms(m) for m in matches]
+
+        mem.TermEmbeddingIndex.lookup_terms = lookup_terms
+        patched.append("typeagent.storage.memory.reltermsindex.TermEmbeddingIndex")
+    except Exception:
+        pass
+    try:
+        from typeagent.knowpro import interfaces  # type: ignore
+        from typeagent.storage.sqlite import reltermsindex as sql  # type: ignore
+
+        async def lookup_terms_sql(self, texts, max_hits=None, min_score=None):
+            matches = await lookup_texts_batched(self._vector_base, texts, max_hits, min_score)
+            return [[interfaces.Term(self._terms_list[m.item], m.score) for m in ms if m.item < len(self._terms_list)] for ms in matches]
+
+        sql.SqliteRelatedTermsFuzzy.lookup_terms = lookup_terms_sql
+        patched.append("typeagent.storage.sqlite.reltermsindex.SqliteRelatedTermsFuzzy")
+    except Exception:
+        pass
+    return patched
+
+
+def best_score_per_message(
+    hits: Sequence[ScoredInt],
+    row_to_message: Callable[[int], int] | Sequence[int] | np.ndarray,
+    max_matches: int | None = None,
+    accept: Callable[[int], bool] | None = None,
+) -> list[ScoredInt]:
+    """Chunk-row hits -> message hits: best score per message, sorted by score (stable), cut at
+    `max_matches` -- the aggregation both providers apply after the VectorBase call
+    (sqlite/messageindex.py:228-257; memory/messageindex.py:185-207).  `accept(message_ordinal)` is the
+    subset filter the sqlite provider applies after the full scan (sqlite/messageindex.py:312-326)."""
+    best: dict[int, float] = {}
+    for h in hits:
+        msg = int(row_to_message(h.item)) if callable(row_to_message) else int(row_to_message[h.item])
+        if accept is not None and not accept(msg):
+            continue
+        if msg not in best or h.score > best[msg]:
+            best[msg] = h.score
+    out = [ScoredInt(m, s) for m, s in best.items()]
+    out.sort(key=lambda x: x.score, reverse=True)
+    return out if max_matches is None else out[:max_matches]
+
+
+def load_embeddings_bin(
+    path: str,
+    embedding_size: int,
+    related_count: int,
+    message_count: int,
+    related_vb: VectorBase | None = None,
+    message_vb: VectorBase | None = None,
+    chunk_rows: int = 1 << 18,
+):
+    """Stream a `<name>_embeddings.bin` sidecar (raw little-endian float32 rows: `related_count`
+    related-term rows, then `message_count` message rows; counts and width come from the
+    `embeddingFileHeader` of `<name>_data.json`, knowpro/serialization.py:84-98, 207-221) straight into
+    the given VectorBases in `chunk_rows`-row pieces (np.memmap -> add_embeddings), so that no second
+    full copy of the file is built on the host.  Returns (related_rows, message_rows) loaded."""
+    expected = (related_count + message_count) * embedding_size * 4
+    actual = os.path.getsize(path)
+    if actual != expected:
+        raise ValueError(f"{path}: {actual} bytes, expected {expected} for {related_count}+{message_count} rows of {embedding_size} float32")
+    rows = np.memmap(path, dtype="<f4", mode="r", shape=(related_count + message_count, embedding_size))
+    done = [0, 0]
+    for which, (vb, lo, hi) in enumerate(((related_vb, 0, related_count), (message_vb, related_count, related_count + message_count))):
+        if vb is None:
+            continue
+        for a in range(lo, hi, chunk_rows):
+            b = min(hi, a + chunk_rows)
+            vb.add_embeddings(None, np.ascontiguousarray(rows[a:b], dtype=np.float32))
+            done[which] += b - a
+    return tuple(done)
