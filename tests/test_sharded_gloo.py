@@ -82,6 +82,15 @@ def _worker(rank: int, world: int, port: int, total_rows: int, dim: int, k: int,
         assert searcher.world == world and searcher.rank == rank
         res = searcher.search(torch.from_numpy(qs), k, min_score)
         ret[rank] = (res.ordinals.copy(), res.scores.copy(), res.counts.copy())
+        # the VectorBase-shaped front end over the same shards gives the same hits
+        from typeagent_py_amd.sharded import ShardedVectorBase
+
+        svb = ShardedVectorBase(HostStandInBackend(v[lo:hi], lo), lo, hi - lo, total_rows)
+        assert len(svb) == total_rows and bool(svb)
+        hits = svb.fuzzy_lookup_embedding(qs[0], max_hits=k, min_score=min_score)
+        m = int(res.counts[0])
+        assert [h.item for h in hits] == res.ordinals[0, :m].tolist()
+        assert [h.score for h in hits] == [float(x) for x in res.scores[0, :m]]
     finally:
         dist.destroy_process_group()
 

@@ -65,24 +65,43 @@ hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, in
 
 // ---------------------------------------------------------------------------
 // K1: y = x / ||x||_2 per row, float32, zero rows unchanged.  One wave per row;
-// HBM-bound (4 B read + 4 B written per element; the row is re-read from L2/L1
-// for the scaling pass, not from HBM, because a row is at most a few KiB).
+// HBM-bound (4 B read + 4 B written per element).
 // The quotient is an IEEE float32 division so that it rounds like numpy's
 // `embeddings / norms` (no reciprocal-multiply).
 // ---------------------------------------------------------------------------
+// Rows of up to 64 * 4 * NC floats are held in registers between the two phases (sum of squares,
+// scale), so HBM sees each element exactly once in and once out; longer rows re-read from L1/L2.
+template <int NC>
 __global__ void __launch_bounds__(256) normalize_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                              int64_t rows, int dim) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const bool vec = (dim % 4 == 0) && (((uintptr_t)in | (uintptr_t)out) % 16 == 0);
+  const int n4 = dim / 4;
+  const bool in_regs = vec && NC > 0 && n4 <= 64 * NC;
   for (int64_t r = wave; r < rows; r += n_waves) {
     const float* x = in + r * (int64_t)dim;
     float* y = out + r * (int64_t)dim;
     float ss = 0.f;
-    if (vec) {
+    f32x4 keep[NC > 0 ? NC : 1];
+    if (in_regs) {
       const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-      for (int i = lane; i < dim / 4; i += 64) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int i = c * 64 + lane;
+        keep[c] = (i < n4) ? x4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        ss = fmaf(keep[c].x, keep[c].x, ss);
+        ss = fmaf(keep[c].y, keep[c].y, ss);
+        ss = fmaf(keep[c].z, keep[c].z, ss);
+        ss = fmaf(keep[c].w, keep[c].w, ss);
+      }
+    } else if (vec) {
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+      for (int i = lane; i < n4; i += 64) {
         const f32x4 v = x4[i];
         ss = fmaf(v.x, v.x, ss);
         ss = fmaf(v.y, v.y, ss);
@@ -95,10 +114,24 @@ __global__ void __launch_bounds__(256) normalize_rows_kernel(const float* __rest
     ss = wave_sum(ss);
     float norm = sqrtf(ss);
     if (!(norm > 0.f)) norm = 1.0f;  // np.where(norms > 0, norms, 1): zero (and NaN) norms divide by 1
-    if (vec) {
+    if (in_regs) {
+      f32x4* y4 = reinterpret_cast<f32x4*>(y);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int i = c * 64 + lane;
+        if (i < n4) {
+          f32x4 v = keep[c];
+          v.x = v.x / norm;
+          v.y = v.y / norm;
+          v.z = v.z / norm;
+          v.w = v.w / norm;
+          y4[i] = v;
+        }
+      }
+    } else if (vec) {
       const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
       f32x4* y4 = reinterpret_cast<f32x4*>(y);
-      for (int i = lane; i < dim / 4; i += 64) {
+      for (int i = lane; i < n4; i += 64) {
         f32x4 v = x4[i];
         v.x = v.x / norm;
         v.y = v.y / norm;
@@ -116,7 +149,12 @@ hipError_t launch_normalize_f32(const float* in, float* out, int64_t rows, int d
   if (rows <= 0) return hipSuccess;
   int64_t blocks = (rows + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, rows, dim);
+  if (dim % 4 == 0 && dim <= 64 * 4 * 6)
+    hipLaunchKernelGGL(normalize_rows_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, rows, dim);
+  else if (dim % 4 == 0 && dim <= 64 * 4 * 16)
+    hipLaunchKernelGGL(normalize_rows_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, rows, dim);
+  else
+    hipLaunchKernelGGL(normalize_rows_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, rows, dim);
   return hipGetLastError();
 }
 

@@ -130,3 +130,61 @@ class ShardedSearcher:
         keys = self.backend.to_host(self.search_keys(queries, k, min_score))
         ords, scs, cnts = _native.decode_keys(keys)
         return ShardedResult(ords, scs, cnts)
+
+
+class ShardedVectorBase:
+    """VectorBase-shaped front end over a row-sharded corpus: every rank holds rows
+    [row_offset, row_offset + local_rows) and every lookup is a collective call (all ranks pass the same
+    query, all ranks get the same global answer).  Covers the lookup methods of the reference class
+    (`fuzzy_lookup_embedding`, `fuzzy_lookup_embeddings`, vectorbase.py:163-190); storage methods stay
+    per-rank on the local VectorBase (`.local`)."""
+
+    def __init__(self, backend: ShardBackend, row_offset: int, local_rows: int, total_rows: int, group=None):
+        self.backend = backend
+        self.row_offset = int(row_offset)
+        self.local_rows = int(local_rows)
+        self.total_rows = int(total_rows)
+        self.searcher = ShardedSearcher(backend, group=group)
+
+    def __len__(self) -> int:
+        return self.total_rows
+
+    def __bool__(self) -> bool:
+        return True
+
+    @classmethod
+    def from_device_shard(cls, device: int, shard_tensor, row_offset: int, total_rows: int, group=None):
+        backend = DeviceShardBackend(device)
+        backend.set_shard(shard_tensor, row_offset=row_offset)
+        return cls(backend, row_offset, shard_tensor.shape[0], total_rows, group=group)
+
+    def _queries(self, q):
+        a = np.ascontiguousarray(q, dtype=np.float32)
+        torch = getattr(self.backend, "torch", None)
+        if torch is None:
+            import torch as _t
+
+            return _t.from_numpy(a)
+        return torch.from_numpy(a).to(torch.device("cuda", self.backend.device))
+
+    def fuzzy_lookup_embeddings(self, embeddings, max_hits: int | None = None, min_score: float | None = None):
+        from .vectorbase import ScoredInt
+
+        if max_hits is None:
+            max_hits = 10
+        if min_score is None:
+            min_score = 0.0
+        q = np.asarray(embeddings, dtype=np.float32)
+        if q.ndim != 2:
+            raise ValueError(f"Expected 2D embeddings array, got {q.ndim}D")
+        if self.total_rows == 0 or len(q) == 0:
+            return [[] for _ in range(len(q))]
+        res = self.searcher.search(self._queries(q), max_hits, min_score)
+        out = []
+        for i in range(len(q)):
+            m = int(res.counts[i])
+            out.append([ScoredInt(int(o), float(s)) for o, s in zip(res.ordinals[i, :m].tolist(), res.scores[i, :m].tolist())])
+        return out
+
+    def fuzzy_lookup_embedding(self, embedding, max_hits: int | None = None, min_score: float | None = None):
+        return self.fuzzy_lookup_embeddings(np.asarray(embedding, dtype=np.float32)[None, :], max_hits, min_score)[0]
