@@ -95,6 +95,17 @@ int tavb_normalize_rows_f32(tavb_ctx* ctx, const float* dev_in, float* dev_out, 
 /* float32 -> float16 (round to nearest even), used to build f16 corpora on device. */
 int tavb_convert_f32_to_f16(tavb_ctx* ctx, const float* dev_in, void* dev_out, int64_t count);
 
+/* K-blocked fp16 image of the corpus for the batched MFMA kernel (our storage extension, like fp16
+ * itself): for every tile of 256 rows and every K step of 32 halves one contiguous 16 KiB block, laid
+ * out exactly as the kernel's LDS operand image, so that each LDS-DMA instruction reads 1 KiB of
+ * contiguous memory.  tavb_tiled_bytes gives the size (rows padded to a multiple of 256; dim % 32 == 0),
+ * tavb_pack_f16_tiled builds it on the device from a row-major f32/f16 matrix, tavb_set_corpus_tiled
+ * attaches it either beside the row-major corpus of the same rows (call it after tavb_set_corpus) or
+ * alone (batch lookups only; the streaming lookups then fail with TAVB_E_NO_CORPUS). */
+int tavb_tiled_bytes(int64_t rows, int32_t dim, int64_t* out_bytes);
+int tavb_pack_f16_tiled(tavb_ctx* ctx, const void* dev_src, int32_t src_dtype, int64_t rows, int32_t dim, void* dev_dst);
+int tavb_set_corpus_tiled(tavb_ctx* ctx, const void* dev_tiled, int64_t rows, int32_t dim, int64_t ordinal_base);
+
 /* ---- synchronous lookups (host in, host out) ---------------------------------- */
 /* fuzzy_lookup_embedding without predicate (vectorbase.py:163-190):
  * up to k best rows with score >= min_score.  out_* hold k entries; *out_count = M. */

@@ -97,6 +97,7 @@ struct tavb_ctx {
   int32_t dim = 0;
   int32_t dtype = TAVB_F32;
   int64_t ordinal_base = 0;
+  const void* tiled = nullptr;  // optional K-blocked fp16 image of the same rows (MFMA path)
 
   tavb::ScanGeometry geom{0, 16, 2, 1, 0, 0};
   int64_t mfma_min_batch = 32;
@@ -105,6 +106,7 @@ struct tavb_ctx {
   int64_t mfma_ablate = 0;
   int64_t mfma_prio = 1;
   int64_t mfma_group = 0;
+  int64_t mfma_use_tiled = 1;
 
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand;
   Buffer h_stage{nullptr, 0, true};
@@ -176,6 +178,8 @@ int scan_blocks_for(const tavb_ctx* c, int64_t n_pos, int waves, int unroll) {
 int search_device_impl(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores /*host, nq*/,
                        const int32_t* d_row_ids, int64_t n_pos, uint32_t index_base, u64_t* d_out,
                        u64_t key_bound = ~0ull) {
+  if (!c->corpus && c->rows != 0)
+    return fail(TAVB_E_NO_CORPUS, "this lookup needs the row-major corpus (only the K-blocked MFMA image is set)");
   if (n_pos <= 0) {
     TAVB_HIP(hipMemsetAsync(d_out, 0, (size_t)nq * k * sizeof(u64_t), c->stream));
     return TAVB_OK;
@@ -224,7 +228,7 @@ int check_ctx(tavb_ctx* c) {
 
 int check_search_args(tavb_ctx* c, int k) {
   if (int rc = check_ctx(c)) return rc;
-  if (!c->corpus && c->rows != 0) return fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
+  if (!c->corpus && !c->tiled && c->rows != 0) return fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
   if (c->dim <= 0) return fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
   if (k < 1) return fail(TAVB_E_INVALID, "k must be >= 1 (got %d)", k);
   if (k > TAVB_MAX_FUSED_K)
@@ -372,6 +376,8 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_variant") {
     if (v < 1 || v > 4) return fail(TAVB_E_INVALID, "mfma_variant must be 1..4");
     c->mfma_variant = v;
+  } else if (n == "mfma_use_tiled") {
+    c->mfma_use_tiled = v ? 1 : 0;
   } else if (n == "mfma_group") {
     if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_group must be 0..2");
     c->mfma_group = v;
@@ -379,7 +385,7 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_prio must be 0..2");
     c->mfma_prio = v;
   } else if (n == "mfma_ablate") {
-    if (v < 0 || v > 63) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..63");
+    if (v < 0 || v > 255) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..255");
     c->mfma_ablate = v;
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");
@@ -418,10 +424,50 @@ int tavb_set_corpus(tavb_ctx* c, const void* dev_rows, int64_t rows, int32_t dim
   if (rows >= 0x7FFFFFFFll) return fail(TAVB_E_UNSUPPORTED, "at most 2^31-2 rows per device shard (got %lld)", (long long)rows);
   if (ordinal_base < 0) return fail(TAVB_E_INVALID, "ordinal_base must be >= 0");
   c->corpus = dev_rows;
+  c->tiled = nullptr;  // a new corpus invalidates the auxiliary image
   c->rows = rows;
   c->dim = dim;
   c->dtype = dtype;
   c->ordinal_base = ordinal_base;
+  return TAVB_OK;
+}
+
+int tavb_tiled_bytes(int64_t rows, int32_t dim, int64_t* out_bytes) {
+  if (!out_bytes) return fail(TAVB_E_INVALID, "null out_bytes");
+  if (rows < 0 || dim < 32 || dim % 32 != 0) return fail(TAVB_E_INVALID, "tiled image needs rows >= 0 and dim a multiple of 32");
+  *out_bytes = (int64_t)tavb::tiled_bytes(rows, dim);
+  return TAVB_OK;
+}
+
+int tavb_pack_f16_tiled(tavb_ctx* c, const void* dev_src, int32_t src_dtype, int64_t rows, int32_t dim, void* dev_dst) {
+  if (int rc = check_ctx(c)) return rc;
+  if (rows < 0 || dim < 32 || dim % 32 != 0) return fail(TAVB_E_INVALID, "tiled image needs dim a multiple of 32");
+  if (src_dtype != TAVB_F32 && src_dtype != TAVB_F16) return fail(TAVB_E_INVALID, "bad source dtype");
+  if (rows == 0) return TAVB_OK;
+  if (!dev_src || !dev_dst) return fail(TAVB_E_INVALID, "null pointer");
+  DeviceGuard guard(c->device);
+  Timed t(c, TAVB_KERNEL_CONVERT);
+  hipError_t e = tavb::launch_pack_tiled(dev_src, src_dtype, rows, dim, dev_dst, c->stream);
+  if (e != hipSuccess) return fail(TAVB_E_HIP, "pack launch failed: %s", hipGetErrorString(e));
+  return TAVB_OK;
+}
+
+int tavb_set_corpus_tiled(tavb_ctx* c, const void* dev_tiled, int64_t rows, int32_t dim, int64_t ordinal_base) {
+  if (int rc = check_ctx(c)) return rc;
+  if (rows < 0 || dim < 32 || dim % 32 != 0) return fail(TAVB_E_INVALID, "tiled image needs dim a multiple of 32");
+  if (rows > 0 && !dev_tiled) return fail(TAVB_E_INVALID, "null tiled pointer");
+  if (rows >= 0x7FFFFFFFll) return fail(TAVB_E_UNSUPPORTED, "at most 2^31-2 rows per device shard");
+  if (c->corpus) {
+    if (rows != c->rows || dim != c->dim)
+      return fail(TAVB_E_INVALID, "tiled image (%lld x %d) does not match the corpus (%lld x %d)", (long long)rows, dim,
+                  (long long)c->rows, c->dim);
+  } else {
+    c->rows = rows;
+    c->dim = dim;
+    c->dtype = TAVB_F16;
+    c->ordinal_base = ordinal_base;
+  }
+  c->tiled = dev_tiled;
   return TAVB_OK;
 }
 
@@ -651,7 +697,8 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
                                 uint32_t index_base, u64_t* d_out) {
   bool uniform_thr = true;
   for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (min_scores[i] == min_scores[0]);
-  if (c->dtype == TAVB_F16 && nq >= c->mfma_min_batch && uniform_thr && tavb::mfma_supported(c->dim, k) && c->rows > 0) {
+  if ((c->dtype == TAVB_F16 || c->tiled) && (nq >= c->mfma_min_batch || !c->corpus) && uniform_thr && tavb::mfma_supported(c->dim, k) &&
+      c->rows > 0 && (c->mfma_variant >= 3 || !c->tiled || c->corpus)) {
     const int qt = tavb::mfma_query_tile();
     const int nq_pad = ((nq + qt - 1) / qt) * qt;
     const size_t q16 = (size_t)nq_pad * c->dim * 2;
@@ -665,7 +712,10 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     if (int rc = c->d_lists.reserve((size_t)nq * splits * k * sizeof(u64_t))) return rc;
     if (int rc = c->d_cand.reserve(tavb::mfma_workspace_bytes(splits, nq_pad))) return rc;
     tavb::MfmaParams p{};
-    p.corpus = c->corpus;
+    const bool use_tiled = c->tiled && c->mfma_variant >= 3 && c->mfma_use_tiled;
+    p.corpus = use_tiled ? c->tiled : c->corpus;
+    p.a_tiled = use_tiled ? 1 : 0;
+    if (!p.corpus) return fail(TAVB_E_NO_CORPUS, "no operand for the MFMA kernel (row-major fp16 corpus or K-blocked image)");
     p.queries = c->d_queries_f16.ptr;
     p.lists = reinterpret_cast<u64_t*>(c->d_lists.ptr);
     p.workspace = reinterpret_cast<u64_t*>(c->d_cand.ptr);

@@ -42,10 +42,13 @@ hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, in
 
 hipError_t launch_normalize_f32(const float* in, float* out, int64_t rows, int dim, hipStream_t stream);
 hipError_t launch_f32_to_f16(const float* in, void* out, int64_t count, hipStream_t stream);
+size_t tiled_bytes(int64_t rows, int dim);
+hipError_t launch_pack_tiled(const void* src, int src_dtype, int64_t rows, int dim, void* dst, hipStream_t stream);
 
 // MFMA batched scan (f16 corpus, f16 queries staged by the launcher)
 struct MfmaParams {
-  const void* corpus;   // f16 [rows, dim]
+  const void* corpus;   // f16 [rows, dim] row-major, or the K-blocked image when a_tiled
+  int32_t a_tiled;
   const void* queries;  // f16 [nq_padded, dim] device
   unsigned long long* lists;  // out [nq, n_splits, k]
   unsigned long long* workspace;  // candidate buffers, mfma_workspace_bytes() bytes

@@ -74,6 +74,7 @@ struct MfmaDeviceParams {
   uint32_t index_base;
   float min_score;
   int32_t group_sel;
+  int32_t a_tiled;  // corpus given as the K-blocked image of pack_tiled_kernel
 };
 
 // Pin a wave-uniform pointer into SGPRs.  Without this the compiler strength-reduces the eight
@@ -466,6 +467,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
       int64_t r = row;
       if (clamp && row0 + r >= p.rows) r = p.rows - 1 - row0;  // stay in bounds; masked in the epilogue
       st_off[j] = (uint32_t)r * (uint32_t)row_bytes + (uint32_t)((st_slot ^ ((row >> 2) & 3)) * 16);
+      if (clamp && p.a_tiled) st_off[j] = (uint32_t)((lw * 4 + j) * 1024 + lane * 16);  // the stored image is the LDS image
     }
   };
   int st_tile = 0;   // tile of the next step this wave stages (group 0 only; group 1's operand has no tiles)
@@ -477,7 +479,8 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
     if (group == 0) {
       const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
       const int64_t src_row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM;  // ablation: every block re-reads tile 0 (L2 resident)
-      const char* g = sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * (KS * 2));
+      const char* g = p.a_tiled ? sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * SLOT)  // block (tile, step): 16 KiB
+                                : sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * (KS * 2));
       unsigned char* l = smem + st_slot_idx * SLOT + lw * 4096;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -721,8 +724,17 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
   // running, wave-uniform source pointer of the next step to stage: +64 bytes per K step; at the end of
   // a tile's K range the A stager jumps to the next tile (or, past the last tile, back to the start of
   // the last one: harmless reloads that keep the vmcnt bookkeeping uniform), the B stager back to k = 0.
-  const int64_t k_rewind = -(int64_t)(steps_per_tile - 1) * (KS * 2);
-  const int64_t tile_jump = is_a ? k_rewind + (int64_t)BM * row_bytes : k_rewind;
+  const bool lin = is_a && p.a_tiled;  // K-blocked corpus image: 16 KiB per (tile, step), already in LDS order
+  if (lin) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st_rowoff[j] = 0;
+      st_slotoff[j] = (uint32_t)((lw * 4 + j) * 1024 + lane * 16);
+    }
+  }
+  const int64_t k_step = lin ? (int64_t)SLOT : (int64_t)(KS * 2);
+  const int64_t k_rewind = -(int64_t)(steps_per_tile - 1) * k_step;
+  const int64_t tile_jump = is_a ? (lin ? k_step : k_rewind + (int64_t)BM * row_bytes) : k_rewind;
   const char* st_ptr = is_a ? corpus + (size_t)((ABL & 4) ? 0 : r_begin) * row_bytes : qbase;
   int64_t st_last_row = is_a ? (p.rows - 1 - r_begin) : 255;  // last valid row of the staged tile, relative to its row 0
   int st_tiles_left = is_a ? n_tiles - 1 : 0;
@@ -742,7 +754,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
     const bool wrap = (st_kt + 1 == steps_per_tile);
     const bool advance = wrap && st_tiles_left > 0 && (ABL & 4) == 0;
     st_kt = wrap ? 0 : st_kt + 1;
-    st_ptr += wrap ? (advance ? tile_jump : k_rewind) : (int64_t)(KS * 2);
+    st_ptr += wrap ? (advance ? tile_jump : k_rewind) : k_step;
     st_last_row -= advance ? BM : 0;
     st_tiles_left -= advance ? 1 : 0;
   };
@@ -943,6 +955,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.index_base = p.index_base;
   d.min_score = p.min_score;
   d.group_sel = p.group_sel;
+  d.a_tiled = p.a_tiled;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
   d.rows_per_split = ((per + BM - 1) / BM) * BM;
   if (!p.workspace) return hipErrorInvalidValue;
@@ -971,6 +984,10 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 3: return go4(mfma_scan_kernel_v4<NA4, NB4, 3>);
       case 4: return go4(mfma_scan_kernel_v4<NA4, NB4, 4>);
       case 34: return go4(mfma_scan_kernel_v4<NA4, NB4, 34>);  // MFMAs + barriers only
+      case 32: return go4(mfma_scan_kernel_v4<NA4, NB4, 32>);  // MFMAs + LDS-DMA, no fragment reads
+      case 36: return go4(mfma_scan_kernel_v4<NA4, NB4, 36>);  // same, corpus tile 0 only (L2 resident)
+      case 33: return go4(mfma_scan_kernel_v4<NA4, NB4, 33>);  // LDS-DMA + barriers only
+      case 37: return go4(mfma_scan_kernel_v4<NA4, NB4, 37>);  // same, L2 resident
       case 10: return go4(mfma_scan_kernel_v4<NA4, NB4, 10>);  // no LDS-DMA, barrier every 2nd step
       case 18: return go4(mfma_scan_kernel_v4<NA4, NB4, 18>);  // no LDS-DMA, barrier every 4th step
       default: return go4(mfma_scan_kernel_v4<NA4, NB4, 0>);
