@@ -4,9 +4,10 @@ export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
 echo "== $(date -u +%FT%TZ)" | tee $OUT/round.log
-for A in 33 97 225 0 64 192; do
-  timeout 900 python bench.py --workload cfg3 --rows 4000000 --steps 4 --warmup 1 --no-cpu-baseline --opt mfma_variant=4 --opt mfma_ablate=$A > $OUT/ab4_$A.json 2> $OUT/ab4_$A.err
+for CFG in "4 0 --no-tiled" "4 256 --no-tiled" "4 0" "4 256" "3 0" "3 0 --no-tiled"; do
+  set -- $CFG
+  timeout 900 python bench.py --workload cfg3 --rows 4000000 --steps 4 --warmup 1 --no-cpu-baseline --opt mfma_variant=$1 --opt mfma_ablate=$2 ${3:-} > $OUT/abx.json 2> $OUT/abx.err
   python -c "
-import json;d=json.load(open('$OUT/ab4_$A.json'));print('v4 ablate $A kernel_ms', round(d['roofline']['kernel_avg_ms'],3), 'TF-eq', round(d['roofline']['achieved'],1))" | tee -a $OUT/round.log
+import json;d=json.load(open('$OUT/abx.json'));print('variant $1 ablate $2 ${3:-tiled} kernel_ms', round(d['roofline']['kernel_avg_ms'],3), 'TF-eq', round(d['roofline']['achieved'],1))" | tee -a $OUT/round.log
 done
 echo "== done" | tee -a $OUT/round.log

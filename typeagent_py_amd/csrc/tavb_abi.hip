@@ -385,7 +385,7 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_prio must be 0..2");
     c->mfma_prio = v;
   } else if (n == "mfma_ablate") {
-    if (v < 0 || v > 255) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..255");
+    if (v < 0 || v > 511) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..511");
     c->mfma_ablate = v;
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");

@@ -414,6 +414,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
   extern __shared__ __align__(16) unsigned char smem[];
   float* thr_lds = reinterpret_cast<float*>(smem + CTRL);
   int* cnt_lds = reinterpret_cast<int*>(smem + CTRL + BN * 4);
+  volatile int* need_compact = reinterpret_cast<volatile int*>(smem + CTRL + BN * 8);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -439,6 +440,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
     thr_lds[i] = (p.min_score != p.min_score) ? __builtin_inff() : thr0;
     cnt_lds[i] = 0;
   }
+  if (tid == 0) *need_compact = 0;
 
   const int D = p.dim;
   const int steps_per_tile = D / KS;
@@ -577,7 +579,6 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
     if (group == 0) TAVB_BARRIER();  // re-align the groups for the epilogue
 
     // ---- epilogue: score, admission test, append
-    bool stored = false;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int ql = wn * 64 + ni * 32 + (lane & 31);
@@ -603,7 +604,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
                 if (row < r_end && s >= p.min_score) {
                   const int pos = atomicAdd(&cnt_lds[ql], 1);
                   if (pos < CAP) my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)row + p.index_base);
-                  stored = true;
+                  if (pos + 1 > CAP - BM) *need_compact = 1;  // this buffer could overflow on the next tile
                 }
               }
             }
@@ -611,10 +612,13 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
         }
       }
     }
-    // appended keys must be in memory before another wave compacts the buffer; only a wave that
-    // stored pays the drain of its (otherwise still flying) LDS-DMA queue
-    if (__builtin_amdgcn_ballot_w64(stored) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Compaction is rare (O(log rows) times per query).  Only then do the appended keys have to be in
+    // memory for another wave to read, so only then does the workgroup pay a drain of its (otherwise
+    // still flying) LDS-DMA queues; normally the epilogue ends at this barrier.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TAVB_BARRIER();
+    if (*need_compact != 0) {  // workgroup-uniform: read after the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TAVB_BARRIER();
     for (int q = wave; q < BN; q += NTHREADS / 64) {
       const int n = cnt_lds[q];
@@ -634,6 +638,10 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     TAVB_BARRIER();
+    if (tid == 0) *need_compact = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TAVB_BARRIER();
+    }
     if (group == 1) TAVB_BARRIER();  // stagger again
   }
   if (group == 0) TAVB_BARRIER();  // pairs with group 1's last stagger barrier
@@ -670,6 +678,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
   extern __shared__ __align__(16) unsigned char smem[];
   float* thr_lds = reinterpret_cast<float*>(smem + CTRL);
   int* cnt_lds = reinterpret_cast<int*>(smem + CTRL + BN * 4);
+  volatile int* need_compact = reinterpret_cast<volatile int*>(smem + CTRL + BN * 8);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -695,6 +704,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
     thr_lds[i] = (p.min_score != p.min_score) ? __builtin_inff() : thr0;
     cnt_lds[i] = 0;
   }
+  if (tid == 0) *need_compact = 0;
 
   const int D = p.dim;
   const int steps_per_tile = D / KS;  // even: D is a multiple of 64
@@ -712,29 +722,25 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
 
   // ---- stager: instruction j covers operand rows (lw*4 + j)*16 .. +15, four 16-byte slots per row.
   //      Branch-free: everything that differs between the A and B stagers is a scalar select.
+  const bool lin = is_a && p.a_tiled;  // K-blocked corpus image: 16 KiB per (tile, step), already in LDS order
   uint32_t st_rowoff[4], st_slotoff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int row = (lw * 4 + j) * 16 + (lane >> 2);
-    st_rowoff[j] = (uint32_t)row * row_bytes;
-    st_slotoff[j] = (uint32_t)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
+    st_rowoff[j] = lin ? 0u : (uint32_t)row * row_bytes;
+    st_slotoff[j] = lin ? (uint32_t)((lw * 4 + j) * 1024 + lane * 16) : (uint32_t)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
   }
   const int ring_n = is_a ? NA : NB;
   const uint32_t ring_base = (is_a ? 0u : (uint32_t)B_RING) + (uint32_t)lw * 4096u;
-  // running, wave-uniform source pointer of the next step to stage: +64 bytes per K step; at the end of
-  // a tile's K range the A stager jumps to the next tile (or, past the last tile, back to the start of
-  // the last one: harmless reloads that keep the vmcnt bookkeeping uniform), the B stager back to k = 0.
-  const bool lin = is_a && p.a_tiled;  // K-blocked corpus image: 16 KiB per (tile, step), already in LDS order
-  if (lin) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      st_rowoff[j] = 0;
-      st_slotoff[j] = (uint32_t)((lw * 4 + j) * 1024 + lane * 16);
-    }
-  }
+  // running, wave-uniform source pointer of the next step to stage: +64 bytes per K step (+16 KiB in the
+  // K-blocked image); at the end of a tile's K range the A stager jumps to the next tile (or, past the last
+  // tile, back to the start of the last one: harmless reloads that keep the vmcnt bookkeeping uniform), the
+  // B stager back to k = 0.
   const int64_t k_step = lin ? (int64_t)SLOT : (int64_t)(KS * 2);
   const int64_t k_rewind = -(int64_t)(steps_per_tile - 1) * k_step;
   const int64_t tile_jump = is_a ? (lin ? k_step : k_rewind + (int64_t)BM * row_bytes) : k_rewind;
+  const int64_t wrap_delta = k_rewind - k_step;        // added when the K range of a tile ends
+  const int64_t advance_delta = tile_jump - k_rewind;  // added on top when the stager moves on to the next tile
   const char* st_ptr = is_a ? corpus + (size_t)((ABL & 4) ? 0 : r_begin) * row_bytes : qbase;
   int64_t st_last_row = is_a ? (p.rows - 1 - r_begin) : 255;  // last valid row of the staged tile, relative to its row 0
   int st_tiles_left = is_a ? n_tiles - 1 : 0;
@@ -754,7 +760,9 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
     const bool wrap = (st_kt + 1 == steps_per_tile);
     const bool advance = wrap && st_tiles_left > 0 && (ABL & 4) == 0;
     st_kt = wrap ? 0 : st_kt + 1;
-    st_ptr += wrap ? (advance ? tile_jump : k_rewind) : k_step;
+    // arithmetic instead of a nested select: the compiler turns a select tree over run-time 64-bit values
+    // into a scratch-resident lookup table, which drags the whole stager state into scratch memory
+    st_ptr += k_step + (int64_t)wrap * wrap_delta + (int64_t)advance * advance_delta;
     st_last_row -= advance ? BM : 0;
     st_tiles_left -= advance ? 1 : 0;
   };
@@ -851,7 +859,6 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
     }
 
     // ---- epilogue: score, admission test, append
-    bool stored = false;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int ql = wn * 64 + ni * 32 + (lane & 31);
@@ -878,7 +885,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
                 if (row < r_end && s >= p.min_score) {
                   const int pos = atomicAdd(&cnt_lds[ql], 1);
                   if (pos < CAP) my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)row + p.index_base);
-                  stored = true;
+                  if (pos + 1 > CAP - BM) *need_compact = 1;  // this buffer could overflow on the next tile
                 }
               }
             }
@@ -886,8 +893,13 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
         }
       }
     }
-    if (__builtin_amdgcn_ballot_w64(stored) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Compaction is rare (O(log rows) times per query).  Only then do the appended keys have to be in
+    // memory for another wave to read, so only then does the workgroup pay a drain of its (otherwise
+    // still flying) LDS-DMA queues; normally the epilogue ends at this barrier.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TAVB_BARRIER();
+    if (*need_compact != 0) {  // workgroup-uniform: read after the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TAVB_BARRIER();
     for (int q = wave; q < BN; q += NTHREADS / 64) {
       const int n = cnt_lds[q];
@@ -907,6 +919,10 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     TAVB_BARRIER();
+    if (tid == 0) *need_compact = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TAVB_BARRIER();
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead LDS-DMA before the block retires
   __syncthreads();
@@ -971,7 +987,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   // grid: groups of 8 consecutive block ids = 8 different row ranges (one per XCD)
   if (p.variant == 4) {
     constexpr int NA4 = 6, NB4 = 3;
-    constexpr int LDS4 = (NA4 + NB4) * 16384 + BN * 8;
+    constexpr int LDS4 = (NA4 + NB4) * 16384 + BN * 8 + 16;
     auto go4 = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
       if (e != hipSuccess) return e;
@@ -983,6 +999,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 2: return go4(mfma_scan_kernel_v4<NA4, NB4, 2>);
       case 3: return go4(mfma_scan_kernel_v4<NA4, NB4, 3>);
       case 4: return go4(mfma_scan_kernel_v4<NA4, NB4, 4>);
+      case 256: return go4(mfma_scan_kernel_v4<NA4, NB4, 256>);  // everything except the admission test / appends
       case 34: return go4(mfma_scan_kernel_v4<NA4, NB4, 34>);  // MFMAs + barriers only
       case 32: return go4(mfma_scan_kernel_v4<NA4, NB4, 32>);  // MFMAs + LDS-DMA, no fragment reads
       case 36: return go4(mfma_scan_kernel_v4<NA4, NB4, 36>);  // same, corpus tile 0 only (L2 resident)
@@ -995,7 +1012,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   }
   if (p.variant == 3) {
     constexpr int NA3 = 6, NB3 = 3;
-    constexpr int LDS3 = (NA3 + NB3) * 16384 + BN * 8;
+    constexpr int LDS3 = (NA3 + NB3) * 16384 + BN * 8 + 16;
     auto go3 = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
       if (e != hipSuccess) return e;
