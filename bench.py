@@ -226,7 +226,7 @@ def main() -> None:
     ap.add_argument("--rows", type=int, default=None, help="override rows per GPU (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-tiled", action="store_true", help="cfg3: feed the MFMA kernel from the row-major corpus instead of the K-blocked image")
+    ap.add_argument("--tiled", action="store_true", help="cfg3: also build the K-blocked fp16 image and feed the MFMA kernel from it (measured: no gain)")
     ap.add_argument("--cfg5-subset", type=int, default=0, help="cfg5: message re-rank over a subset of this many ordinals (0 = full scan)")
     ap.add_argument("--cfg5-separate", action="store_true", help="cfg5: issue the six lookups as separate synchronous calls")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (e.g. scan_unroll=4)")
@@ -272,7 +272,7 @@ def main() -> None:
         with torch.cuda.stream(backend.stream):
             corpus = make_device_corpus(eng, rows, dim, 100_043 + rank, wl["dtype"])
         backend.set_shard(corpus, row_offset=rank * rows)
-        if wl["bound"] == "mfma" and not args.no_tiled:
+        if wl["bound"] == "mfma" and args.tiled:
             with torch.cuda.stream(backend.stream):
                 eng.build_tiled()
         searcher = ShardedSearcher(backend, always_collective=True)
@@ -280,7 +280,7 @@ def main() -> None:
         eng = _native.Engine(dev)
         corpus = make_device_corpus(eng, rows, dim, 1043, wl["dtype"])
         eng.set_corpus_tensor(corpus)
-        if wl["bound"] == "mfma" and not args.no_tiled:
+        if wl["bound"] == "mfma" and args.tiled:
             eng.build_tiled()  # K-blocked fp16 image beside the row-major corpus: what the MFMA kernel streams
         searcher = None
     for item in args.opt:

@@ -4,10 +4,10 @@ export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
 echo "== $(date -u +%FT%TZ)" | tee $OUT/round.log
-for CFG in "4 0 --no-tiled" "4 256 --no-tiled" "4 0" "4 256" "3 0" "3 0 --no-tiled"; do
+for CFG in "4 0" "4 512" "4 256"; do
   set -- $CFG
-  timeout 900 python bench.py --workload cfg3 --rows 4000000 --steps 4 --warmup 1 --no-cpu-baseline --opt mfma_variant=$1 --opt mfma_ablate=$2 ${3:-} > $OUT/abx.json 2> $OUT/abx.err
+  timeout 900 python bench.py --workload cfg3 --rows 4000000 --steps 4 --warmup 1 --no-cpu-baseline --opt mfma_variant=$1 --opt mfma_ablate=$2 > $OUT/abx.json 2> $OUT/abx.err
   python -c "
-import json;d=json.load(open('$OUT/abx.json'));print('variant $1 ablate $2 ${3:-tiled} kernel_ms', round(d['roofline']['kernel_avg_ms'],3), 'TF-eq', round(d['roofline']['achieved'],1))" | tee -a $OUT/round.log
+import json;d=json.load(open('$OUT/abx.json'));print('variant $1 ablate $2 kernel_ms', round(d['roofline']['kernel_avg_ms'],3), 'TF-eq', round(d['roofline']['achieved'],1))" | tee -a $OUT/round.log
 done
 echo "== done" | tee -a $OUT/round.log

@@ -593,20 +593,35 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
           any = any || (ABL == 0 && sc[r] > thr);
         }
         if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-          if (any) {
+          // slow path, taken by the whole wave when any lane admits something: every lane builds the
+          // bit mask of its admitted rows, reserves that many buffer slots with ONE LDS atomic (the
+          // latency of the returning atomic is paid once per 32x32 block, not once per key), then
+          // stores its keys with predicated stores.
+          const int64_t row_base = row0 + wm * 128 + mi * 32 + 4 * (lane >> 5);
+          unsigned admit = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              if (sc[r] > thr) {
-                const int64_t row = row0 + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float s = sc[r];
-                s = (s > 0.0f) ? s : 0.0f;
-                s = (s > 1.0f) ? 1.0f : s;
-                if (row < r_end && s >= p.min_score) {
-                  const int pos = atomicAdd(&cnt_lds[ql], 1);
-                  if (pos < CAP) my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)row + p.index_base);
-                  if (pos + 1 > CAP - BM) *need_compact = 1;  // this buffer could overflow on the next tile
-                }
-              }
+          for (int r = 0; r < 16; ++r) {
+            float s = sc[r];
+            s = (s > 0.0f) ? s : 0.0f;
+            s = (s > 1.0f) ? 1.0f : s;
+            const bool ok = (sc[r] > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s >= p.min_score);
+            admit |= ok ? (1u << r) : 0u;
+          }
+          const int n_adm = __popc(admit);
+          int pos = 0;
+          if (n_adm > 0) {
+            pos = atomicAdd(&cnt_lds[ql], n_adm);
+            if (pos + n_adm > CAP - BM) *need_compact = 1;  // this buffer could overflow on the next tile
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if ((admit >> r) & 1u) {
+              float s = sc[r];
+              s = (s > 0.0f) ? s : 0.0f;
+              s = (s > 1.0f) ? 1.0f : s;
+              if (pos < CAP)
+                my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
+              ++pos;
             }
           }
         }
@@ -870,24 +885,40 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
-          any = any || (ABL == 0 && sc[r] > thr);
+          any = any || ((ABL == 0 || ABL == 512) && sc[r] > thr);
         }
         if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi][ni]));
-        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-          if (any) {
+        if constexpr (ABL == 512) asm volatile("" ::"s"(__builtin_amdgcn_ballot_w64(any)));
+        if (ABL != 512 && __builtin_amdgcn_ballot_w64(any) != 0ull) {
+          // slow path, taken by the whole wave when any lane admits something: every lane builds the
+          // bit mask of its admitted rows, reserves that many buffer slots with ONE LDS atomic (the
+          // latency of the returning atomic is paid once per 32x32 block, not once per key), then
+          // stores its keys with predicated stores.
+          const int64_t row_base = row0 + wm * 128 + mi * 32 + 4 * (lane >> 5);
+          unsigned admit = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              if (sc[r] > thr) {
-                const int64_t row = row0 + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float s = sc[r];
-                s = (s > 0.0f) ? s : 0.0f;
-                s = (s > 1.0f) ? 1.0f : s;
-                if (row < r_end && s >= p.min_score) {
-                  const int pos = atomicAdd(&cnt_lds[ql], 1);
-                  if (pos < CAP) my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)row + p.index_base);
-                  if (pos + 1 > CAP - BM) *need_compact = 1;  // this buffer could overflow on the next tile
-                }
-              }
+          for (int r = 0; r < 16; ++r) {
+            float s = sc[r];
+            s = (s > 0.0f) ? s : 0.0f;
+            s = (s > 1.0f) ? 1.0f : s;
+            const bool ok = (sc[r] > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s >= p.min_score);
+            admit |= ok ? (1u << r) : 0u;
+          }
+          const int n_adm = __popc(admit);
+          int pos = 0;
+          if (n_adm > 0) {
+            pos = atomicAdd(&cnt_lds[ql], n_adm);
+            if (pos + n_adm > CAP - BM) *need_compact = 1;  // this buffer could overflow on the next tile
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if ((admit >> r) & 1u) {
+              float s = sc[r];
+              s = (s > 0.0f) ? s : 0.0f;
+              s = (s > 1.0f) ? 1.0f : s;
+              if (pos < CAP)
+                my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
+              ++pos;
             }
           }
         }
@@ -999,6 +1030,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 2: return go4(mfma_scan_kernel_v4<NA4, NB4, 2>);
       case 3: return go4(mfma_scan_kernel_v4<NA4, NB4, 3>);
       case 4: return go4(mfma_scan_kernel_v4<NA4, NB4, 4>);
+      case 512: return go4(mfma_scan_kernel_v4<NA4, NB4, 512>);  // admission test computed, slow path never taken
       case 256: return go4(mfma_scan_kernel_v4<NA4, NB4, 256>);  // everything except the admission test / appends
       case 34: return go4(mfma_scan_kernel_v4<NA4, NB4, 34>);  // MFMAs + barriers only
       case 32: return go4(mfma_scan_kernel_v4<NA4, NB4, 32>);  // MFMAs + LDS-DMA, no fragment reads
