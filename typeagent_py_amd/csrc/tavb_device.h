@@ -47,10 +47,24 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int lane /* wave-uniform */) 
   return ((u64)hi << 32) | (u64)lo;
 }
 
+// Sum over the 64 lanes, returned wave-uniform.  Four DPP adds (quad swaps, half-row mirror, row mirror:
+// full-rate VALU, no LDS crossbar) leave each 16-lane row holding its row sum; the four row sums are
+// read with v_readlane and added.  Fixed summation order, identical in every lane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_t(float v) {
+  const int x = __float_as_int(v);
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-  return v;  // identical in every lane (fp add commutes)
+  v = dpp_add_t<0xB1>(v);   // quad_perm [1,0,3,2]  (lane ^ 1)
+  v = dpp_add_t<0x4E>(v);   // quad_perm [2,3,0,1]  (lane ^ 2)
+  v = dpp_add_t<0x141>(v);  // row_half_mirror: the two quads of each 8 lanes
+  v = dpp_add_t<0x140>(v);  // row_mirror: the two halves of each 16-lane row
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ float wave_uniform(float v) {
