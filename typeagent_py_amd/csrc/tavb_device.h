@@ -41,6 +41,34 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src_lane) {
   return ((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo;
 }
 
+// Value of lane (l ^ M).  Strides below 16 stay inside a 16-lane DPP row and use DPP moves (VALU,
+// a few cycles of latency); 16 and 32 cross rows and go through ds_bpermute (~100 cycles).  The bitonic
+// stages that dominate merging and sorting are chains of such exchanges, so latency is what counts.
+template <int M>
+__device__ __forceinline__ int xor_lane_i32(int x, int lane) {
+  if constexpr (M == 1) {
+    return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+  } else if constexpr (M == 2) {
+    return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+  } else if constexpr (M == 4) {
+    // banks (groups of 4 lanes) 0 and 2 read 4 lanes up, banks 1 and 3 read 4 lanes down
+    int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);  // row_shl:4 -> lane i <- lane i+4
+    t = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);      // row_shr:4 -> lane i <- lane i-4
+    return t;
+  } else if constexpr (M == 8) {
+    return __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);  // row_ror:8 == lane ^ 8 within the row
+  } else {
+    return __shfl(x, lane ^ M, kWave);
+  }
+}
+
+template <int M>
+__device__ __forceinline__ u64 xor_lane_u64(u64 v, int lane) {
+  const int lo = xor_lane_i32<M>((int)(uint32_t)v, lane);
+  const int hi = xor_lane_i32<M>((int)(uint32_t)(v >> 32), lane);
+  return ((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo;
+}
+
 __device__ __forceinline__ u64 readlane_u64(u64 v, int lane /* wave-uniform */) {
   uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
   uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
@@ -136,16 +164,24 @@ struct WaveTopK {
     } else if constexpr (KPL == 2) {
       order(key[0], key[1]);
     }
+    exchange_stage<32>(lane);
+    exchange_stage<16>(lane);
+    exchange_stage<8>(lane);
+    exchange_stage<4>(lane);
+    exchange_stage<2>(lane);
+    exchange_stage<1>(lane);
+  }
+
+  // one stage of the descending bitonic merge: lanes l and l ^ M keep the larger / smaller key
+  template <int M>
+  __device__ __forceinline__ void exchange_stage(int lane) {
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-#pragma unroll
-      for (int s = 0; s < KPL; ++s) {
-        const u64 mine = key[s];
-        const u64 other = shfl_u64(mine, lane ^ m);
-        const bool keep_big = (lane & m) == 0;
-        const bool mine_big = mine > other;
-        key[s] = (keep_big == mine_big) ? mine : other;
-      }
+    for (int s = 0; s < KPL; ++s) {
+      const u64 mine = key[s];
+      const u64 other = xor_lane_u64<M>(mine, lane);
+      const bool keep_big = (lane & M) == 0;
+      const bool mine_big = mine > other;
+      key[s] = (keep_big == mine_big) ? mine : other;
     }
   }
 

@@ -88,20 +88,39 @@ __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
 }
 
 // ascending bitonic sort of one key per lane (lane 63 ends up with the largest)
-__device__ __forceinline__ u64 sort64_ascending(u64 key, int lane) {
-#pragma unroll
-  for (int size = 2; size <= 64; size <<= 1) {
-#pragma unroll
-    for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-      const u64 other = shfl_u64(key, lane ^ stride);
-      const bool asc_block = (lane & size) == 0 || size == 64;
-      const bool lower = (lane & stride) == 0;
-      const bool keep_min = (lower == asc_block);
-      const bool mine_small = key < other;
-      key = (keep_min == mine_small) ? key : other;
-    }
-  }
-  return key;
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ u64 sort_stage(u64 key, int lane) {
+  const u64 other = xor_lane_u64<STRIDE>(key, lane);
+  const bool asc_block = (lane & SIZE) == 0 || SIZE == 64;
+  const bool lower = (lane & STRIDE) == 0;
+  const bool keep_min = (lower == asc_block);
+  const bool mine_small = key < other;
+  return (keep_min == mine_small) ? key : other;
+}
+
+__device__ __forceinline__ u64 sort64_ascending(u64 k, int lane) {
+  k = sort_stage<2, 1>(k, lane);
+  k = sort_stage<4, 2>(k, lane);
+  k = sort_stage<4, 1>(k, lane);
+  k = sort_stage<8, 4>(k, lane);
+  k = sort_stage<8, 2>(k, lane);
+  k = sort_stage<8, 1>(k, lane);
+  k = sort_stage<16, 8>(k, lane);
+  k = sort_stage<16, 4>(k, lane);
+  k = sort_stage<16, 2>(k, lane);
+  k = sort_stage<16, 1>(k, lane);
+  k = sort_stage<32, 16>(k, lane);
+  k = sort_stage<32, 8>(k, lane);
+  k = sort_stage<32, 4>(k, lane);
+  k = sort_stage<32, 2>(k, lane);
+  k = sort_stage<32, 1>(k, lane);
+  k = sort_stage<64, 32>(k, lane);
+  k = sort_stage<64, 16>(k, lane);
+  k = sort_stage<64, 8>(k, lane);
+  k = sort_stage<64, 4>(k, lane);
+  k = sort_stage<64, 2>(k, lane);
+  k = sort_stage<64, 1>(k, lane);
+  return k;
 }
 
 // Reduce one query's candidate buffer (n unsorted keys) to its best 64, sorted best-first and
