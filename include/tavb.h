@@ -168,13 +168,14 @@ int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* 
 /* ---- measurement ------------------------------------------------------------ */
 /* HIP-event timing of the kernels this context launches, on the stream they run on.
  * kernel ids: 0 = streaming scan (dot + score + select), 1 = list merge,
- *             2 = MFMA batched scan, 3 = normalise, 4 = f32->f16 convert. */
+ *             2 = MFMA batched scan, 3 = normalise, 4 = f32->f16 convert / pack, 5 = MFMA sample pass. */
 #define TAVB_KERNEL_SCAN 0
 #define TAVB_KERNEL_MERGE 1
 #define TAVB_KERNEL_MFMA 2
 #define TAVB_KERNEL_NORMALIZE 3
 #define TAVB_KERNEL_CONVERT 4
-#define TAVB_KERNEL_COUNT 5
+#define TAVB_KERNEL_MFMA_SAMPLE 5 /* threshold-seeding pass of the MFMA path over the first rows */
+#define TAVB_KERNEL_COUNT 6
 int tavb_profile_enable(tavb_ctx* ctx, int32_t on);
 int tavb_profile_reset(tavb_ctx* ctx);
 int tavb_profile_read(tavb_ctx* ctx, int32_t kernel_id, double* out_total_ms, int64_t* out_launches);

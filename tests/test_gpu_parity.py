@@ -558,6 +558,32 @@ def test_mfma_on_k_blocked_image(n, nq, k, ms, splits, alone, variant):
     eng.close()
 
 
+@pytest.mark.parametrize("n,nq,k,ms,sample", [(70_001, 300, 10, 0.52, 4096), (40_000, 64, 32, 0.0, 2048), (33_000, 1024, 32, 0.0, 1024), (20_000, 40, 64, 0.0, 256)])
+def test_mfma_sample_pass_seeds_thresholds_without_changing_results(n, nq, k, ms, sample):
+    """The threshold-seeding pass over the first rows (a valid lower bound on every query's k-th best score)
+    must not change any answer: same ordinals/scores as with the pass switched off, and as the oracle."""
+    v, _ = make_corpus(n, 1536, 9300 + n % 91)
+    qs = make_queries(nq, 1536, 9301 + nq)
+    qs[0] = v[5]       # best hit inside the sample
+    qs[1] = v[n - 3]   # best hit far outside the sample
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    eng.set_option("mfma_min_batch", 32)
+    eng.set_option("mfma_sample_rows", sample)
+    eng.profile_enable(True)
+    eng.profile_reset()
+    with_pass = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
+    assert eng.profile_read(_native.KERNEL_MFMA_SAMPLE)[1] == 1 and eng.profile_read(_native.KERNEL_MFMA)[1] == 1
+    eng.set_option("mfma_sample_rows", 0)
+    without = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
+    v16, q16 = _f16(v), _f16(qs)
+    for qi in range(nq):
+        assert [(r.item, r.score) for r in with_pass[qi]] == [(r.item, r.score) for r in without[qi]]
+    for qi in list(range(0, nq, max(1, nq // 24))) + [1]:
+        vo.check_topk_parity(vo.scores_full(v16, q16[qi]), *items_scores(with_pass[qi]), k, ms)
+    assert with_pass[0][0].item == 5 and with_pass[1][0].item == n - 3
+
+
 def test_mfma_batch_equals_streaming_path_on_f16_representable_queries():
     v, _ = make_corpus(12_345, 1536, 7200)
     qs = _f16(make_queries(48, 1536, 7201))

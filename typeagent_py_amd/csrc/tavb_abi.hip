@@ -107,8 +107,9 @@ struct tavb_ctx {
   int64_t mfma_prio = 1;
   int64_t mfma_group = 0;
   int64_t mfma_use_tiled = 1;
+  int64_t mfma_sample_rows = 131072;  // rows of the threshold-seeding sample pass (0 = off)
 
-  Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand;
+  Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand, d_thr, d_sample_keys;
   Buffer h_stage{nullptr, 0, true};
   Buffer h_out{nullptr, 0, true};  // pinned + device-visible: the last kernel of a synchronous lookup writes its keys straight here
 
@@ -336,6 +337,8 @@ int tavb_destroy(tavb_ctx* c) {
   c->d_out.release();
   c->d_rows.release();
   c->d_cand.release();
+  c->d_thr.release();
+  c->d_sample_keys.release();
   c->h_stage.release();
   c->h_out.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -376,6 +379,9 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_variant") {
     if (v < 1 || v > 4) return fail(TAVB_E_INVALID, "mfma_variant must be 1..4");
     c->mfma_variant = v;
+  } else if (n == "mfma_sample_rows") {
+    if (v < 0) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= 0");
+    c->mfma_sample_rows = v;
   } else if (n == "mfma_use_tiled") {
     c->mfma_use_tiled = v ? 1 : 0;
   } else if (n == "mfma_group") {
@@ -731,6 +737,32 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     p.ablate = (int)c->mfma_ablate;
     p.prio = (int)c->mfma_prio;
     p.group_sel = (int)c->mfma_group;
+    p.thr_in = nullptr;
+    // Sample pass: the exact top-k of the first `mfma_sample_rows` rows gives every query a valid admission
+    // threshold (the k-th best score of a subset never exceeds the k-th best of the whole corpus), so the
+    // main pass starts selective instead of admitting its first 512 rows per query and compacting.
+    const int64_t sample = c->mfma_sample_rows;
+    if (sample > 0 && c->rows >= 8 * sample && c->mfma_ablate == 0) {
+      if (int rc = c->d_thr.reserve((size_t)nq_pad * sizeof(float))) return rc;
+      if (int rc = c->d_sample_keys.reserve((size_t)nq * k * sizeof(u64_t))) return rc;
+      tavb::MfmaParams ps = p;
+      ps.rows = sample;
+      ps.n_splits = tavb::mfma_pick_splits(sample, nq_pad, c->n_cu);
+      if (ps.n_splits > splits) ps.n_splits = splits;  // lists / candidate buffers are sized for `splits`
+      {
+        Timed t(c, TAVB_KERNEL_MFMA_SAMPLE);
+        hipError_t e = tavb::launch_mfma_scan(ps, c->stream);
+        if (e != hipSuccess) return fail(TAVB_E_HIP, "mfma sample launch failed: %s", hipGetErrorString(e));
+      }
+      hipError_t e = tavb::launch_merge(ps.lists, ps.n_splits, nq, k, /*query_major=*/true,
+                                        reinterpret_cast<u64_t*>(c->d_sample_keys.ptr), c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "sample merge launch failed: %s", hipGetErrorString(e));
+      TAVB_HIP(hipMemsetAsync(c->d_thr.ptr, 0xFF, (size_t)nq_pad * sizeof(float), c->stream));  // NaN bits: ignored by `>`
+      e = tavb::launch_sample_thresholds(reinterpret_cast<const u64_t*>(c->d_sample_keys.ptr), nq, k,
+                                         reinterpret_cast<float*>(c->d_thr.ptr), c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "threshold launch failed: %s", hipGetErrorString(e));
+      p.thr_in = reinterpret_cast<const float*>(c->d_thr.ptr);
+    }
     {
       Timed t(c, TAVB_KERNEL_MFMA);
       hipError_t e = tavb::launch_mfma_scan(p, c->stream);

@@ -64,8 +64,10 @@ struct MfmaParams {
   int32_t group_sel; // ping-pong grouping: 0 = wave>>2, 1 = wave&1, 2 = (wave>>1)&1
   int32_t prio;      // s_setprio placement: 0 none, 1 MFMA phase, 2 LOAD phase
   int32_t ablate;    // measurement only: bit 0 = drop MFMAs, bit 1 = drop LDS-DMA (garbage results)
+  const float* thr_in;  // optional per-query admission thresholds (device, [nq_padded]) from a sample pass
 };
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
+hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, float* thr, hipStream_t stream);
 int mfma_query_tile();                    // queries per workgroup tile
 int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu);
 bool mfma_supported(int dim, int k);

@@ -75,6 +75,7 @@ struct MfmaDeviceParams {
   float min_score;
   int32_t group_sel;
   int32_t a_tiled;  // corpus given as the K-blocked image of pack_tiled_kernel
+  const float* thr_in;  // optional [nq_padded] admission thresholds from a sample pass (exclusive bound)
 };
 
 // Pin a wave-uniform pointer into SGPRs.  Without this the compiler strength-reduces the eight
@@ -180,7 +181,11 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel(const MfmaDevicePar
   // admission is `score > thr`: start just below min_score (or at -inf when everything qualifies)
   const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
   for (int i = tid; i < BN; i += NTHREADS) {
-    thr_lds[i] = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
+    float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
+    const int qg0 = qtile * BN + i;
+    if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
+    else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best of the sample pass: a valid lower bound
+    thr_lds[i] = t0;
     cnt_lds[i] = 0;
   }
 
@@ -456,7 +461,11 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
 
   const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
   for (int i = tid; i < BN; i += NTHREADS) {
-    thr_lds[i] = (p.min_score != p.min_score) ? __builtin_inff() : thr0;
+    float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
+    const int qg0 = qtile * BN + i;
+    if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
+    else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best of the sample pass: a valid lower bound
+    thr_lds[i] = t0;
     cnt_lds[i] = 0;
   }
   if (tid == 0) *need_compact = 0;
@@ -735,7 +744,11 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
 
   const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
   for (int i = tid; i < BN; i += NTHREADS) {
-    thr_lds[i] = (p.min_score != p.min_score) ? __builtin_inff() : thr0;
+    float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
+    const int qg0 = qtile * BN + i;
+    if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
+    else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best of the sample pass: a valid lower bound
+    thr_lds[i] = t0;
     cnt_lds[i] = 0;
   }
   if (tid == 0) *need_compact = 0;
@@ -989,6 +1002,25 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
 
 }  // namespace
 
+// thr[q] = the largest float below the k-th best score of the sample pass (so that `score > thr` admits
+// every row scoring >= that k-th best), or -inf when the sample did not yield k hits.
+__global__ void sample_threshold_kernel(const u64* __restrict__ keys, int nq, int k, float* __restrict__ thr) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const u64 kth = keys[(size_t)q * k + (k - 1)];
+  float t = -__builtin_inff();
+  if (kth != 0ull) {
+    const uint32_t bits = (uint32_t)(kth >> 32);
+    t = bits ? __uint_as_float(bits - 1u) : -__builtin_inff();
+  }
+  thr[q] = t;
+}
+
+hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, float* thr, hipStream_t stream) {
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, keys, nq, k, thr);
+  return hipGetLastError();
+}
+
 int mfma_query_tile() { return BN; }
 
 bool mfma_supported(int dim, int k) { return dim % BK == 0 && dim >= BK && k >= 1 && k <= 64; }
@@ -1022,6 +1054,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.min_score = p.min_score;
   d.group_sel = p.group_sel;
   d.a_tiled = p.a_tiled;
+  d.thr_in = p.thr_in;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
   d.rows_per_split = ((per + BM - 1) / BM) * BM;
   if (!p.workspace) return hipErrorInvalidValue;
