@@ -802,6 +802,66 @@ def test_cfg3_full_size_batch_against_chunked_oracle():
     eng.close()
 
 
+def _two_rank_worker(rank, world, port, ret):
+    import os
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.synth import make_corpus, make_queries
+        from typeagent_py_amd.sharded import DeviceShardBackend, ShardedSearcher, shard_range
+
+        v, _ = make_corpus(30_001, 1536, 8200)
+        qs = make_queries(7, 1536, 8201)
+        lo, hi = shard_range(len(v), world, rank)
+        backend = DeviceShardBackend(0)  # both ranks share GPU 0 here; RCCL refuses that, so the exchange goes over gloo
+        with torch.cuda.stream(backend.stream):
+            shard = torch.from_numpy(v[lo:hi]).cuda()
+        backend.set_shard(shard, row_offset=lo)
+
+        def gather_over_gloo(local):
+            host = local.cpu()
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(parts, host)
+            return torch.stack(parts).contiguous().cuda()
+
+        searcher = ShardedSearcher(backend, gather_fn=gather_over_gloo)
+        res = searcher.search(torch.from_numpy(qs).cuda(), 32, 0.0)
+        ret[rank] = (res.ordinals.copy(), res.scores.copy(), res.counts.copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_device_kernels_gloo_exchange():
+    """Two processes, each holding half of the rows on the device with its ordinal offset baked into the
+    keys; per-shard HIP search + merge kernel on both ranks; only the exchange itself is gloo instead of
+    RCCL (two ranks cannot share one GPU under RCCL).  Both ranks must return the whole-corpus answer."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_two_rank_worker, args=(2, port, ret), nprocs=2, join=True)
+    v, _ = make_corpus(30_001, 1536, 8200)
+    qs = make_queries(7, 1536, 8201)
+    for qi in range(7):
+        np.testing.assert_array_equal(ret[0][0][qi], ret[1][0][qi])
+        np.testing.assert_array_equal(ret[0][1][qi], ret[1][1][qi])
+        rep = vo.check_topk_parity(vo.scores_full(v, qs[qi]), ret[0][0][qi].tolist(), ret[0][1][qi].tolist(), 32, 0.0)
+        assert rep.ordinals_bit_exact
+    assert ret[0][0].max() > 15_001  # hits from the second shard carry their global ordinals
+
+
 def test_device_only_corpus_and_lazy_host_copy():
     import torch
 

@@ -98,13 +98,14 @@ class ShardedSearcher:
     same queries (they are tiny next to the corpus: <= 3 MiB for 1024 x 1536 fp16, so the
     caller broadcasts/duplicates them) and every rank gets the same global result."""
 
-    def __init__(self, backend: ShardBackend, group=None, always_collective: bool = False):
+    def __init__(self, backend: ShardBackend, group=None, always_collective: bool = False, gather_fn=None):
         import torch.distributed as dist
 
         self.dist = dist
         self.backend = backend
         self.group = group
         self.always_collective = always_collective  # run the all-gather even for one rank (tests)
+        self.gather_fn = gather_fn  # test hook: (local [nq,k]) -> gathered [world,nq,k] by other means than RCCL
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -117,6 +118,8 @@ class ShardedSearcher:
         if self.world == 1 and not (self.always_collective and self.dist.is_initialized()):
             return local
         nq = local.shape[0]
+        if self.gather_fn is not None:
+            return self.backend.merge(self.gather_fn(local))
         gathered = self.backend.empty_gather(self.world, nq, k)
         stream = getattr(self.backend, "stream", None)
         if stream is not None:
