@@ -229,6 +229,7 @@ def main() -> None:
     ap.add_argument("--tiled", action="store_true", help="cfg3: also build the K-blocked fp16 image and feed the MFMA kernel from it (measured: no gain)")
     ap.add_argument("--cfg5-subset", type=int, default=0, help="cfg5: message re-rank over a subset of this many ordinals (0 = full scan)")
     ap.add_argument("--cfg5-separate", action="store_true", help="cfg5: issue the six lookups as separate synchronous calls")
+    ap.add_argument("--min-score", type=float, default=0.0, help="score threshold of the lookups (0.0 = every row survives: worst case for selection; 0.85 = the reference's related-terms default)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (e.g. scan_unroll=4)")
     args = ap.parse_args()
 
@@ -261,7 +262,8 @@ def main() -> None:
     torch.cuda.set_device(dev)
 
     rows, dim, k, nq = wl["rows"], wl["dim"], wl["k"], wl["nq"]
-    thr = float(_native.f32_threshold(0.0))
+    min_score = args.min_score
+    thr = float(_native.f32_threshold(min_score))
     queries = host_queries(max(64, nq), dim, 4242)  # identical on every rank
 
     if distributed:
@@ -295,10 +297,10 @@ def main() -> None:
             qi = i % len(queries)
             if searcher is None:
                 return eng.search(queries[qi], k, np.float32(thr))
-            return searcher.search(dq_all[qi:qi + 1], k, 0.0)
+            return searcher.search(dq_all[qi:qi + 1], k, min_score)
         if searcher is None:
             return eng.search_batch(queries[:nq], k, np.float32(thr))
-        return searcher.search(dq_all[:nq], k, 0.0)
+        return searcher.search(dq_all[:nq], k, min_score)
 
     for i in range(warmup):
         one_step(i)
@@ -378,7 +380,7 @@ def main() -> None:
             "dtype": "f32" if wl["dtype"] == "fp32" else "f16 storage, f32 accumulate",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: {rows}x{dim} {wl['dtype']} rows per GPU, {nq} quer{'y' if nq == 1 else 'ies'}/step, top-{k}, min_score 0.0",
+                "workload": f"{args.workload}: {rows}x{dim} {wl['dtype']} rows per GPU, {nq} quer{'y' if nq == 1 else 'ies'}/step, top-{k}, min_score {min_score}",
                 "rows_per_gpu": rows,
                 "total_rows": rows * world,
                 "queries_per_step": nq,
@@ -400,7 +402,7 @@ def main() -> None:
 
             o, s = eng.search(queries[0], k, np.float32(thr)) if n_host == rows else (None, None)
             if o is not None:
-                vo.check_topk_parity(vo.scores_full(host, queries[0]), o.tolist(), s.tolist(), k, 0.0)
+                vo.check_topk_parity(vo.scores_full(host, queries[0]), o.tolist(), s.tolist(), k, min_score)
                 out["parity_check"] = "query 0: top-k ordinals/scores match the oracle on the same corpus bytes"
             base = cpu_baseline(host, queries, k, args.cpu_seconds)
             if n_host != rows:
