@@ -377,7 +377,7 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch must be >= 1");
     c->mfma_min_batch = v;
   } else if (n == "mfma_variant") {
-    if (v < 1 || v > 5) return fail(TAVB_E_INVALID, "mfma_variant must be 1..5");
+    if (v < 1 || v > 4) return fail(TAVB_E_INVALID, "mfma_variant must be 1..4");
     c->mfma_variant = v;
   } else if (n == "mfma_sample_rows") {
     if (v < 0) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= 0");

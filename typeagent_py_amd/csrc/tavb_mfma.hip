@@ -1000,296 +1000,6 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// VARIANT 5: variant 3's ping-pong (the two wave groups half a phase apart) with variant 4's branch-free
-// stager, and the LDS-DMA issue moved out of the LOAD phase into the MFMA phase, where the four
-// instructions ride in the gaps behind the last four MFMAs (sched_group_barrier).  The LOAD phase is then
-// only the 12 fragment reads (~350 cycles) and fits under the other group's 16 MFMAs (512 cycles).
-//   group g, step S:  LOAD  { ds_reads of ring slot S;  [B stager: vmcnt -> B(S+1) landed];  lgkmcnt(0) }  s_barrier
-//                     MFMA  { 16 MFMAs | LDS-DMA of step S+D into the slot freed one step ago;
-//                             [A stager: vmcnt -> A(S+1) landed] }  s_barrier
-// ---------------------------------------------------------------------------------------------
-template <int NA, int NB, int ABL>
-__global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v5(const MfmaDeviceParams p) {
-  constexpr int KS = 32;
-  constexpr int SLOT = 256 * KS * 2;
-  constexpr int B_RING = NA * SLOT;
-  constexpr int CTRL = (NA + NB) * SLOT;
-  extern __shared__ __align__(16) unsigned char smem[];
-  float* thr_lds = reinterpret_cast<float*>(smem + CTRL);
-  int* cnt_lds = reinterpret_cast<int*>(smem + CTRL + BN * 4);
-  volatile int* need_compact = reinterpret_cast<volatile int*>(smem + CTRL + BN * 8);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2;
-  const int wn = wave & 3;
-  const bool is_a = wave < 4;  // waves 0-3 stage the corpus operand, waves 4-7 the query operand
-  const int lw = wave & 3;
-
-  const int b = blockIdx.x;
-  const int xcd = b & 7;
-  const int t = b >> 3;
-  const int qtile = t % p.n_qtiles;
-  const int split = (t / p.n_qtiles) * 8 + xcd;
-  if (split >= p.n_splits) return;
-  const int64_t r_begin = (int64_t)split * p.rows_per_split;
-  const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
-  const int logical_block = split * p.n_qtiles + qtile;
-  u64* my_cand = p.cand + (size_t)logical_block * BN * CAP;
-
-  const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
-  for (int i = tid; i < BN; i += NTHREADS) {
-    float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
-    const int qg0 = qtile * BN + i;
-    if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
-    else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best of the sample pass: a valid lower bound
-    thr_lds[i] = t0;
-    cnt_lds[i] = 0;
-  }
-  if (tid == 0) *need_compact = 0;
-
-  const int D = p.dim;
-  const int steps_per_tile = D / KS;  // even: D is a multiple of 64
-  const uint32_t row_bytes = (uint32_t)D * 2u;
-  const char* corpus = reinterpret_cast<const char*>(p.corpus);
-  const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * BN * row_bytes;
-  const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BM - 1) / BM) : 0;
-  if (n_tiles == 0) {
-    for (int q = wave; q < BN; q += NTHREADS / 64) {
-      const int qg = qtile * BN + q;
-      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.n_splits + split) * (size_t)p.k + lane] = 0ull;
-    }
-    return;
-  }
-
-  // ---- stager: instruction j covers operand rows (lw*4 + j)*16 .. +15, four 16-byte slots per row.
-  //      Branch-free: everything that differs between the A and B stagers is a scalar select.
-  const bool lin = is_a && p.a_tiled;  // K-blocked corpus image: 16 KiB per (tile, step), already in LDS order
-  uint32_t st_rowoff[4], st_slotoff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (lw * 4 + j) * 16 + (lane >> 2);
-    st_rowoff[j] = lin ? 0u : (uint32_t)row * row_bytes;
-    st_slotoff[j] = lin ? (uint32_t)((lw * 4 + j) * 1024 + lane * 16) : (uint32_t)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
-  }
-  const int ring_n = is_a ? NA : NB;
-  const uint32_t ring_base = (is_a ? 0u : (uint32_t)B_RING) + (uint32_t)lw * 4096u;
-  // running, wave-uniform source pointer of the next step to stage: +64 bytes per K step (+16 KiB in the
-  // K-blocked image); at the end of a tile's K range the A stager jumps to the next tile (or, past the last
-  // tile, back to the start of the last one: harmless reloads that keep the vmcnt bookkeeping uniform), the
-  // B stager back to k = 0.
-  const int64_t k_step = lin ? (int64_t)SLOT : (int64_t)(KS * 2);
-  const int64_t k_rewind = -(int64_t)(steps_per_tile - 1) * k_step;
-  const int64_t tile_jump = is_a ? (lin ? k_step : k_rewind + (int64_t)BM * row_bytes) : k_rewind;
-  const int64_t wrap_delta = k_rewind - k_step;        // added when the K range of a tile ends
-  const int64_t advance_delta = tile_jump - k_rewind;  // added on top when the stager moves on to the next tile
-  const char* st_ptr = is_a ? corpus + (size_t)((ABL & 4) ? 0 : r_begin) * row_bytes : qbase;
-  int64_t st_last_row = is_a ? (p.rows - 1 - r_begin) : 255;  // last valid row of the staged tile, relative to its row 0
-  int st_tiles_left = is_a ? n_tiles - 1 : 0;
-  int st_kt = 0, st_slot = 0;
-
-  auto stage_next = [&]() {
-    const char* g = sgpr_ptr(st_ptr);
-    // rows past the end of the corpus are clamped to its last row (they are masked in the epilogue)
-    const uint32_t max_rowoff = (uint32_t)(st_last_row < 255 ? st_last_row : 255) * row_bytes;
-    unsigned char* l = smem + ring_base + (uint32_t)st_slot * SLOT;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t off = (st_rowoff[j] < max_rowoff ? st_rowoff[j] : max_rowoff) + st_slotoff[j];
-      __builtin_amdgcn_global_load_lds((global_void*)(g + (size_t)off), (lds_void*)(l + j * 1024), 16, 0, 0);
-    }
-    st_slot = (st_slot + 1 == ring_n) ? 0 : st_slot + 1;
-    const bool wrap = (st_kt + 1 == steps_per_tile);
-    const bool advance = wrap && st_tiles_left > 0 && (ABL & 4) == 0;
-    st_kt = wrap ? 0 : st_kt + 1;
-    // arithmetic instead of a nested select: the compiler turns a select tree over run-time 64-bit values
-    // into a scratch-resident lookup table, which drags the whole stager state into scratch memory
-    st_ptr += k_step + (int64_t)wrap * wrap_delta + (int64_t)advance * advance_delta;
-    st_last_row -= advance ? BM : 0;
-    st_tiles_left -= advance ? 1 : 0;
-  };
-
-  const int frag_row = lane & 31;
-  const uint32_t frag_x = (uint32_t)(((lane >> 5) ^ ((frag_row >> 2) & 3)) << 4);
-  const uint32_t a_lane = (uint32_t)((wm * 128 + frag_row) * 64);
-  const uint32_t b_lane = (uint32_t)(B_RING + (wn * 64 + frag_row) * 64);
-
-  auto read_frags = [&](f16x8(&af)[2][4], f16x8(&bf)[2][2], int slot_a, int slot_b) {
-    const unsigned char* abase = smem + slot_a * SLOT;
-    const unsigned char* bbase = smem + slot_b * SLOT;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const uint32_t kx = (uint32_t)(kk << 5) ^ frag_x;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[kk][mi] = *reinterpret_cast<const f16x8*>(abase + (a_lane + kx) + mi * 2048);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bf[kk][ni] = *reinterpret_cast<const f16x8*>(bbase + (b_lane + kx) + ni * 2048);
-    }
-  };
-
-  // ---- prologue: DA / DB steps in flight, wait for step 0
-  constexpr int DA = NA - 1, DB = NB - 1;
-  if (is_a) {
-#pragma unroll 1
-    for (int i = 0; i < DA; ++i) stage_next();
-    wait_vmcnt<4 * (DA - 1)>();
-  } else {
-#pragma unroll 1
-    for (int i = 0; i < DB; ++i) stage_next();
-    wait_vmcnt<4 * (DB - 1)>();
-  }
-  TAVB_BARRIER();
-  if (!is_a) TAVB_BARRIER();  // group 1 (waves 4-7) runs one barrier interval behind group 0
-  int rd_a = 0, rd_b = 0;  // ring slots of the step being consumed
-
-  f32x16 acc[4][2];
-
-  auto step = [&]() {
-    // ---- LOAD phase
-    f16x8 af[2][4], bf[2][2];
-    read_frags(af, bf, rd_a, rd_b);
-    if (!is_a) wait_vmcnt<4 * (DB - 2)>();  // B of the next step has landed (this wave's newest DB-2 steps may still fly)
-    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): fragments in registers, the slot may be refilled
-    TAVB_BARRIER();
-    // ---- MFMA phase, with this wave's four LDS-DMA instructions behind the last four MFMAs
-    __builtin_amdgcn_s_setprio(1);
-    if constexpr ((ABL & 2) == 0) stage_next();
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          if constexpr ((ABL & 1) == 0)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
-          else
-            asm volatile("" ::"v"(af[kk][mi]), "v"(bf[kk][ni]));
-        }
-    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    if (is_a) wait_vmcnt<4 * (DA - 1)>();  // A of the next step has landed
-    TAVB_BARRIER();
-    rd_a = (rd_a + 1 == NA) ? 0 : rd_a + 1;
-    rd_b = (rd_b + 1 == NB) ? 0 : rd_b + 1;
-  };
-
-  for (int tile = 0; tile < n_tiles; ++tile) {
-    const int64_t row0 = r_begin + (int64_t)tile * BM;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-#pragma unroll 1
-    for (int kt = 0; kt < steps_per_tile; ++kt) step();
-    if (is_a) TAVB_BARRIER();  // re-align the groups for the epilogue
-
-    // ---- epilogue: score, admission test, append
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int ql = wn * 64 + ni * 32 + (lane & 31);
-      const float thr = thr_lds[ql];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        bool any = false;
-        float sc[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
-          any = any || ((ABL == 0 || ABL == 512) && sc[r] > thr);
-        }
-        if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi][ni]));
-        if constexpr (ABL == 512) asm volatile("" ::"s"(__builtin_amdgcn_ballot_w64(any)));
-        if (ABL != 512 && __builtin_amdgcn_ballot_w64(any) != 0ull) {
-          // slow path, taken by the whole wave when any lane admits something: every lane builds the
-          // bit mask of its admitted rows, reserves that many buffer slots with ONE LDS atomic (the
-          // latency of the returning atomic is paid once per 32x32 block, not once per key), then
-          // stores its keys with predicated stores.
-          const int64_t row_base = row0 + wm * 128 + mi * 32 + 4 * (lane >> 5);
-          unsigned admit = 0;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float s = sc[r];
-            s = (s > 0.0f) ? s : 0.0f;
-            s = (s > 1.0f) ? 1.0f : s;
-            const bool ok = (sc[r] > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s >= p.min_score);
-            admit |= ok ? (1u << r) : 0u;
-          }
-          const int n_adm = __popc(admit);
-          int pos = 0;
-          if (n_adm > 0) {
-            pos = atomicAdd(&cnt_lds[ql], n_adm);
-            if (pos + n_adm > CAP - BM) *need_compact = 1;  // this buffer could overflow on the next tile
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if ((admit >> r) & 1u) {
-              float s = sc[r];
-              s = (s > 0.0f) ? s : 0.0f;
-              s = (s > 1.0f) ? 1.0f : s;
-              if (pos < CAP)
-                my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
-              ++pos;
-            }
-          }
-        }
-      }
-    }
-    // Compaction is rare (O(log rows) times per query).  Only then do the appended keys have to be in
-    // memory for another wave to read, so only then does the workgroup pay a drain of its (otherwise
-    // still flying) LDS-DMA queues; normally the epilogue ends at this barrier.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    if (*need_compact != 0) {  // workgroup-uniform: read after the barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    for (int q = wave; q < BN; q += NTHREADS / 64) {
-      const int n = cnt_lds[q];
-      if (n > CAP - BM) {
-        u64* buf = my_cand + (size_t)q * CAP;
-        const WaveTopK<1> best = best_of_buffer(buf, n < CAP ? n : CAP, lane);
-        if (lane < p.k) buf[lane] = best.key[0];
-        const int kept = __popcll(__ballot(best.key[0] != 0ull && lane < p.k));
-        const u64 kth = best.at(p.k - 1);
-        if (lane == 0) {
-          cnt_lds[q] = kept;
-          const float kth_score = __uint_as_float((uint32_t)(kth >> 32));
-          if (kth != 0ull && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    if (tid == 0) *need_compact = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    }
-    if (!is_a) TAVB_BARRIER();  // stagger again
-  }
-  if (is_a) TAVB_BARRIER();  // pairs with group 1's last stagger barrier
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead LDS-DMA before the block retires
-  __syncthreads();
-
-  for (int q = wave; q < BN; q += NTHREADS / 64) {
-    const int qg = qtile * BN + q;
-    if (qg >= p.nq) continue;
-    const int n = cnt_lds[q];
-    const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane);
-    u64* out = p.lists + ((size_t)qg * p.n_splits + split) * (size_t)p.k;
-    if (lane < p.k) out[lane] = best.key[0];
-  }
-}
-
 }  // namespace
 
 // thr[q] = the largest float below the k-th best score of the sample pass (so that `score > thr` admits
@@ -1358,20 +1068,6 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
     return hipGetLastError();
   };
   // grid: groups of 8 consecutive block ids = 8 different row ranges (one per XCD)
-  if (p.variant == 5) {
-    constexpr int NA5 = 5, NB5 = 4;
-    constexpr int LDS5 = (NA5 + NB5) * 16384 + BN * 8 + 16;
-    auto go5 = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS5, stream, d);
-      return hipGetLastError();
-    };
-    switch (p.ablate) {
-      case 256: return go5(mfma_scan_kernel_v5<NA5, NB5, 256>);
-      default: return go5(mfma_scan_kernel_v5<NA5, NB5, 0>);
-    }
-  }
   if (p.variant == 4) {
     constexpr int NA4 = 6, NB4 = 3;
     constexpr int LDS4 = (NA4 + NB4) * 16384 + BN * 8 + 16;
