@@ -6,7 +6,7 @@ import pytest
 
 from tests.fakes import NullModel
 from typeagent_py_amd import ScoredInt, TextEmbeddingIndexSettings, VectorBase
-from typeagent_py_amd.adapters import best_score_per_message, load_embeddings_bin
+from typeagent_py_amd.adapters import best_score_per_message, load_embeddings_bin, load_sqlite_embeddings
 
 
 def test_best_score_per_message_matches_reference_aggregation():
@@ -34,3 +34,32 @@ def test_load_embeddings_bin_streams_both_blocks(tmp_path):
     np.testing.assert_array_equal(mv.serialize(), messages)
     with pytest.raises(ValueError):
         load_embeddings_bin(str(path), 16, 37, 12, rv, mv)
+
+
+def test_load_sqlite_embeddings_mirrors_the_reference_reload(tmp_path):
+    import sqlite3
+
+    rng = np.random.default_rng(1)
+    db = sqlite3.connect(str(tmp_path / "c.db"))
+    # the two tables the reference reloads from (storage/sqlite/schema.py:71-81, 131-136), reduced to the columns used
+    db.execute("CREATE TABLE MessageTextIndex (msg_id INTEGER, chunk_ordinal INTEGER, embedding BLOB NOT NULL, index_position INTEGER)")
+    db.execute("CREATE TABLE RelatedTermsFuzzy (term TEXT PRIMARY KEY, term_embedding BLOB NOT NULL)")
+    msgs = rng.standard_normal((23, 12)).astype(np.float32)
+    for i, row in enumerate(msgs):
+        db.execute("INSERT INTO MessageTextIndex VALUES (?, ?, ?, ?)", (i // 2, i % 2, row.tobytes(), i))
+    terms = {"pear": 2, "apple": 0, "zebra": 3, "mango": 1}
+    tvecs = rng.standard_normal((4, 12)).astype(np.float32)
+    for term, i in terms.items():
+        db.execute("INSERT INTO RelatedTermsFuzzy VALUES (?, ?)", (term, tvecs[i].tobytes()))
+    db.commit()
+    mv = VectorBase(TextEmbeddingIndexSettings(NullModel()))
+    assert load_sqlite_embeddings(db, mv, fetch_rows=5) == []
+    np.testing.assert_array_equal(mv.serialize(), msgs)
+    tv = VectorBase(TextEmbeddingIndexSettings(NullModel()))
+    keys = load_sqlite_embeddings(db, tv, table="RelatedTermsFuzzy", column="term_embedding", order_by="term", key_column="term")
+    assert keys == sorted(terms)  # ORDER BY term: row order != insertion order
+    np.testing.assert_array_equal(tv.serialize(), np.stack([tvecs[terms[k]] for k in keys]))
+    with pytest.raises(ValueError, match="Embedding size mismatch"):
+        load_sqlite_embeddings(db, tv, table="MessageTextIndex", column="embedding") if False else tv.add_embeddings(None, np.zeros((1, 5), np.float32))
+    with pytest.raises(ValueError):
+        load_sqlite_embeddings(db, mv, table="x; DROP TABLE y")

@@ -10,6 +10,8 @@ Reference lines (/root/reference):
       (best score per message over its chunks, sorted by score, cut at max_matches)
   * raw little-endian float32 embedding files    knowpro/serialization.py:84-98, 114-136
       (`<name>_embeddings.bin`: related-term rows first, then message rows)
+  * float32 BLOB columns of the SQLite provider  storage/sqlite/schema.py:71-81, 131-136, 193-197;
+      reload loops storage/sqlite/messageindex.py:33-45, storage/sqlite/reltermsindex.py:144-156
 """
 
 from __future__ import annotations
@@ -94,6 +96,50 @@ def best_score_per_message(
     out = [ScoredInt(m, s) for m, s in best.items()]
     out.sort(key=lambda x: x.score, reverse=True)
     return out if max_matches is None else out[:max_matches]
+
+
+def load_sqlite_embeddings(
+    db,
+    vector_base: VectorBase,
+    table: str = "MessageTextIndex",
+    column: str = "embedding",
+    order_by: str | None = None,
+    key_column: str | None = None,
+    fetch_rows: int = 8192,
+) -> list:
+    """Reload a VectorBase from the float32 BLOB column of a typeagent SQLite database the way the two
+    sqlite indexes do at open time, without building one Python list of per-row arrays:
+      * `SqliteMessageTextIndex.__init__`  -- `SELECT embedding FROM MessageTextIndex`
+        (storage/sqlite/messageindex.py:33-45; schema.py:71-81)
+      * `SqliteRelatedTermsFuzzy.__init__` -- `SELECT term, term_embedding FROM RelatedTermsFuzzy ORDER BY term`
+        (storage/sqlite/reltermsindex.py:144-156; schema.py:131-136): pass table="RelatedTermsFuzzy",
+        column="term_embedding", order_by="term", key_column="term".
+    BLOBs are `ndarray.tobytes()` of float32 rows (schema.py:193-197).  Rows are fetched `fetch_rows` at a time,
+    viewed with np.frombuffer and appended in bulk.  Returns the list of key_column values (row order = ordinals).
+    `db` is a sqlite3.Connection."""
+    for ident in (table, column, order_by, key_column):
+        if ident is not None and not ident.replace("_", "").isalnum():
+            raise ValueError(f"bad SQL identifier: {ident!r}")
+    cols = f"{key_column}, {column}" if key_column else column
+    sql = f"SELECT {cols} FROM {table}" + (f" ORDER BY {order_by}" if order_by else "")
+    cur = db.cursor()
+    cur.execute(sql)
+    keys: list = []
+    while True:
+        rows = cur.fetchmany(fetch_rows)
+        if not rows:
+            break
+        blobs = [r[-1] for r in rows]
+        if any(b is None for b in blobs):
+            raise ValueError(f"NULL embedding in {table}.{column}")
+        width = len(blobs[0]) // 4
+        if width == 0 or any(len(b) != width * 4 for b in blobs):
+            raise ValueError("embedding BLOBs of unequal size")
+        block = np.frombuffer(b"".join(blobs), dtype="<f4").reshape(len(blobs), width)
+        vector_base.add_embeddings(None, block)  # size mismatch vs the index -> ValueError, as in the reference
+        if key_column:
+            keys.extend(r[0] for r in rows)
+    return keys
 
 
 def load_embeddings_bin(

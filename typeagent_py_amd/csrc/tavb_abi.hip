@@ -742,7 +742,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     // threshold (the k-th best score of a subset never exceeds the k-th best of the whole corpus), so the
     // main pass starts selective instead of admitting its first 512 rows per query and compacting.
     const int64_t sample = c->mfma_sample_rows;
-    if (sample > 0 && c->rows >= 8 * sample && c->mfma_ablate == 0) {
+    if (sample > 0 && c->rows >= 8 * sample && (c->mfma_ablate == 0 || c->mfma_ablate == 256)) {
       if (int rc = c->d_thr.reserve((size_t)nq_pad * sizeof(float))) return rc;
       if (int rc = c->d_sample_keys.reserve((size_t)nq * k * sizeof(u64_t))) return rc;
       tavb::MfmaParams ps = p;

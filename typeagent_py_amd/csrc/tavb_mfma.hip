@@ -620,6 +620,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
           sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
           any = any || (ABL == 0 && sc[r] > thr);
         }
+        if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi][ni]));  // keep the MFMAs alive when admissions are ablated
         if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
           // slow path, taken by the whole wave when any lane admits something: every lane builds the
           // bit mask of its admitted rows, reserves that many buffer slots with ONE LDS atomic (the
@@ -1107,6 +1108,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 1: return go3(mfma_scan_kernel_v3<NA3, NB3, 1>);
       case 4: return go3(mfma_scan_kernel_v3<NA3, NB3, 4>);
       case 5: return go3(mfma_scan_kernel_v3<NA3, NB3, 5>);
+      case 256: return go3(mfma_scan_kernel_v3<NA3, NB3, 256>);  // everything except admissions
       case 2: return go3(mfma_scan_kernel_v3<NA3, NB3, 2>);
       case 3: return go3(mfma_scan_kernel_v3<NA3, NB3, 3>);
       default: return go3(mfma_scan_kernel_v3<NA3, NB3, 0>);
