@@ -400,6 +400,33 @@ def test_lookup_texts_batched_equals_sequential_fuzzy_lookup():
     assert asyncio.run(lookup_texts_batched(vb, [])) == []
 
 
+def test_message_lookup_adapters_match_provider_semantics():
+    """chunk rows -> message ordinals, in the order of operations of each provider."""
+    from typeagent_py_amd.adapters import lookup_messages_by_embedding, lookup_messages_in_subset
+
+    v, q = make_corpus(6000, 384, 9400)
+    row_to_msg = (np.arange(6000) // 3).tolist()  # three chunks per message
+    vb = new_vb(v)
+    sc = vo.scores_full(v, q)
+    # sqlite style: top-25 chunks of the whole corpus, then the message filter, then max per message
+    got = lookup_messages_by_embedding(vb, q, row_to_msg, max_matches=25, threshold_score=0.5, accept=lambda m: m % 2 == 0)
+    top = sorted(range(6000), key=lambda i: (-sc[i], i))[:25]
+    want: dict[int, float] = {}
+    for i in top:
+        if sc[i] >= np.float32(0.5) and (i // 3) % 2 == 0:
+            want[i // 3] = max(want.get(i // 3, 0.0), float(sc[i]))
+    want_sorted = sorted(want.items(), key=lambda t: -t[1])
+    assert [h.item for h in got] == [m for m, _ in want_sorted]
+    np.testing.assert_allclose([h.score for h in got], [s for _, s in want_sorted], atol=SCORE_TOL, rtol=0)
+    # memory style: gather the subset rows, then max per message
+    subset = list(range(100, 400))
+    got = lookup_messages_in_subset(vb, q, subset, row_to_msg, max_matches=10, threshold_score=0.0)
+    best: dict[int, float] = {}
+    for i in sorted(subset, key=lambda i: (-sc[i], i))[:10]:
+        best[i // 3] = max(best.get(i // 3, 0.0), float(sc[i]))
+    assert [h.item for h in got] == [m for m, _ in sorted(best.items(), key=lambda t: -t[1])]
+
+
 def test_subset_semantics_from_reference_tests():
     vb = VectorBase(TextEmbeddingIndexSettings(create_test_embedding_model()))
     samples = [np.array(x, dtype=np.float32) for x in ([0.1, 0.2, 0.3], [0.4, 0.5, 0.6], [0.7, 0.8, 0.9])]

@@ -98,6 +98,36 @@ def best_score_per_message(
     return out if max_matches is None else out[:max_matches]
 
 
+def lookup_messages_by_embedding(
+    vector_base: VectorBase,
+    embedding,
+    row_to_message,
+    max_matches: int | None = None,
+    threshold_score: float | None = None,
+    accept: Callable[[int], bool] | None = None,
+) -> list[ScoredInt]:
+    """`SqliteMessageTextIndex.lookup_by_embedding` / `lookup_in_subset_by_embedding` restated on the device
+    path (storage/sqlite/messageindex.py:296-326): ONE full-corpus top-`max_matches` chunk lookup, THEN the
+    message-ordinal filter, THEN best score per message, THEN the cut -- in that order, so that it returns
+    exactly what the sqlite provider returns (possibly fewer than `max_matches` messages)."""
+    hits = vector_base.fuzzy_lookup_embedding(embedding, max_hits=max_matches, min_score=threshold_score)
+    return best_score_per_message(hits, row_to_message, max_matches, accept)
+
+
+def lookup_messages_in_subset(
+    vector_base: VectorBase,
+    embedding,
+    rows_of_subset: Sequence[int],
+    row_to_message,
+    max_matches: int | None = None,
+    threshold_score: float | None = None,
+) -> list[ScoredInt]:
+    """The memory provider's form (storage/memory/messageindex.py:173-207 via knowpro/textlocindex.py:164-177):
+    a true subset gather on the device, then best score per message and the cut."""
+    hits = vector_base.fuzzy_lookup_embedding_in_subset(embedding, list(rows_of_subset), max_hits=max_matches, min_score=threshold_score)
+    return best_score_per_message(hits, row_to_message, max_matches)
+
+
 def load_sqlite_embeddings(
     db,
     vector_base: VectorBase,
