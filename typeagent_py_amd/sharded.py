@@ -65,6 +65,8 @@ class DeviceShardBackend:
         self.stream = torch.cuda.Stream(self.device)
         with torch.cuda.stream(self.stream):
             self.engine = _native.Engine(self.device, use_torch_stream=True)
+        self._pinned: dict = {}
+        self._gather: dict = {}
 
     def set_shard(self, tensor, row_offset: int, rows: int | None = None) -> None:
         self.engine.set_corpus_tensor(tensor, rows=rows, ordinal_base=row_offset)
@@ -78,12 +80,25 @@ class DeviceShardBackend:
             return self.engine.merge_device(gathered)
 
     def to_host(self, keys) -> np.ndarray:
+        # pinned staging buffer, reused: one async copy + one stream sync, no allocation per lookup
+        shape = tuple(keys.shape)
+        pinned = self._pinned.get(shape)
+        if pinned is None:
+            pinned = self.torch.empty(shape, dtype=self.torch.int64).pin_memory()
+            self._pinned[shape] = pinned
         with self.torch.cuda.stream(self.stream):
-            host = keys.cpu()
-        return host.numpy()
+            pinned.copy_(keys, non_blocking=True)
+        self.stream.synchronize()
+        return pinned.numpy().copy()
 
     def empty_gather(self, world: int, nq: int, k: int):
-        return self.torch.empty((world, nq, k), dtype=self.torch.int64, device=self.torch.device("cuda", self.device))
+        shape = (world, nq, k)
+        buf = self._gather.get(shape)
+        if buf is None:
+            with self.torch.cuda.stream(self.stream):
+                buf = self.torch.empty(shape, dtype=self.torch.int64, device=self.torch.device("cuda", self.device))
+            self._gather[shape] = buf
+        return buf
 
 
 @dataclass
