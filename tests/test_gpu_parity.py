@@ -611,6 +611,28 @@ def test_mfma_sample_pass_seeds_thresholds_without_changing_results(n, nq, k, ms
     assert with_pass[0][0].item == 5 and with_pass[1][0].item == n - 3
 
 
+@pytest.mark.parametrize("opts", [{"mfma_rendezvous": 1}, {"mfma_a_nt": 1}, {"mfma_rendezvous": 1, "mfma_a_nt": 1}])
+def test_mfma_rendezvous_and_stream_policy_do_not_change_results(opts):
+    """The tile rendezvous between the workgroups of a row range and the non-temporal corpus stream are scheduling /
+    cache-policy knobs: identical answers with and without them (1024 queries = 4 query tiles per row range)."""
+    n, nq, k = 150_000, 1024, 32
+    v, _ = make_corpus(n, 1536, 9400)
+    qs = make_queries(nq, 1536, 9401)
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    eng.set_option("mfma_min_batch", 32)
+    base = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    for name, val in opts.items():
+        eng.set_option(name, val)
+    for _ in range(2):  # counters are re-zeroed per launch
+        tuned = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+        for a, b in zip(base, tuned):
+            assert [(r.item, r.score) for r in a] == [(r.item, r.score) for r in b]
+    v16, q16 = _f16(v), _f16(qs)
+    for qi in range(0, nq, 97):
+        vo.check_topk_parity(vo.scores_full(v16, q16[qi]), *items_scores(tuned[qi]), k, 0.0)
+
+
 def test_mfma_batch_equals_streaming_path_on_f16_representable_queries():
     v, _ = make_corpus(12_345, 1536, 7200)
     qs = _f16(make_queries(48, 1536, 7201))

@@ -105,6 +105,8 @@ struct tavb_ctx {
   int64_t mfma_variant = 3;
   int64_t mfma_ablate = 0;
   int64_t mfma_prio = 1;
+  int64_t mfma_rendezvous = 0;
+  int64_t mfma_a_nt = 0;
   int64_t mfma_group = 0;
   int64_t mfma_use_tiled = 1;
   int64_t mfma_sample_rows = 131072;  // rows of the threshold-seeding sample pass (0 = off)
@@ -387,6 +389,10 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_group") {
     if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_group must be 0..2");
     c->mfma_group = v;
+  } else if (n == "mfma_rendezvous") {
+    c->mfma_rendezvous = v ? 1 : 0;
+  } else if (n == "mfma_a_nt") {
+    c->mfma_a_nt = v ? 1 : 0;
   } else if (n == "mfma_prio") {
     if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_prio must be 0..2");
     c->mfma_prio = v;
@@ -736,6 +742,8 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     p.variant = (int)c->mfma_variant;
     p.ablate = (int)c->mfma_ablate;
     p.prio = (int)c->mfma_prio;
+    p.rendezvous = (int)c->mfma_rendezvous;
+    p.a_nt = (int)c->mfma_a_nt;
     p.group_sel = (int)c->mfma_group;
     p.thr_in = nullptr;
     // Sample pass: the exact top-k of the first `mfma_sample_rows` rows gives every query a valid admission

@@ -65,6 +65,8 @@ struct MfmaParams {
   int32_t prio;      // s_setprio placement: 0 none, 1 MFMA phase, 2 LOAD phase
   int32_t ablate;    // measurement only: bit 0 = drop MFMAs, bit 1 = drop LDS-DMA (garbage results)
   const float* thr_in;  // optional per-query admission thresholds (device, [nq_padded]) from a sample pass
+  int32_t rendezvous;   // variant 3: the workgroups of a row range meet at every tile start (L2 sharing of corpus slices)
+  int32_t a_nt;         // variant 3: non-temporal policy on the corpus LDS-DMA stream
 };
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
 hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, float* thr, hipStream_t stream);

@@ -76,6 +76,7 @@ struct MfmaDeviceParams {
   int32_t group_sel;
   int32_t a_tiled;  // corpus given as the K-blocked image of pack_tiled_kernel
   const float* thr_in;  // optional [nq_padded] admission thresholds from a sample pass (exclusive bound)
+  int* sync;            // optional [n_splits] tile rendezvous counters (zeroed before the launch), variant 3
 };
 
 // Pin a wave-uniform pointer into SGPRs.  Without this the compiler strength-reduces the eight
@@ -428,7 +429,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int NA, int NB, int ABL>
+template <int NA, int NB, int ABL, int A_AUX = 0>
 __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDeviceParams p) {
   constexpr int KS = 32;                 // halves per step
   constexpr int SLOT = 256 * KS * 2;     // 16 KiB: one operand, one step
@@ -505,8 +506,34 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
   int st_slot_idx = 0;  // ring slot it goes to
   set_offsets(r_begin, group == 0);
 
+  // Tile rendezvous.  The n_qtiles workgroups of a row range stream the same corpus rows and sit on the same XCD
+  // (same L2).  Left alone they drift apart (their admission work differs) until each re-read of a corpus slice
+  // misses L2 and comes from the Infinity Cache at a third of the rate.  So the corpus stagers meet at every tile
+  // start: one lane counts the workgroup in, the stager waves poll the counter with a scalar load (lgkmcnt: the
+  // counted vmcnt queue of the LDS-DMA stream is left alone) until all n_qtiles workgroups have arrived.  The wait is
+  // bounded -- a peer that is not resident (fewer free CUs than workgroups) only costs the first time-out, after
+  // which this workgroup stops waiting -- so the result never depends on it.
+  int* const sync_ctr = (p.sync != nullptr && p.n_qtiles > 1) ? p.sync + split : nullptr;
+  bool sync_on = sync_ctr != nullptr;
+  auto rendezvous = [&](int tile) {
+    if (lw == 0 && lane == 0) __hip_atomic_fetch_add(sync_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!sync_on) return;
+    const int want = p.n_qtiles * (tile + 1);
+    for (int spin = 0;; ++spin) {
+      int seen;
+      asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(sync_ctr) : "memory");
+      if (seen >= want) break;
+      if (spin >= 256) {  // ~100 us: give up for good
+        sync_on = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  };
+
   auto stage_next = [&]() {
     if (group == 0) {
+      if (sync_ctr != nullptr && st_kt == 0 && st_tile < n_tiles) rendezvous(st_tile);
       const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
       const int64_t src_row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM;  // ablation: every block re-reads tile 0 (L2 resident)
       const char* g = p.a_tiled ? sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * SLOT)  // block (tile, step): 16 KiB
@@ -514,7 +541,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
       unsigned char* l = smem + st_slot_idx * SLOT + lw * 4096;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_global_load_lds((global_void*)(g + (size_t)st_off[j]), (lds_void*)(l + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((global_void*)(g + (size_t)st_off[j]), (lds_void*)(l + j * 1024), 16, 0, A_AUX);
       if (++st_slot_idx == NA) st_slot_idx = 0;
       if (++st_kt == steps_per_tile) {
         st_kt = 0;
@@ -1035,8 +1062,13 @@ int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu) {
   return splits;
 }
 
-size_t mfma_workspace_bytes(int n_splits, int nq_padded) {
+static size_t mfma_cand_bytes(int n_splits, int nq_padded) {
   return (size_t)n_splits * (size_t)(nq_padded / BN) * BN * CAP * sizeof(u64);
+}
+
+size_t mfma_workspace_bytes(int n_splits, int nq_padded) {
+  // candidate buffers, then one rendezvous counter per row range (padded to 256 bytes)
+  return mfma_cand_bytes(n_splits, nq_padded) + (((size_t)n_splits * sizeof(int) + 255) & ~(size_t)255);
 }
 
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
@@ -1060,6 +1092,12 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.rows_per_split = ((per + BM - 1) / BM) * BM;
   if (!p.workspace) return hipErrorInvalidValue;
   d.cand = p.workspace;
+  d.sync = nullptr;
+  if (p.rendezvous && p.variant == 3 && d.n_qtiles > 1) {
+    d.sync = reinterpret_cast<int*>(reinterpret_cast<char*>(p.workspace) + mfma_cand_bytes(p.n_splits, p.nq_padded));
+    hipError_t e = hipMemsetAsync(d.sync, 0, (size_t)p.n_splits * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+  }
   const int groups = (p.n_splits + 7) / 8;
   const int grid = groups * d.n_qtiles * 8;
   auto go = [&](auto kern) -> hipError_t {
@@ -1111,7 +1149,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 256: return go3(mfma_scan_kernel_v3<NA3, NB3, 256>);  // everything except admissions
       case 2: return go3(mfma_scan_kernel_v3<NA3, NB3, 2>);
       case 3: return go3(mfma_scan_kernel_v3<NA3, NB3, 3>);
-      default: return go3(mfma_scan_kernel_v3<NA3, NB3, 0>);
+      default: return p.a_nt ? go3(mfma_scan_kernel_v3<NA3, NB3, 0, 2>) : go3(mfma_scan_kernel_v3<NA3, NB3, 0>);
     }
   }
   if (p.variant == 1) return go(mfma_scan_kernel<1, 0, 0>);
