@@ -585,30 +585,48 @@ def test_mfma_on_k_blocked_image(n, nq, k, ms, splits, alone, variant):
     eng.close()
 
 
-@pytest.mark.parametrize("n,nq,k,ms,sample", [(70_001, 300, 10, 0.52, 4096), (40_000, 64, 32, 0.0, 2048), (33_000, 1024, 32, 0.0, 1024), (20_000, 40, 64, 0.0, 256)])
-def test_mfma_sample_pass_seeds_thresholds_without_changing_results(n, nq, k, ms, sample):
-    """The threshold-seeding pass over the first rows (a valid lower bound on every query's k-th best score)
-    must not change any answer: same ordinals/scores as with the pass switched off, and as the oracle."""
+def _ladder_phases(rows: int, sample: int, growth: int) -> int:
+    """Phase count of the threshold ladder (tavb_abi.hip, tavb_search_device_dispatch)."""
+    sample = (sample + 255) // 256 * 256
+    if sample <= 0 or rows < 8 * sample:
+        return 1
+    bounds, done = 2, sample
+    while growth > 0 and done * (growth + 1) * 2 <= rows and bounds < 8:
+        done += done * growth
+        bounds += 1
+    return bounds
+
+
+@pytest.mark.parametrize("n,nq,k,ms,sample,ladder", [(70_001, 300, 10, 0.52, 4096, 0), (70_001, 300, 10, 0.52, 2048, 4), (40_000, 64, 32, 0.0, 2048, 0),
+                                                      (33_000, 1024, 32, 0.0, 1024, 1), (20_000, 40, 64, 0.0, 256, 4), (150_000, 256, 32, 0.0, 512, 2)])
+def test_mfma_threshold_ladder_does_not_change_results(n, nq, k, ms, sample, ladder):
+    """The phases of the threshold ladder (every row scanned once; the k-th best so far, a valid lower bound on every
+    query's final k-th best score, seeds the next phase's admission test) must not change any answer: same
+    ordinals/scores as a single un-seeded pass, and as the oracle."""
     v, _ = make_corpus(n, 1536, 9300 + n % 91)
     qs = make_queries(nq, 1536, 9301 + nq)
-    qs[0] = v[5]       # best hit inside the sample
-    qs[1] = v[n - 3]   # best hit far outside the sample
+    qs[0] = v[5]       # best hit inside the first phase
+    qs[1] = v[n - 3]   # best hit in the last phase
+    qs[2] = v[sample + 7]  # best hit right behind the first boundary
     vb = new_vb(v, dtype="fp16")
     eng = vb.engine
     eng.set_option("mfma_min_batch", 32)
     eng.set_option("mfma_sample_rows", sample)
+    eng.set_option("mfma_ladder", ladder)
     eng.profile_enable(True)
     eng.profile_reset()
     with_pass = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
-    assert eng.profile_read(_native.KERNEL_MFMA_SAMPLE)[1] == 1 and eng.profile_read(_native.KERNEL_MFMA)[1] == 1
+    phases = _ladder_phases(n, sample, ladder)
+    assert phases >= 2 and (ladder == 0) == (phases == 2)
+    assert eng.profile_read(_native.KERNEL_MFMA_SAMPLE)[1] == phases - 1 and eng.profile_read(_native.KERNEL_MFMA)[1] == 1
     eng.set_option("mfma_sample_rows", 0)
     without = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
     v16, q16 = _f16(v), _f16(qs)
     for qi in range(nq):
         assert [(r.item, r.score) for r in with_pass[qi]] == [(r.item, r.score) for r in without[qi]]
-    for qi in list(range(0, nq, max(1, nq // 24))) + [1]:
+    for qi in list(range(0, nq, max(1, nq // 24))) + [1, 2]:
         vo.check_topk_parity(vo.scores_full(v16, q16[qi]), *items_scores(with_pass[qi]), k, ms)
-    assert with_pass[0][0].item == 5 and with_pass[1][0].item == n - 3
+    assert with_pass[0][0].item == 5 and with_pass[1][0].item == n - 3 and with_pass[2][0].item == sample + 7
 
 
 @pytest.mark.parametrize("opts", [{"mfma_rendezvous": 1}, {"mfma_a_nt": 1}, {"mfma_rendezvous": 1, "mfma_a_nt": 1}])

@@ -109,7 +109,8 @@ struct tavb_ctx {
   int64_t mfma_a_nt = 0;
   int64_t mfma_group = 0;
   int64_t mfma_use_tiled = 1;
-  int64_t mfma_sample_rows = 131072;  // rows of the threshold-seeding sample pass (0 = off)
+  int64_t mfma_sample_rows = 131072;  // rows of the first (threshold-seeding) phase (0 = one phase, no seeding)
+  int64_t mfma_ladder = 4;            // each further phase scans this many times the rows scanned so far (0 = seed once)
 
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand, d_thr, d_sample_keys;
   Buffer h_stage{nullptr, 0, true};
@@ -389,6 +390,9 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_group") {
     if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_group must be 0..2");
     c->mfma_group = v;
+  } else if (n == "mfma_ladder") {
+    if (v < 0 || v > 64) return fail(TAVB_E_INVALID, "mfma_ladder must be 0..64");
+    c->mfma_ladder = v;
   } else if (n == "mfma_rendezvous") {
     c->mfma_rendezvous = v ? 1 : 0;
   } else if (n == "mfma_a_nt") {
@@ -420,6 +424,8 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "force_tier") *out = c->geom.tier;
   else if (n == "mfma_min_batch") *out = c->mfma_min_batch;
   else if (n == "mfma_splits") *out = c->mfma_splits;
+  else if (n == "mfma_ladder") *out = c->mfma_ladder;
+  else if (n == "mfma_sample_rows") *out = c->mfma_sample_rows;
   else if (n == "mfma_variant") *out = c->mfma_variant;
   else if (n == "compute_units") *out = c->n_cu;
   else if (n == "last_tier") *out = c->last_tier;
@@ -721,7 +727,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
       if (e != hipSuccess) return fail(TAVB_E_HIP, "query convert launch failed: %s", hipGetErrorString(e));
     }
     const int splits = c->mfma_splits > 0 ? (int)c->mfma_splits : tavb::mfma_pick_splits(c->rows, nq_pad, c->n_cu);
-    if (int rc = c->d_lists.reserve((size_t)nq * splits * k * sizeof(u64_t))) return rc;
+    if (int rc = c->d_lists.reserve((size_t)nq * (splits + 1) * k * sizeof(u64_t))) return rc;  // + the carried-over top-k
     if (int rc = c->d_cand.reserve(tavb::mfma_workspace_bytes(splits, nq_pad))) return rc;
     tavb::MfmaParams p{};
     const bool use_tiled = c->tiled && c->mfma_variant >= 3 && c->mfma_use_tiled;
@@ -746,40 +752,65 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     p.a_nt = (int)c->mfma_a_nt;
     p.group_sel = (int)c->mfma_group;
     p.thr_in = nullptr;
-    // Sample pass: the exact top-k of the first `mfma_sample_rows` rows gives every query a valid admission
-    // threshold (the k-th best score of a subset never exceeds the k-th best of the whole corpus), so the
-    // main pass starts selective instead of admitting its first 512 rows per query and compacting.
-    const int64_t sample = c->mfma_sample_rows;
+    // Threshold ladder.  The corpus is scanned in phases of growing size -- the first `mfma_sample_rows` rows, then
+    // `mfma_ladder` times everything scanned so far, ..., then the rest -- every row exactly once.  After each
+    // phase the exact top-k so far is merged; its k-th best score is a valid admission threshold for every later row
+    // (the k-th best of a subset never exceeds the k-th best of the whole corpus), so each phase starts selective
+    // instead of admitting whatever comes first and compacting, and the running top-k rides along as one more list
+    // of the next phase's merge.  Expected admissions per query drop from k * rows / sample (one seeding phase)
+    // to ~k * ladder per phase.  Results do not depend on the phase boundaries.
+    std::vector<int64_t> bounds;  // phase i scans rows [bounds[i], bounds[i+1])
+    bounds.push_back(0);
+    const int64_t sample = (c->mfma_sample_rows + 255) / 256 * 256;
     if (sample > 0 && c->rows >= 8 * sample && (c->mfma_ablate == 0 || c->mfma_ablate == 256)) {
+      int64_t done = sample;
+      bounds.push_back(done);
+      const int64_t growth = c->mfma_ladder;
+      while (growth > 0 && done * (growth + 1) * 2 <= c->rows && bounds.size() < 8) {
+        done += done * growth;
+        bounds.push_back(done);
+      }
+    }
+    bounds.push_back(c->rows);
+    const int n_phases = (int)bounds.size() - 1;
+    if (n_phases > 1) {
       if (int rc = c->d_thr.reserve((size_t)nq_pad * sizeof(float))) return rc;
       if (int rc = c->d_sample_keys.reserve((size_t)nq * k * sizeof(u64_t))) return rc;
-      tavb::MfmaParams ps = p;
-      ps.rows = sample;
-      ps.n_splits = tavb::mfma_pick_splits(sample, nq_pad, c->n_cu);
-      if (ps.n_splits > splits) ps.n_splits = splits;  // lists / candidate buffers are sized for `splits`
-      {
-        Timed t(c, TAVB_KERNEL_MFMA_SAMPLE);
-        hipError_t e = tavb::launch_mfma_scan(ps, c->stream);
-        if (e != hipSuccess) return fail(TAVB_E_HIP, "mfma sample launch failed: %s", hipGetErrorString(e));
+    }
+    const size_t row_bytes = (size_t)c->dim * 2;
+    for (int ph = 0; ph < n_phases; ++ph) {
+      const bool last = (ph == n_phases - 1);
+      tavb::MfmaParams pp = p;
+      pp.corpus = reinterpret_cast<const char*>(p.corpus) + (size_t)bounds[ph] * row_bytes;  // same offset in the K-blocked image
+      pp.rows = bounds[ph + 1] - bounds[ph];
+      pp.index_base = index_base + (uint32_t)bounds[ph];
+      pp.n_splits = tavb::mfma_pick_splits(pp.rows, nq_pad, c->n_cu);
+      if (c->mfma_splits > 0 || pp.n_splits > splits) pp.n_splits = splits;  // lists / candidate buffers are sized for `splits`
+      const int carried = ph > 0 ? 1 : 0;  // the running top-k of the earlier phases occupies one more list slot
+      pp.list_stride = pp.n_splits + carried;
+      pp.thr_in = ph > 0 ? reinterpret_cast<const float*>(c->d_thr.ptr) : nullptr;
+      if (carried) {
+        TAVB_HIP(hipMemcpy2DAsync(pp.lists + (size_t)pp.n_splits * k, (size_t)pp.list_stride * k * sizeof(u64_t), c->d_sample_keys.ptr,
+                                  (size_t)k * sizeof(u64_t), (size_t)k * sizeof(u64_t), (size_t)nq, hipMemcpyDeviceToDevice, c->stream));
       }
-      hipError_t e = tavb::launch_merge(ps.lists, ps.n_splits, nq, k, /*query_major=*/true,
-                                        reinterpret_cast<u64_t*>(c->d_sample_keys.ptr), c->stream);
-      if (e != hipSuccess) return fail(TAVB_E_HIP, "sample merge launch failed: %s", hipGetErrorString(e));
-      TAVB_HIP(hipMemsetAsync(c->d_thr.ptr, 0xFF, (size_t)nq_pad * sizeof(float), c->stream));  // NaN bits: ignored by `>`
-      e = tavb::launch_sample_thresholds(reinterpret_cast<const u64_t*>(c->d_sample_keys.ptr), nq, k,
-                                         reinterpret_cast<float*>(c->d_thr.ptr), c->stream);
-      if (e != hipSuccess) return fail(TAVB_E_HIP, "threshold launch failed: %s", hipGetErrorString(e));
-      p.thr_in = reinterpret_cast<const float*>(c->d_thr.ptr);
-    }
-    {
-      Timed t(c, TAVB_KERNEL_MFMA);
-      hipError_t e = tavb::launch_mfma_scan(p, c->stream);
-      if (e != hipSuccess) return fail(TAVB_E_HIP, "mfma scan launch failed: %s", hipGetErrorString(e));
-    }
-    {
-      Timed t(c, TAVB_KERNEL_MERGE);
-      hipError_t e = tavb::launch_merge(p.lists, splits, nq, k, /*query_major=*/true, d_out, c->stream);
-      if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
+      {
+        Timed t(c, last ? TAVB_KERNEL_MFMA : TAVB_KERNEL_MFMA_SAMPLE);
+        hipError_t e = tavb::launch_mfma_scan(pp, c->stream);
+        if (e != hipSuccess) return fail(TAVB_E_HIP, "mfma scan launch failed (phase %d): %s", ph, hipGetErrorString(e));
+      }
+      if (last) {
+        Timed t(c, TAVB_KERNEL_MERGE);
+        hipError_t e = tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true, d_out, c->stream);
+        if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
+      } else {
+        hipError_t e = tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true,
+                                          reinterpret_cast<u64_t*>(c->d_sample_keys.ptr), c->stream);
+        if (e != hipSuccess) return fail(TAVB_E_HIP, "phase merge launch failed: %s", hipGetErrorString(e));
+        TAVB_HIP(hipMemsetAsync(c->d_thr.ptr, 0xFF, (size_t)nq_pad * sizeof(float), c->stream));  // NaN bits: ignored by `>`
+        e = tavb::launch_sample_thresholds(reinterpret_cast<const u64_t*>(c->d_sample_keys.ptr), nq, k,
+                                           reinterpret_cast<float*>(c->d_thr.ptr), c->stream);
+        if (e != hipSuccess) return fail(TAVB_E_HIP, "threshold launch failed: %s", hipGetErrorString(e));
+      }
     }
     return TAVB_OK;
   }

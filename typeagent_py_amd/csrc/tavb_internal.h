@@ -60,6 +60,7 @@ struct MfmaParams {
   uint32_t index_base;
   float min_score;
   int32_t n_splits;  // row ranges the corpus is cut into (one list per (query, split))
+  int32_t list_stride;  // lists per query in `lists`; 0 = n_splits (extra slots are the caller's, e.g. a carried-over top-k)
   int32_t variant;   // 1 = lock-step K loop, 2 = ping-pong wave groups
   int32_t group_sel; // ping-pong grouping: 0 = wave>>2, 1 = wave&1, 2 = (wave>>1)&1
   int32_t prio;      // s_setprio placement: 0 none, 1 MFMA phase, 2 LOAD phase

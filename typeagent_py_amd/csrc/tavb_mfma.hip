@@ -70,6 +70,7 @@ struct MfmaDeviceParams {
   int32_t nq;
   int32_t n_qtiles;
   int32_t n_splits;
+  int32_t list_stride;      // lists per query in `lists` (>= n_splits; extra slots belong to the caller)
   int32_t k;
   uint32_t index_base;
   float min_score;
@@ -403,7 +404,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel(const MfmaDevicePar
     if (qg >= p.nq) continue;
     const int n = cnt_lds[q];
     const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane);
-    u64* out = p.lists + ((size_t)qg * p.n_splits + split) * (size_t)p.k;
+    u64* out = p.lists + ((size_t)qg * p.list_stride + split) * (size_t)p.k;
     if (lane < p.k) out[lane] = best.key[0];
   }
 }
@@ -481,7 +482,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
     // empty row range: emit empty lists
     for (int q = wave; q < BN; q += NTHREADS / 64) {
       const int qg = qtile * BN + q;
-      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.n_splits + split) * (size_t)p.k + lane] = 0ull;
+      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.list_stride + split) * (size_t)p.k + lane] = 0ull;
     }
     return;
   }
@@ -638,17 +639,21 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
     for (int ni = 0; ni < 2; ++ni) {
       const int ql = wn * 64 + ni * 32 + (lane & 31);
       const float thr = thr_lds[ql];
+      // Fast test on the raw dot products: score = fma(dot, 0.5, 0.5) is monotone in dot, so `score > thr` implies
+      // `dot > 2 thr - 1 - 2^-21` (the margin covers the roundings of both fmas with room to spare).  One max3
+      // chain + one compare per 32x32 block instead of 16 fmas + 16 compares; the exact test is in the slow path.
+      const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        bool any = false;
-        float sc[16];
+        float top = acc[mi][ni][0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
-          any = any || (ABL == 0 && sc[r] > thr);
-        }
+        for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, acc[mi][ni][r]);
+        const bool any = (ABL == 0) && (top > thr_pre);
         if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi][ni]));  // keep the MFMAs alive when admissions are ablated
         if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+          float sc[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
           // slow path, taken by the whole wave when any lane admits something: every lane builds the
           // bit mask of its admitted rows, reserves that many buffer slots with ONE LDS atomic (the
           // latency of the returning atomic is paid once per 32x32 block, not once per key), then
@@ -724,7 +729,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
     if (qg >= p.nq) continue;
     const int n = cnt_lds[q];
     const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane);
-    u64* out = p.lists + ((size_t)qg * p.n_splits + split) * (size_t)p.k;
+    u64* out = p.lists + ((size_t)qg * p.list_stride + split) * (size_t)p.k;
     if (lane < p.k) out[lane] = best.key[0];
   }
 }
@@ -790,7 +795,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
   if (n_tiles == 0) {
     for (int q = wave; q < BN; q += NTHREADS / 64) {
       const int qg = qtile * BN + q;
-      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.n_splits + split) * (size_t)p.k + lane] = 0ull;
+      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.list_stride + split) * (size_t)p.k + lane] = 0ull;
     }
     return;
   }
@@ -1023,7 +1028,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
     if (qg >= p.nq) continue;
     const int n = cnt_lds[q];
     const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane);
-    u64* out = p.lists + ((size_t)qg * p.n_splits + split) * (size_t)p.k;
+    u64* out = p.lists + ((size_t)qg * p.list_stride + split) * (size_t)p.k;
     if (lane < p.k) out[lane] = best.key[0];
   }
 }
@@ -1082,6 +1087,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.nq = p.nq;
   d.n_qtiles = p.nq_padded / BN;
   d.n_splits = p.n_splits;
+  d.list_stride = p.list_stride > p.n_splits ? p.list_stride : p.n_splits;
   d.k = p.k;
   d.index_base = p.index_base;
   d.min_score = p.min_score;
