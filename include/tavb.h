@@ -74,7 +74,14 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "scan_nt"       1 = non-temporal corpus loads (default 1)
  *   "scan_pipe"     1 = software-prefetch next rows before reducing current ones
  *   "force_tier"    0 = auto, 1 = fixed-D kernel, 2 = vector kernel, 3 = scalar kernel
- *   "mfma_min_batch" smallest batch routed to the MFMA kernel on f16 corpora
+ *   "mfma_min_batch" smallest batch routed to the 256-query MFMA tile on f16 corpora (default 33)
+ *   "skinny_min_batch_f32" / "skinny_min_batch_f16"  smallest batch routed to the 32-query MFMA tile on fp32 / fp16
+ *                   corpora (defaults 8 / 6; fp32 corpora have no other matrix-core path, fp16 ones use it up to
+ *                   mfma_min_batch - 1); smaller batches use the streaming tiers
+ *   "mfma_sample_rows", "mfma_ladder"  phases of the MFMA paths' threshold ladder (rows of the first phase; growth)
+ *   "mfma_variant", "mfma_splits", "mfma_rendezvous", "mfma_a_nt", ...  experiment knobs, see DESIGN.md
+ *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile,
+ *                   5 = 32-query MFMA tile
  */
 int tavb_set_option(tavb_ctx* ctx, const char* name, int64_t value);
 int tavb_get_option(tavb_ctx* ctx, const char* name, int64_t* out_value);
@@ -175,7 +182,8 @@ int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* 
 #define TAVB_KERNEL_NORMALIZE 3
 #define TAVB_KERNEL_CONVERT 4
 #define TAVB_KERNEL_MFMA_SAMPLE 5 /* threshold-seeding pass of the MFMA path over the first rows */
-#define TAVB_KERNEL_COUNT 6
+#define TAVB_KERNEL_SKINNY 6 /* 32-query MFMA tile (small batches; every batch on fp32 corpora) */
+#define TAVB_KERNEL_COUNT 7
 int tavb_profile_enable(tavb_ctx* ctx, int32_t on);
 int tavb_profile_reset(tavb_ctx* ctx);
 int tavb_profile_read(tavb_ctx* ctx, int32_t kernel_id, double* out_total_ms, int64_t* out_launches);

@@ -657,11 +657,96 @@ def test_mfma_batch_equals_streaming_path_on_f16_representable_queries():
     vb = new_vb(v, dtype="fp16")
     vb.engine.set_option("mfma_min_batch", 32)
     batch = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
-    vb.engine.set_option("mfma_min_batch", 1 << 30)  # force the streaming kernels
+    assert vb.engine.get_option("last_tier") == 4
+    vb.engine.set_option("mfma_min_batch", 1 << 30)  # 32-query tiles (two per row range here)
+    skinny = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert vb.engine.get_option("last_tier") == 5
+    vb.engine.set_option("skinny_min_batch_f16", 1 << 30)  # force the streaming kernels
     stream = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
-    for a, b in zip(batch, stream):
-        assert [r.item for r in a] == [r.item for r in b]
-        np.testing.assert_allclose([r.score for r in a], [r.score for r in b], atol=3e-7, rtol=0)
+    assert vb.engine.get_option("last_tier") in (1, 2, 3)
+    for other in (skinny, stream):
+        for a, b in zip(batch, other):
+            assert [r.item for r in a] == [r.item for r in b]
+            np.testing.assert_allclose([r.score for r in a], [r.score for r in b], atol=3e-7, rtol=0)
+
+
+# --------------------------------------------------------------------------------------
+# 32-query MFMA tile ("skinny" kernel): small batches on fp16 corpora, every batch >= 8 on fp32 corpora
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("n,d,nq,k,ms", [
+    (1000, 1536, 8, 10, 0.0), (257, 1536, 9, 1, 0.0), (70_001, 1536, 31, 32, 0.0), (40_000, 1536, 24, 64, 0.5),
+    (33_333, 1536, 17, 32, 0.0), (20_000, 384, 12, 10, 0.52), (255, 1536, 12, 5, 0.0), (5, 1536, 8, 10, 0.0),
+    (3_000, 64, 10, 7, 0.0), (100_000, 1536, 30, 32, 0.0),
+])
+def test_skinny_kernel_against_oracle(dtype, n, d, nq, k, ms):
+    """fp32 corpus: `v_mfma_f32_32x32x2_f32` on fp32 rows and fp32 queries.  fp16 corpus: fp32 queries split into fp16
+    high + low planes, i.e. the same arithmetic meaning as the streaming tiers (fp32 query x fp16 rows), so the oracle
+    gets the fp16-rounded corpus and the UNROUNDED queries."""
+    v, _ = make_corpus(n, d, 9500 + n % 89 + d)
+    qs = make_queries(nq, d, 9501 + nq)
+    if n > 10:
+        qs[0] = v[n - 2]  # exact self-match in the last rows
+    vb = new_vb(v, dtype=dtype)
+    got = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
+    assert vb.engine.get_option("last_tier") == 5
+    ref_v = v if dtype == "fp32" else _f16(v)
+    for qi in range(nq):
+        vo.check_topk_parity(vo.scores_full(ref_v, qs[qi]), *items_scores(got[qi]), k, ms)
+    if n > 10:
+        assert got[0][0].item == n - 2
+
+
+@pytest.mark.parametrize("nq", [40, 64, 200])
+def test_skinny_kernel_serves_large_batches_on_fp32_corpora(nq):
+    """More than one 32-query tile per row range (the workgroups of a row range share it through L2)."""
+    n, k = 30_000, 32
+    v, _ = make_corpus(n, 1536, 9600)
+    qs = make_queries(nq, 1536, 9601 + nq)
+    vb = new_vb(v)
+    got = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert vb.engine.get_option("last_tier") == 5
+    for qi in range(0, nq, 7):
+        vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(got[qi]), k, 0.0)
+    # the same batch through the streaming tier
+    vb.engine.set_option("skinny_min_batch_f32", 1 << 30)
+    ref = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert vb.engine.get_option("last_tier") in (2, 3)
+    for a, b in zip(got, ref):
+        sa, sb = [r.score for r in a], [r.score for r in b]
+        np.testing.assert_allclose(sa, sb, atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_skinny_kernel_with_threshold_ladder_nan_and_zero_rows(dtype):
+    n, nq, k = 70_001, 20, 32
+    v, _ = make_corpus(n, 1536, 9700)
+    v[1234] = 0.0          # zero row: score exactly 0.5
+    v[4321, 7] = np.nan    # NaN row: never returned
+    qs = make_queries(nq, 1536, 9701)
+    qs[3] = v[60_000]
+    vb = new_vb(v, dtype=dtype)
+    eng = vb.engine
+    eng.set_option("mfma_sample_rows", 2048)
+    eng.profile_enable(True)
+    eng.profile_reset()
+    got = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert eng.get_option("last_tier") == 5
+    assert eng.profile_read(_native.KERNEL_SKINNY)[1] == 1 and eng.profile_read(_native.KERNEL_MFMA_SAMPLE)[1] == _ladder_phases(n, 2048, 4) - 1
+    eng.set_option("mfma_sample_rows", 0)
+    plain = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    ref_v = v if dtype == "fp32" else _f16(v)
+    for qi in range(nq):
+        assert [(r.item, r.score) for r in got[qi]] == [(r.item, r.score) for r in plain[qi]]
+        assert 4321 not in [r.item for r in got[qi]]
+        sc = vo.scores_full(ref_v, qs[qi])
+        vo.check_topk_parity(sc, *items_scores(got[qi]), k, 0.0)
+    assert got[3][0].item == 60_000
+    # the zero row scores exactly 0.5 for every query: ask for a window of scores that contains little else
+    neg = -qs[:8]  # rows that score s for q score 1 - s for -q; with min_score 0.5 the zero row survives
+    low = vb.fuzzy_lookup_embeddings(neg, max_hits=64, min_score=0.5)
+    for qi in range(8):
+        vo.check_topk_parity(vo.scores_full(ref_v, neg[qi]), *items_scores(low[qi]), 64, 0.5)
 
 
 # --------------------------------------------------------------------------------------

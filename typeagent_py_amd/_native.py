@@ -21,7 +21,7 @@ TAVB_F16 = 1
 MAX_FUSED_K = 256
 MAX_STREAM_QUERIES = 8
 
-KERNEL_SCAN, KERNEL_MERGE, KERNEL_MFMA, KERNEL_NORMALIZE, KERNEL_CONVERT, KERNEL_MFMA_SAMPLE = range(6)
+KERNEL_SCAN, KERNEL_MERGE, KERNEL_MFMA, KERNEL_NORMALIZE, KERNEL_CONVERT, KERNEL_MFMA_SAMPLE, KERNEL_SKINNY = range(7)
 
 _LIB_NAME = "libtavb.so"
 _lib = None

@@ -100,7 +100,7 @@ struct tavb_ctx {
   const void* tiled = nullptr;  // optional K-blocked fp16 image of the same rows (MFMA path)
 
   tavb::ScanGeometry geom{0, 16, 2, 1, 0, 0};
-  int64_t mfma_min_batch = 32;
+  int64_t mfma_min_batch = 33;  // fp16 corpora: batches from this size up use the 256-query tile (6 .. 32 the 32-query tile)
   int64_t mfma_splits = 0;  // 0 = auto
   int64_t mfma_variant = 3;
   int64_t mfma_ablate = 0;
@@ -110,6 +110,8 @@ struct tavb_ctx {
   int64_t mfma_group = 0;
   int64_t mfma_use_tiled = 1;
   int64_t mfma_sample_rows = 131072;  // rows of the first (threshold-seeding) phase (0 = one phase, no seeding)
+  int64_t skinny_min_batch_f32 = 8;   // fp32 corpus: batches from this size up use the 32-query MFMA tile
+  int64_t skinny_min_batch_f16 = 6;   // fp16 corpus: batches from this size up to mfma_min_batch - 1 use it
   int64_t mfma_ladder = 4;            // each further phase scans this many times the rows scanned so far (0 = seed once)
 
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand, d_thr, d_sample_keys;
@@ -390,6 +392,12 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_group") {
     if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_group must be 0..2");
     c->mfma_group = v;
+  } else if (n == "skinny_min_batch_f32") {
+    if (v < 1) return fail(TAVB_E_INVALID, "skinny_min_batch_f32 must be >= 1");
+    c->skinny_min_batch_f32 = v;
+  } else if (n == "skinny_min_batch_f16") {
+    if (v < 1) return fail(TAVB_E_INVALID, "skinny_min_batch_f16 must be >= 1");
+    c->skinny_min_batch_f16 = v;
   } else if (n == "mfma_ladder") {
     if (v < 0 || v > 64) return fail(TAVB_E_INVALID, "mfma_ladder must be 0..64");
     c->mfma_ladder = v;
@@ -425,6 +433,8 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "mfma_min_batch") *out = c->mfma_min_batch;
   else if (n == "mfma_splits") *out = c->mfma_splits;
   else if (n == "mfma_ladder") *out = c->mfma_ladder;
+  else if (n == "skinny_min_batch_f32") *out = c->skinny_min_batch_f32;
+  else if (n == "skinny_min_batch_f16") *out = c->skinny_min_batch_f16;
   else if (n == "mfma_sample_rows") *out = c->mfma_sample_rows;
   else if (n == "mfma_variant") *out = c->mfma_variant;
   else if (n == "compute_units") *out = c->n_cu;
@@ -715,22 +725,41 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
                                 uint32_t index_base, u64_t* d_out) {
   bool uniform_thr = true;
   for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (min_scores[i] == min_scores[0]);
-  if ((c->dtype == TAVB_F16 || c->tiled) && (nq >= c->mfma_min_batch || !c->corpus) && uniform_thr && tavb::mfma_supported(c->dim, k) &&
-      c->rows > 0 && (c->mfma_variant >= 3 || !c->tiled || c->corpus)) {
-    const int qt = tavb::mfma_query_tile();
+  const bool f16c = (c->dtype == TAVB_F16);
+  const bool wide = (f16c || c->tiled) && (nq >= c->mfma_min_batch || !c->corpus) && uniform_thr && tavb::mfma_supported(c->dim, k) &&
+                    c->rows > 0 && (c->mfma_variant >= 3 || !c->tiled || c->corpus);
+  // 32-query tiles at HBM speed: small batches on fp16 corpora, every batch from `skinny_min_batch_f32` up on fp32 ones
+  const bool skinny = !wide && c->corpus && uniform_thr && c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c) &&
+                      nq >= (f16c ? c->skinny_min_batch_f16 : c->skinny_min_batch_f32);
+  if (wide || skinny) {
+    const int qt = skinny ? tavb::skinny_query_tile() : tavb::mfma_query_tile();
     const int nq_pad = ((nq + qt - 1) / qt) * qt;
-    const size_t q16 = (size_t)nq_pad * c->dim * 2;
-    if (int rc = c->d_queries_f16.reserve(q16)) return rc;
-    TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16, c->stream));
-    {
+    const bool q32 = skinny && !f16c;  // the skinny kernel on an fp32 corpus multiplies fp32 queries
+    const bool split = skinny && f16c;  // ... and on an fp16 corpus fp32 queries split into fp16 high + low planes
+    const size_t plane = (size_t)nq_pad * c->dim * (q32 ? 4 : 2);
+    const size_t qbytes = plane * (split ? 2 : 1);
+    if (int rc = c->d_queries_f16.reserve(qbytes)) return rc;
+    TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, qbytes, c->stream));
+    if (q32) {
+      TAVB_HIP(hipMemcpyAsync(c->d_queries_f16.ptr, d_q, (size_t)nq * c->dim * 4, hipMemcpyDeviceToDevice, c->stream));
+    } else if (split) {
+      hipError_t e = tavb::launch_f32_split_f16(d_q, c->d_queries_f16.ptr, reinterpret_cast<char*>(c->d_queries_f16.ptr) + plane,
+                                                (int64_t)nq * c->dim, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "query split launch failed: %s", hipGetErrorString(e));
+    } else {
       hipError_t e = tavb::launch_f32_to_f16(d_q, c->d_queries_f16.ptr, (int64_t)nq * c->dim, c->stream);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "query convert launch failed: %s", hipGetErrorString(e));
     }
-    const int splits = c->mfma_splits > 0 ? (int)c->mfma_splits : tavb::mfma_pick_splits(c->rows, nq_pad, c->n_cu);
+    auto pick_splits = [&](int64_t rows) {
+      return skinny ? tavb::skinny_pick_splits(rows, nq_pad, c->n_cu) : tavb::mfma_pick_splits(rows, nq_pad, c->n_cu);
+    };
+    auto launch = [&](const tavb::MfmaParams& q) { return skinny ? tavb::launch_skinny_scan(q, c->stream) : tavb::launch_mfma_scan(q, c->stream); };
+    c->last_tier = skinny ? 5 : 4;  // 1-3 = streaming tiers, 4 = 256-query MFMA tile, 5 = 32-query MFMA tile
+    const int splits = c->mfma_splits > 0 ? (int)c->mfma_splits : pick_splits(c->rows);
     if (int rc = c->d_lists.reserve((size_t)nq * (splits + 1) * k * sizeof(u64_t))) return rc;  // + the carried-over top-k
     if (int rc = c->d_cand.reserve(tavb::mfma_workspace_bytes(splits, nq_pad))) return rc;
     tavb::MfmaParams p{};
-    const bool use_tiled = c->tiled && c->mfma_variant >= 3 && c->mfma_use_tiled;
+    const bool use_tiled = !skinny && c->tiled && c->mfma_variant >= 3 && c->mfma_use_tiled;
     p.corpus = use_tiled ? c->tiled : c->corpus;
     p.a_tiled = use_tiled ? 1 : 0;
     if (!p.corpus) return fail(TAVB_E_NO_CORPUS, "no operand for the MFMA kernel (row-major fp16 corpus or K-blocked image)");
@@ -751,6 +780,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     p.rendezvous = (int)c->mfma_rendezvous;
     p.a_nt = (int)c->mfma_a_nt;
     p.group_sel = (int)c->mfma_group;
+    p.f32 = q32 ? 1 : 0;
     p.thr_in = nullptr;
     // Threshold ladder.  The corpus is scanned in phases of growing size -- the first `mfma_sample_rows` rows, then
     // `mfma_ladder` times everything scanned so far, ..., then the rest -- every row exactly once.  After each
@@ -777,14 +807,14 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
       if (int rc = c->d_thr.reserve((size_t)nq_pad * sizeof(float))) return rc;
       if (int rc = c->d_sample_keys.reserve((size_t)nq * k * sizeof(u64_t))) return rc;
     }
-    const size_t row_bytes = (size_t)c->dim * 2;
+    const size_t row_bytes = (size_t)c->dim * (q32 ? 4 : 2);  // of the corpus operand
     for (int ph = 0; ph < n_phases; ++ph) {
       const bool last = (ph == n_phases - 1);
       tavb::MfmaParams pp = p;
       pp.corpus = reinterpret_cast<const char*>(p.corpus) + (size_t)bounds[ph] * row_bytes;  // same offset in the K-blocked image
       pp.rows = bounds[ph + 1] - bounds[ph];
       pp.index_base = index_base + (uint32_t)bounds[ph];
-      pp.n_splits = tavb::mfma_pick_splits(pp.rows, nq_pad, c->n_cu);
+      pp.n_splits = pick_splits(pp.rows);
       if (c->mfma_splits > 0 || pp.n_splits > splits) pp.n_splits = splits;  // lists / candidate buffers are sized for `splits`
       const int carried = ph > 0 ? 1 : 0;  // the running top-k of the earlier phases occupies one more list slot
       pp.list_stride = pp.n_splits + carried;
@@ -794,8 +824,8 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
                                   (size_t)k * sizeof(u64_t), (size_t)k * sizeof(u64_t), (size_t)nq, hipMemcpyDeviceToDevice, c->stream));
       }
       {
-        Timed t(c, last ? TAVB_KERNEL_MFMA : TAVB_KERNEL_MFMA_SAMPLE);
-        hipError_t e = tavb::launch_mfma_scan(pp, c->stream);
+        Timed t(c, !last ? TAVB_KERNEL_MFMA_SAMPLE : (skinny ? TAVB_KERNEL_SKINNY : TAVB_KERNEL_MFMA));
+        hipError_t e = launch(pp);
         if (e != hipSuccess) return fail(TAVB_E_HIP, "mfma scan launch failed (phase %d): %s", ph, hipGetErrorString(e));
       }
       if (last) {

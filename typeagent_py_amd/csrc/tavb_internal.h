@@ -42,6 +42,7 @@ hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, in
 
 hipError_t launch_normalize_f32(const float* in, float* out, int64_t rows, int dim, hipStream_t stream);
 hipError_t launch_f32_to_f16(const float* in, void* out, int64_t count, hipStream_t stream);
+hipError_t launch_f32_split_f16(const float* in, void* hi, void* lo, int64_t count, hipStream_t stream);
 size_t tiled_bytes(int64_t rows, int dim);
 hipError_t launch_pack_tiled(const void* src, int src_dtype, int64_t rows, int dim, void* dst, hipStream_t stream);
 
@@ -68,6 +69,7 @@ struct MfmaParams {
   const float* thr_in;  // optional per-query admission thresholds (device, [nq_padded]) from a sample pass
   int32_t rendezvous;   // variant 3: the workgroups of a row range meet at every tile start (L2 sharing of corpus slices)
   int32_t a_nt;         // variant 3: non-temporal policy on the corpus LDS-DMA stream
+  int32_t f32;          // skinny kernel only: corpus and queries are fp32 (else fp16)
 };
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
 hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, float* thr, hipStream_t stream);
@@ -75,5 +77,10 @@ int mfma_query_tile();                    // queries per workgroup tile
 int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu);
 bool mfma_supported(int dim, int k);
 size_t mfma_workspace_bytes(int n_splits, int nq_padded);
+// 32-query tiles at HBM speed, fp32 or fp16 corpora (same parameter block; `queries` in the corpus dtype)
+hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream);
+int skinny_query_tile();
+int skinny_pick_splits(int64_t rows, int nq_padded, int n_cu);
+bool skinny_supported(int dim, int k, bool f32);
 
 }  // namespace tavb

@@ -1033,6 +1033,293 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SKINNY kernel: 8 .. 32 queries per pass at HBM speed, on fp32 AND fp16 corpora.
+//
+// The streaming tiers keep the queries in LDS and every lane re-reads them for every row, so beyond four
+// queries they are LDS-bound (6.9 TB/s of corpus at one query, 4.8 at eight, then one more pass per eight
+// queries); the 256-query MFMA tile above wastes 7/8 of its operand traffic on padding at 32 queries and
+// only exists for fp16.  This kernel is the piece in between -- and the only matrix-core path for the
+// reference's own dtype, fp32: `v_mfma_f32_32x32x2_f32` multiplies fp32 exactly and accumulates in fp32
+// (157 TFLOP/s peak, enough to keep up with HBM at 32 queries: 3.1e3 flop per corpus row-byte^-1 ...
+// 1M x 1536 x 32 x 2 = 98 GFLOP per 6.1 GB pass).
+//   * tile = 256 corpus rows x 32 queries, 4 waves, each wave owns 64 rows (two 32 x 32 MFMA tiles);
+//     two workgroups per CU (72 KiB of LDS, < 128 VGPRs each) overlap each other's waits.
+//   * K advances 64 bytes per row per step for either dtype (16 floats / 32 halves).  A wave stages the four
+//     1 KiB pieces of ITS OWN 64 rows by LDS-DMA, so the corpus operand needs no cross-wave synchronisation;
+//     waves 0 and 1 also stage one piece each of the query operand (32 queries x 64 bytes), which all waves
+//     read: one barrier per step.  Ring of 4 slots, counted vmcnt (two to three steps in flight).
+//   * LDS image, source-side XOR swizzle and fragment reads are those of variant 3 (64-byte rows).  For fp32
+//     a lane's 16-byte fragment is four consecutive k of its row -- lanes 0-31 take k = 8g .. 8g+3, lanes 32-63
+//     k = 8g+4 .. 8g+7 -- and feeds four MFMAs: MFMA e multiplies k = 8g+e (lower half-wave) and 8g+4+e
+//     (upper), the same pairing on both operands, which is all a dot product needs.
+//   * epilogue / candidate buffers / compaction / lists exactly as in the wide kernel (32 queries per block).
+// ---------------------------------------------------------------------------------------------
+constexpr int SQ = 32;              // queries per tile
+constexpr int S_THREADS = 256;
+constexpr int S_SLOT_A = BM * 64;   // 16 KiB
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// fp32: one query operand plane, ring of 4 (72 KiB).  fp16: the fp32 queries are split into an fp16 high and an fp16
+// low plane (q = hi + lo to 2^-22; both are multiplied -- the kernel is load-bound, the second MFMA is free), so a
+// lookup on an fp16 corpus means the same thing here as in the streaming tiers (fp32 query x fp16 rows); ring of 3 (60 KiB).
+template <typename T>
+struct SkinnyGeom {
+  static constexpr bool F32 = sizeof(T) == 4;
+  static constexpr int PLANES = F32 ? 1 : 2;
+  static constexpr int RING = F32 ? 4 : 3;
+  static constexpr int SLOT_B = PLANES * SQ * 64;
+  static constexpr int B_RING = RING * S_SLOT_A;
+  static constexpr int CTRL = RING * (S_SLOT_A + SLOT_B);
+  static constexpr int LDS = CTRL + SQ * 8 + 16;
+};
+
+template <typename T, int ABL>
+__global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDeviceParams p) {
+  using G = SkinnyGeom<T>;
+  constexpr bool F32 = G::F32;
+  constexpr int S_RING = G::RING, S_SLOT_B = G::SLOT_B, S_B_RING = G::B_RING, S_CTRL = G::CTRL;
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* thr_lds = reinterpret_cast<float*>(smem + S_CTRL);
+  int* cnt_lds = reinterpret_cast<int*>(smem + S_CTRL + SQ * 4);
+  volatile int* need_compact = reinterpret_cast<volatile int*>(smem + S_CTRL + SQ * 8);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // rows wave * 64 .. of the tile
+
+  const int b = blockIdx.x;
+  const int xcd = b & 7;
+  const int t = b >> 3;
+  const int qtile = t % p.n_qtiles;
+  const int split = (t / p.n_qtiles) * 8 + xcd;
+  if (split >= p.n_splits) return;
+  const int64_t r_begin = (int64_t)split * p.rows_per_split;
+  const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
+  const int logical_block = split * p.n_qtiles + qtile;
+  u64* my_cand = p.cand + (size_t)logical_block * SQ * CAP;
+
+  const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
+  if (tid < SQ) {
+    float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
+    const int qg0 = qtile * SQ + tid;
+    if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
+    else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best so far: a valid lower bound
+    thr_lds[tid] = t0;
+    cnt_lds[tid] = 0;
+  }
+  if (tid == 0) *need_compact = 0;
+
+  const size_t row_bytes = (size_t)p.dim * sizeof(T);
+  const int steps_per_tile = (int)(row_bytes / 64);
+  const char* corpus = reinterpret_cast<const char*>(p.corpus);
+  const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * SQ * row_bytes;
+  const size_t plane_bytes = (size_t)p.n_qtiles * SQ * row_bytes;  // fp16: the low plane follows the high plane
+  const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BM - 1) / BM) : 0;
+  if (n_tiles == 0) {
+    for (int q = wave; q < SQ; q += S_THREADS / 64) {
+      const int qg = qtile * SQ + q;
+      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.list_stride + split) * (size_t)p.k + lane] = 0ull;
+    }
+    return;
+  }
+
+  // ---- stager: piece j of this wave = corpus rows wave * 64 + j * 16 .. + 15 of the tile (its own rows); lane l = row
+  //      l >> 2, 16-byte slot l & 3, fetched from the XOR-swizzled source slot.  Waves 0 / 1 add query rows 0-15 / 16-31.
+  const int st_row_in_piece = lane >> 2;
+  const uint32_t st_slot16 = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  uint32_t st_off[4];
+  auto set_offsets = [&](int64_t row0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t r = wave * 64 + j * 16 + st_row_in_piece;
+      if (row0 + r >= p.rows) r = p.rows - 1 - row0;  // stay in bounds; masked in the epilogue
+      st_off[j] = (uint32_t)r * (uint32_t)row_bytes + st_slot16;
+    }
+  };
+  const uint32_t st_off_b = (uint32_t)(wave * 16 + st_row_in_piece) * (uint32_t)row_bytes + st_slot16;
+  const bool stages_b = wave < 2;
+  int st_tile = 0, st_kt = 0, st_slot = 0;
+  set_offsets(r_begin);
+
+  auto stage_next = [&]() {
+    const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
+    const int64_t src_row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM;
+    const char* ga = sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * 64);
+    unsigned char* la = smem + st_slot * S_SLOT_A + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((global_void*)(ga + (size_t)st_off[j]), (lds_void*)(la + j * 1024), 16, 0, 0);  // (a non-temporal policy here measured 30 % slower)
+    if (stages_b) {
+      const char* gb = sgpr_ptr(qbase + (size_t)st_kt * 64);
+      unsigned char* lb = smem + S_B_RING + st_slot * S_SLOT_B + wave * 1024;
+      __builtin_amdgcn_global_load_lds((global_void*)(gb + (size_t)st_off_b), (lds_void*)lb, 16, 0, 0);
+      if constexpr (!F32) {  // the low plane of the split queries
+        const char* gl = sgpr_ptr(qbase + plane_bytes + (size_t)st_kt * 64);
+        __builtin_amdgcn_global_load_lds((global_void*)(gl + (size_t)st_off_b), (lds_void*)(lb + SQ * 64), 16, 0, 0);
+      }
+    }
+    if (++st_slot == S_RING) st_slot = 0;
+    if (++st_kt == steps_per_tile) {
+      st_kt = 0;
+      ++st_tile;
+      if (st_tile < n_tiles) set_offsets(r_begin + (int64_t)st_tile * BM);
+    }
+  };
+  auto wait_landed = [&]() {  // all but the newest S_RING - 2 steps of this wave's loads have landed
+    if (stages_b)
+      wait_vmcnt<(4 + G::PLANES) * (S_RING - 2)>();
+    else
+      wait_vmcnt<4 * (S_RING - 2)>();
+  };
+
+  // ---- fragment addresses: row (lane & 31) of a 32-row block, logical 16-byte slot 2 * g + (lane >> 5)
+  const int frag_row = lane & 31;
+  const uint32_t frag_x = (uint32_t)(((lane >> 5) ^ ((frag_row >> 2) & 3)) << 4);
+  const uint32_t a_lane = (uint32_t)((wave * 64 + frag_row) * 64);  // + mi * 2048
+  const uint32_t b_lane = (uint32_t)(S_B_RING + frag_row * 64);
+
+  // ---- prologue: S_RING - 1 steps in flight
+#pragma unroll 1
+  for (int i = 0; i < S_RING - 1; ++i) stage_next();
+
+  int rd = 0;
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const int64_t row0 = r_begin + (int64_t)tile * BM;
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+#pragma unroll 1
+    for (int kt = 0; kt < steps_per_tile; ++kt) {
+      if constexpr ((ABL & 2) == 0) wait_landed();  // this wave's share of step S is in LDS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TAVB_BARRIER();  // the query piece of step S is visible; everybody is done with the slot of step S - 1
+      if constexpr ((ABL & 2) == 0) stage_next();  // step S + S_RING - 1 -> the slot of step S - 1
+      const unsigned char* abase = smem + rd * S_SLOT_A;
+      const unsigned char* bbase = smem + rd * S_SLOT_B;
+      f32x4 af[2][2], bf[2], bl[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint32_t kx = (uint32_t)(g << 5) ^ frag_x;
+        bf[g] = *reinterpret_cast<const f32x4*>(bbase + (b_lane + kx));
+        if constexpr (!F32) bl[g] = *reinterpret_cast<const f32x4*>(bbase + (b_lane + kx) + SQ * 64);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[g][mi] = *reinterpret_cast<const f32x4*>(abase + (a_lane + kx) + mi * 2048);
+      }
+      if constexpr ((ABL & 1) == 0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if constexpr (F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int mi = 0; mi < 2; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mi][e], bf[g][e], acc[mi], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+              acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[g][mi]), __builtin_bit_cast(f16x8, bl[g]),
+                                                               acc[mi], 0, 0, 0);
+              acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[g][mi]), __builtin_bit_cast(f16x8, bf[g]),
+                                                               acc[mi], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+        asm volatile("" ::"v"(af[0][0]), "v"(af[1][1]), "v"(bf[0]), "v"(bf[1]));
+        if constexpr (!F32) asm volatile("" ::"v"(bl[0]), "v"(bl[1]));
+      }
+      if (++rd == S_RING) rd = 0;
+    }
+
+    // ---- epilogue: admission test on the raw dot products, append (see variant 3)
+    {
+      const int ql = lane & 31;
+      const float thr = thr_lds[ql];
+      const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        float top = acc[mi][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, acc[mi][r]);
+        const bool any = (ABL == 0) && (top > thr_pre);
+        if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi]));
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+          float sc[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] = fmaf(acc[mi][r], 0.5f, 0.5f);
+          const int64_t row_base = row0 + wave * 64 + mi * 32 + 4 * (lane >> 5);
+          unsigned admit = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float s1 = sc[r];
+            s1 = (s1 > 0.0f) ? s1 : 0.0f;
+            s1 = (s1 > 1.0f) ? 1.0f : s1;
+            const bool ok = (sc[r] > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s1 >= p.min_score);
+            admit |= ok ? (1u << r) : 0u;
+          }
+          const int n_adm = __popc(admit);
+          int pos = 0;
+          if (n_adm > 0) {
+            pos = atomicAdd(&cnt_lds[ql], n_adm);
+            if (pos + n_adm > CAP - BM) *need_compact = 1;  // this buffer could overflow on the next tile
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if ((admit >> r) & 1u) {
+              float s1 = sc[r];
+              s1 = (s1 > 0.0f) ? s1 : 0.0f;
+              s1 = (s1 > 1.0f) ? 1.0f : s1;
+              if (pos < CAP)
+                my_cand[(size_t)ql * CAP + pos] = make_key(s1, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
+              ++pos;
+            }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TAVB_BARRIER();
+    if (*need_compact != 0) {  // workgroup-uniform: read after the barrier
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TAVB_BARRIER();
+      for (int q = wave; q < SQ; q += S_THREADS / 64) {
+        const int n = cnt_lds[q];
+        if (n > CAP - BM) {
+          u64* buf = my_cand + (size_t)q * CAP;
+          const WaveTopK<1> best = best_of_buffer(buf, n < CAP ? n : CAP, lane);
+          if (lane < p.k) buf[lane] = best.key[0];
+          const int kept = __popcll(__ballot(best.key[0] != 0ull && lane < p.k));
+          const u64 kth = best.at(p.k - 1);
+          if (lane == 0) {
+            cnt_lds[q] = kept;
+            const float kth_score = __uint_as_float((uint32_t)(kth >> 32));
+            if (kth != 0ull && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TAVB_BARRIER();
+      if (tid == 0) *need_compact = 0;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TAVB_BARRIER();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead LDS-DMA before the block retires
+  __syncthreads();
+
+  for (int q = wave; q < SQ; q += S_THREADS / 64) {
+    const int qg = qtile * SQ + q;
+    if (qg >= p.nq) continue;
+    const int n = cnt_lds[q];
+    const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane);
+    u64* out = p.lists + ((size_t)qg * p.list_stride + split) * (size_t)p.k;
+    if (lane < p.k) out[lane] = best.key[0];
+  }
+}
+
 }  // namespace
 
 // thr[q] = the largest float below the k-th best score of the sample pass (so that `score > thr` admits
@@ -1068,7 +1355,7 @@ int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu) {
 }
 
 static size_t mfma_cand_bytes(int n_splits, int nq_padded) {
-  return (size_t)n_splits * (size_t)(nq_padded / BN) * BN * CAP * sizeof(u64);
+  return (size_t)n_splits * (size_t)nq_padded * CAP * sizeof(u64);  // nq_padded = tiles x queries per tile (256 or 32)
 }
 
 size_t mfma_workspace_bytes(int n_splits, int nq_padded) {
@@ -1170,6 +1457,69 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
     case 2 * 4 + 2: return go(mfma_scan_kernel<2, 2, 2>);
     case 3 * 4 + 0: return go(mfma_scan_kernel<2, 3, 0>);
     default: return go(mfma_scan_kernel<2, 0, 0>);
+  }
+}
+
+int skinny_query_tile() { return SQ; }
+
+bool skinny_supported(int dim, int k, bool f32) {
+  return (dim * (f32 ? 4 : 2)) % 64 == 0 && dim > 0 && k >= 1 && k <= 64;
+}
+
+int skinny_pick_splits(int64_t rows, int nq_padded, int n_cu) {
+  const int n_qtiles = nq_padded / SQ;
+  int splits = (2 * n_cu) / (n_qtiles > 0 ? n_qtiles : 1);  // two workgroups per CU
+  splits = (splits / 8) * 8;                                 // whole groups of 8 (one row range per XCD)
+  if (splits < 8) splits = 8;
+  const int64_t tiles = (rows + BM - 1) / BM;
+  if (splits > tiles) splits = (int)tiles;
+  return splits;
+}
+
+// Same contract as launch_mfma_scan.  p.queries: fp32 corpus -> [nq_padded, dim] fp32; fp16 corpus -> [2, nq_padded, dim]
+// fp16, the high and the low plane of the split fp32 queries (launch_f32_split_f16).  nq_padded is a multiple of 32.
+hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
+  const bool f32 = p.f32 != 0;
+  if (!skinny_supported(p.dim, p.k, f32) || p.nq_padded % SQ != 0 || p.n_splits < 1 || !p.workspace) return hipErrorInvalidValue;
+  MfmaDeviceParams d{};
+  d.corpus = reinterpret_cast<const _Float16*>(p.corpus);
+  d.queries = reinterpret_cast<const _Float16*>(p.queries);
+  d.lists = p.lists;
+  d.rows = p.rows;
+  d.dim = p.dim;
+  d.nq = p.nq;
+  d.n_qtiles = p.nq_padded / SQ;
+  d.n_splits = p.n_splits;
+  d.list_stride = p.list_stride > p.n_splits ? p.list_stride : p.n_splits;
+  d.k = p.k;
+  d.index_base = p.index_base;
+  d.min_score = p.min_score;
+  d.thr_in = p.thr_in;
+  d.cand = p.workspace;
+  d.sync = nullptr;
+  const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
+  d.rows_per_split = ((per + BM - 1) / BM) * BM;
+  const int groups = (p.n_splits + 7) / 8;
+  const int grid = groups * d.n_qtiles * 8;
+  const int lds = f32 ? SkinnyGeom<float>::LDS : SkinnyGeom<_Float16>::LDS;
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(S_THREADS), lds, stream, d);
+    return hipGetLastError();
+  };
+  if (f32) {
+    switch (p.ablate) {
+      case 1: return go(skinny_scan_kernel<float, 1>);
+      case 2: return go(skinny_scan_kernel<float, 2>);
+      case 256: return go(skinny_scan_kernel<float, 256>);
+      default: return go(skinny_scan_kernel<float, 0>);
+    }
+  }
+  switch (p.ablate) {
+    case 1: return go(skinny_scan_kernel<_Float16, 1>);
+    case 256: return go(skinny_scan_kernel<_Float16, 256>);
+    default: return go(skinny_scan_kernel<_Float16, 0>);
   }
 }
 

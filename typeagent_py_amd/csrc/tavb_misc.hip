@@ -193,6 +193,29 @@ hipError_t launch_f32_to_f16(const float* in, void* out, int64_t count, hipStrea
   return hipGetLastError();
 }
 
+// q = hi + lo with hi = fp16(q) and lo = fp16(q - hi): the pair carries q to ~2^-22 of its magnitude (2^-24 absolute
+// where lo is an fp16 subnormal), so hi.x + lo.x on the matrix cores reproduces the fp32-query dot product of the
+// streaming kernels on fp16 corpora.  Element-wise; a few KiB per lookup.
+__global__ void __launch_bounds__(256) f32_split_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ hi,
+                                                            _Float16* __restrict__ lo, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const float q = in[i];
+    const _Float16 h = (_Float16)q;
+    const float hf = (float)h;
+    hi[i] = h;
+    lo[i] = (hf - hf == 0.0f) ? (_Float16)(q - hf) : (_Float16)0.0f;  // inf / NaN highs get a zero low part
+  }
+}
+
+hipError_t launch_f32_split_f16(const float* in, void* hi, void* lo, int64_t count, hipStream_t stream) {
+  if (count <= 0) return hipSuccess;
+  int64_t blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(f32_split_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, reinterpret_cast<_Float16*>(hi),
+                     reinterpret_cast<_Float16*>(lo), count);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // Row-major [rows, dim] (f32 or f16) -> "K-blocked" fp16 image for the MFMA kernel:
 //   for each tile of 256 rows, for each K step of 32 halves: one 16 KiB block holding the 256 rows'
