@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
+MFMA_F32_PEAK_TFLOPS = 157.3   # fp32 matrix rate (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md peak table
 
 WORKLOADS = {
     #            rows/GPU    dim   dtype   queries/step  k
@@ -46,6 +47,10 @@ WORKLOADS = {
     "cfg2_f16": dict(rows=1_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm"),
     "cfg3": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma"),
     "cfg1": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="hbm"),
+    # batches on the reference's own dtype (fp32): the 32-query MFMA tile.  32 queries ride one HBM pass; 1024 are bound by
+    # the fp32 matrix rate.
+    "cfg2_b32": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=32, k=32, bound="hbm"),
+    "cfg2_b1024": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1024, k=32, bound="mfma"),
     # fused multi-index user query: 4 term lookups k=50@0.85 on a 10M-row terms corpus + 1 message
     # re-rank k=25@0.7 on a 10M-row message corpus (full scan, or --cfg5-subset 1000) + 1 thread lookup k=10@0.7 on 1k rows
     "cfg5": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=6, k=50, bound="hbm"),
@@ -323,14 +328,15 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kid = _native.KERNEL_MFMA if (wl["bound"] == "mfma") else _native.KERNEL_SCAN
+    # the kernel family that served the steps: 256-query MFMA tile, 32-query MFMA tile, or a streaming tier
+    kid = _native.KERNEL_SCAN
+    for cand in (_native.KERNEL_MFMA, _native.KERNEL_SKINNY):
+        if eng.profile_read(cand)[1]:
+            kid = cand
     kern_ms, kern_n = eng.profile_read(kid)
-    if kid == _native.KERNEL_MFMA and kern_n:  # the threshold-seeding sample pass is part of the same job: charge its time
+    if kid != _native.KERNEL_SCAN:  # the earlier phases of the threshold ladder are part of the same job: charge their time
         s_ms, _ = eng.profile_read(_native.KERNEL_MFMA_SAMPLE)
         kern_ms += s_ms
-    if kern_n == 0 and kid == _native.KERNEL_MFMA:  # batch fell back to the streaming kernel
-        kid = _native.KERNEL_SCAN
-        kern_ms, kern_n = eng.profile_read(kid)
     merge_ms, merge_n = eng.profile_read(_native.KERNEL_MERGE)
     eng.profile_enable(False)
 
@@ -348,9 +354,8 @@ def main() -> None:
             nq_per_launch = nq / max(launches_per_step, 1e-9)
             alg = 2.0 * nq_per_launch * rows * dim
             achieved = alg / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
-            peak = MFMA_F16_PEAK_TFLOPS if kid == _native.KERNEL_MFMA else HBM_PEAK_GBS
-            roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS,
-                    "traffic": None}
+            peak = MFMA_F16_PEAK_TFLOPS if wl["dtype"] == "fp16" else MFMA_F32_PEAK_TFLOPS
+            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}
         try:  # HBM traffic comes from a separate rocprofv3 --pmc pass (bench.py cannot count it itself)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f).get(args.workload)
@@ -360,7 +365,8 @@ def main() -> None:
                 roof["traffic_source"] = pmc["source"]
         except Exception:
             pass
-        roof["kernel"] = {0: "scan (tavb::scan_*_kernel)", 2: "mfma (tavb::mfma_scan_kernel)"}.get(kid, str(kid))
+        roof["kernel"] = {0: "scan (tavb::scan_*_kernel)", 2: "mfma (tavb::mfma_scan_kernel_v3)",
+                          6: "skinny (tavb::skinny_scan_kernel)"}.get(kid, str(kid))
         roof["kernel_avg_ms"] = avg_kernel_s * 1e3
         roof["kernel_launches"] = kern_n
         roof["algorithmic_per_launch"] = alg

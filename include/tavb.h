@@ -76,7 +76,7 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "force_tier"    0 = auto, 1 = fixed-D kernel, 2 = vector kernel, 3 = scalar kernel
  *   "mfma_min_batch" smallest batch routed to the 256-query MFMA tile on f16 corpora (default 33)
  *   "skinny_min_batch_f32" / "skinny_min_batch_f16"  smallest batch routed to the 32-query MFMA tile on fp32 / fp16
- *                   corpora (defaults 8 / 6; fp32 corpora have no other matrix-core path, fp16 ones use it up to
+ *                   corpora (defaults 5 / 3, the measured break-even; fp32 corpora have no other matrix-core path, fp16 ones use it up to
  *                   mfma_min_batch - 1); smaller batches use the streaming tiers
  *   "mfma_sample_rows", "mfma_ladder"  phases of the MFMA paths' threshold ladder (rows of the first phase; growth)
  *   "mfma_variant", "mfma_splits", "mfma_rendezvous", "mfma_a_nt", ...  experiment knobs, see DESIGN.md

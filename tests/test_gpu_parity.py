@@ -671,7 +671,7 @@ def test_mfma_batch_equals_streaming_path_on_f16_representable_queries():
 
 
 # --------------------------------------------------------------------------------------
-# 32-query MFMA tile ("skinny" kernel): small batches on fp16 corpora, every batch >= 8 on fp32 corpora
+# 32-query MFMA tile ("skinny" kernel): batches of 3..32 on fp16 corpora, every batch >= 5 on fp32 corpora
 # --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 @pytest.mark.parametrize("n,d,nq,k,ms", [

@@ -110,8 +110,8 @@ struct tavb_ctx {
   int64_t mfma_group = 0;
   int64_t mfma_use_tiled = 1;
   int64_t mfma_sample_rows = 131072;  // rows of the first (threshold-seeding) phase (0 = one phase, no seeding)
-  int64_t skinny_min_batch_f32 = 8;   // fp32 corpus: batches from this size up use the 32-query MFMA tile
-  int64_t skinny_min_batch_f16 = 6;   // fp16 corpus: batches from this size up to mfma_min_batch - 1 use it
+  int64_t skinny_min_batch_f32 = 5;   // fp32 corpus: batches from this size up use the 32-query MFMA tile
+  int64_t skinny_min_batch_f16 = 3;   // fp16 corpus: batches from this size up to mfma_min_batch - 1 use it
   int64_t mfma_ladder = 4;            // each further phase scans this many times the rows scanned so far (0 = seed once)
 
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand, d_thr, d_sample_keys;
