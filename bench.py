@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """Benchmark of the VectorBase kNN hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg2_f16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2_f16|cfg2_b32|cfg2_b1024|cfg3|cfg4|cfg5|cfg1]
 
 Contract (one JSON line on stdout from rank 0):
   * a "step" is one lookup pass of the hot path over the resident corpus:
       cfg2 (default, BASELINE.json configs[1]): 1M x 1536 fp32 corpus, ONE query, top-32,
            through the synchronous C-ABI call `tavb_search` (query H2D + scan + merge +
            result D2H + sync) -- what a `VectorBase.fuzzy_lookup_embedding` caller sees;
-      cfg3 (configs[2]): 10M x 1536 fp16 corpus, a 1024-query batch, top-32 (MFMA path).
+      cfg3 (configs[2]): 10M x 1536 fp16 corpus, a 1024-query batch, top-32 (256-query MFMA tile);
+      cfg4 (configs[3]): cfg3 at 12.5M rows per GPU (100M rows when run with --gpus 8);
+      cfg2_b32 / cfg2_b1024: 32 / 1024-query batches on the cfg2 fp32 corpus (32-query fp32 MFMA tile);
+      cfg5 (configs[4]): fused multi-index user query; cfg1 (configs[0]): the reference's own 10k-row case.
   * value = queries/sec over the timed K steps (wall clock, barrier + synchronize on both
     sides, max over ranks).  With --gpus N the corpus is row-sharded, 1M (cfg2) / 10M (cfg3)
     rows PER GPU (weak scaling: total rows = N x that), per-shard top-k lists are
@@ -46,6 +49,7 @@ WORKLOADS = {
     "cfg2": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1, k=32, bound="hbm"),
     "cfg2_f16": dict(rows=1_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm"),
     "cfg3": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma"),
+    "cfg4": dict(rows=12_500_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma"),  # x8 GPUs = 100M rows
     "cfg1": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="hbm"),
     # batches on the reference's own dtype (fp32): the 32-query MFMA tile.  32 queries ride one HBM pass; 1024 are bound by
     # the fp32 matrix rate.

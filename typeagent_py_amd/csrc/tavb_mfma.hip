@@ -36,6 +36,12 @@
 //     expected number of compactions per query is O(log(rows / CAP)).  At the end every
 //     buffer is compacted and written as a sorted list; tavb_merge merges the lists of
 //     the row ranges.
+//   * the host scans the corpus in phases of growing size (threshold ladder, tavb_abi.hip): the
+//     k-th best score after a phase seeds the admission thresholds of the next (`thr_in`).
+//
+// Two kernel families live here: the 256-query fp16 tile described above (variants 1-4 of its K
+// loop; 3 is the default) and, at the end of the file, a 32-query tile for fp32 and fp16 corpora
+// that carries small batches -- and every batch on the reference's fp32 layout -- at HBM speed.
 
 #include <hip/hip_runtime.h>
 
