@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the VectorBase kNN hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2_f16|cfg2_b32|cfg2_b1024|cfg3|cfg4|cfg5|cfg1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2_f16|cfg2_b32|cfg2_b1024|cfg3|cfg3_q1|cfg4|cfg5|cfg1]
 
 Contract (one JSON line on stdout from rank 0):
   * a "step" is one lookup pass of the hot path over the resident corpus:
@@ -49,6 +49,8 @@ WORKLOADS = {
     "cfg2": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1, k=32, bound="hbm"),
     "cfg2_f16": dict(rows=1_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm"),
     "cfg3": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma"),
+    # the north star's single-query target on the cfg3 corpus: HBM-bound, 30.72 GB per query
+    "cfg3_q1": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm"),
     "cfg4": dict(rows=12_500_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma"),  # x8 GPUs = 100M rows
     "cfg1": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="hbm"),
     # batches on the reference's own dtype (fp32): the 32-query MFMA tile.  32 queries ride one HBM pass; 1024 are bound by
