@@ -30,17 +30,10 @@ class IEmbedder(Protocol):
 
 
 @runtime_checkable
-class IEmbeddingModel(Protocol):
-    """Consumer interface: provider + cache."""
-
-    @property
-    def model_name(self) -> str: ...
+class IEmbeddingModel(IEmbedder, Protocol):
+    """Consumer interface: the provider's three members plus a key -> embedding cache."""
 
     def add_embedding(self, key: str, embedding: NormalizedEmbedding) -> None: ...
-
-    async def get_embedding_nocache(self, input: str) -> NormalizedEmbedding: ...
-
-    async def get_embeddings_nocache(self, input: list[str]) -> NormalizedEmbeddings: ...
 
     async def get_embedding(self, key: str) -> NormalizedEmbedding: ...
 
