@@ -483,7 +483,7 @@ def _f16(a):
     (33_000, 1024, 32, 0.0, 0),
     (9_000, 50, 5, 0.9, 8),
 ])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_mfma_batch_against_oracle(n, nq, k, ms, splits, variant):
     v, _ = make_corpus(n, 1536, 7000 + n % 97)
     qs = make_queries(nq, 1536, 7100 + nq)

@@ -102,7 +102,7 @@ struct tavb_ctx {
   tavb::ScanGeometry geom{0, 16, 2, 1, 0, 0};
   int64_t mfma_min_batch = 33;  // fp16 corpora: batches from this size up use the 256-query tile (6 .. 32 the 32-query tile)
   int64_t mfma_splits = 0;  // 0 = auto
-  int64_t mfma_variant = 3;
+  int64_t mfma_variant = 0;  // 0 = auto: variant 3, and variant 5 (384-row tile) for the big last phases of large batches
   int64_t mfma_ablate = 0;
   int64_t mfma_prio = 1;
   int64_t mfma_rendezvous = 0;
@@ -382,7 +382,7 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch must be >= 1");
     c->mfma_min_batch = v;
   } else if (n == "mfma_variant") {
-    if (v < 1 || v > 4) return fail(TAVB_E_INVALID, "mfma_variant must be 1..4");
+    if (v < 0 || v > 5) return fail(TAVB_E_INVALID, "mfma_variant must be 0..5");
     c->mfma_variant = v;
   } else if (n == "mfma_sample_rows") {
     if (v < 0) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= 0");
@@ -727,7 +727,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (min_scores[i] == min_scores[0]);
   const bool f16c = (c->dtype == TAVB_F16);
   const bool wide = (f16c || c->tiled) && (nq >= c->mfma_min_batch || !c->corpus) && uniform_thr && tavb::mfma_supported(c->dim, k) &&
-                    c->rows > 0 && (c->mfma_variant >= 3 || !c->tiled || c->corpus);
+                    c->rows > 0 && (c->mfma_variant == 0 || c->mfma_variant == 3 || c->mfma_variant == 4 || !c->tiled || c->corpus);
   // 32-query tiles at HBM speed: small batches on fp16 corpora, every batch from `skinny_min_batch_f32` up on fp32 ones
   const bool skinny = !wide && c->corpus && uniform_thr && c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c) &&
                       nq >= (f16c ? c->skinny_min_batch_f16 : c->skinny_min_batch_f32);
@@ -759,7 +759,8 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     if (int rc = c->d_lists.reserve((size_t)nq * (splits + 1) * k * sizeof(u64_t))) return rc;  // + the carried-over top-k
     if (int rc = c->d_cand.reserve(tavb::mfma_workspace_bytes(splits, nq_pad))) return rc;
     tavb::MfmaParams p{};
-    const bool use_tiled = !skinny && c->tiled && c->mfma_variant >= 3 && c->mfma_use_tiled;
+    const bool takes_tiled = c->mfma_variant == 0 || c->mfma_variant == 3 || c->mfma_variant == 4;  // the variants that can read the K-blocked image
+    const bool use_tiled = !skinny && c->tiled && takes_tiled && (c->mfma_use_tiled || !c->corpus);
     p.corpus = use_tiled ? c->tiled : c->corpus;
     p.a_tiled = use_tiled ? 1 : 0;
     if (!p.corpus) return fail(TAVB_E_NO_CORPUS, "no operand for the MFMA kernel (row-major fp16 corpus or K-blocked image)");
@@ -774,7 +775,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     p.index_base = index_base;
     p.min_score = min_scores[0];
     p.n_splits = splits;
-    p.variant = (int)c->mfma_variant;
+    p.variant = c->mfma_variant == 0 ? 3 : (int)c->mfma_variant;
     p.ablate = (int)c->mfma_ablate;
     p.prio = (int)c->mfma_prio;
     p.rendezvous = (int)c->mfma_rendezvous;
@@ -792,7 +793,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     std::vector<int64_t> bounds;  // phase i scans rows [bounds[i], bounds[i+1])
     bounds.push_back(0);
     const int64_t sample = (c->mfma_sample_rows + 255) / 256 * 256;
-    if (sample > 0 && c->rows >= 8 * sample && (c->mfma_ablate == 0 || c->mfma_ablate == 256)) {
+    if (sample > 0 && c->rows >= 8 * sample && (c->mfma_ablate == 0 || c->mfma_ablate == 256 || c->mfma_ablate == 512)) {
       int64_t done = sample;
       bounds.push_back(done);
       const int64_t growth = c->mfma_ladder;
@@ -815,6 +816,8 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
       pp.rows = bounds[ph + 1] - bounds[ph];
       pp.index_base = index_base + (uint32_t)bounds[ph];
       pp.n_splits = pick_splits(pp.rows);
+      if (!skinny && c->mfma_variant == 0)  // measured: the 384-row tile wins from a few million rows per launch, 4+ query tiles
+        pp.variant = (pp.rows >= 4000000 && nq_pad >= 4 * qt && !use_tiled) ? 5 : 3;
       if (c->mfma_splits > 0 || pp.n_splits > splits) pp.n_splits = splits;  // lists / candidate buffers are sized for `splits`
       const int carried = ph > 0 ? 1 : 0;  // the running top-k of the earlier phases occupies one more list slot
       pp.list_stride = pp.n_splits + carried;

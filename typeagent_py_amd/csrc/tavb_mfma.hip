@@ -45,6 +45,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "tavb_device.h"
 #include "tavb_internal.h"
 
@@ -130,6 +132,24 @@ __device__ __forceinline__ u64 sort64_ascending(u64 k, int lane) {
   k = sort_stage<64, 2>(k, lane);
   k = sort_stage<64, 1>(k, lane);
   return k;
+}
+
+// LDS read-modify-write / store that the compiler cannot see as LDS traffic.  hipcc's wait-count pass orders every LDS
+// write or atomic behind all in-flight LDS-DMA (`s_waitcnt vmcnt(0)`): it cannot tell that the fill counters and flags
+// never alias the operand rings.  In these kernels that wait sits in the admission slow path and drains up to twenty
+// 1 KiB loads (1-2 us) every time a 32 x 32 block admits a row.
+__device__ __forceinline__ int lds_add_rtn(int* counter, int v) {
+  const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int*)counter;
+  int old;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(v) : "memory");
+  return old;
+}
+__device__ __forceinline__ void lds_store_i32(__attribute__((address_space(3))) volatile int* flag, int v) {
+  const uint32_t addr = (uint32_t)(uintptr_t)flag;
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_store_i32(volatile int* flag, int v) {
+  lds_store_i32((__attribute__((address_space(3))) volatile int*)flag, v);
 }
 
 // Reduce one query's candidate buffer (n unsorted keys) to its best 64, sorted best-first and
@@ -677,8 +697,8 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
           const int n_adm = __popc(admit);
           int pos = 0;
           if (n_adm > 0) {
-            pos = atomicAdd(&cnt_lds[ql], n_adm);
-            if (pos + n_adm > CAP - BM) *need_compact = 1;  // this buffer could overflow on the next tile
+            pos = lds_add_rtn(&cnt_lds[ql], n_adm);
+            if (pos + n_adm > CAP - BM) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -978,8 +998,8 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
           const int n_adm = __popc(admit);
           int pos = 0;
           if (n_adm > 0) {
-            pos = atomicAdd(&cnt_lds[ql], n_adm);
-            if (pos + n_adm > CAP - BM) *need_compact = 1;  // this buffer could overflow on the next tile
+            pos = lds_add_rtn(&cnt_lds[ql], n_adm);
+            if (pos + n_adm > CAP - BM) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -1038,6 +1058,380 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDevice
     if (lane < p.k) out[lane] = best.key[0];
   }
 }
+
+ 
+// ---------------------------------------------------------------------------------------------
+// VARIANT 5: fewer operand bytes per flop.  Variants 1-4 sit on the machine balance between the
+// L2 -> CU fabric and the matrix pipe (profiles/r01_cfg3_operand_path.md): a 256 x 256 tile pulls
+// 32 KiB through L2 per 1024 MFMA cycles.  Here the tile is 384 corpus rows x 256 queries held by
+// FOUR waves (2 x 2), one per SIMD, each with the whole 512-register budget: a 192 x 128 sub-tile =
+// 6 x 4 MFMA tiles = 384 accumulator registers + two 40-register fragment sets.  hipcc selects the AGPR or the
+// VGPR form of an MFMA builtin per FUNCTION, so 384 accumulators cannot be split over the two files through
+// the builtin (600 spills); the MFMAs are therefore inline asm with explicit register classes: 16 tiles
+// accumulate in AGPRs ("+a"), 8 in VGPRs ("+v").  A volatile asm is ordered against memory operations, so
+// the program order below -- MFMA, LDS read, MFMA, ..., MFMA, LDS-DMA -- IS the schedule (no
+// sched_group_barrier needed).  Per flop
+// that is 17 % fewer L2 -> LDS bytes and LDS-DMA instructions, 44 % fewer LDS fragment-read bytes
+// and a third fewer barriers than the 8-wave tile.
+//   * K advances in steps of 32 halves; a step is two half-steps (k16 slices) of 24 MFMAs each.
+//   * one ring of 3 slots per operand (A: 24 KiB per slot, B: 16 KiB); every wave stages
+//     6 A pieces + 4 B pieces (1 KiB each) per step, five per half-step, so its vmcnt queue has
+//     the same shape in every wave and one counted wait serves both operands.
+//   * software pipeline of one wave (no partner wave on the SIMD to hide anything):
+//       (S,0): MFMAs on frag set 0 (step S, k 0-15)  | read set 1 <- slot S, k 16-31   | stage 2nd half of step S+2
+//       ---- vmcnt(10): step S+1 landed in this wave; lgkmcnt(0); s_barrier (the only one per step) ----
+//       (S,1): MFMAs on frag set 1                   | read set 0 <- slot S+1, k 0-15  | stage 1st half of step S+3
+//     Slot S is last read in (S,0), so after the barrier it takes step S+3; slot S+1 is first read
+//     after the barrier that follows the wait for its loads; loads have >= 1.5 steps to land.
+//   * the step stream runs across tile boundaries; the epilogue (admission test on the raw dot
+//     products, appends, rare compaction) is as in variant 3.
+// ---------------------------------------------------------------------------------------------
+constexpr int BM5 = 384;
+constexpr int NT5 = 256;
+constexpr int SLOT_A5 = BM5 * 64;   // 24 KiB
+constexpr int SLOT_B5 = BN * 64;    // 16 KiB
+constexpr int RING_A5 = 3;  // (a fourth A slot with the corpus stream one step further ahead measured no gain)
+constexpr int RING_B5 = 3;
+constexpr int B_RING5 = RING_A5 * SLOT_A5;
+constexpr int CTRL5 = RING_A5 * SLOT_A5 + RING_B5 * SLOT_B5;
+constexpr int LDS5 = CTRL5 + BN * 8 + 16;
+
+template <int ABL>
+__global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* thr_lds = reinterpret_cast<float*>(smem + CTRL5);
+  int* cnt_lds = reinterpret_cast<int*>(smem + CTRL5 + BN * 4);
+  typedef __attribute__((address_space(3))) volatile int lds_flag;
+  lds_flag* need_compact = (lds_flag*)(smem + CTRL5 + BN * 8);  // explicit LDS pointer: the generic-pointer form miscompiles in this kernel
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1;  // rows wm * 192 ..
+  const int wn = wave & 1;   // queries wn * 128 ..
+
+  const int b = blockIdx.x;
+  const int xcd = b & 7;
+  const int t = b >> 3;
+  const int qtile = t % p.n_qtiles;
+  const int split = (t / p.n_qtiles) * 8 + xcd;
+  if (split >= p.n_splits) return;
+  const int64_t r_begin = (int64_t)split * p.rows_per_split;
+  const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
+  const int logical_block = split * p.n_qtiles + qtile;
+  u64* my_cand = p.cand + (size_t)logical_block * BN * CAP;
+
+  const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
+  for (int i = tid; i < BN; i += NT5) {
+    float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
+    const int qg0 = qtile * BN + i;
+    if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
+    else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best so far: a valid lower bound
+    thr_lds[i] = t0;
+    cnt_lds[i] = 0;
+  }
+  if (tid == 0) *need_compact = 0;
+
+  const int D = p.dim;
+  const int steps_per_tile = D / 32;
+  const uint32_t row_bytes = (uint32_t)D * 2u;
+  const char* corpus = reinterpret_cast<const char*>(p.corpus);
+  const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * BN * row_bytes;
+  const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BM5 - 1) / BM5) : 0;
+  if (n_tiles == 0) {
+    for (int q = wave; q < BN; q += NT5 / 64) {
+      const int qg = qtile * BN + q;
+      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.list_stride + split) * (size_t)p.k + lane] = 0ull;
+    }
+    return;
+  }
+
+  // ---- stager.  Piece = 16 operand rows x 64 bytes -> 1 KiB of LDS, lane l = row l >> 2, 16-byte slot l & 3 of that
+  //      row, fetched from the XOR-swizzled source slot.  Wave w stages A pieces 6w .. 6w+5 and B pieces 4w .. 4w+3.
+  // The five per-lane constants of the K loop: two staging offsets, three fragment-address terms.
+  int a_off0, b_off0;
+  uint32_t frag_x, a_lane, b_lane;
+  auto set_lane_constants = [&]() {
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero));
+    const uint32_t lane_row = (uint32_t)(ln >> 2);
+    const uint32_t lane_slot = (uint32_t)(((ln & 3) ^ ((ln >> 4) & 3)) * 16);
+    a_off0 = (int)(((uint32_t)wave * 96u + lane_row) * row_bytes + lane_slot);
+    b_off0 = (int)(((uint32_t)wave * 64u + lane_row) * row_bytes + lane_slot);
+    const int frag_row = ln & 31;
+    frag_x = (uint32_t)(((ln >> 5) ^ ((frag_row >> 2) & 3)) << 4);
+    a_lane = (uint32_t)((wm * 192 + frag_row) * 64);            // + mi * 2048
+    b_lane = (uint32_t)(B_RING5 + (wn * 128 + frag_row) * 64);  // + ni * 2048
+  };
+  set_lane_constants();
+  // Staging goes through buffer descriptors (`buffer_load_dwordx4 ... lds`): the per-lane part of an address is ONE
+  // persistent 32-bit VGPR offset per operand, the piece (16 rows apart) and the K step are the scalar offset, the tile is
+  // the descriptor base, and rows past the end of the corpus are cut off by the descriptor's size (they read as zero; the
+  // epilogue masks them anyway).  A per-piece VGPR address temp -- what the flat form needs once a clamp is involved --
+  // would be overwritten while its LDS-DMA is in flight, which hipcc guards with `s_waitcnt vmcnt(0)` inside the K loop.
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sgpr_ptr(qbase)), 0, (int)(BN * row_bytes), 0x00020000);
+  // Separate A / B stager state (the two streams could run at different depths; they run at the same one).
+  int sa_kt = 0, sa_tile = 0, sa_slot = 0;  // next A step to stage: K step, tile, ring slot (of RING_A5)
+  int sb_kt = 0, sb_slot = 0;               // next B step to stage
+  auto stage_a_piece = [&](auto aj_tag) {
+    constexpr int AJ = decltype(aj_tag)::value;
+    const int tile = sa_tile < n_tiles ? sa_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
+    const int64_t row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM5;
+    const int64_t left = p.rows - row0;
+    const int valid = (int)(left < BM5 ? left : BM5);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(sgpr_ptr(corpus + (size_t)row0 * row_bytes)), 0, __builtin_amdgcn_readfirstlane(valid * (int)row_bytes), 0x00020000);
+    unsigned char* la = smem + sa_slot * SLOT_A5 + wave * 6144;
+    const int soff = __builtin_amdgcn_readfirstlane(sa_kt * 64 + AJ * 16 * (int)row_bytes);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(la + AJ * 1024), 16, a_off0, soff, 0, 0);
+    if constexpr (AJ == 5) {
+      sa_slot = (sa_slot + 1 == RING_A5) ? 0 : sa_slot + 1;
+      const bool wrap = (sa_kt + 1 == steps_per_tile);
+      sa_kt = wrap ? 0 : sa_kt + 1;
+      sa_tile += wrap ? 1 : 0;
+    }
+  };
+  auto stage_b_piece = [&](auto bj_tag) {
+    constexpr int BJ = decltype(bj_tag)::value;
+    unsigned char* lb = smem + B_RING5 + sb_slot * SLOT_B5 + wave * 4096;
+    const int soff = __builtin_amdgcn_readfirstlane(sb_kt * 64 + BJ * 16 * (int)row_bytes);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void*)(lb + BJ * 1024), 16, b_off0, soff, 0, 0);
+    if constexpr (BJ == 3) {
+      sb_slot = (sb_slot + 1 == RING_B5) ? 0 : sb_slot + 1;
+      sb_kt = (sb_kt + 1 == steps_per_tile) ? 0 : sb_kt + 1;
+    }
+  };
+  // piece J of stage half HALF: HALF 0 = A pieces 0-4; HALF 1 = A piece 5, then B pieces 0-3
+  auto stage_piece = [&](auto half_tag, auto j_tag) {
+    constexpr int HALF = decltype(half_tag)::value;
+    constexpr int J = decltype(j_tag)::value;
+    if constexpr (HALF == 0)
+      stage_a_piece(std::integral_constant<int, J>{});
+    else if constexpr (J == 0)
+      stage_a_piece(std::integral_constant<int, 5>{});
+    else
+      stage_b_piece(std::integral_constant<int, J - 1>{});
+  };
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  using J2 = std::integral_constant<int, 2>;
+  using J3 = std::integral_constant<int, 3>;
+  using J4 = std::integral_constant<int, 4>;
+  auto stage_half = [&](auto half_tag) {  // prologue only: a whole half at once
+    stage_piece(half_tag, J0{});
+    stage_piece(half_tag, J1{});
+    stage_piece(half_tag, J2{});
+    stage_piece(half_tag, J3{});
+    stage_piece(half_tag, J4{});
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+
+  // ---- fragment reads: row (lane & 31) of a 32-row block, logical 16-byte slot 2 * kk + (lane >> 5)
+  auto read_frags = [&](f16x8(&af)[6], f16x8(&bf)[4], int slot_a, int slot_b, int kk) {
+    const uint32_t kx = (uint32_t)(kk << 5) ^ frag_x;
+    const unsigned char* abase = smem + slot_a * SLOT_A5 + (a_lane + kx);
+    const unsigned char* bbase = smem + slot_b * SLOT_B5 + (b_lane + kx);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bf[ni] = *reinterpret_cast<const f16x8*>(bbase + ni * 2048);
+#pragma unroll
+    for (int mi = 0; mi < 6; ++mi) af[mi] = *reinterpret_cast<const f16x8*>(abase + mi * 2048);
+  };
+
+  // ---- prologue: steps 0 and 1 and the first half of step 2 in flight; wait for step 0 (everything but the last 15
+  //      pieces); read the first fragments
+  stage_half(H0{}); stage_half(H1{});
+  stage_half(H0{}); stage_half(H1{});
+  stage_half(H0{});
+  wait_vmcnt<15>();
+  __syncthreads();  // step 0 landed everywhere, thresholds initialised (the wait above is counted: nothing is drained)
+  f16x8 a0[6], b0[4], a1[6], b1[4];
+  read_frags(a0, b0, 0, 0, 0);
+  int rd_a = 0, rd_b = 0;  // ring slots of the step being multiplied
+
+  f32x16 acc_a[16];  // tiles (mi 0..3, ni 0..3): AGPRs
+  f32x16 acc_v[8];   // tiles (mi 4..5, ni 0..3): VGPRs
+  typedef int i32x4 __attribute__((ext_vector_type(4)));  // an <8 x half> asm operand gets repacked with v_perm; 4 x i32 does not
+#define TAVB_MFMA_A(ACC, A, B) \
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(__builtin_bit_cast(i32x4, A)), "v"(__builtin_bit_cast(i32x4, B)))
+#define TAVB_MFMA_V(ACC, A, B) \
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(__builtin_bit_cast(i32x4, A)), "v"(__builtin_bit_cast(i32x4, B)))
+
+  // One half-step: the 24 MFMAs of k-slice KK of the current step on fragments (fa, fb), with the 10 fragment reads of
+  // the next half-step (into (na, nb), ring slot `nslot`, k-slice NKK) and the five LDS-DMA pieces of stage half SH
+  // slotted between them in program order.
+  auto half_step = [&](f16x8(&fa)[6], f16x8(&fb)[4], f16x8(&na)[6], f16x8(&nb)[4], int nslot_a, int nslot_b, auto nkk_tag, auto sh_tag,
+                       const bool do_read) {
+    constexpr int NKK = decltype(nkk_tag)::value;
+    const uint32_t kx = (uint32_t)(NKK << 5) ^ frag_x;
+    const unsigned char* abase = smem + nslot_a * SLOT_A5 + (a_lane + kx);
+    const unsigned char* bbase = smem + nslot_b * SLOT_B5 + (b_lane + kx);
+    // 24 MFMAs in (mi, ni) order; behind MFMA i: a B read (i = 0..3), an A read (i = 4..9), and one staging piece
+    // behind MFMAs 3, 8, 13, 18, 23.
+    auto mfma_at = [&](auto i_tag) {
+      constexpr int I = decltype(i_tag)::value;
+      constexpr int mi = I >> 2, ni = I & 3;
+      if constexpr ((ABL & 1) == 0) {
+        if constexpr (mi < 4)
+          TAVB_MFMA_A(acc_a[mi * 4 + ni], fa[mi], fb[ni]);
+        else
+          TAVB_MFMA_V(acc_v[(mi - 4) * 4 + ni], fa[mi], fb[ni]);
+      }
+      if constexpr ((ABL & 32) == 0) {
+        if (do_read) {  // wave-uniform
+          if constexpr (I < 4) nb[I] = *reinterpret_cast<const f16x8*>(bbase + I * 2048);
+          if constexpr (I >= 4 && I < 10) na[I - 4] = *reinterpret_cast<const f16x8*>(abase + (I - 4) * 2048);
+        }
+      }
+      if constexpr ((ABL & 2) == 0) {
+        if constexpr (I == 3) stage_piece(sh_tag, J0{});
+        if constexpr (I == 8) stage_piece(sh_tag, J1{});
+        if constexpr (I == 13) stage_piece(sh_tag, J2{});
+        if constexpr (I == 18) stage_piece(sh_tag, J3{});
+        if constexpr (I == 23) stage_piece(sh_tag, J4{});
+      }
+    };
+    [&]<int... I>(std::integer_sequence<int, I...>) { (mfma_at(std::integral_constant<int, I>{}), ...); }
+    (std::make_integer_sequence<int, 24>{});
+    if constexpr ((ABL & 1) != 0) asm volatile("" ::"v"(fa[0]), "v"(fa[5]), "v"(fb[0]), "v"(fb[3]));
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const int64_t row0 = r_begin + (int64_t)tile * BM5;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_a[i][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_v[i][r] = 0.f;
+
+#pragma unroll 1
+    for (int kt = 0; kt < steps_per_tile; ++kt) {
+      const int rd_a_next = (rd_a + 1 == RING_A5) ? 0 : rd_a + 1;
+      const int rd_b_next = (rd_b + 1 == RING_B5) ? 0 : rd_b + 1;
+      // ---- (S,0): multiply k 0-15 of step S; fetch its k 16-31 fragments; stage the second half of step S+2
+      half_step(a0, b0, a1, b1, rd_a, rd_b, K1{}, H1{}, true);
+      // ---- step S+1 has landed in this wave; slot S is read out; meet
+      if constexpr ((ABL & 2) == 0) wait_vmcnt<10>();
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) through the builtin: visible to the compiler's wait-count pass
+      TAVB_BARRIER();
+      // ---- (S,1): multiply k 16-31; fetch k 0-15 of step S+1 (across the tile boundary too); stage the first half of S+3.
+      //      (Skipping the fetch on a tile's last step -- to free its 40 registers for the epilogue -- needs a run-time
+      //      predicate on the reads, whose branches between the MFMAs cost the K loop 30 %.)
+      half_step(a1, b1, a0, b0, rd_a_next, rd_b_next, K0{}, H0{}, true);
+      rd_a = rd_a_next;
+      rd_b = rd_b_next;
+    }
+
+    // ---- epilogue: admission test on the raw dot products, append.  The asm MFMAs are invisible to the compiler's
+    //      hazard recognizer: a 32x32x16 MFMA needs 18 wait states before its result may be read.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // Everything the epilogue derives from the lane id is derived HERE, from a laundered copy: hoisted out of the tile
+    // loop these per-lane constants (candidate-buffer pointers, LDS addresses, exchange masks) do not fit next to 384
+    // accumulators and would be spilled -- and a spill reload is a VMEM load queued behind the whole in-flight LDS-DMA.
+    int zero_e = 0;
+    asm volatile("" : "+v"(zero_e));  // (the lane id proper sits in a spill slot by now: recompute it from nothing)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_e));
+    // The VGPR-resident tiles (mi 4, 5) go first: once tested they are dead, and their 128 registers are what the
+    // AGPR-resident tiles' copies then live in (interleaved, the allocator runs out and spills).
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int ql = wn * 128 + ni * 32 + (lane_e & 31);
+      const float thr = thr_lds[ql];
+      const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;  // score > thr implies dot > thr_pre (see variant 3)
+#pragma unroll
+      for (int mi = (pass == 0 ? 4 : 0); mi < (pass == 0 ? 6 : 4); ++mi) {
+        const f32x16 dots = (mi < 4) ? acc_a[mi * 4 + ni] : acc_v[(mi - 4) * 4 + ni];
+        float top = dots[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, dots[r]);
+        TAVB_SB();  // one block at a time: the scheduler would otherwise pull several blocks' accumulator reads forward (spills)
+        const bool any = (ABL == 0 || ABL == 512) && (top > thr_pre);
+        if constexpr (ABL == 512) asm volatile("" ::"s"(__builtin_amdgcn_ballot_w64(any)));  // test computed, slow path never taken
+        if (ABL != 512 && __builtin_amdgcn_ballot_w64(any) != 0ull) {
+          // (scores are recomputed where they are used: sixteen more live registers here would be spilled, and a spill
+          //  reload is a VMEM load behind the whole in-flight LDS-DMA queue)
+          const int64_t row_base = row0 + wm * 192 + mi * 32 + 4 * (lane_e >> 5);
+          unsigned admit = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float sc = fmaf(dots[r], 0.5f, 0.5f);
+            float s1 = (sc > 0.0f) ? sc : 0.0f;
+            s1 = (s1 > 1.0f) ? 1.0f : s1;
+            const bool ok = (sc > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s1 >= p.min_score);
+            admit |= ok ? (1u << r) : 0u;
+          }
+          const int n_adm = __popc(admit);
+          int pos = 0;
+          if (n_adm > 0) {
+            pos = lds_add_rtn(&cnt_lds[ql], n_adm);
+            if (pos + n_adm > CAP - BM5) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            TAVB_SB();  // one key at a time (sixteen keys and addresses in flight would not fit)
+            if ((admit >> r) & 1u) {
+              const float sc = fmaf(dots[r], 0.5f, 0.5f);
+              float s1 = (sc > 0.0f) ? sc : 0.0f;
+              s1 = (s1 > 1.0f) ? 1.0f : s1;
+              if (pos < CAP)
+                my_cand[(size_t)ql * CAP + pos] = make_key(s1, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
+              ++pos;
+            }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TAVB_BARRIER();
+    if (*need_compact != 0) {  // workgroup-uniform: read after the barrier
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TAVB_BARRIER();
+      for (int q = wave; q < BN; q += NT5 / 64) {
+        const int n = cnt_lds[q];
+        if (n > CAP - BM5) {
+          u64* buf = my_cand + (size_t)q * CAP;
+          const WaveTopK<1> best = best_of_buffer(buf, n < CAP ? n : CAP, lane_e);
+          if (lane_e < p.k) buf[lane_e] = best.key[0];
+          const int kept = __popcll(__ballot(best.key[0] != 0ull && lane_e < p.k));
+          const u64 kth = best.at(p.k - 1);
+          if (lane_e == 0) {
+            cnt_lds[q] = kept;
+            const float kth_score = __uint_as_float((uint32_t)(kth >> 32));
+            if (kth != 0ull && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TAVB_BARRIER();
+      if (tid == 0) *need_compact = 0;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TAVB_BARRIER();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead LDS-DMA before the block retires
+  __syncthreads();
+
+  for (int q = wave; q < BN; q += NT5 / 64) {
+    const int qg = qtile * BN + q;
+    if (qg >= p.nq) continue;
+    const int n = cnt_lds[q];
+    int lane_f = lane;
+    asm volatile("" : "+v"(lane_f));
+    const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane_f);
+    u64* out = p.lists + ((size_t)qg * p.list_stride + split) * (size_t)p.k;
+    if (lane_f < p.k) out[lane_f] = best.key[0];
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // SKINNY kernel: 8 .. 32 queries per pass at HBM speed, on fp32 AND fp16 corpora.
@@ -1268,8 +1662,8 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
           const int n_adm = __popc(admit);
           int pos = 0;
           if (n_adm > 0) {
-            pos = atomicAdd(&cnt_lds[ql], n_adm);
-            if (pos + n_adm > CAP - BM) *need_compact = 1;  // this buffer could overflow on the next tile
+            pos = lds_add_rtn(&cnt_lds[ql], n_adm);
+            if (pos + n_adm > CAP - BM) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -1349,7 +1743,7 @@ hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int 
 
 int mfma_query_tile() { return BN; }
 
-bool mfma_supported(int dim, int k) { return dim % BK == 0 && dim >= BK && k >= 1 && k <= 64; }
+bool mfma_supported(int dim, int k) { return dim % BK == 0 && dim >= BK && dim <= 16384 && k >= 1 && k <= 64; }
 
 int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu) {
   const int n_qtiles = nq_padded / BN;
@@ -1388,7 +1782,8 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.a_tiled = p.a_tiled;
   d.thr_in = p.thr_in;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
-  d.rows_per_split = ((per + BM - 1) / BM) * BM;
+  const int bm = (p.variant == 5) ? BM5 : BM;
+  d.rows_per_split = ((per + bm - 1) / bm) * bm;
   if (!p.workspace) return hipErrorInvalidValue;
   d.cand = p.workspace;
   d.sync = nullptr;
@@ -1430,6 +1825,24 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 10: return go4(mfma_scan_kernel_v4<NA4, NB4, 10>);  // no LDS-DMA, barrier every 2nd step
       case 18: return go4(mfma_scan_kernel_v4<NA4, NB4, 18>);  // no LDS-DMA, barrier every 4th step
       default: return go4(mfma_scan_kernel_v4<NA4, NB4, 0>);
+    }
+  }
+  if (p.variant == 5) {
+    if (p.a_tiled) return hipErrorInvalidValue;  // row-major operand only
+    auto go5 = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(NT5), LDS5, stream, d);
+      return hipGetLastError();
+    };
+    switch (p.ablate) {
+      case 1: return go5(mfma_scan_kernel_v5<1>);      // no MFMAs
+      case 2: return go5(mfma_scan_kernel_v5<2>);      // no LDS-DMA after the prologue
+      case 256: return go5(mfma_scan_kernel_v5<256>);  // everything except admissions
+      case 260: return go5(mfma_scan_kernel_v5<260>);  // same, corpus tile 0 re-read by every block (L2 resident)
+      case 288: return go5(mfma_scan_kernel_v5<288>);  // same as 256 without the fragment reads
+      case 512: return go5(mfma_scan_kernel_v5<512>);  // admission test computed, slow path never taken
+      default: return go5(mfma_scan_kernel_v5<0>);
     }
   }
   if (p.variant == 3) {
