@@ -371,7 +371,7 @@ def main() -> None:
                 roof["traffic_source"] = pmc["source"]
         except Exception:
             pass
-        roof["kernel"] = {0: "scan (tavb::scan_*_kernel)", 2: "mfma (tavb::mfma_scan_kernel_v3)",
+        roof["kernel"] = {0: "scan (tavb::scan_*_kernel)", 2: "mfma (tavb::mfma_scan_kernel_v3 for the small ladder phases, _v5 for the big ones)",
                           6: "skinny (tavb::skinny_scan_kernel)"}.get(kid, str(kid))
         roof["kernel_avg_ms"] = avg_kernel_s * 1e3
         roof["kernel_launches"] = kern_n
