@@ -1250,8 +1250,12 @@ __global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParam
   read_frags(a0, b0, 0, 0, 0);
   int rd_a = 0, rd_b = 0;  // ring slots of the step being multiplied
 
-  f32x16 acc_a[16];  // tiles (mi 0..3, ni 0..3): AGPRs
-  f32x16 acc_v[8];   // tiles (mi 4..5, ni 0..3): VGPRs
+  // tile t = mi * 4 + ni.  Fifteen tiles accumulate in AGPRs, nine in VGPRs: the sixteen AGPRs left over are where the
+  // register allocator parks VGPR values during the epilogue (v_accvgpr_write / read, no memory involved); with all 256
+  // AGPRs taken it parks them in scratch instead, and a scratch reload is a VMEM load behind the LDS-DMA queue.
+  constexpr int NA_TILES = 15;
+  f32x16 acc_a[NA_TILES];       // tiles 0 .. 14
+  f32x16 acc_v[24 - NA_TILES];  // tiles 15 .. 23
   typedef int i32x4 __attribute__((ext_vector_type(4)));  // an <8 x half> asm operand gets repacked with v_perm; 4 x i32 does not
 #define TAVB_MFMA_A(ACC, A, B) \
   asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(__builtin_bit_cast(i32x4, A)), "v"(__builtin_bit_cast(i32x4, B)))
@@ -1273,10 +1277,10 @@ __global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParam
       constexpr int I = decltype(i_tag)::value;
       constexpr int mi = I >> 2, ni = I & 3;
       if constexpr ((ABL & 1) == 0) {
-        if constexpr (mi < 4)
-          TAVB_MFMA_A(acc_a[mi * 4 + ni], fa[mi], fb[ni]);
+        if constexpr (I < NA_TILES)
+          TAVB_MFMA_A(acc_a[I], fa[mi], fb[ni]);
         else
-          TAVB_MFMA_V(acc_v[(mi - 4) * 4 + ni], fa[mi], fb[ni]);
+          TAVB_MFMA_V(acc_v[I - NA_TILES], fa[mi], fb[ni]);
       }
       if constexpr ((ABL & 32) == 0) {
         if (do_read) {  // wave-uniform
@@ -1302,11 +1306,11 @@ __global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParam
   for (int tile = 0; tile < n_tiles; ++tile) {
     const int64_t row0 = r_begin + (int64_t)tile * BM5;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < NA_TILES; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc_a[i][r] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 24 - NA_TILES; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc_v[i][r] = 0.f;
 
@@ -1337,8 +1341,8 @@ __global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParam
     int zero_e = 0;
     asm volatile("" : "+v"(zero_e));  // (the lane id proper sits in a spill slot by now: recompute it from nothing)
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_e));
-    // The VGPR-resident tiles (mi 4, 5) go first: once tested they are dead, and their 128 registers are what the
-    // AGPR-resident tiles' copies then live in (interleaved, the allocator runs out and spills).
+    // The VGPR-resident tiles go first: once tested they are dead, and their registers are what the AGPR-resident
+    // tiles' copies then live in (interleaved, the allocator runs out and spills).
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
@@ -1347,8 +1351,9 @@ __global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParam
       const float thr = thr_lds[ql];
       const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;  // score > thr implies dot > thr_pre (see variant 3)
 #pragma unroll
-      for (int mi = (pass == 0 ? 4 : 0); mi < (pass == 0 ? 6 : 4); ++mi) {
-        const f32x16 dots = (mi < 4) ? acc_a[mi * 4 + ni] : acc_v[(mi - 4) * 4 + ni];
+      for (int mi = 0; mi < 6; ++mi) {
+        if ((mi * 4 + ni >= NA_TILES) != (pass == 0)) continue;  // pass 0: VGPR tiles, pass 1: AGPR tiles
+        const f32x16 dots = (mi * 4 + ni < NA_TILES) ? acc_a[mi * 4 + ni] : acc_v[mi * 4 + ni - NA_TILES];
         float top = dots[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, dots[r]);
