@@ -482,6 +482,7 @@ def _f16(a):
     (70_001, 256, 32, 0.0, 17),
     (33_000, 1024, 32, 0.0, 0),
     (9_000, 50, 5, 0.9, 8),
+    (30_000, 700, 32, 0.0, 0),  # three query tiles: 80 row ranges, 240 workgroups
 ])
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_mfma_batch_against_oracle(n, nq, k, ms, splits, variant):

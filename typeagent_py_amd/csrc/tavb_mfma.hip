@@ -1751,9 +1751,12 @@ int mfma_query_tile() { return BN; }
 bool mfma_supported(int dim, int k) { return dim % BK == 0 && dim >= BK && dim <= 16384 && k >= 1 && k <= 64; }
 
 int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu) {
-  const int n_qtiles = nq_padded / BN;
-  int splits = n_cu / (n_qtiles > 0 ? n_qtiles : 1);
-  if (splits < 1) splits = 1;
+  // One workgroup per CU and all of them resident at once: the grid is (groups of 8 row ranges) x query tiles x 8, so the
+  // number of row ranges is a multiple of 8 with groups * n_qtiles * 8 <= n_cu.  (85 ranges for 3 query tiles made 264
+  // workgroups on 256 CUs: a second scheduling round for the last 8, and a 768-query batch slower than a 1024-query one.)
+  const int n_qtiles = nq_padded / BN > 0 ? nq_padded / BN : 1;
+  int splits = (n_cu / (8 * n_qtiles)) * 8;
+  if (splits < 8) splits = 8;
   const int64_t tiles = (rows + BM - 1) / BM;
   if (splits > tiles) splits = (int)tiles;
   return splits;
