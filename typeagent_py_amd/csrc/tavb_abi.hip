@@ -409,7 +409,7 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_prio must be 0..2");
     c->mfma_prio = v;
   } else if (n == "mfma_ablate") {
-    if (v < 0 || v > 1023) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..1023");
+    if (v < 0 || v > 4095) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..4095");
     c->mfma_ablate = v;
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");

@@ -1321,9 +1321,9 @@ __global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParam
       // ---- (S,0): multiply k 0-15 of step S; fetch its k 16-31 fragments; stage the second half of step S+2
       half_step(a0, b0, a1, b1, rd_a, rd_b, K1{}, H1{}, true);
       // ---- step S+1 has landed in this wave; slot S is read out; meet
-      if constexpr ((ABL & 2) == 0) wait_vmcnt<10>();
+      if constexpr ((ABL & 2) == 0 && (ABL & 1024) == 0) wait_vmcnt<10>();
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) through the builtin: visible to the compiler's wait-count pass
-      TAVB_BARRIER();
+      if constexpr ((ABL & 2048) == 0) TAVB_BARRIER();
       // ---- (S,1): multiply k 16-31; fetch k 0-15 of step S+1 (across the tile boundary too); stage the first half of S+3.
       //      (Skipping the fetch on a tile's last step -- to free its 40 registers for the epilogue -- needs a run-time
       //      predicate on the reads, whose branches between the MFMAs cost the K loop 30 %.)
@@ -1850,6 +1850,8 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 260: return go5(mfma_scan_kernel_v5<260>);  // same, corpus tile 0 re-read by every block (L2 resident)
       case 288: return go5(mfma_scan_kernel_v5<288>);  // same as 256 without the fragment reads
       case 512: return go5(mfma_scan_kernel_v5<512>);  // admission test computed, slow path never taken
+      case 1280: return go5(mfma_scan_kernel_v5<1280>);  // 256 without the counted vmcnt wait (garbage: timing only)
+      case 3328: return go5(mfma_scan_kernel_v5<3328>);  // ... and without the barrier
       default: return go5(mfma_scan_kernel_v5<0>);
     }
   }
