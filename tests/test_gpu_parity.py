@@ -652,6 +652,43 @@ def test_mfma_rendezvous_and_stream_policy_do_not_change_results(opts):
         vo.check_topk_parity(vo.scores_full(v16, q16[qi]), *items_scores(tuned[qi]), k, 0.0)
 
 
+def test_mfma_variants_3_and_5_agree_on_a_large_corpus():
+    """Two independent K loops (8 waves / builtin MFMAs / flat LDS-DMA vs 4 waves / inline-asm MFMAs with AGPR+VGPR
+    accumulators / buffer-descriptor LDS-DMA) over 786k rows x 1024 queries: every returned ordinal identical, scores to
+    the last bits (same products, same k order per accumulator).  Variant 5's MFMAs are invisible to the compiler's hazard
+    recognizer, so this is the test that would notice a scheduling change breaking them."""
+    import torch
+
+    n, nq, k = 786_432 + 77, 1024, 32
+    eng = _native.Engine(0)
+    corpus = torch.empty((n, 1536), dtype=torch.float16, device="cuda")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4242)
+    for lo in range(0, n, 131072):
+        hi = min(n, lo + 131072)
+        tmp = torch.empty((hi - lo, 1536), dtype=torch.float32, device="cuda")
+        tmp.normal_(generator=gen)
+        eng.normalize_rows_(tmp)
+        corpus[lo:hi].copy_(eng.to_f16(tmp))
+    eng.set_corpus_tensor(corpus)
+    dq = torch.from_numpy(make_queries(nq, 1536, 4243)).cuda()
+    eng.set_option("mfma_sample_rows", 16384)  # several ladder phases
+    keys = {}
+    for variant in (3, 5):
+        eng.set_option("mfma_variant", variant)
+        out = eng.search_device(dq, k, 0.0)
+        eng.synchronize()
+        assert eng.get_option("last_tier") == 4
+        keys[variant] = _native.decode_keys(out.cpu().numpy())
+    o3, s3, c3 = keys[3]
+    o5, s5, c5 = keys[5]
+    np.testing.assert_array_equal(c3, c5)
+    np.testing.assert_array_equal(o3, o5)
+    np.testing.assert_allclose(s3, s5, atol=2e-7, rtol=0)
+    assert np.all(c3 == k) and np.all(np.diff(s3, axis=1) <= 0)
+    eng.close()
+
+
 def test_mfma_batch_equals_streaming_path_on_f16_representable_queries():
     v, _ = make_corpus(12_345, 1536, 7200)
     qs = _f16(make_queries(48, 1536, 7201))
