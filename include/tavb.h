@@ -79,7 +79,8 @@ int tavb_synchronize(tavb_ctx* ctx);
  *                   corpora (defaults 5 / 3, the measured break-even; fp32 corpora have no other matrix-core path, fp16 ones use it up to
  *                   mfma_min_batch - 1); smaller batches use the streaming tiers
  *   "mfma_sample_rows", "mfma_ladder"  phases of the MFMA paths' threshold ladder (rows of the first phase; growth)
- *   "mfma_variant", "mfma_splits", "mfma_rendezvous", "mfma_a_nt", ...  experiment knobs, see DESIGN.md
+ *   "mfma_variant"  K loop of the 256-query tile: 0 = auto (3 for small ladder phases, 5 for big ones), 1..5 fixed
+ *   "mfma_splits", "mfma_rendezvous", "mfma_a_nt", "mfma_ablate", ...  experiment knobs, see DESIGN.md
  *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile,
  *                   5 = 32-query MFMA tile
  */
@@ -175,13 +176,15 @@ int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* 
 /* ---- measurement ------------------------------------------------------------ */
 /* HIP-event timing of the kernels this context launches, on the stream they run on.
  * kernel ids: 0 = streaming scan (dot + score + select), 1 = list merge,
- *             2 = MFMA batched scan, 3 = normalise, 4 = f32->f16 convert / pack, 5 = MFMA sample pass. */
+ *             2 = MFMA batched scan (256-query tile: the last phase of the threshold ladder), 3 = normalise,
+ *             4 = f32->f16 convert / pack, 5 = the earlier phases of the ladder (either MFMA tile), 6 = 32-query MFMA tile
+ *             (last phase). */
 #define TAVB_KERNEL_SCAN 0
 #define TAVB_KERNEL_MERGE 1
 #define TAVB_KERNEL_MFMA 2
 #define TAVB_KERNEL_NORMALIZE 3
 #define TAVB_KERNEL_CONVERT 4
-#define TAVB_KERNEL_MFMA_SAMPLE 5 /* threshold-seeding pass of the MFMA path over the first rows */
+#define TAVB_KERNEL_MFMA_SAMPLE 5 /* threshold-seeding phases of the MFMA paths (all ladder phases but the last) */
 #define TAVB_KERNEL_SKINNY 6 /* 32-query MFMA tile (small batches; every batch on fp32 corpora) */
 #define TAVB_KERNEL_COUNT 7
 int tavb_profile_enable(tavb_ctx* ctx, int32_t on);
