@@ -735,9 +735,10 @@ def test_skinny_kernel_against_oracle(dtype, n, d, nq, k, ms):
         assert got[0][0].item == n - 2
 
 
-@pytest.mark.parametrize("nq", [40, 64, 200])
+@pytest.mark.parametrize("nq", [33, 40, 64, 65, 200])
 def test_skinny_kernel_serves_large_batches_on_fp32_corpora(nq):
-    """More than one 32-query tile per row range (the workgroups of a row range share it through L2)."""
+    """Batches of 33+ use 64-query tiles, several per row range from 65 queries (the workgroups of a row range share it
+    through L2)."""
     n, k = 30_000, 32
     v, _ = make_corpus(n, 1536, 9600)
     qs = make_queries(nq, 1536, 9601 + nq)
@@ -749,10 +750,27 @@ def test_skinny_kernel_serves_large_batches_on_fp32_corpora(nq):
     # the same batch through the streaming tier
     vb.engine.set_option("skinny_min_batch_f32", 1 << 30)
     ref = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
-    assert vb.engine.get_option("last_tier") in (2, 3)
+    assert vb.engine.get_option("last_tier") in (1, 2, 3)
     for a, b in zip(got, ref):
         sa, sb = [r.score for r in a], [r.score for r in b]
         np.testing.assert_allclose(sa, sb, atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("nq", [33, 48, 64])
+def test_skinny_64_query_tile_on_fp16_corpora(nq):
+    """33 .. 64 queries on an fp16 corpus: one 64-query tile (fp32 queries split into fp16 high + low planes), the same
+    arithmetic meaning as the streaming tiers."""
+    n, k = 50_001, 32
+    v, _ = make_corpus(n, 1536, 9800)
+    qs = make_queries(nq, 1536, 9801 + nq)
+    qs[1] = v[n - 5]
+    vb = new_vb(v, dtype="fp16")
+    got = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert vb.engine.get_option("last_tier") == 5
+    v16 = _f16(v)
+    for qi in range(nq):
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(got[qi]), k, 0.0)
+    assert got[1][0].item == n - 5
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])

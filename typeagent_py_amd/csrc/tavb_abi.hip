@@ -100,7 +100,7 @@ struct tavb_ctx {
   const void* tiled = nullptr;  // optional K-blocked fp16 image of the same rows (MFMA path)
 
   tavb::ScanGeometry geom{0, 16, 2, 1, 0, 0};
-  int64_t mfma_min_batch = 33;  // fp16 corpora: batches from this size up use the 256-query tile (6 .. 32 the 32-query tile)
+  int64_t mfma_min_batch = 65;  // fp16 corpora: batches from this size up use the 256-query tile (3 .. 64 the 32/64-query tile)
   int64_t mfma_splits = 0;  // 0 = auto
   int64_t mfma_variant = 0;  // 0 = auto: variant 3, and variant 5 (384-row tile) for the big last phases of large batches
   int64_t mfma_ablate = 0;
@@ -732,7 +732,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   const bool skinny = !wide && c->corpus && uniform_thr && c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c) &&
                       nq >= (f16c ? c->skinny_min_batch_f16 : c->skinny_min_batch_f32);
   if (wide || skinny) {
-    const int qt = skinny ? tavb::skinny_query_tile() : tavb::mfma_query_tile();
+    const int qt = skinny ? tavb::skinny_query_tile(nq) : tavb::mfma_query_tile();
     const int nq_pad = ((nq + qt - 1) / qt) * qt;
     const bool q32 = skinny && !f16c;  // the skinny kernel on an fp32 corpus multiplies fp32 queries
     const bool split = skinny && f16c;  // ... and on an fp16 corpus fp32 queries split into fp16 high + low planes
@@ -751,7 +751,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
       if (e != hipSuccess) return fail(TAVB_E_HIP, "query convert launch failed: %s", hipGetErrorString(e));
     }
     auto pick_splits = [&](int64_t rows) {
-      return skinny ? tavb::skinny_pick_splits(rows, nq_pad, c->n_cu) : tavb::mfma_pick_splits(rows, nq_pad, c->n_cu);
+      return skinny ? tavb::skinny_pick_splits(rows, nq_pad, qt, c->n_cu) : tavb::mfma_pick_splits(rows, nq_pad, c->n_cu);
     };
     auto launch = [&](const tavb::MfmaParams& q) { return skinny ? tavb::launch_skinny_scan(q, c->stream) : tavb::launch_mfma_scan(q, c->stream); };
     c->last_tier = skinny ? 5 : 4;  // 1-3 = streaming tiers, 4 = 256-query MFMA tile, 5 = 32-query MFMA tile
@@ -782,6 +782,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     p.a_nt = (int)c->mfma_a_nt;
     p.group_sel = (int)c->mfma_group;
     p.f32 = q32 ? 1 : 0;
+    p.skinny_tile = skinny ? qt : 0;
     p.thr_in = nullptr;
     // Threshold ladder.  The corpus is scanned in phases of growing size -- the first `mfma_sample_rows` rows, then
     // `mfma_ladder` times everything scanned so far, ..., then the rest -- every row exactly once.  After each

@@ -70,6 +70,7 @@ struct MfmaParams {
   int32_t rendezvous;   // variant 3: the workgroups of a row range meet at every tile start (L2 sharing of corpus slices)
   int32_t a_nt;         // variant 3: non-temporal policy on the corpus LDS-DMA stream
   int32_t f32;          // skinny kernel only: corpus and queries are fp32 (else fp16)
+  int32_t skinny_tile;  // skinny kernel only: queries per tile, 32 or 64
 };
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
 hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, float* thr, hipStream_t stream);
@@ -79,8 +80,8 @@ bool mfma_supported(int dim, int k);
 size_t mfma_workspace_bytes(int n_splits, int nq_padded);
 // 32-query tiles at HBM speed, fp32 or fp16 corpora (same parameter block; `queries` in the corpus dtype)
 hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream);
-int skinny_query_tile();
-int skinny_pick_splits(int64_t rows, int nq_padded, int n_cu);
+int skinny_query_tile(int nq);  // 32, or 64 for batches of 33 and more
+int skinny_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu);
 bool skinny_supported(int dim, int k, bool f32);
 
 }  // namespace tavb

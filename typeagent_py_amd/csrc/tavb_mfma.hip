@@ -1460,27 +1460,33 @@ __global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParam
 //     (upper), the same pairing on both operands, which is all a dot product needs.
 //   * epilogue / candidate buffers / compaction / lists exactly as in the wide kernel (32 queries per block).
 // ---------------------------------------------------------------------------------------------
-constexpr int SQ = 32;              // queries per tile
+constexpr int SQ32 = 32;            // queries per 32 x 32 MFMA block; a tile is NI of them (32 or 64 queries)
 constexpr int S_THREADS = 256;
 constexpr int S_SLOT_A = BM * 64;   // 16 KiB
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // fp32: one query operand plane, ring of 4 (72 KiB).  fp16: the fp32 queries are split into an fp16 high and an fp16
 // low plane (q = hi + lo to 2^-22; both are multiplied -- the kernel is load-bound, the second MFMA is free), so a
 // lookup on an fp16 corpus means the same thing here as in the streaming tiers (fp32 query x fp16 rows); ring of 3 (60 KiB).
-template <typename T>
+// NI = 2 (64 queries per tile): twice the MFMAs per operand byte -- for batches of 33+ queries, which would otherwise
+// stream the corpus once per 32 queries (fp32) or pay for a 256-query tile (fp16, 33 .. 64 queries).  Ring of 3.
+template <typename T, int NI>
 struct SkinnyGeom {
   static constexpr bool F32 = sizeof(T) == 4;
+  static constexpr int SQ = NI * SQ32;
   static constexpr int PLANES = F32 ? 1 : 2;
-  static constexpr int RING = F32 ? 4 : 3;
-  static constexpr int SLOT_B = PLANES * SQ * 64;
+  static constexpr int RING = (F32 && NI == 1) ? 4 : 3;
+  static constexpr int PLANE_B = SQ * 64;          // one query operand plane, one step
+  static constexpr int SLOT_B = PLANES * PLANE_B;
   static constexpr int B_RING = RING * S_SLOT_A;
   static constexpr int CTRL = RING * (S_SLOT_A + SLOT_B);
   static constexpr int LDS = CTRL + SQ * 8 + 16;
+  static constexpr int B_WAVES = SQ / 16;          // waves that stage a query piece (per plane): 2 or 4
 };
 
-template <typename T, int ABL>
+template <typename T, int NI, int ABL>
 __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDeviceParams p) {
-  using G = SkinnyGeom<T>;
+  using G = SkinnyGeom<T, NI>;
+  constexpr int SQ = G::SQ;
   constexpr bool F32 = G::F32;
   constexpr int S_RING = G::RING, S_SLOT_B = G::SLOT_B, S_B_RING = G::B_RING, S_CTRL = G::CTRL;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1504,7 +1510,7 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
   u64* my_cand = p.cand + (size_t)logical_block * SQ * CAP;
 
   const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
-  if (tid < SQ) {
+  if (tid < SQ) {  // SQ <= 64 < S_THREADS
     float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
     const int qg0 = qtile * SQ + tid;
     if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
@@ -1542,7 +1548,7 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
     }
   };
   const uint32_t st_off_b = (uint32_t)(wave * 16 + st_row_in_piece) * (uint32_t)row_bytes + st_slot16;
-  const bool stages_b = wave < 2;
+  const bool stages_b = wave < G::B_WAVES;
   int st_tile = 0, st_kt = 0, st_slot = 0;
   set_offsets(r_begin);
 
@@ -1560,7 +1566,7 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
       __builtin_amdgcn_global_load_lds((global_void*)(gb + (size_t)st_off_b), (lds_void*)lb, 16, 0, 0);
       if constexpr (!F32) {  // the low plane of the split queries
         const char* gl = sgpr_ptr(qbase + plane_bytes + (size_t)st_kt * 64);
-        __builtin_amdgcn_global_load_lds((global_void*)(gl + (size_t)st_off_b), (lds_void*)(lb + SQ * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((global_void*)(gl + (size_t)st_off_b), (lds_void*)(lb + G::PLANE_B), 16, 0, 0);
       }
     }
     if (++st_slot == S_RING) st_slot = 0;
@@ -1590,11 +1596,13 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
   int rd = 0;
   for (int tile = 0; tile < n_tiles; ++tile) {
     const int64_t row0 = r_begin + (int64_t)tile * BM;
-    f32x16 acc[2];
+    f32x16 acc[2][NI];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
 #pragma unroll 1
     for (int kt = 0; kt < steps_per_tile; ++kt) {
@@ -1604,12 +1612,15 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
       if constexpr ((ABL & 2) == 0) stage_next();  // step S + S_RING - 1 -> the slot of step S - 1
       const unsigned char* abase = smem + rd * S_SLOT_A;
       const unsigned char* bbase = smem + rd * S_SLOT_B;
-      f32x4 af[2][2], bf[2], bl[2];
+      f32x4 af[2][2], bf[2][NI], bl[2][NI];
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const uint32_t kx = (uint32_t)(g << 5) ^ frag_x;
-        bf[g] = *reinterpret_cast<const f32x4*>(bbase + (b_lane + kx));
-        if constexpr (!F32) bl[g] = *reinterpret_cast<const f32x4*>(bbase + (b_lane + kx) + SQ * 64);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          bf[g][ni] = *reinterpret_cast<const f32x4*>(bbase + (b_lane + kx) + ni * 2048);
+          if constexpr (!F32) bl[g][ni] = *reinterpret_cast<const f32x4*>(bbase + (b_lane + kx) + ni * 2048 + G::PLANE_B);
+        }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) af[g][mi] = *reinterpret_cast<const f32x4*>(abase + (a_lane + kx) + mi * 2048);
       }
@@ -1620,40 +1631,46 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int mi = 0; mi < 2; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mi][e], bf[g][e], acc[mi], 0, 0, 0);
+              for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mi][e], bf[g][ni][e], acc[mi][ni], 0, 0, 0);
           } else {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-              acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[g][mi]), __builtin_bit_cast(f16x8, bl[g]),
-                                                               acc[mi], 0, 0, 0);
-              acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[g][mi]), __builtin_bit_cast(f16x8, bf[g]),
-                                                               acc[mi], 0, 0, 0);
-            }
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) {
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[g][mi]), __builtin_bit_cast(f16x8, bl[g][ni]),
+                                                                     acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[g][mi]), __builtin_bit_cast(f16x8, bf[g][ni]),
+                                                                     acc[mi][ni], 0, 0, 0);
+              }
           }
         }
       } else {
-        asm volatile("" ::"v"(af[0][0]), "v"(af[1][1]), "v"(bf[0]), "v"(bf[1]));
-        if constexpr (!F32) asm volatile("" ::"v"(bl[0]), "v"(bl[1]));
+        asm volatile("" ::"v"(af[0][0]), "v"(af[1][1]), "v"(bf[0][0]), "v"(bf[1][NI - 1]));
+        if constexpr (!F32) asm volatile("" ::"v"(bl[0][0]), "v"(bl[1][NI - 1]));
       }
       if (++rd == S_RING) rd = 0;
     }
 
     // ---- epilogue: admission test on the raw dot products, append (see variant 3)
-    {
-      const int ql = lane & 31;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int ql = ni * 32 + (lane & 31);
       const float thr = thr_lds[ql];
       const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        float top = acc[mi][0];
+        float top = acc[mi][ni][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, acc[mi][r]);
+        for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, acc[mi][ni][r]);
         const bool any = (ABL == 0) && (top > thr_pre);
-        if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi]));
+        if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi][ni]));
         if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
           float sc[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sc[r] = fmaf(acc[mi][r], 0.5f, 0.5f);
+          for (int r = 0; r < 16; ++r) sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
           const int64_t row_base = row0 + wave * 64 + mi * 32 + 4 * (lane >> 5);
           unsigned admit = 0;
 #pragma unroll
@@ -1889,14 +1906,14 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   }
 }
 
-int skinny_query_tile() { return SQ; }
+int skinny_query_tile(int nq) { return nq > SQ32 ? 2 * SQ32 : SQ32; }  // 64-query tiles for batches of 33 and more
 
 bool skinny_supported(int dim, int k, bool f32) {
   return (dim * (f32 ? 4 : 2)) % 64 == 0 && dim > 0 && k >= 1 && k <= 64;
 }
 
-int skinny_pick_splits(int64_t rows, int nq_padded, int n_cu) {
-  const int n_qtiles = nq_padded / SQ;
+int skinny_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu) {
+  const int n_qtiles = nq_padded / tile;
   int splits = (2 * n_cu) / (n_qtiles > 0 ? n_qtiles : 1);  // two workgroups per CU
   splits = (splits / 8) * 8;                                 // whole groups of 8 (one row range per XCD)
   if (splits < 8) splits = 8;
@@ -1906,10 +1923,12 @@ int skinny_pick_splits(int64_t rows, int nq_padded, int n_cu) {
 }
 
 // Same contract as launch_mfma_scan.  p.queries: fp32 corpus -> [nq_padded, dim] fp32; fp16 corpus -> [2, nq_padded, dim]
-// fp16, the high and the low plane of the split fp32 queries (launch_f32_split_f16).  nq_padded is a multiple of 32.
+// fp16, the high and the low plane of the split fp32 queries (launch_f32_split_f16).  nq_padded is a multiple of the
+// tile (p.skinny_tile = 32 or 64 queries).
 hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
   const bool f32 = p.f32 != 0;
-  if (!skinny_supported(p.dim, p.k, f32) || p.nq_padded % SQ != 0 || p.n_splits < 1 || !p.workspace) return hipErrorInvalidValue;
+  const int tile = p.skinny_tile == 64 ? 64 : 32;
+  if (!skinny_supported(p.dim, p.k, f32) || p.nq_padded % tile != 0 || p.n_splits < 1 || !p.workspace) return hipErrorInvalidValue;
   MfmaDeviceParams d{};
   d.corpus = reinterpret_cast<const _Float16*>(p.corpus);
   d.queries = reinterpret_cast<const _Float16*>(p.queries);
@@ -1917,7 +1936,7 @@ hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
   d.rows = p.rows;
   d.dim = p.dim;
   d.nq = p.nq;
-  d.n_qtiles = p.nq_padded / SQ;
+  d.n_qtiles = p.nq_padded / tile;
   d.n_splits = p.n_splits;
   d.list_stride = p.list_stride > p.n_splits ? p.list_stride : p.n_splits;
   d.k = p.k;
@@ -1930,26 +1949,18 @@ hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
   d.rows_per_split = ((per + BM - 1) / BM) * BM;
   const int groups = (p.n_splits + 7) / 8;
   const int grid = groups * d.n_qtiles * 8;
-  const int lds = f32 ? SkinnyGeom<float>::LDS : SkinnyGeom<_Float16>::LDS;
-  auto go = [&](auto kern) -> hipError_t {
+  auto go = [&](auto kern, int lds) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(S_THREADS), lds, stream, d);
     return hipGetLastError();
   };
   if (f32) {
-    switch (p.ablate) {
-      case 1: return go(skinny_scan_kernel<float, 1>);
-      case 2: return go(skinny_scan_kernel<float, 2>);
-      case 256: return go(skinny_scan_kernel<float, 256>);
-      default: return go(skinny_scan_kernel<float, 0>);
-    }
+    if (tile == 64) return go(skinny_scan_kernel<float, 2, 0>, SkinnyGeom<float, 2>::LDS);
+    return go(skinny_scan_kernel<float, 1, 0>, SkinnyGeom<float, 1>::LDS);
   }
-  switch (p.ablate) {
-    case 1: return go(skinny_scan_kernel<_Float16, 1>);
-    case 256: return go(skinny_scan_kernel<_Float16, 256>);
-    default: return go(skinny_scan_kernel<_Float16, 0>);
-  }
+  if (tile == 64) return go(skinny_scan_kernel<_Float16, 2, 0>, SkinnyGeom<_Float16, 2>::LDS);
+  return go(skinny_scan_kernel<_Float16, 1, 0>, SkinnyGeom<_Float16, 1>::LDS);
 }
 
 }  // namespace tavb
