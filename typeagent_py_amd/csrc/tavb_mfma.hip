@@ -1439,26 +1439,25 @@ __global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParam
 
 
 // ---------------------------------------------------------------------------------------------
-// SKINNY kernel: 8 .. 32 queries per pass at HBM speed, on fp32 AND fp16 corpora.
+// SKINNY kernel: 3 .. 32 queries per pass at HBM speed (32-query tile), 33+ on 64-query tiles; fp32 AND fp16 corpora.
 //
 // The streaming tiers keep the queries in LDS and every lane re-reads them for every row, so beyond four
 // queries they are LDS-bound (6.9 TB/s of corpus at one query, 4.8 at eight, then one more pass per eight
 // queries); the 256-query MFMA tile above wastes 7/8 of its operand traffic on padding at 32 queries and
 // only exists for fp16.  This kernel is the piece in between -- and the only matrix-core path for the
 // reference's own dtype, fp32: `v_mfma_f32_32x32x2_f32` multiplies fp32 exactly and accumulates in fp32
-// (157 TFLOP/s peak, enough to keep up with HBM at 32 queries: 3.1e3 flop per corpus row-byte^-1 ...
-// 1M x 1536 x 32 x 2 = 98 GFLOP per 6.1 GB pass).
-//   * tile = 256 corpus rows x 32 queries, 4 waves, each wave owns 64 rows (two 32 x 32 MFMA tiles);
+// (157 TFLOP/s peak, enough to keep up with HBM at 32 queries: 1M x 1536 x 32 x 2 = 98 GFLOP per 6.1 GB pass).
+//   * tile = 256 corpus rows x 32 (or 64) queries, 4 waves, each wave owns 64 rows (two, or four, 32 x 32 MFMA tiles);
 //     two workgroups per CU (72 KiB of LDS, < 128 VGPRs each) overlap each other's waits.
 //   * K advances 64 bytes per row per step for either dtype (16 floats / 32 halves).  A wave stages the four
 //     1 KiB pieces of ITS OWN 64 rows by LDS-DMA, so the corpus operand needs no cross-wave synchronisation;
-//     waves 0 and 1 also stage one piece each of the query operand (32 queries x 64 bytes), which all waves
-//     read: one barrier per step.  Ring of 4 slots, counted vmcnt (two to three steps in flight).
+//     waves 0 and 1 (all four for 64 queries) also stage one piece each of the query operand (16 queries x 64 bytes per
+//     piece), which all waves read: one barrier per step.  Ring of 3 or 4 slots, counted vmcnt.
 //   * LDS image, source-side XOR swizzle and fragment reads are those of variant 3 (64-byte rows).  For fp32
 //     a lane's 16-byte fragment is four consecutive k of its row -- lanes 0-31 take k = 8g .. 8g+3, lanes 32-63
 //     k = 8g+4 .. 8g+7 -- and feeds four MFMAs: MFMA e multiplies k = 8g+e (lower half-wave) and 8g+4+e
 //     (upper), the same pairing on both operands, which is all a dot product needs.
-//   * epilogue / candidate buffers / compaction / lists exactly as in the wide kernel (32 queries per block).
+//   * epilogue / candidate buffers / compaction / lists exactly as in the wide kernel (32 or 64 queries per block).
 // ---------------------------------------------------------------------------------------------
 constexpr int SQ32 = 32;            // queries per 32 x 32 MFMA block; a tile is NI of them (32 or 64 queries)
 constexpr int S_THREADS = 256;
