@@ -1,29 +1,33 @@
 #!/usr/bin/env python3
 """Benchmark of the VectorBase kNN hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2_f16|cfg2_b32|cfg2_b1024|cfg3|cfg3_q1|cfg4|cfg5|cfg1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak] [--workload NAME]
 
-Contract (one JSON line on stdout from rank 0):
-  * a "step" is one lookup pass of the hot path over the resident corpus:
-      cfg2 (default, BASELINE.json configs[1]): 1M x 1536 fp32 corpus, ONE query, top-32,
-           through the synchronous C-ABI call `tavb_search` (query H2D + scan + merge +
-           result D2H + sync) -- what a `VectorBase.fuzzy_lookup_embedding` caller sees;
-      cfg3 (configs[2]): 10M x 1536 fp16 corpus, a 1024-query batch, top-32 (256-query MFMA tile);
-      cfg4 (configs[3]): cfg3 at 12.5M rows per GPU (100M rows when run with --gpus 8);
-      cfg2_b32 / cfg2_b1024: 32 / 1024-query batches on the cfg2 fp32 corpus (32-query fp32 MFMA tile);
-      cfg5 (configs[4]): fused multi-index user query; cfg1 (configs[0]): the reference's own 10k-row case.
-  * value = queries/sec over the timed K steps (wall clock, barrier + synchronize on both
-    sides, max over ranks).  With --gpus N the corpus is row-sharded, 1M (cfg2) / 10M (cfg3)
-    rows PER GPU (weak scaling: total rows = N x that), per-shard top-k lists are
-    all-gathered over RCCL and merged on every rank; `value` then counts shard-scans,
-    i.e. queries/s x N (rows scanned per second / rows per shard), and the plain
-    end-to-end rate is reported beside it as `queries_per_sec`.
-  * roofline: algorithmic bytes (cfg2: N*D*4 per query) or flops (cfg3: 2*Q*N*D per batch)
-    divided by the scan kernel's mean duration measured with HIP events on the stream the
-    kernel runs on (libtavb's profile API), against 8 TB/s HBM / 2.5 PFLOP/s dense fp16 MFMA.
-  * cpu_baseline: the numpy oracle (a restatement of the reference's VectorBase arithmetic,
-    oracle/vectorbase_oracle.py) timed on this box's host cores on the same corpus.
-Synthetic data: gaussian rows, L2-normalised on the device (no dataset exists for this path).
+One JSON line on stdout (rank 0).  Without --workload this is the north-star suite:
+
+  headline   cfg3 = BASELINE.json configs[2]: 10M x 1536 fp16 corpus, ONE 1024-query batch per step, top-32,
+             through the synchronous C-ABI call `tavb_search_batch` (query H2D, MFMA scan over the whole corpus,
+             candidate rescoring, merges, result D2H, one sync) -- what `VectorBase.fuzzy_lookup_embeddings` costs.
+             `value` = queries/s over exactly K timed steps; `roofline` = 2*Q*N*D flops per batch / the summed
+             duration of the MFMA scan launches of one batch (HIP events on the library's stream) against the
+             2.5 PFLOP/s dense fp16 MFMA peak.
+  sub.cfg3_q1  the same corpus, ONE query per step (north star's single-query target: HBM-bound, 30.72 GB/query)
+  sub.cfg2     configs[1]: 1M x 1536 fp32 corpus, one query per step (HBM-bound, 6.144 GB/query)
+
+  Every record carries `roofline` (kernel, mean launch duration, algorithmic work, counter traffic from the committed
+  rocprofv3 --pmc pass), a `parity` object (the GPU answers for >= 16 sampled queries checked against the CPU oracle
+  over the WHOLE corpus, delivered to the oracle in 1M-row chunks) and, at N = 1, `cpu_baseline` (the reference's own
+  VectorBase -- verbatim when /root/reference exists, else its numpy port -- timed on this host's cores).
+
+--gpus N > 1: one process per GPU over RCCL.  When WORLD_SIZE is not set the script re-launches itself under
+  `python -m torch.distributed.run --nproc-per-node N`; when it is set it must equal N.  The corpus is row-sharded
+  (contiguous ranges), every rank scans its shard for every query, the per-shard top-k key lists are all-gathered and
+  merged on every rank.  `value` is always the end-to-end rate of global lookups (queries/s).
+    --scaling strong (default): the SAME 10M-row corpus split over the N GPUs (total work fixed).
+    --scaling weak: cfg4 = configs[3], 12.5M rows PER GPU (100M rows at N = 8); `row_queries_per_sec` is reported too.
+
+Synthetic data: gaussian rows generated on the device per 262144-row chunk (seeded per chunk, so any rank can
+reproduce any row range), L2-normalised by our K1 kernel, rounded to fp16 by our convert kernel.
 """
 
 from __future__ import annotations
@@ -31,6 +35,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,49 +49,61 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32 matrix rate (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md peak table
+CHUNK_ROWS = 262_144           # generation granule of the synthetic corpus
+ORACLE_CHUNK = 1_000_000       # rows handed to the CPU oracle at a time (a reference-sized VectorBase)
+PARITY_QUERIES = 16
 
 WORKLOADS = {
-    #            rows/GPU    dim   dtype   queries/step  k
-    "cfg2": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1, k=32, bound="hbm"),
-    "cfg2_f16": dict(rows=1_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm"),
-    "cfg3": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma"),
+    #            rows (total)  dim   dtype   queries/step  k   bound   seed
+    "cfg2": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1, k=32, bound="hbm", seed=1043),
+    "cfg2_f16": dict(rows=1_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm", seed=1043),
+    "cfg3": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma", seed=10043),
     # the north star's single-query target on the cfg3 corpus: HBM-bound, 30.72 GB per query
-    "cfg3_q1": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm"),
-    "cfg4": dict(rows=12_500_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma"),  # x8 GPUs = 100M rows
-    "cfg1": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="hbm"),
-    # batches on the reference's own dtype (fp32): the 32-query MFMA tile.  32 queries ride one HBM pass; 1024 are bound by
-    # the fp32 matrix rate.
-    "cfg2_b32": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=32, k=32, bound="hbm"),
-    "cfg2_b1024": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1024, k=32, bound="mfma"),
-    # fused multi-index user query: 4 term lookups k=50@0.85 on a 10M-row terms corpus + 1 message
-    # re-rank k=25@0.7 on a 10M-row message corpus (full scan, or --cfg5-subset 1000) + 1 thread lookup k=10@0.7 on 1k rows
-    "cfg5": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=6, k=50, bound="hbm"),
+    "cfg3_q1": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm", seed=10043),
+    "cfg4": dict(rows=12_500_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma", seed=100043),  # PER GPU (weak scaling)
+    "cfg1": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="hbm", seed=43),
+    # batches on the reference's own dtype (fp32): 32 queries ride one HBM pass; 1024 are bound by the fp32 matrix rate
+    "cfg2_b32": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=32, k=32, bound="hbm", seed=1043),
+    "cfg2_b1024": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1024, k=32, bound="mfma", seed=1043),
+    # middle batch sizes on the fp16 corpus (the 64/128-query tiles)
+    "cfg3_b32": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=32, k=32, bound="hbm", seed=10043),
+    "cfg3_b128": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=128, k=32, bound="mfma", seed=10043),
+    # fused multi-index user query
+    "cfg5": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=6, k=50, bound="hbm", seed=50043),
 }
 
 
-def make_device_corpus(eng, rows: int, dim: int, seed: int, dtype: str, chunk: int = 262_144):
-    """Gaussian rows generated on the device, normalised by our K1 kernel (and rounded to
-    fp16 by our convert kernel).  The host never holds more than it asks for."""
+# ----------------------------------------------------------------------------------------------------------------
+# synthetic corpus: reproducible per chunk, generated where it is used
+# ----------------------------------------------------------------------------------------------------------------
+def gen_rows(eng, lo: int, hi: int, dim: int, seed: int, dtype: str):
+    """Rows [lo, hi) of the synthetic corpus `seed` as a device tensor (fp32 or fp16).  Chunk c (CHUNK_ROWS rows) is
+    torch.randn with generator seed `seed * 1000003 + c`, L2-normalised by our K1 kernel and (fp16) rounded by our
+    convert kernel, so every rank / the parity checker reproduce the same bytes for any row range."""
     import torch
 
     dev = torch.device("cuda", eng.device)
+    out = torch.empty((hi - lo, dim), dtype=torch.float16 if dtype == "fp16" else torch.float32, device=dev)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    out = torch.empty((rows, dim), dtype=torch.float16 if dtype == "fp16" else torch.float32, device=dev)
-    for lo in range(0, rows, chunk):
-        hi = min(rows, lo + chunk)
-        if dtype == "fp16":
-            tmp = torch.empty((hi - lo, dim), dtype=torch.float32, device=dev)
-            tmp.normal_(generator=gen)
-            eng.normalize_rows_(tmp)
-            out[lo:hi].copy_(eng.to_f16(tmp))
-            del tmp
-        else:
-            view = out[lo:hi]
-            view.normal_(generator=gen)
-            eng.normalize_rows_(view)
+    c = lo // CHUNK_ROWS
+    while c * CHUNK_ROWS < hi:
+        c_lo = c * CHUNK_ROWS
+        gen.manual_seed(seed * 1_000_003 + c)
+        tmp = torch.empty((CHUNK_ROWS, dim), dtype=torch.float32, device=dev)
+        tmp.normal_(generator=gen)
+        a, b = max(lo, c_lo), min(hi, c_lo + CHUNK_ROWS)
+        part = tmp[a - c_lo : b - c_lo]
+        eng.normalize_rows_(part)
+        out[a - lo : b - lo].copy_(eng.to_f16(part) if dtype == "fp16" else part)
+        del tmp
+        c += 1
     torch.cuda.synchronize(dev)
     return out
+
+
+def make_device_corpus(eng, rows: int, dim: int, seed: int, dtype: str):
+    """Whole corpus on one device (tests import this)."""
+    return gen_rows(eng, 0, rows, dim, seed, dtype)
 
 
 def host_queries(count: int, dim: int, seed: int) -> np.ndarray:
@@ -95,44 +113,342 @@ def host_queries(count: int, dim: int, seed: int) -> np.ndarray:
     return q
 
 
-def cpu_baseline(corpus_host: np.ndarray, queries: np.ndarray, k: int, budget_s: float = 15.0) -> dict:
+# ----------------------------------------------------------------------------------------------------------------
+# CPU legs: parity oracle and the reported baseline
+# ----------------------------------------------------------------------------------------------------------------
+def oracle_chunks(eng, resident, resident_lo: int, total_rows: int, dim: int, seed: int, dtype: str):
+    """The whole corpus as float32 host chunks of ORACLE_CHUNK rows (fp16 values widened, as the kernels see them):
+    rows this rank holds come from the resident tensor, the rest are regenerated on the device."""
+    for lo in range(0, total_rows, ORACLE_CHUNK):
+        hi = min(total_rows, lo + ORACLE_CHUNK)
+        if resident is not None and lo >= resident_lo and hi <= resident_lo + resident.shape[0]:
+            t = resident[lo - resident_lo : hi - resident_lo]
+        else:
+            t = gen_rows(eng, lo, hi, dim, seed, dtype)
+        yield t.float().cpu().numpy()
+
+
+def parity_check(eng, resident, resident_lo, wl, queries: np.ndarray, sample: list[int], got: dict, min_score: float) -> dict:
+    """got[qi] = (ordinals, scores) from the GPU path.  Oracle = numpy restatement of vectorbase.py:163-190 over the
+    whole corpus (oracle/vectorbase_oracle.py), near-tie policy of SURVEY section 7."""
     from oracle import vectorbase_oracle as vo
 
+    t0 = time.perf_counter()
+    ref = vo.scores_full_chunked(oracle_chunks(eng, resident, resident_lo, wl["rows_total"], wl["dim"], wl["seed"], wl["dtype"]),
+                                 queries[sample])
+    exact = permuted = near = 0
+    worst = 0.0
+    try:
+        for j, qi in enumerate(sample):
+            o, s = got[qi]
+            rep, n_near = vo.check_topk_parity_large(ref[j], o.tolist(), s.tolist(), wl["k"], min_score)
+            exact += rep.exact_positions
+            permuted += rep.tie_permuted_positions
+            near += n_near
+            worst = max(worst, float(np.max(np.abs(ref[j][o] - s))) if len(o) else 0.0)
+    except AssertionError as exc:
+        return {"ok": False, "error": str(exc)[:300], "queries_checked": len(sample), "rows": wl["rows_total"]}
+    return {
+        "ok": True,
+        "queries_checked": len(sample),
+        "rows": wl["rows_total"],
+        "oracle": "numpy restatement of vectorbase.py:163-190 over the whole corpus in %d-row chunks" % ORACLE_CHUNK,
+        "positions_exact": exact,
+        "positions_permuted_inside_near_ties": permuted,
+        "near_tie_pairs_in_reference_topk": near,
+        "max_abs_score_error": worst,
+        "score_tolerance": vo.SCORE_TOL,
+        "seconds": round(time.perf_counter() - t0, 1),
+    }
+
+
+def cpu_baseline(host: np.ndarray, queries: np.ndarray, k: int, rows_total: int, nq: int, budget_s: float) -> dict:
+    """The reference's VectorBase.fuzzy_lookup_embedding on this host's cores, same corpus bytes (first rows of it),
+    sequential single-query calls (the reference has no batch entry point: storage/memory/reltermsindex.py:320-332).
+    Verbatim class when /root/reference is present (build container), else its numpy port (oracle/)."""
+    from oracle import ref_loader
+    from oracle import vectorbase_oracle as vo
+
+    kind = "port"
+    if ref_loader.reference_available():
+        vb = ref_loader.make_reference_vectorbase(host)
+        kind = "reference"
+
+        def one(q):
+            return vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=0.0)
+    else:
+        def one(q):
+            return vo.lookup(host, q, k, 0.0)
+
     cores = len(os.sched_getaffinity(0))
-    vo.lookup(corpus_host, queries[0], k, 0.0)  # warm-up (BLAS thread pool, page-in)
+    one(queries[0])  # warm-up (BLAS thread pool, page-in)
     times = []
     t_end = time.perf_counter() + budget_s
     i = 0
     while (time.perf_counter() < t_end and i < 400) or i < 3:
         q = queries[i % len(queries)]
         t0 = time.perf_counter_ns()
-        vo.lookup(corpus_host, q, k, 0.0)
+        one(q)
         times.append((time.perf_counter_ns() - t0) / 1e9)
         i += 1
     med = float(np.median(times))
-    one_thread = None
-    try:  # also report the reference arithmetic on one core
+    scale = rows_total / host.shape[0]
+    out = {
+        "value": 1.0 / (med * scale),
+        "unit": "queries/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": f"{len(times)} sequential fuzzy_lookup_embedding calls (numpy {np.__version__} / OpenBLAS sgemv, default threads) on "
+                  f"{host.shape[0]}x{host.shape[1]} fp32 rows of the same corpus, median {med * 1e3:.2f} ms, min {min(times) * 1e3:.2f} ms"
+                  + (f"; per-query time extrapolated x{scale:g} to the {rows_total} rows of the workload (the fp32 host matrix the reference needs, "
+                     f"{rows_total * host.shape[1] * 4 / 1e9:.0f} GB, is not materialised)" if scale != 1 else "")
+                  + (f"; a {nq}-query batch is {nq} such calls" if nq > 1 else ""),
+        "p50_ms_per_query_on_sample": med * 1e3,
+    }
+    try:  # SURVEY 8d: also the reference arithmetic on one core
         from threadpoolctl import threadpool_limits
 
         with threadpool_limits(limits=1, user_api="blas"):
             t1 = []
             for j in range(3):
                 t0 = time.perf_counter_ns()
-                vo.lookup(corpus_host, queries[j % len(queries)], k, 0.0)
+                one(queries[j % len(queries)])
                 t1.append((time.perf_counter_ns() - t0) / 1e9)
-        one_thread = {"value": 1.0 / float(np.median(t1)), "unit": "queries/s", "cores": 1, "sample": f"3 lookups, median {np.median(t1) * 1e3:.1f} ms"}
+        out["one_thread"] = {"value": 1.0 / (float(np.median(t1)) * scale), "unit": "queries/s", "cores": 1,
+                             "sample": f"3 calls, median {np.median(t1) * 1e3:.1f} ms on the same sample"}
     except Exception:
         pass
-    return {
-        "value": 1.0 / med,
-        "unit": "queries/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"{len(times)} sequential single-query lookups on the same {corpus_host.shape[0]}x{corpus_host.shape[1]} fp32 corpus "
-                  f"(numpy {np.__version__} / OpenBLAS sgemv, default threads), median {med * 1e3:.2f} ms, min {min(times) * 1e3:.2f} ms",
-        "p50_ms": med * 1e3,
-        "one_thread": one_thread,
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# one workload on the resident corpus
+# ----------------------------------------------------------------------------------------------------------------
+class Ctx:
+    """Process-wide state: rank layout, engine, optional sharded searcher."""
+
+    def __init__(self, args):
+        import torch
+
+        self.args = args
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.distributed = self.world > 1 or os.environ.get("TAVB_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank dry run of the N>1 code
+        self.dist = None
+        if self.distributed:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+            if dist.get_world_size() != args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        self.dev = self.local_rank if self.distributed else 0
+        torch.cuda.set_device(self.dev)
+        from typeagent_py_amd import _native
+
+        self.native = _native
+        if self.distributed:
+            from typeagent_py_amd.sharded import DeviceShardBackend
+
+            self.backend = DeviceShardBackend(self.dev)
+            self.eng = self.backend.engine
+        else:
+            self.backend = None
+            self.eng = _native.Engine(self.dev)
+        for item in args.opt:
+            name, val = item.split("=")
+            self.eng.set_option(name, int(val))
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, x: float) -> float:
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.torch.device("cuda", self.dev))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def kernel_times(ctx: Ctx) -> dict:
+    n = ctx.native
+    ids = {"scan": n.KERNEL_SCAN, "merge": n.KERNEL_MERGE, "mfma_last_phase": n.KERNEL_MFMA, "mfma_earlier_phases": n.KERNEL_MFMA_SAMPLE,
+           "skinny_last_phase": n.KERNEL_SKINNY, "convert": n.KERNEL_CONVERT, "rescore": n.KERNEL_RESCORE}
+    return {name: ctx.eng.profile_read(kid) for name, kid in ids.items()}
+
+
+def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int, warmup: int, with_cpu: bool) -> dict:
+    """Time `steps` lookups of workload `wl` on the corpus already resident on this rank; returns the record (rank 0)."""
+    args, eng, torch = ctx.args, ctx.eng, ctx.torch
+    dim, k, nq = wl["dim"], wl["k"], wl["nq"]
+    rows_local, rows_total = int(corpus.shape[0]), wl["rows_total"]
+    min_score = args.min_score
+    thr = float(ctx.native.f32_threshold(min_score))
+    queries = host_queries(max(64, nq), dim, 4242)  # identical on every rank; arbitrary fp32 values (not fp16-representable)
+
+    searcher = None
+    if ctx.distributed:
+        from typeagent_py_amd.sharded import ShardedSearcher
+
+        ctx.backend.set_shard(corpus, row_offset=shard_lo)
+        searcher = ShardedSearcher(ctx.backend, always_collective=True)
+        dq_all = torch.from_numpy(queries).to(torch.device("cuda", ctx.dev))
+    else:
+        eng.set_corpus_tensor(corpus)
+
+    def one_step(i: int):
+        if nq == 1:
+            qi = i % len(queries)
+            if searcher is None:
+                return eng.search(queries[qi], k, np.float32(thr))
+            r = searcher.search(dq_all[qi : qi + 1], k, min_score)
+            return r.ordinals[0, : r.counts[0]], r.scores[0, : r.counts[0]]
+        if searcher is None:
+            return eng.search_batch(queries[:nq], k, np.float32(thr))
+        r = searcher.search(dq_all[:nq], k, min_score)
+        return r.ordinals, r.scores, r.counts
+
+    for i in range(warmup):
+        one_step(i)
+    eng.profile_enable(True)
+    eng.profile_reset()
+    ctx.barrier()
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        s0 = time.perf_counter_ns()
+        one_step(warmup + i)
+        lat.append((time.perf_counter_ns() - s0) / 1e3)
+    ctx.barrier()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    kt = kernel_times(ctx)
+    eng.profile_enable(False)
+
+    # answers for the parity sample (outside the timed region)
+    if nq == 1:
+        sample = list(range(PARITY_QUERIES))
+        got = {qi: one_step(qi)[:2] for qi in sample}
+    else:
+        sample = sorted(set(np.linspace(0, nq - 1, PARITY_QUERIES).astype(int).tolist()))
+        o, s, c = one_step(0)
+        got = {qi: (o[qi, : c[qi]], s[qi, : c[qi]]) for qi in sample}
+    if ctx.rank != 0:
+        # rank 0 regenerates what it needs for the oracle; the others only keep the collective calls aligned
+        return {}
+
+    qps = steps * nq / elapsed
+    esize = 2 if wl["dtype"] == "fp16" else 4
+    if wl["bound"] == "hbm" and kt["scan"][1]:
+        kern_name, parts = "tavb::scan_*_kernel (streaming dot + score + select)", ["scan"]
+    elif kt["mfma_last_phase"][1]:
+        kern_name, parts = "tavb::mfma_scan_kernel_* (256-query fp16 MFMA tile; all threshold-ladder phases of a batch)", ["mfma_last_phase", "mfma_earlier_phases"]
+    elif kt["skinny_last_phase"][1]:
+        kern_name, parts = "tavb::skinny_scan_kernel (32/64/128-query MFMA tile; all threshold-ladder phases)", ["skinny_last_phase", "mfma_earlier_phases"]
+    else:
+        kern_name, parts = "tavb::scan_*_kernel", ["scan"]
+    kern_ms_per_step = sum(kt[p][0] for p in parts) / steps
+    launches_per_step = sum(kt[p][1] for p in parts) / steps
+    passes = kt[parts[0]][1] / steps  # corpus passes per step (a batch bigger than one pass serves is split)
+    if wl["bound"] == "hbm":
+        alg = rows_local * dim * esize * passes  # bytes the scan must read per step: this rank's shard once per pass
+        achieved = alg / (kern_ms_per_step * 1e-3) / 1e9 if kern_ms_per_step > 0 else 0.0
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+    else:
+        alg = 2.0 * nq * rows_local * dim
+        achieved = alg / (kern_ms_per_step * 1e-3) / 1e12 if kern_ms_per_step > 0 else 0.0
+        peak = MFMA_F16_PEAK_TFLOPS if wl["dtype"] == "fp16" else MFMA_F32_PEAK_TFLOPS
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}
+    try:  # HBM traffic comes from a separate rocprofv3 --pmc pass (bench.py cannot count it itself)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f).get(name)
+        if pmc and pmc.get("traffic_bytes_per_step") and rows_local == WORKLOADS[name]["rows"] and ctx.world == 1:
+            roof["traffic"] = pmc["traffic_bytes_per_step"]
+            roof["traffic_unit"] = "B per step (FETCH_SIZE x 1024 x 2, the guide's gfx950 correction)"
+            roof["traffic_source"] = pmc["source"]
+    except Exception:
+        pass
+    roof.update({
+        "kernel": kern_name,
+        "kernel_ms_per_step": kern_ms_per_step,
+        "kernel_launches_per_step": launches_per_step,
+        "algorithmic_per_step": alg,
+        "algorithmic_unit": "B" if wl["bound"] == "hbm" else "flop",
+        "kernel_parts_ms_per_step": {p: kt[p][0] / steps for p in parts},
+        "other_kernels_ms_per_step": {p: kt[p][0] / steps for p in kt if p not in parts and kt[p][1]},
+    })
+    rec = {
+        "workload": f"{name}: {rows_total}x{dim} {wl['dtype']}"
+                    + (f" row-sharded over {ctx.world} GPUs ({rows_local} rows on rank 0)" if ctx.world > 1 else "")
+                    + f", {nq} quer{'y' if nq == 1 else 'ies'}/step, top-{k}, min_score {min_score}",
+        "queries_per_sec": qps,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "p50_latency_us": float(np.percentile(lat, 50)),
+        "p99_latency_us": float(np.percentile(lat, 99)),
+        "min_latency_us": float(np.min(lat)),
+        "dtype": "f32" if wl["dtype"] == "fp32" else "f16 storage, f32 accumulate",
+        "roofline": roof,
     }
+    if not args.no_parity:
+        rec["parity"] = parity_check(eng, corpus, shard_lo, wl, queries, sample, got, min_score)
+    if with_cpu and not args.no_cpu_baseline:
+        n_host = min(rows_local, ORACLE_CHUNK)
+        host = corpus[:n_host].float().cpu().numpy()
+        rec["cpu_baseline"] = cpu_baseline(host, queries, k, rows_total, nq, args.cpu_seconds)
+    return rec
+
+
+def shard_bounds(total: int, world: int, rank: int) -> tuple[int, int]:
+    from typeagent_py_amd.sharded import shard_range
+
+    return shard_range(total, world, rank)
+
+
+def headline_line(ctx: Ctx, rec: dict, name: str, wl: dict, scaling: str, sub: dict | None) -> dict:
+    out = {
+        "metric": "queries/sec + p50 lookup latency, 1536-d top-32 kNN",
+        "value": rec["queries_per_sec"],
+        "unit": "queries/s",
+        "n_gpus": ctx.world,
+        "steps": rec["steps"],
+        "warmup": rec["warmup"],
+        "ms_per_step": rec["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": scaling,
+        "vs_baseline": None,
+        "dtype": rec["dtype"],
+        "data": "synthetic",
+        "config": {
+            "workload": rec["workload"],
+            "total_rows": wl["rows_total"],
+            "queries_per_step": wl["nq"],
+            "k": wl["k"],
+            "parallelism": (f"row-sharded x{ctx.world} ({scaling} scaling), RCCL all-gather of per-shard top-k keys + merge kernel on every rank"
+                            if ctx.world > 1 else "single GPU"),
+            "value_counts": "global lookups per second (every query searches all rows of the workload)",
+        },
+        "queries_per_sec": rec["queries_per_sec"],
+        "p50_latency_us": rec["p50_latency_us"],
+        "p99_latency_us": rec["p99_latency_us"],
+        "min_latency_us": rec["min_latency_us"],
+        "roofline": rec["roofline"],
+        "cpu_baseline": rec.get("cpu_baseline"),
+    }
+    if "parity" in rec:
+        out["parity"] = rec["parity"]
+    if scaling == "weak" and ctx.world >= 1:
+        out["row_queries_per_sec"] = rec["queries_per_sec"] * wl["rows_total"]
+    if sub:
+        out["sub"] = sub
+    return out
 
 
 def run_cfg5(args, wl) -> None:
@@ -228,204 +544,101 @@ def run_cfg5(args, wl) -> None:
     print(json.dumps(out))
 
 
+def respawn_under_torchrun(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no rank environment: become the launcher (one rank per GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--rows", type=int, default=None, help="override rows per GPU (debugging)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="one workload only (default: the north-star suite, headline cfg3)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="--gpus N > 1: split the same corpus (strong) or 12.5M rows per GPU (weak, cfg4)")
+    ap.add_argument("--rows", type=int, default=None, help="override the row count (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-sub", action="store_true", help="north-star suite: headline only")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--tiled", action="store_true", help="cfg3: also build the K-blocked fp16 image and feed the MFMA kernel from it (measured: no gain)")
     ap.add_argument("--cfg5-subset", type=int, default=0, help="cfg5: message re-rank over a subset of this many ordinals (0 = full scan)")
     ap.add_argument("--cfg5-separate", action="store_true", help="cfg5: issue the six lookups as separate synchronous calls")
     ap.add_argument("--min-score", type=float, default=0.0, help="score threshold of the lookups (0.0 = every row survives: worst case for selection; 0.85 = the reference's related-terms default)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (e.g. scan_unroll=4)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn_under_torchrun(args))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
 
-    import torch
-
-    from typeagent_py_amd import _native
-
-    wl = dict(WORKLOADS[args.workload])
-    if args.rows:
-        wl["rows"] = args.rows
     if args.workload == "cfg5":
+        wl = dict(WORKLOADS["cfg5"])
+        if args.rows:
+            wl["rows"] = args.rows
         run_cfg5(args, wl)
         return
+
+    ctx = Ctx(args)
+    suite = args.workload is None
+    name = args.workload or ("cfg4" if (ctx.world > 1 and args.scaling == "weak") else "cfg3")
+    wl = dict(WORKLOADS[name])
+    if args.rows:
+        wl["rows"] = args.rows
+    weak = (name == "cfg4") or (ctx.world > 1 and args.scaling == "weak")
+    scaling = "weak" if weak else "strong"
+    if ctx.world == 1:
+        scaling = "weak" if name == "cfg4" else "strong"
+    if weak:
+        wl["rows_total"] = wl["rows"] * ctx.world
+        lo, hi = ctx.rank * wl["rows"], (ctx.rank + 1) * wl["rows"]
+    else:
+        wl["rows_total"] = wl["rows"]
+        lo, hi = shard_bounds(wl["rows"], ctx.world, ctx.rank)
     steps = args.steps if args.steps is not None else (200 if wl["nq"] == 1 else 10)
     warmup = args.warmup if args.warmup is not None else (20 if wl["nq"] == 1 else 2)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or os.environ.get("TAVB_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank dry run of the N>1 code
-    if distributed:
-        import torch.distributed as dist
+    torch = ctx.torch
+    stream_ctx = torch.cuda.stream(ctx.backend.stream) if ctx.backend is not None else torch.cuda.stream(torch.cuda.current_stream(ctx.dev))
+    with stream_ctx:
+        corpus = gen_rows(ctx.eng, lo, hi, wl["dim"], wl["seed"], wl["dtype"])
+    rec = run_record(ctx, name, wl, corpus, lo, steps, warmup, with_cpu=(ctx.world == 1))
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and args.gpus > 1:
-        sys.stderr.write(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run\n")
-    dev = local_rank if distributed else 0
-    torch.cuda.set_device(dev)
+    sub = None
+    if suite and ctx.world == 1 and not args.no_sub:
+        sub = {}
+        # the single-query target on the same 10M-row corpus
+        w2 = dict(WORKLOADS["cfg3_q1"], rows_total=wl["rows_total"], rows=wl["rows"])
+        sub["cfg3_q1"] = run_record(ctx, "cfg3_q1", w2, corpus, 0, 40, 5, with_cpu=False)
+        del corpus
+        torch.cuda.empty_cache()
+        w3 = dict(WORKLOADS["cfg2"])
+        w3["rows_total"] = w3["rows"]
+        c2 = gen_rows(ctx.eng, 0, w3["rows"], w3["dim"], w3["seed"], w3["dtype"])
+        sub["cfg2"] = run_record(ctx, "cfg2", w3, c2, 0, 100, 10, with_cpu=True)
+        del c2
 
-    rows, dim, k, nq = wl["rows"], wl["dim"], wl["k"], wl["nq"]
-    min_score = args.min_score
-    thr = float(_native.f32_threshold(min_score))
-    queries = host_queries(max(64, nq), dim, 4242)  # identical on every rank
-
-    if distributed:
-        from typeagent_py_amd.sharded import DeviceShardBackend, ShardedSearcher
-
-        backend = DeviceShardBackend(dev)
-        eng = backend.engine
-        with torch.cuda.stream(backend.stream):
-            corpus = make_device_corpus(eng, rows, dim, 100_043 + rank, wl["dtype"])
-        backend.set_shard(corpus, row_offset=rank * rows)
-        if wl["bound"] == "mfma" and args.tiled:
-            with torch.cuda.stream(backend.stream):
-                eng.build_tiled()
-        searcher = ShardedSearcher(backend, always_collective=True)
-    else:
-        eng = _native.Engine(dev)
-        corpus = make_device_corpus(eng, rows, dim, 1043, wl["dtype"])
-        eng.set_corpus_tensor(corpus)
-        if wl["bound"] == "mfma" and args.tiled:
-            eng.build_tiled()  # K-blocked fp16 image beside the row-major corpus: what the MFMA kernel streams
-        searcher = None
-    for item in args.opt:
-        name, val = item.split("=")
-        eng.set_option(name, int(val))
-
-    dq_all = torch.from_numpy(queries).to(torch.device("cuda", dev))
-    torch.cuda.synchronize(dev)
-
-    def one_step(i: int):
-        if nq == 1:
-            qi = i % len(queries)
-            if searcher is None:
-                return eng.search(queries[qi], k, np.float32(thr))
-            return searcher.search(dq_all[qi:qi + 1], k, min_score)
-        if searcher is None:
-            return eng.search_batch(queries[:nq], k, np.float32(thr))
-        return searcher.search(dq_all[:nq], k, min_score)
-
-    for i in range(warmup):
-        one_step(i)
-    eng.profile_enable(True)
-    eng.profile_reset()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    lat = []
-    t0 = time.perf_counter()
-    for i in range(steps):
-        s0 = time.perf_counter_ns()
-        one_step(warmup + i)
-        lat.append((time.perf_counter_ns() - s0) / 1e3)
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", dev))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # the kernel family that served the steps: 256-query MFMA tile, 32-query MFMA tile, or a streaming tier
-    kid = _native.KERNEL_SCAN
-    for cand in (_native.KERNEL_MFMA, _native.KERNEL_SKINNY):
-        if eng.profile_read(cand)[1]:
-            kid = cand
-    kern_ms, kern_n = eng.profile_read(kid)
-    if kid != _native.KERNEL_SCAN:  # the earlier phases of the threshold ladder are part of the same job: charge their time
-        s_ms, _ = eng.profile_read(_native.KERNEL_MFMA_SAMPLE)
-        kern_ms += s_ms
-    merge_ms, merge_n = eng.profile_read(_native.KERNEL_MERGE)
-    eng.profile_enable(False)
-
-    if rank == 0:
-        qps = steps * nq / elapsed
-        esize = 2 if wl["dtype"] == "fp16" else 4
-        avg_kernel_s = (kern_ms / max(kern_n, 1)) * 1e-3
-        launches_per_step = kern_n / steps
-        if wl["bound"] == "hbm":
-            alg = rows * dim * esize  # bytes one launch must read: the shard once
-            achieved = alg / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None}
-        else:
-            nq_per_launch = nq / max(launches_per_step, 1e-9)
-            alg = 2.0 * nq_per_launch * rows * dim
-            achieved = alg / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
-            peak = MFMA_F16_PEAK_TFLOPS if wl["dtype"] == "fp16" else MFMA_F32_PEAK_TFLOPS
-            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}
-        try:  # HBM traffic comes from a separate rocprofv3 --pmc pass (bench.py cannot count it itself)
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pmc = json.load(f).get(args.workload)
-            if pmc and pmc.get("traffic_bytes_per_launch") and not args.rows:
-                roof["traffic"] = pmc["traffic_bytes_per_launch"] / (1e9 if wl["bound"] == "hbm" else 1.0)
-                roof["traffic_unit"] = "GB per launch" if wl["bound"] == "hbm" else "B per launch"
-                roof["traffic_source"] = pmc["source"]
-        except Exception:
-            pass
-        roof["kernel"] = {0: "scan (tavb::scan_*_kernel)", 2: "mfma (tavb::mfma_scan_kernel_v3 for the small ladder phases, _v5 for the big ones)",
-                          6: "skinny (tavb::skinny_scan_kernel)"}.get(kid, str(kid))
-        roof["kernel_avg_ms"] = avg_kernel_s * 1e3
-        roof["kernel_launches"] = kern_n
-        roof["algorithmic_per_launch"] = alg
-        roof["merge_avg_us"] = (merge_ms / max(merge_n, 1)) * 1e3
-
-        out = {
-            "metric": "queries/sec + p50 lookup latency, 1536-d top-32 kNN",
-            "value": qps * world,
-            "unit": "queries/s",
-            "n_gpus": world,
-            "steps": steps,
-            "warmup": warmup,
-            "ms_per_step": elapsed / steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32" if wl["dtype"] == "fp32" else "f16 storage, f32 accumulate",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{args.workload}: {rows}x{dim} {wl['dtype']} rows per GPU, {nq} quer{'y' if nq == 1 else 'ies'}/step, top-{k}, min_score {min_score}",
-                "rows_per_gpu": rows,
-                "total_rows": rows * world,
-                "queries_per_step": nq,
-                "k": k,
-                "parallelism": f"row-sharded x{world}, RCCL all-gather of per-shard top-k + merge" if world > 1 else "single GPU",
-                "value_counts": "queries/s x n_gpus (shard scans per second)" if world > 1 else "queries/s",
-            },
-            "queries_per_sec": qps,
-            "p50_latency_us": float(np.percentile(lat, 50)),
-            "p99_latency_us": float(np.percentile(lat, 99)),
-            "min_latency_us": float(np.min(lat)),
-            "roofline": roof,
-        }
-        if not args.no_cpu_baseline and not distributed:
-            n_host = min(rows, 1_000_000)
-            host = corpus[:n_host].float().cpu().numpy()
-            # the GPU answer for query 0 must be the oracle's answer on the same bytes
-            from oracle import vectorbase_oracle as vo
-
-            o, s = eng.search(queries[0], k, np.float32(thr)) if n_host == rows else (None, None)
-            if o is not None:
-                vo.check_topk_parity(vo.scores_full(host, queries[0]), o.tolist(), s.tolist(), k, min_score)
-                out["parity_check"] = "query 0: top-k ordinals/scores match the oracle on the same corpus bytes"
-            base = cpu_baseline(host, queries, k, args.cpu_seconds)
-            if n_host != rows:
-                base["sample"] += f"; first {n_host} of {rows} rows only"
-            out["cpu_baseline"] = base
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    ok = True
+    if ctx.rank == 0:
+        line = headline_line(ctx, rec, name, wl, scaling, sub)
+        print(json.dumps(line), flush=True)
+        checks = [rec.get("parity")] + [r.get("parity") for r in (sub or {}).values()]
+        ok = all(c is None or c.get("ok") for c in checks)
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
+    if not ok:
+        sys.stderr.write("bench.py: PARITY CHECK FAILED (see the `parity` objects in the line above)\n")
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -79,8 +79,9 @@ int tavb_synchronize(tavb_ctx* ctx);
  *                   corpora (defaults 5 / 3, the measured break-even; fp32 corpora have no other matrix-core path, fp16 ones use it up to
  *                   mfma_min_batch - 1); smaller batches use the streaming tiers
  *   "mfma_sample_rows", "mfma_ladder"  phases of the MFMA paths' threshold ladder (rows of the first phase; growth)
- *   "mfma_variant"  K loop of the 256-query tile: 0 = auto (3 for small ladder phases, 5 for big ones), 1..5 fixed
- *   "mfma_splits", "mfma_rendezvous", "mfma_a_nt", "mfma_ablate", ...  experiment knobs, see DESIGN.md
+ *   "mfma_variant"  K loop of the 256-query tile: 0 = auto (6 for ladder phases of at least "mfma_v6_min_rows" rows, else 3),
+ *                   3 / 6 = that K loop for every phase
+ *   "mfma_splits", "mfma_sched", "mfma_ablate"  measurement knobs, see DESIGN.md
  *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile,
  *                   5 = 32-query MFMA tile
  */
@@ -102,17 +103,6 @@ int tavb_normalize_rows_f32(tavb_ctx* ctx, const float* dev_in, float* dev_out, 
 
 /* float32 -> float16 (round to nearest even), used to build f16 corpora on device. */
 int tavb_convert_f32_to_f16(tavb_ctx* ctx, const float* dev_in, void* dev_out, int64_t count);
-
-/* K-blocked fp16 image of the corpus for the batched MFMA kernel (our storage extension, like fp16
- * itself): for every tile of 256 rows and every K step of 32 halves one contiguous 16 KiB block, laid
- * out exactly as the kernel's LDS operand image, so that each LDS-DMA instruction reads 1 KiB of
- * contiguous memory.  tavb_tiled_bytes gives the size (rows padded to a multiple of 256; dim % 32 == 0),
- * tavb_pack_f16_tiled builds it on the device from a row-major f32/f16 matrix, tavb_set_corpus_tiled
- * attaches it either beside the row-major corpus of the same rows (call it after tavb_set_corpus) or
- * alone (batch lookups only; the streaming lookups then fail with TAVB_E_NO_CORPUS). */
-int tavb_tiled_bytes(int64_t rows, int32_t dim, int64_t* out_bytes);
-int tavb_pack_f16_tiled(tavb_ctx* ctx, const void* dev_src, int32_t src_dtype, int64_t rows, int32_t dim, void* dev_dst);
-int tavb_set_corpus_tiled(tavb_ctx* ctx, const void* dev_tiled, int64_t rows, int32_t dim, int64_t ordinal_base);
 
 /* ---- synchronous lookups (host in, host out) ---------------------------------- */
 /* fuzzy_lookup_embedding without predicate (vectorbase.py:163-190):
@@ -177,8 +167,8 @@ int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* 
 /* HIP-event timing of the kernels this context launches, on the stream they run on.
  * kernel ids: 0 = streaming scan (dot + score + select), 1 = list merge,
  *             2 = MFMA batched scan (256-query tile: the last phase of the threshold ladder), 3 = normalise,
- *             4 = f32->f16 convert / pack, 5 = the earlier phases of the ladder (either MFMA tile), 6 = 32-query MFMA tile
- *             (last phase). */
+ *             4 = f32->f16 convert, 5 = the earlier phases of the ladder (either MFMA tile), 6 = 32-query MFMA tile
+ *             (last phase), 7 = candidate rescoring of the 256-query tile. */
 #define TAVB_KERNEL_SCAN 0
 #define TAVB_KERNEL_MERGE 1
 #define TAVB_KERNEL_MFMA 2
@@ -186,7 +176,8 @@ int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* 
 #define TAVB_KERNEL_CONVERT 4
 #define TAVB_KERNEL_MFMA_SAMPLE 5 /* threshold-seeding phases of the MFMA paths (all ladder phases but the last) */
 #define TAVB_KERNEL_SKINNY 6 /* 32-query MFMA tile (small batches; every batch on fp32 corpora) */
-#define TAVB_KERNEL_COUNT 7
+#define TAVB_KERNEL_RESCORE 7 /* exact fp32-query rescoring of the 256-query tile's candidates (+ query preparation) */
+#define TAVB_KERNEL_COUNT 8
 int tavb_profile_enable(tavb_ctx* ctx, int32_t on);
 int tavb_profile_reset(tavb_ctx* ctx);
 int tavb_profile_read(tavb_ctx* ctx, int32_t kernel_id, double* out_total_ms, int64_t* out_launches);

@@ -307,3 +307,40 @@ def f32_threshold(min_score) -> np.float32:
         return t
     with np.errstate(over="ignore"):
         return np.float32(min_score)
+
+
+# --------------------------------------------------------------------------
+# corpora larger than one reference-sized VectorBase (bench.py / full-size GPU tests)
+# --------------------------------------------------------------------------
+def scores_full_chunked(chunks: Iterable[np.ndarray], queries: np.ndarray) -> np.ndarray:
+    """float32 [nq, N] score matrix for a handful of queries over a corpus delivered in row chunks (each chunk a
+    reference-sized float32 matrix).  Per chunk this is vectorbase.py:176 for every query at once (`np.dot(chunk,
+    Q.T)`: sgemm instead of nq sgemv calls -- the summation order differs from the reference's by the usual fp32
+    noise, which `check_topk_parity` already treats as a near-tie matter)."""
+    queries = np.ascontiguousarray(queries, dtype=np.float32)
+    parts = [cosine_to_score(np.dot(chunk, queries.T)).T for chunk in chunks]
+    return np.ascontiguousarray(np.concatenate(parts, axis=1), dtype=np.float32)
+
+
+def check_topk_parity_large(
+    ref_scores: np.ndarray,
+    got_items: Sequence[int],
+    got_scores: Sequence[float],
+    max_hits: int,
+    min_score: float = 0.0,
+    margin: int = 256,
+) -> tuple[ParityReport, int]:
+    """`check_topk_parity` for multi-million-row score vectors: the reference ranking is only needed down to rank
+    `max_hits` (+ `margin` rows of slack for near-tie groups), so the check runs on the best `max_hits + margin`
+    reference rows.  A returned ordinal outside that set fails the check, as it should.  Also returns the number of
+    adjacent reference pairs within TIE_EPS among ranks 0..max_hits (how many near-ties the answer contains)."""
+    ref_scores = np.asarray(ref_scores, dtype=np.float32)
+    n = ref_scores.shape[0]
+    keep = min(n, max_hits + margin)
+    clean = np.where(np.isnan(ref_scores), np.float32(-1.0), ref_scores)
+    top = np.argpartition(-clean, keep - 1)[:keep] if keep < n else np.arange(n)
+    top = top[np.lexsort((top, -clean[top].astype(np.float64)))]
+    rep = check_topk_parity(ref_scores[top], got_items, got_scores, max_hits, min_score, candidate_ordinals=top)
+    head = clean[top[: max_hits + 1]].astype(np.float64)
+    near = int(np.sum(np.abs(np.diff(head)) <= TIE_EPS))
+    return rep, near

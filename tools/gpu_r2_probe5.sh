@@ -1,0 +1,15 @@
+#!/bin/bash
+mkdir -p gpurun_out/r2p5
+B="python bench.py --workload cfg3 --no-cpu-baseline --no-parity --steps 5 --warmup 2"
+for v in "mfma_variant=6 --opt mfma_ablate=256" "mfma_variant=6 --opt mfma_ablate=260" "mfma_variant=6 --opt mfma_ablate=264" "mfma_variant=6 --opt mfma_ablate=268" "mfma_variant=6 --opt mfma_ablate=258" "mfma_variant=6 --opt mfma_ablate=256"; do
+  echo "== $v" >> gpurun_out/r2p5/cfg3.jsonl
+  $B --opt $v >> gpurun_out/r2p5/cfg3.jsonl 2>> gpurun_out/r2p5/cfg3.err
+done
+python - <<'PY'
+import json
+for l in open('gpurun_out/r2p5/cfg3.jsonl'):
+    if l.startswith('=='): print(l.strip()); continue
+    try:
+        d=json.loads(l); r=d['roofline']; print('   ms/step %.2f  kernel %.2f ms  frac %.4f' % (d['ms_per_step'], r['kernel_ms_per_step'], r['frac']))
+    except Exception as e: print('   ??', l[:200])
+PY

@@ -27,9 +27,11 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ src, size_t wi
   i32x4 a = {lane, 1, 2, 3}, b = {4, 5, 6, lane};
   // rows_pattern: a piece = 16 rows x 64 bytes of a 3072-byte-pitch matrix (what the MFMA kernels stage), 48 K steps along
   // the rows before moving to the next 80-row block; otherwise a piece = 1 KiB contiguous.
-  const int voff = rows_pattern ? (lane >> 2) * 3072 + (lane & 3) * 16 : lane * 16;
-  const int piece = rows_pattern ? 16 * 3072 : 1024;
-  const size_t blk = rows_pattern ? (size_t)80 * 3072 : 5120;
+  // rows_pattern 2: a piece = 8 rows x 128 bytes (whole cache lines) of the same matrix, 24 K steps along the rows.
+  const int voff = rows_pattern == 2 ? (lane >> 3) * 3072 + (lane & 7) * 16 : rows_pattern ? (lane >> 2) * 3072 + (lane & 3) * 16 : lane * 16;
+  const int piece = rows_pattern == 2 ? 8 * 3072 : rows_pattern ? 16 * 3072 : 1024;
+  const size_t blk = rows_pattern == 2 ? (size_t)40 * 3072 : rows_pattern ? (size_t)80 * 3072 : 5120;
+  const int kstep = rows_pattern == 2 ? 128 : 64, ksteps = rows_pattern == 2 ? 24 : 48;
   const size_t nblk = window / blk;
   size_t rb = ((size_t)blockIdx.x * 4 + wave) % nblk;
   int kt = 0;
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ src, size_t wi
   for (int j = 0; j < 10; ++j) fr[j] = i32x4{0, 0, 0, 0};
   unsigned char* my_lds = smem + wave * 5120;
   for (int it = 0; it < iters; ++it) {
-    const char* g = src + rb * blk + (rows_pattern ? kt * 64 : 0);
+    const char* g = src + rb * blk + (rows_pattern ? kt * kstep : 0);
     const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)g);
     const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)g >> 32));
     const char* ug = (const char*)(((unsigned long long)hi << 32) | lo);
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ src, size_t wi
       for (int i = 0; i < 10; ++i) a.x ^= fr[i].x & 1;
     }
     if (MODE == 1 || MODE == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    if (rows_pattern && ++kt < 48) continue;
+    if (rows_pattern && ++kt < ksteps) continue;
     kt = 0;
     rb += (size_t)gridDim.x * 4;
     while (rb >= nblk) rb -= nblk;
@@ -90,7 +92,7 @@ static void run(const char* name, const char* d, size_t window, int iters, float
   (void)hipEventSynchronize(e1);
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);
-  printf("%-34s %s window %8.1f MiB: %8.3f ms  %7.1f ns per iteration (24 MFMAs + 5 KiB per wave)  %6.1f TFLOP/s-eq\n", name, pat ? "rows16x64B" : "contiguous", window / 1048576.0, ms,
+  printf("%-34s %s window %8.1f MiB: %8.3f ms  %7.1f ns per iteration (24 MFMAs + 5 KiB per wave)  %6.1f TFLOP/s-eq\n", name, pat == 2 ? "rows8x128B" : pat ? "rows16x64B" : "contiguous", window / 1048576.0, ms,
          ms * 1e6 / iters, 24.0 * 32768 * 4 * cus * iters / (ms * 1e-3) / 1e12);
 }
 
@@ -105,7 +107,7 @@ int main() {
   (void)hipMalloc(&sink, 4);
   const int iters = 20000;
   for (size_t window : {(size_t)983040, (size_t)64 << 20, big}) {
-    for (int pat = 0; pat < 2; ++pat) {
+    for (int pat = 0; pat < 3; ++pat) {
       if (pat == 0 && window != 983040) continue;
       run<0>("MFMAs only", d, window, iters, sink, cus, pat);
       run<1>("+ 5 LDS-DMA pieces", d, window, iters, sink, cus, pat);

@@ -27,14 +27,16 @@ __global__ __launch_bounds__(512) void load_kernel(const char* __restrict__ src,
   const size_t step = ((size_t)gridDim.x * 8 * 4096) % window;
   const int nrb = (int)(window / (64 * 3072));
   int rb = (blockIdx.x * 8 + wave) % (nrb > 0 ? nrb : 1), chunk = 0;
-  const size_t lane_off = rows_pattern ? (size_t)(lane >> 2) * 3072 + (lane & 3) * 16 : (size_t)lane * 16;
-  const size_t piece = rows_pattern ? (size_t)16 * 3072 : 1024;
+  // rows_pattern 2: a piece = 8 rows x 128 B (whole cache lines), 24 column chunks per 32-row block (x2 blocks = the same 64 rows).
+  const size_t lane_off = rows_pattern == 2 ? (size_t)(lane >> 3) * 3072 + (lane & 7) * 16 : rows_pattern ? (size_t)(lane >> 2) * 3072 + (lane & 3) * 16 : (size_t)lane * 16;
+  const size_t piece = rows_pattern == 2 ? (size_t)8 * 3072 : rows_pattern ? (size_t)16 * 3072 : 1024;
+  const int kbytes = rows_pattern == 2 ? 128 : 64, kchunks = rows_pattern == 2 ? 24 : 48;
   auto base = [&]() -> const char* {
-    return rows_pattern ? src + (size_t)rb * 64 * 3072 + chunk * 64 + lane_off : src + off + lane_off;
+    return rows_pattern ? src + (size_t)rb * 64 * 3072 + (size_t)chunk * kbytes + lane_off : src + off + lane_off;
   };
   auto advance = [&]() {
     if (rows_pattern) {
-      if (++chunk == 48) {
+      if (++chunk == kchunks) {
         chunk = 0;
         rb = (rb + gridDim.x * 8) % nrb;
       }
@@ -107,7 +109,7 @@ static void run(const char* name, const char* d, size_t window, int iters, u32* 
   float ms = 0;
   hipEventElapsedTime(&ms, a, b);
   double bytes_per_cu = (double)iters * 8 * 4096;
-  printf("%-28s %s window %7.1f MiB: %8.3f ms  %7.1f GB/s per CU  %6.2f TB/s chip  (%.1f ns per 1 KiB piece per CU)\n", name, rows_pattern ? "rows16x64B" : "contiguous",
+  printf("%-28s %s window %7.1f MiB: %8.3f ms  %7.1f GB/s per CU  %6.2f TB/s chip  (%.1f ns per 1 KiB piece per CU)\n", name, rows_pattern == 2 ? "rows8x128B" : rows_pattern ? "rows16x64B" : "contiguous",
          window / 1048576.0, ms, bytes_per_cu / ms * 1e-6, bytes_per_cu * cus / ms * 1e-9, ms * 1e6 / (iters * 8 * 4.0));
 }
 
@@ -125,7 +127,7 @@ int main() {
     size_t w = window - window % ((size_t)64 * 3072);
     // the window must be a multiple of 4 KiB; offsets wrap by subtraction
     int iters = 20000;
-    for (int pat = 0; pat < 2; ++pat) {
+    for (int pat = 0; pat < 3; ++pat) {
       run<0>("lds-dma", d, w, iters, sink, cus, pat);
       run<1>("vgpr", d, w, iters, sink, cus, pat);
       run<2>("vgpr + ds_write", d, w, iters, sink, cus, pat);

@@ -21,7 +21,7 @@ TAVB_F16 = 1
 MAX_FUSED_K = 256
 MAX_STREAM_QUERIES = 8
 
-KERNEL_SCAN, KERNEL_MERGE, KERNEL_MFMA, KERNEL_NORMALIZE, KERNEL_CONVERT, KERNEL_MFMA_SAMPLE, KERNEL_SKINNY = range(7)
+KERNEL_SCAN, KERNEL_MERGE, KERNEL_MFMA, KERNEL_NORMALIZE, KERNEL_CONVERT, KERNEL_MFMA_SAMPLE, KERNEL_SKINNY, KERNEL_RESCORE = range(8)
 
 _LIB_NAME = "libtavb.so"
 _lib = None
@@ -40,9 +40,6 @@ _SIGNATURES = [
     ("tavb_set_corpus", c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64]),
     ("tavb_normalize_rows_f32", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
     ("tavb_convert_f32_to_f16", c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
-    ("tavb_tiled_bytes", c_int, [c_int64, c_int32, POINTER(c_int64)]),
-    ("tavb_pack_f16_tiled", c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
-    ("tavb_set_corpus_tiled", c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64]),
     ("tavb_search", c_int, [c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, POINTER(c_int32)]),
     ("tavb_search_subset", c_int,
      [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, POINTER(c_int32)]),
@@ -165,7 +162,6 @@ class Engine:
         self._h = handle
         self._lock = threading.Lock()
         self.corpus = None  # torch tensor [capacity, dim]
-        self.tiled = None  # optional K-blocked fp16 image (MFMA path)
         self.rows = 0
         self.dim = 0
         self.dtype = TAVB_F32
@@ -232,7 +228,6 @@ class Engine:
             torch.cuda.current_stream(self.device).synchronize()
         _check(self.lib, self.lib.tavb_set_corpus(self._h, c_void_p(tensor.data_ptr()), n, tensor.shape[1], dt, int(ordinal_base)))
         self.corpus, self.rows, self.dim, self.dtype, self.ordinal_base = tensor, n, int(tensor.shape[1]), dt, int(ordinal_base)
-        self.tiled = None  # the C side drops the auxiliary image when the corpus changes
 
     def upload_rows(self, host_rows: np.ndarray, start: int, dtype: int, capacity_hint: int = 0) -> None:
         """Make device rows [start, start+len) equal to `host_rows` (f32), growing the
@@ -260,30 +255,6 @@ class Engine:
                 src = src.astype(np.float16)  # round-to-nearest-even, same as v_cvt_f16_f32
             self.corpus[start:n_new].copy_(torch.from_numpy(src))
         self.set_corpus_tensor(self.corpus, rows=n_new, ordinal_base=self.ordinal_base)
-
-    def build_tiled(self, source=None, attach: bool = True):
-        """Pack `source` (default: the current row-major corpus tensor) into the K-blocked fp16 image the
-        MFMA kernel streams best (include/tavb.h: tavb_pack_f16_tiled) and attach it.  Returns the tensor."""
-        torch = self._torch
-        src = self.corpus[: self.rows] if source is None else source
-        rows, dim = int(src.shape[0]), int(src.shape[1])
-        nbytes = c_int64(0)
-        _check(self.lib, self.lib.tavb_tiled_bytes(rows, dim, byref(nbytes)))
-        tiled = torch.empty(nbytes.value // 2, dtype=torch.float16, device=src.device)
-        dt = TAVB_F16 if src.dtype == torch.float16 else TAVB_F32
-        torch.cuda.current_stream(self.device).synchronize()
-        _check(self.lib, self.lib.tavb_pack_f16_tiled(self._h, c_void_p(src.data_ptr()), dt, rows, dim, c_void_p(tiled.data_ptr())))
-        self.synchronize()
-        if attach:
-            self.set_tiled(tiled, rows, dim)
-        return tiled
-
-    def set_tiled(self, tiled, rows: int, dim: int, ordinal_base: int | None = None) -> None:
-        base = self.ordinal_base if ordinal_base is None else int(ordinal_base)
-        _check(self.lib, self.lib.tavb_set_corpus_tiled(self._h, c_void_p(tiled.data_ptr()), int(rows), int(dim), base))
-        self.tiled = tiled
-        if self.corpus is None:
-            self.rows, self.dim, self.dtype, self.ordinal_base = int(rows), int(dim), TAVB_F16, base
 
     def clear(self) -> None:
         if self.corpus is not None:

@@ -97,18 +97,14 @@ struct tavb_ctx {
   int32_t dim = 0;
   int32_t dtype = TAVB_F32;
   int64_t ordinal_base = 0;
-  const void* tiled = nullptr;  // optional K-blocked fp16 image of the same rows (MFMA path)
 
   tavb::ScanGeometry geom{0, 16, 2, 1, 0, 0};
   int64_t mfma_min_batch = 65;  // fp16 corpora: batches from this size up use the 256-query tile (3 .. 64 the 32/64-query tile)
   int64_t mfma_splits = 0;  // 0 = auto
-  int64_t mfma_variant = 0;  // 0 = auto: variant 3, and variant 5 (384-row tile) for the big last phases of large batches
+  int64_t mfma_variant = 0;  // 0 = auto (see tavb_search_device_dispatch); 3, 6 = that K loop for every phase
   int64_t mfma_ablate = 0;
-  int64_t mfma_prio = 1;
-  int64_t mfma_rendezvous = 0;
-  int64_t mfma_a_nt = 0;
-  int64_t mfma_group = 0;
-  int64_t mfma_use_tiled = 1;
+  int64_t mfma_sched = 0;
+  int64_t mfma_v6_min_rows = 400000;  // auto variant: phases of at least this many rows run the whole-line tile (variant 6)
   int64_t mfma_sample_rows = 131072;  // rows of the first (threshold-seeding) phase (0 = one phase, no seeding)
   int64_t skinny_min_batch_f32 = 5;   // fp32 corpus: batches from this size up use the 32-query MFMA tile
   int64_t skinny_min_batch_f16 = 3;   // fp16 corpus: batches from this size up to mfma_min_batch - 1 use it
@@ -184,8 +180,7 @@ int scan_blocks_for(const tavb_ctx* c, int64_t n_pos, int waves, int unroll) {
 int search_device_impl(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores /*host, nq*/,
                        const int32_t* d_row_ids, int64_t n_pos, uint32_t index_base, u64_t* d_out,
                        u64_t key_bound = ~0ull) {
-  if (!c->corpus && c->rows != 0)
-    return fail(TAVB_E_NO_CORPUS, "this lookup needs the row-major corpus (only the K-blocked MFMA image is set)");
+  if (!c->corpus && c->rows != 0) return fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
   if (n_pos <= 0) {
     TAVB_HIP(hipMemsetAsync(d_out, 0, (size_t)nq * k * sizeof(u64_t), c->stream));
     return TAVB_OK;
@@ -234,11 +229,11 @@ int check_ctx(tavb_ctx* c) {
 
 int check_search_args(tavb_ctx* c, int k) {
   if (int rc = check_ctx(c)) return rc;
-  if (!c->corpus && !c->tiled && c->rows != 0) return fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
+  if (!c->corpus && c->rows != 0) return fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
   if (c->dim <= 0) return fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
   if (k < 1) return fail(TAVB_E_INVALID, "k must be >= 1 (got %d)", k);
   if (k > TAVB_MAX_FUSED_K)
-    return fail(TAVB_E_UNSUPPORTED, "k=%d exceeds the fused-select limit %d; use tavb_search_thresholded_page", k,
+    return fail(TAVB_E_UNSUPPORTED, "k=%d exceeds the fused-select limit %d; page with tavb_search_after / tavb_search_subset_after", k,
                 TAVB_MAX_FUSED_K);
   return TAVB_OK;
 }
@@ -382,16 +377,17 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch must be >= 1");
     c->mfma_min_batch = v;
   } else if (n == "mfma_variant") {
-    if (v < 0 || v > 5) return fail(TAVB_E_INVALID, "mfma_variant must be 0..5");
+    if (v != 0 && v != 3 && v != 6) return fail(TAVB_E_INVALID, "mfma_variant must be 0 (auto), 3 or 6");
     c->mfma_variant = v;
   } else if (n == "mfma_sample_rows") {
     if (v < 0) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= 0");
     c->mfma_sample_rows = v;
-  } else if (n == "mfma_use_tiled") {
-    c->mfma_use_tiled = v ? 1 : 0;
-  } else if (n == "mfma_group") {
-    if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_group must be 0..2");
-    c->mfma_group = v;
+  } else if (n == "mfma_v6_min_rows") {
+    if (v < 0) return fail(TAVB_E_INVALID, "mfma_v6_min_rows must be >= 0");
+    c->mfma_v6_min_rows = v;
+  } else if (n == "mfma_sched") {
+    if (v < 0 || v > 3) return fail(TAVB_E_INVALID, "mfma_sched must be 0..3");
+    c->mfma_sched = v;
   } else if (n == "skinny_min_batch_f32") {
     if (v < 1) return fail(TAVB_E_INVALID, "skinny_min_batch_f32 must be >= 1");
     c->skinny_min_batch_f32 = v;
@@ -401,13 +397,6 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_ladder") {
     if (v < 0 || v > 64) return fail(TAVB_E_INVALID, "mfma_ladder must be 0..64");
     c->mfma_ladder = v;
-  } else if (n == "mfma_rendezvous") {
-    c->mfma_rendezvous = v ? 1 : 0;
-  } else if (n == "mfma_a_nt") {
-    c->mfma_a_nt = v ? 1 : 0;
-  } else if (n == "mfma_prio") {
-    if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "mfma_prio must be 0..2");
-    c->mfma_prio = v;
   } else if (n == "mfma_ablate") {
     if (v < 0 || v > 4095) return fail(TAVB_E_INVALID, "mfma_ablate must be 0..4095");
     c->mfma_ablate = v;
@@ -452,50 +441,10 @@ int tavb_set_corpus(tavb_ctx* c, const void* dev_rows, int64_t rows, int32_t dim
   if (rows >= 0x7FFFFFFFll) return fail(TAVB_E_UNSUPPORTED, "at most 2^31-2 rows per device shard (got %lld)", (long long)rows);
   if (ordinal_base < 0) return fail(TAVB_E_INVALID, "ordinal_base must be >= 0");
   c->corpus = dev_rows;
-  c->tiled = nullptr;  // a new corpus invalidates the auxiliary image
   c->rows = rows;
   c->dim = dim;
   c->dtype = dtype;
   c->ordinal_base = ordinal_base;
-  return TAVB_OK;
-}
-
-int tavb_tiled_bytes(int64_t rows, int32_t dim, int64_t* out_bytes) {
-  if (!out_bytes) return fail(TAVB_E_INVALID, "null out_bytes");
-  if (rows < 0 || dim < 32 || dim % 32 != 0) return fail(TAVB_E_INVALID, "tiled image needs rows >= 0 and dim a multiple of 32");
-  *out_bytes = (int64_t)tavb::tiled_bytes(rows, dim);
-  return TAVB_OK;
-}
-
-int tavb_pack_f16_tiled(tavb_ctx* c, const void* dev_src, int32_t src_dtype, int64_t rows, int32_t dim, void* dev_dst) {
-  if (int rc = check_ctx(c)) return rc;
-  if (rows < 0 || dim < 32 || dim % 32 != 0) return fail(TAVB_E_INVALID, "tiled image needs dim a multiple of 32");
-  if (src_dtype != TAVB_F32 && src_dtype != TAVB_F16) return fail(TAVB_E_INVALID, "bad source dtype");
-  if (rows == 0) return TAVB_OK;
-  if (!dev_src || !dev_dst) return fail(TAVB_E_INVALID, "null pointer");
-  DeviceGuard guard(c->device);
-  Timed t(c, TAVB_KERNEL_CONVERT);
-  hipError_t e = tavb::launch_pack_tiled(dev_src, src_dtype, rows, dim, dev_dst, c->stream);
-  if (e != hipSuccess) return fail(TAVB_E_HIP, "pack launch failed: %s", hipGetErrorString(e));
-  return TAVB_OK;
-}
-
-int tavb_set_corpus_tiled(tavb_ctx* c, const void* dev_tiled, int64_t rows, int32_t dim, int64_t ordinal_base) {
-  if (int rc = check_ctx(c)) return rc;
-  if (rows < 0 || dim < 32 || dim % 32 != 0) return fail(TAVB_E_INVALID, "tiled image needs dim a multiple of 32");
-  if (rows > 0 && !dev_tiled) return fail(TAVB_E_INVALID, "null tiled pointer");
-  if (rows >= 0x7FFFFFFFll) return fail(TAVB_E_UNSUPPORTED, "at most 2^31-2 rows per device shard");
-  if (c->corpus) {
-    if (rows != c->rows || dim != c->dim)
-      return fail(TAVB_E_INVALID, "tiled image (%lld x %d) does not match the corpus (%lld x %d)", (long long)rows, dim,
-                  (long long)c->rows, c->dim);
-  } else {
-    c->rows = rows;
-    c->dim = dim;
-    c->dtype = TAVB_F16;
-    c->ordinal_base = ordinal_base;
-  }
-  c->tiled = dev_tiled;
   return TAVB_OK;
 }
 
@@ -726,8 +675,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   bool uniform_thr = true;
   for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (min_scores[i] == min_scores[0]);
   const bool f16c = (c->dtype == TAVB_F16);
-  const bool wide = (f16c || c->tiled) && (nq >= c->mfma_min_batch || !c->corpus) && uniform_thr && tavb::mfma_supported(c->dim, k) &&
-                    c->rows > 0 && (c->mfma_variant == 0 || c->mfma_variant == 3 || c->mfma_variant == 4 || !c->tiled || c->corpus);
+  const bool wide = f16c && c->corpus && nq >= c->mfma_min_batch && uniform_thr && tavb::mfma_supported(c->dim, k) && c->rows > 0;
   // 32-query tiles at HBM speed: small batches on fp16 corpora, every batch from `skinny_min_batch_f32` up on fp32 ones
   const bool skinny = !wide && c->corpus && uniform_thr && c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c) &&
                       nq >= (f16c ? c->skinny_min_batch_f16 : c->skinny_min_batch_f32);
@@ -759,11 +707,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     if (int rc = c->d_lists.reserve((size_t)nq * (splits + 1) * k * sizeof(u64_t))) return rc;  // + the carried-over top-k
     if (int rc = c->d_cand.reserve(tavb::mfma_workspace_bytes(splits, nq_pad))) return rc;
     tavb::MfmaParams p{};
-    const bool takes_tiled = c->mfma_variant == 0 || c->mfma_variant == 3 || c->mfma_variant == 4;  // the variants that can read the K-blocked image
-    const bool use_tiled = !skinny && c->tiled && takes_tiled && (c->mfma_use_tiled || !c->corpus);
-    p.corpus = use_tiled ? c->tiled : c->corpus;
-    p.a_tiled = use_tiled ? 1 : 0;
-    if (!p.corpus) return fail(TAVB_E_NO_CORPUS, "no operand for the MFMA kernel (row-major fp16 corpus or K-blocked image)");
+    p.corpus = c->corpus;
     p.queries = c->d_queries_f16.ptr;
     p.lists = reinterpret_cast<u64_t*>(c->d_lists.ptr);
     p.workspace = reinterpret_cast<u64_t*>(c->d_cand.ptr);
@@ -775,12 +719,9 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     p.index_base = index_base;
     p.min_score = min_scores[0];
     p.n_splits = splits;
-    p.variant = c->mfma_variant == 0 ? 3 : (int)c->mfma_variant;
+    p.variant = c->mfma_variant == 0 ? 3 : (int)c->mfma_variant;  // auto: decided per phase below
     p.ablate = (int)c->mfma_ablate;
-    p.prio = (int)c->mfma_prio;
-    p.rendezvous = (int)c->mfma_rendezvous;
-    p.a_nt = (int)c->mfma_a_nt;
-    p.group_sel = (int)c->mfma_group;
+    p.sched = (int)c->mfma_sched;
     p.f32 = q32 ? 1 : 0;
     p.skinny_tile = skinny ? qt : 0;
     p.thr_in = nullptr;
@@ -794,7 +735,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     std::vector<int64_t> bounds;  // phase i scans rows [bounds[i], bounds[i+1])
     bounds.push_back(0);
     const int64_t sample = (c->mfma_sample_rows + 255) / 256 * 256;
-    if (sample > 0 && c->rows >= 8 * sample && (c->mfma_ablate == 0 || c->mfma_ablate == 256 || c->mfma_ablate == 512)) {
+    if (sample > 0 && c->rows >= 8 * sample) {
       int64_t done = sample;
       bounds.push_back(done);
       const int64_t growth = c->mfma_ladder;
@@ -813,12 +754,12 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     for (int ph = 0; ph < n_phases; ++ph) {
       const bool last = (ph == n_phases - 1);
       tavb::MfmaParams pp = p;
-      pp.corpus = reinterpret_cast<const char*>(p.corpus) + (size_t)bounds[ph] * row_bytes;  // same offset in the K-blocked image
+      pp.corpus = reinterpret_cast<const char*>(p.corpus) + (size_t)bounds[ph] * row_bytes;
       pp.rows = bounds[ph + 1] - bounds[ph];
       pp.index_base = index_base + (uint32_t)bounds[ph];
       pp.n_splits = pick_splits(pp.rows);
-      if (!skinny && c->mfma_variant == 0)  // measured: the 384-row tile wins from a few million rows per launch, 4+ query tiles
-        pp.variant = (pp.rows >= 4000000 && nq_pad >= 4 * qt && !use_tiled) ? 5 : 3;
+      if (!skinny && c->mfma_variant == 0)  // the 4-wave whole-line tile needs dim % 64 == 0 and enough tiles per workgroup to amortise its longer prologue
+        pp.variant = (c->dim % 64 == 0 && pp.rows >= c->mfma_v6_min_rows) ? 6 : 3;
       if (c->mfma_splits > 0 || pp.n_splits > splits) pp.n_splits = splits;  // lists / candidate buffers are sized for `splits`
       const int carried = ph > 0 ? 1 : 0;  // the running top-k of the earlier phases occupies one more list slot
       pp.list_stride = pp.n_splits + carried;

@@ -43,13 +43,10 @@ hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, in
 hipError_t launch_normalize_f32(const float* in, float* out, int64_t rows, int dim, hipStream_t stream);
 hipError_t launch_f32_to_f16(const float* in, void* out, int64_t count, hipStream_t stream);
 hipError_t launch_f32_split_f16(const float* in, void* hi, void* lo, int64_t count, hipStream_t stream);
-size_t tiled_bytes(int64_t rows, int dim);
-hipError_t launch_pack_tiled(const void* src, int src_dtype, int64_t rows, int dim, void* dst, hipStream_t stream);
 
 // MFMA batched scan (f16 corpus, f16 queries staged by the launcher)
 struct MfmaParams {
-  const void* corpus;   // f16 [rows, dim] row-major, or the K-blocked image when a_tiled
-  int32_t a_tiled;
+  const void* corpus;   // f16 [rows, dim] row-major (skinny kernel: f32 or f16)
   const void* queries;  // f16 [nq_padded, dim] device
   unsigned long long* lists;  // out [nq, n_splits, k]
   unsigned long long* workspace;  // candidate buffers, mfma_workspace_bytes() bytes
@@ -62,13 +59,11 @@ struct MfmaParams {
   float min_score;
   int32_t n_splits;  // row ranges the corpus is cut into (one list per (query, split))
   int32_t list_stride;  // lists per query in `lists`; 0 = n_splits (extra slots are the caller's, e.g. a carried-over top-k)
-  int32_t variant;   // 1 = lock-step K loop, 2 = ping-pong wave groups
-  int32_t group_sel; // ping-pong grouping: 0 = wave>>2, 1 = wave&1, 2 = (wave>>1)&1
-  int32_t prio;      // s_setprio placement: 0 none, 1 MFMA phase, 2 LOAD phase
-  int32_t ablate;    // measurement only: bit 0 = drop MFMAs, bit 1 = drop LDS-DMA (garbage results)
-  const float* thr_in;  // optional per-query admission thresholds (device, [nq_padded]) from a sample pass
-  int32_t rendezvous;   // variant 3: the workgroups of a row range meet at every tile start (L2 sharing of corpus slices)
-  int32_t a_nt;         // variant 3: non-temporal policy on the corpus LDS-DMA stream
+  int32_t variant;   // K loop of the 256-query tile: 3 = 256-row tile on 8 waves, K steps of 32 halves;
+                     // 6 = 320-row tile on 4 waves, K steps of 64 halves (whole cache lines)
+  int32_t sched;     // variant 6: staging schedule (measurement)
+  int32_t ablate;    // measurement only (garbage results): see launch_mfma_scan
+  const float* thr_in;  // optional per-query admission thresholds (device, [nq_padded]) from the earlier ladder phases
   int32_t f32;          // skinny kernel only: corpus and queries are fp32 (else fp16)
   int32_t skinny_tile;  // skinny kernel only: queries per tile, 32 or 64
 };

@@ -16,13 +16,11 @@
 //     threshold register per lane and one v_cmp per score.
 //   * workgroup = 8 waves (2 along rows x 4 along queries), each wave a 128 x 64
 //     sub-tile = 4 x 2 MFMA tiles of 32 x 32 (128 accumulator registers).
-//   * K loop in steps of BK = 64 halves: both operand slabs (32 KiB each) are staged
-//     into LDS with LDS-DMA (global_load_lds, 16 B per lane), double buffered: slab
-//     t+1 is in flight while slab t feeds the MFMAs.  The 16-byte slots of each 128-byte
-//     LDS row are XOR-swizzled with ((row >> 1) & 7) -- applied to the per-lane global
-//     SOURCE address, because LDS-DMA writes lane-linear -- so that the ds_read_b128
-//     fragment reads (16 lanes of a group read 16 different rows at one k-slot) hit 16
-//     different bank slots instead of two.
+//   * K loop: both operand slabs are staged into LDS by LDS-DMA (16 B per lane) through rings that run ahead of the
+//     MFMAs across tile boundaries, with counted `s_waitcnt vmcnt(N)` and raw `s_barrier` (variant 3: K steps of 32
+//     halves, 6 + 3 slots of 16 KiB; variant 6: K steps of 64 halves, see its header).  The 16-byte slots of each LDS row
+//     are XOR-swizzled -- on the per-lane global SOURCE address, because LDS-DMA writes lane-linear, and on the
+//     fragment reads -- so that the 16 lanes of a ds_read_b128 group hit 16 different bank slots.
 //   * a workgroup owns one query tile and one contiguous range of corpus rows and walks
 //     that range tile by tile (persistent); the workgroups that share a row range (one
 //     per query tile) get block ids congruent mod 8 so they run on the same XCD at the
@@ -39,9 +37,10 @@
 //   * the host scans the corpus in phases of growing size (threshold ladder, tavb_abi.hip): the
 //     k-th best score after a phase seeds the admission thresholds of the next (`thr_in`).
 //
-// Two kernel families live here: the 256-query fp16 tile described above (variants 1-4 of its K
-// loop; 3 is the default) and, at the end of the file, a 32-query tile for fp32 and fp16 corpora
-// that carries small batches -- and every batch on the reference's fp32 layout -- at HBM speed.
+// Two kernel families live here: the 256-query fp16 tile described above (variant 3 = this 8-wave form with K steps of
+// 32 halves, used for the small phases of the ladder; variant 6 = four waves, 320-row tile, K steps of whole cache lines,
+// used for the big ones) and, at the end of the file, a 32/64-query tile for fp32 and fp16 corpora that carries small
+// batches -- and every batch on the reference's fp32 layout -- at HBM speed.
 
 #include <hip/hip_runtime.h>
 
@@ -56,12 +55,9 @@ namespace {
 
 constexpr int BM = 256;   // corpus rows per tile
 constexpr int BN = 256;   // queries per tile
-constexpr int BK = 64;    // halves per K step (128 bytes per row)
+constexpr int BK = 64;    // dim must be a multiple of this
 constexpr int NTHREADS = 512;
 constexpr int CAP = 512;  // candidate keys per (workgroup, query); must be >= BM + max k
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 64 KiB
-constexpr int A_BYTES = BM * BK * 2;             // 32 KiB
-constexpr int LDS_BYTES = 2 * STAGE_BYTES + BN * 8;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
@@ -82,10 +78,7 @@ struct MfmaDeviceParams {
   int32_t k;
   uint32_t index_base;
   float min_score;
-  int32_t group_sel;
-  int32_t a_tiled;  // corpus given as the K-blocked image of pack_tiled_kernel
   const float* thr_in;  // optional [nq_padded] admission thresholds from a sample pass (exclusive bound)
-  int* sync;            // optional [n_splits] tile rendezvous counters (zeroed before the launch), variant 3
 };
 
 // Pin a wave-uniform pointer into SGPRs.  Without this the compiler strength-reduces the eight
@@ -166,11 +159,6 @@ __device__ __forceinline__ WaveTopK<1> best_of_buffer(const u64* buf, int n, int
   return best;
 }
 
-// VARIANT 1: every wave alternates {read fragments, 8 MFMAs} in lock step, one barrier per K step.
-// VARIANT 2: the two wave groups (rows 0-127 / 128-255 of the tile = waves 0-3 / 4-7, one wave of
-//            each group per SIMD) run half a phase apart: while one group issues its 16 MFMAs of a
-//            half K step, the other group reads its next fragments from LDS and issues the LDS-DMA
-//            for the next slab.  Raw s_barrier (no implied vmcnt drain), counted waits placed by hand.
 #define TAVB_SB() __builtin_amdgcn_sched_barrier(0)
 #define TAVB_BARRIER()            \
   do {                            \
@@ -178,263 +166,6 @@ __device__ __forceinline__ WaveTopK<1> best_of_buffer(const u64* buf, int n, int
     __builtin_amdgcn_s_barrier(); \
     TAVB_SB();                    \
   } while (0)
-
-// ABLATE (measurement only, results are garbage): 1 = no MFMAs, 2 = no LDS-DMA after the first slab,
-// 3 = neither (barriers + fragment reads only).
-// PRIO: 0 = no s_setprio, 1 = MFMA phase at priority 1, 2 = LOAD phase at priority 1.
-template <int VARIANT, int ABLATE, int PRIO>
-__global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel(const MfmaDeviceParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  float* thr_lds = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);      // [BN] admission threshold (exclusive)
-  int* cnt_lds = reinterpret_cast<int*>(smem + 2 * STAGE_BYTES + BN * 4);  // [BN] buffer fill
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2;  // 0..1 : which 128 rows of the tile
-  const int wn = wave & 3;   // 0..3 : which 64 queries of the tile
-
-  // block -> (row range, query tile); ranges sharing rows are congruent mod 8 (same XCD)
-  const int b = blockIdx.x;
-  const int xcd = b & 7;
-  const int t = b >> 3;
-  const int qtile = t % p.n_qtiles;
-  const int split = (t / p.n_qtiles) * 8 + xcd;
-  if (split >= p.n_splits) return;
-  const int64_t r_begin = (int64_t)split * p.rows_per_split;
-  const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
-  const int logical_block = split * p.n_qtiles + qtile;
-  u64* my_cand = p.cand + (size_t)logical_block * BN * CAP;
-
-  // admission is `score > thr`: start just below min_score (or at -inf when everything qualifies)
-  const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
-  for (int i = tid; i < BN; i += NTHREADS) {
-    float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
-    const int qg0 = qtile * BN + i;
-    if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
-    else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best of the sample pass: a valid lower bound
-    thr_lds[i] = t0;
-    cnt_lds[i] = 0;
-  }
-
-  const int D = p.dim;
-  const int n_ksteps = D / BK;
-  const size_t row_bytes = (size_t)D * 2;
-  const char* corpus = reinterpret_cast<const char*>(p.corpus);
-  const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * BN * row_bytes;
-
-  // --- staging: each wave issues 4 LDS-DMA instructions per operand per K step; instruction i
-  //     covers tile rows 8i .. 8i+7 (8 lanes x 16 B per 128-byte row).  Addresses are a wave-uniform
-  //     base (SGPRs) plus a 32-bit per-lane offset that is loop invariant.
-  const int st_row_in_inst = lane >> 3;
-  const int st_slot = lane & 7;
-  uint32_t st_off_b[4];  // query operand: constant for the whole kernel
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 8 + st_row_in_inst;
-    st_off_b[j] = (uint32_t)row * (uint32_t)row_bytes + (uint32_t)((st_slot ^ ((row >> 1) & 7)) * 16);
-  }
-  uint32_t st_off_a[4];  // corpus operand: per tile (rows past the corpus end are clamped)
-
-  auto set_tile_offsets = [&](int64_t row0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = (wave * 4 + j) * 8 + st_row_in_inst;
-      int64_t grow = row0 + row;
-      if (grow >= p.rows) grow = p.rows - 1;  // stay in bounds; masked in the epilogue
-      st_off_a[j] = (uint32_t)(grow - row0) * (uint32_t)row_bytes + (uint32_t)((st_slot ^ ((row >> 1) & 7)) * 16);
-    }
-  };
-
-  auto stage = [&](int buf, int64_t row0, int kt) {
-    unsigned char* abase = smem + buf * STAGE_BYTES + wave * 4096;
-    unsigned char* bbase = abase + A_BYTES;
-    const char* ga = sgpr_ptr(corpus + (size_t)row0 * row_bytes + (size_t)kt * (BK * 2));  // wave-uniform
-    const char* gb = sgpr_ptr(qbase + (size_t)kt * (BK * 2));                               // wave-uniform
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds((global_void*)(ga + (size_t)st_off_a[j]), (lds_void*)(abase + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((global_void*)(gb + (size_t)st_off_b[j]), (lds_void*)(bbase + j * 1024), 16, 0, 0);
-    }
-  };
-
-  // fragment reads: lane l reads row (l & 31) of a 32-row block at logical 16-byte slot
-  // 2*k16 + (l >> 5); the physical slot is that XOR ((row >> 1) & 7), and because the block bases
-  // are multiples of 16 rows the XOR term depends on the lane only: offset = (k16 << 5) ^ frag_x.
-  const int frag_row = lane & 31;
-  const uint32_t frag_x = (uint32_t)(((lane >> 5) ^ ((frag_row >> 1) & 7)) << 4);
-  const uint32_t a_lane = (uint32_t)((wm * 128 + frag_row) * 128);            // + mi * 4096
-  const uint32_t b_lane = (uint32_t)(A_BYTES + (wn * 64 + frag_row) * 128);   // + ni * 4096
-
-  __syncthreads();  // thresholds / counters initialised
-
-  for (int64_t row0 = r_begin; row0 < r_end; row0 += BM) {
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    if constexpr (VARIANT == 1) {
-      set_tile_offsets(row0);
-      stage(0, row0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      int cur = 0;
-      for (int kt = 0; kt < n_ksteps; ++kt) {
-        if (kt + 1 < n_ksteps) stage(cur ^ 1, row0, kt + 1);
-        const unsigned char* sbase = smem + cur * STAGE_BYTES;
-#pragma unroll
-        for (int k16 = 0; k16 < 4; ++k16) {
-          const uint32_t kx = (uint32_t)(k16 << 5) ^ frag_x;
-          f16x8 af[4], bf[2];
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            af[mi] = *reinterpret_cast<const f16x8*>(sbase + (a_lane + kx) + mi * 4096);
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            bf[ni] = *reinterpret_cast<const f16x8*>(sbase + (b_lane + kx) + ni * 4096);
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
-      }
-    } else {
-      // slab 0 of this tile: issued here for the first tile, under the previous epilogue otherwise
-      if (row0 == r_begin) {
-        set_tile_offsets(row0);
-        stage(0, row0, 0);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      // which waves form a ping-pong group: the two groups must hold one wave per SIMD each
-      const int group = (p.group_sel == 0) ? (wave >> 2) : (p.group_sel == 1) ? (wave & 1) : ((wave >> 1) & 1);  // wave-uniform
-      if (group == 1) TAVB_BARRIER();  // group 1 runs one barrier interval behind group 0
-      for (int kt = 0; kt < n_ksteps; ++kt) {
-        const unsigned char* sbase = smem + (kt & 1) * STAGE_BYTES;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          // ---- LOAD phase: fragments of two k16 sub-steps, next slab's LDS-DMA
-          if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
-          f16x8 af[2][4], bf[2][2];
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            const uint32_t kx = (uint32_t)((half * 2 + kk) << 5) ^ frag_x;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-              af[kk][mi] = *reinterpret_cast<const f16x8*>(sbase + (a_lane + kx) + mi * 4096);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              bf[kk][ni] = *reinterpret_cast<const f16x8*>(sbase + (b_lane + kx) + ni * 4096);
-          }
-          if ((ABLATE & 2) == 0 && half == 0 && kt + 1 < n_ksteps) stage((kt + 1) & 1, row0, kt + 1);
-          // the slab issued during this K step must have landed before the barrier that precedes group
-          // 0's first read of it (group 1 waits here, group 0 after its MFMAs below)
-          if (half == 1 && group == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the buffer can be restaged
-          if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
-          TAVB_BARRIER();
-          // ---- MFMA phase
-          if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < 2; ++ni) {
-                if constexpr ((ABLATE & 1) == 0)
-                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
-                else
-                  asm volatile("" ::"v"(af[kk][mi]), "v"(bf[kk][ni]));
-              }
-          if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-          if (half == 1 && group == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          TAVB_BARRIER();
-        }
-      }
-      if (group == 0) TAVB_BARRIER();  // re-align the groups
-      if ((ABLATE & 2) == 0 && row0 + BM < r_end) {  // next tile's first slab flies under the epilogue
-        set_tile_offsets(row0 + BM);
-        stage(0, row0 + BM, 0);
-      }
-    }
-
-    // ---- epilogue: score, admission test, append ------------------------------------
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int ql = wn * 64 + ni * 32 + (lane & 31);  // this lane's query within the tile
-      const float thr = thr_lds[ql];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        bool any = false;
-        float sc[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);  // == (dot + 1) / 2 rounded once
-          any = any || (sc[r] > thr);
-        }
-        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-          if (any) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              if (sc[r] > thr) {
-                const int64_t row = row0 + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float s = sc[r];
-                s = (s > 0.0f) ? s : 0.0f;
-                s = (s > 1.0f) ? 1.0f : s;
-                if (row < r_end && s >= p.min_score) {
-                  const int pos = atomicAdd(&cnt_lds[ql], 1);
-                  if (pos < CAP) my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)row + p.index_base);
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __threadfence_block();
-    __syncthreads();
-
-    // ---- compaction of buffers that could overflow on the next tile ---------------------
-    for (int q = wave; q < BN; q += NTHREADS / 64) {
-      const int n = cnt_lds[q];  // wave-uniform (same address)
-      if (n > CAP - BM) {
-        u64* buf = my_cand + (size_t)q * CAP;
-        const WaveTopK<1> best = best_of_buffer(buf, n < CAP ? n : CAP, lane);
-        if (lane < p.k) buf[lane] = best.key[0];  // keep the best k at the front
-        const int kept = __popcll(__ballot(best.key[0] != 0ull && lane < p.k));
-        const u64 kth = best.at(p.k - 1);
-        if (lane == 0) {
-          cnt_lds[q] = kept;
-          const float kth_score = __uint_as_float((uint32_t)(kth >> 32));
-          if (kth != 0ull && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __threadfence_block();
-    __syncthreads();
-  }
-
-  // ---- final: every buffer -> sorted list of k keys ---------------------------------------
-  for (int q = wave; q < BN; q += NTHREADS / 64) {
-    const int qg = qtile * BN + q;
-    if (qg >= p.nq) continue;
-    const int n = cnt_lds[q];
-    const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane);
-    u64* out = p.lists + ((size_t)qg * p.list_stride + split) * (size_t)p.k;
-    if (lane < p.k) out[lane] = best.key[0];
-  }
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // VARIANT 3: same tile shape and ping-pong wave groups as variant 2, but the operand stream is
@@ -456,7 +187,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int NA, int NB, int ABL, int A_AUX = 0>
+template <int NA, int NB, int ABL>
 __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDeviceParams p) {
   constexpr int KS = 32;                 // halves per step
   constexpr int SLOT = 256 * KS * 2;     // 16 KiB: one operand, one step
@@ -525,7 +256,6 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
       int64_t r = row;
       if (clamp && row0 + r >= p.rows) r = p.rows - 1 - row0;  // stay in bounds; masked in the epilogue
       st_off[j] = (uint32_t)r * (uint32_t)row_bytes + (uint32_t)((st_slot ^ ((row >> 2) & 3)) * 16);
-      if (clamp && p.a_tiled) st_off[j] = (uint32_t)((lw * 4 + j) * 1024 + lane * 16);  // the stored image is the LDS image
     }
   };
   int st_tile = 0;   // tile of the next step this wave stages (group 0 only; group 1's operand has no tiles)
@@ -533,42 +263,15 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
   int st_slot_idx = 0;  // ring slot it goes to
   set_offsets(r_begin, group == 0);
 
-  // Tile rendezvous.  The n_qtiles workgroups of a row range stream the same corpus rows and sit on the same XCD
-  // (same L2).  Left alone they drift apart (their admission work differs) until each re-read of a corpus slice
-  // misses L2 and comes from the Infinity Cache at a third of the rate.  So the corpus stagers meet at every tile
-  // start: one lane counts the workgroup in, the stager waves poll the counter with a scalar load (lgkmcnt: the
-  // counted vmcnt queue of the LDS-DMA stream is left alone) until all n_qtiles workgroups have arrived.  The wait is
-  // bounded -- a peer that is not resident (fewer free CUs than workgroups) only costs the first time-out, after
-  // which this workgroup stops waiting -- so the result never depends on it.
-  int* const sync_ctr = (p.sync != nullptr && p.n_qtiles > 1) ? p.sync + split : nullptr;
-  bool sync_on = sync_ctr != nullptr;
-  auto rendezvous = [&](int tile) {
-    if (lw == 0 && lane == 0) __hip_atomic_fetch_add(sync_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!sync_on) return;
-    const int want = p.n_qtiles * (tile + 1);
-    for (int spin = 0;; ++spin) {
-      int seen;
-      asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(sync_ctr) : "memory");
-      if (seen >= want) break;
-      if (spin >= 256) {  // ~100 us: give up for good
-        sync_on = false;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(4);
-    }
-  };
-
   auto stage_next = [&]() {
     if (group == 0) {
-      if (sync_ctr != nullptr && st_kt == 0 && st_tile < n_tiles) rendezvous(st_tile);
       const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
       const int64_t src_row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM;  // ablation: every block re-reads tile 0 (L2 resident)
-      const char* g = p.a_tiled ? sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * SLOT)  // block (tile, step): 16 KiB
-                                : sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * (KS * 2));
+      const char* g = sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * (KS * 2));
       unsigned char* l = smem + st_slot_idx * SLOT + lw * 4096;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_global_load_lds((global_void*)(g + (size_t)st_off[j]), (lds_void*)(l + j * 1024), 16, 0, A_AUX);
+        __builtin_amdgcn_global_load_lds((global_void*)(g + (size_t)st_off[j]), (lds_void*)(l + j * 1024), 16, 0, 0);
       if (++st_slot_idx == NA) st_slot_idx = 0;
       if (++st_kt == steps_per_tile) {
         st_kt = 0;
@@ -760,354 +463,83 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
   }
 }
 
-
 // ---------------------------------------------------------------------------------------------
-// VARIANT 4: no ping-pong.  Every wave software-pipelines itself: while its 16 MFMAs of step S
-// issue (one every 32 cycles), the 12 fragment reads of step S+1 (second register set) and its 4
-// LDS-DMA instructions for step S+N are slotted into the gaps between them
-// (sched_group_barrier: 1 MFMA : 1 DS read / 1 VMEM).  One barrier per K step.  Rings, swizzle,
-// decoupled stagers (waves 0-3 stage A, waves 4-7 stage B) and counted vmcnt waits as in variant 3.
-//   step S:  [stager: vmcnt(4*(N-2)) -> step S+1 landed]  lgkmcnt(0)  s_barrier
-//            { MFMAs(S) on frag set S&1 | ds_reads of ring slot S+1 into frag set (S+1)&1 |
-//              LDS-DMA of step S+N into ring slot S (everyone finished reading it before the barrier) }
+// VARIANT 6: four waves with the whole register file each, K steps of whole cache lines.
+//
+// Why four waves: the 8-wave tile of variant 3 sits on the machine balance between the L2 -> CU operand path and the
+// matrix pipe (32 KiB of operands per 256 x 256 x 32 step).  Fewer operand bytes per flop needs a bigger tile per CU,
+// and the biggest one the register file allows is held by FOUR waves (2 x 2), one per SIMD, each with the full
+// 512-register budget.  hipcc picks the AGPR or the VGPR form of an MFMA builtin per FUNCTION, so > 256 accumulators
+// cannot be split over the two files through the builtin (hundreds of spills); the MFMAs are therefore inline asm with
+// explicit register classes ("+a" / "+v").  A volatile asm is ordered against memory operations, so the program order
+// -- MFMA, LDS read, MFMA, ..., MFMA, LDS-DMA -- IS the schedule (no sched_group_barrier).  The asm MFMAs are invisible
+// to the compiler's hazard recognizer: the epilogue opens with the wait states an MFMA result needs.
+//
+// Why whole lines: a staging piece of variant 3 (K steps of 32 halves) is sixteen 64-byte HALF lines; the CU's
+// texture-address path serves a 1 KiB piece of that shape in ~14 ns from L2 against ~7.7 ns for eight whole 128-byte
+// lines (tools/microbench/load_paths.hip, all CUs pulling; profiles/r02_operand_path.md).  A round-1 four-wave kernel
+// with 32-half steps kept that path ~90 % busy and its waves stalled at the ISSUE of their staging loads.  Here a K
+// step is 64 halves = one 128-byte line per row:
+//   * tile = 320 corpus rows x 256 queries; a wave owns 160 x 128 = 5 x 4 MFMA tiles (320 accumulator registers: 15
+//     tiles in AGPRs, 5 in VGPRs; the spare AGPRs are where the register allocator parks VGPR values during the
+//     epilogue -- with all 256 taken it parks them in scratch, and a scratch reload is a VMEM load queued behind the
+//     whole in-flight LDS-DMA).  (384 rows at K = 64 need 2 x 80 KiB of LDS: all 160 KiB, nothing left for the
+//     selection state.)
+//   * LDS: two slots per operand (A 40 KiB, B 32 KiB each) = 144 KiB.  Rows are 128 bytes; 16-byte slot j of row r
+//     sits at physical slot j ^ ((r >> 1) & 7) (applied to the global SOURCE address of the staging loads, because
+//     LDS-DMA writes lane-linear, and to the fragment reads), which spreads the 16 lanes of every ds_read_b128 group
+//     over the 16 bank slots: SQ_LDS_BANK_CONFLICT = 0 measured.
+//   * staging goes through buffer descriptors (`buffer_load_dwordx4 ... lds`): the per-lane part of an address is one
+//     of two persistent 32-bit VGPR offsets (even / odd piece: the swizzle term has a piece-parity bit), the piece and the
+//     K step are the scalar offset, the tile is the descriptor base, and rows past the end of the corpus are cut off by
+//     the descriptor's size (they read as zero; the epilogue masks them anyway).  A piece = 8 rows x 128 bytes; per
+//     step 40 A + 32 B pieces = 18 per wave (the 32-half form needed 40 per wave for the same K range).
+//   * a step is four quarters (k16 slices) of 20 MFMAs.  Quarter q multiplies fragment set q & 1 while the 9
+//     fragment reads of the next quarter fill the other set; one barrier per step, in front of quarter 3:
+//       q0, q1, q2: multiply slices 0-2 of slot P; fetch slices 1-3 of slot P
+//       ---- vmcnt(0): this wave's pieces of step S+1 landed; lgkmcnt(0): slot P read out; s_barrier ----
+//       q3: multiply slice 3; fetch slice 0 of slot P^1 (step S+1, across tile boundaries too)
+//     Slot P is then free: the pieces of step S+2 are issued behind the MFMAs of q3 (N3 of them), of the next q0 (N0)
+//     and q1 (N1) -- corpus pieces first, they have the longest way -- and have until the next barrier to land.
+//   * the first quarter of a tile multiplies into a ZERO C operand instead of clearing 320 registers.
+//   * epilogue / candidate buffers / compaction / lists as in variant 3.
+// Measured and rejected (profiles/r02_cfg3_ablation.md): touching the corpus lines of the step 1 / 2 / 4 steps ahead
+// into L2 with one 4-byte load per line (-3 .. -6 %); other piece-per-quarter schedules (no difference).
 // ---------------------------------------------------------------------------------------------
-template <int NA, int NB, int ABL>
-__global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v4(const MfmaDeviceParams p) {
-  constexpr int KS = 32;
-  constexpr int SLOT = 256 * KS * 2;
-  constexpr int B_RING = NA * SLOT;
-  constexpr int CTRL = (NA + NB) * SLOT;
-  extern __shared__ __align__(16) unsigned char smem[];
-  float* thr_lds = reinterpret_cast<float*>(smem + CTRL);
-  int* cnt_lds = reinterpret_cast<int*>(smem + CTRL + BN * 4);
-  volatile int* need_compact = reinterpret_cast<volatile int*>(smem + CTRL + BN * 8);
+constexpr int BM6 = 320;
+constexpr int NT6 = 256;
+constexpr int SLOT_A6 = BM6 * 128;  // 40 KiB
+constexpr int SLOT_B6 = BN * 128;   // 32 KiB
+constexpr int B_RING6 = 2 * SLOT_A6;
+constexpr int CTRL6 = 2 * SLOT_A6 + 2 * SLOT_B6;
+constexpr int LDS6 = CTRL6 + BN * 8 + 16;
+constexpr int PIECES_A6 = BM6 / 8 / 4;  // per wave per step: 10
+constexpr int PIECES_B6 = BN / 8 / 4;   // 8
+constexpr int PIECES6 = PIECES_A6 + PIECES_B6;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2;
-  const int wn = wave & 3;
-  const bool is_a = wave < 4;  // waves 0-3 stage the corpus operand, waves 4-7 the query operand
-  const int lw = wave & 3;
-
-  const int b = blockIdx.x;
-  const int xcd = b & 7;
-  const int t = b >> 3;
-  const int qtile = t % p.n_qtiles;
-  const int split = (t / p.n_qtiles) * 8 + xcd;
-  if (split >= p.n_splits) return;
-  const int64_t r_begin = (int64_t)split * p.rows_per_split;
-  const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
-  const int logical_block = split * p.n_qtiles + qtile;
-  u64* my_cand = p.cand + (size_t)logical_block * BN * CAP;
-
-  const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
-  for (int i = tid; i < BN; i += NTHREADS) {
-    float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
-    const int qg0 = qtile * BN + i;
-    if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
-    else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best of the sample pass: a valid lower bound
-    thr_lds[i] = t0;
-    cnt_lds[i] = 0;
-  }
-  if (tid == 0) *need_compact = 0;
-
-  const int D = p.dim;
-  const int steps_per_tile = D / KS;  // even: D is a multiple of 64
-  const uint32_t row_bytes = (uint32_t)D * 2u;
-  const char* corpus = reinterpret_cast<const char*>(p.corpus);
-  const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * BN * row_bytes;
-  const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BM - 1) / BM) : 0;
-  if (n_tiles == 0) {
-    for (int q = wave; q < BN; q += NTHREADS / 64) {
-      const int qg = qtile * BN + q;
-      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.list_stride + split) * (size_t)p.k + lane] = 0ull;
-    }
-    return;
-  }
-
-  // ---- stager: instruction j covers operand rows (lw*4 + j)*16 .. +15, four 16-byte slots per row.
-  //      Branch-free: everything that differs between the A and B stagers is a scalar select.
-  const bool lin = is_a && p.a_tiled;  // K-blocked corpus image: 16 KiB per (tile, step), already in LDS order
-  uint32_t st_rowoff[4], st_slotoff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (lw * 4 + j) * 16 + (lane >> 2);
-    st_rowoff[j] = lin ? 0u : (uint32_t)row * row_bytes;
-    st_slotoff[j] = lin ? (uint32_t)((lw * 4 + j) * 1024 + lane * 16) : (uint32_t)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
-  }
-  const int ring_n = is_a ? NA : NB;
-  const uint32_t ring_base = (is_a ? 0u : (uint32_t)B_RING) + (uint32_t)lw * 4096u;
-  // running, wave-uniform source pointer of the next step to stage: +64 bytes per K step (+16 KiB in the
-  // K-blocked image); at the end of a tile's K range the A stager jumps to the next tile (or, past the last
-  // tile, back to the start of the last one: harmless reloads that keep the vmcnt bookkeeping uniform), the
-  // B stager back to k = 0.
-  const int64_t k_step = lin ? (int64_t)SLOT : (int64_t)(KS * 2);
-  const int64_t k_rewind = -(int64_t)(steps_per_tile - 1) * k_step;
-  const int64_t tile_jump = is_a ? (lin ? k_step : k_rewind + (int64_t)BM * row_bytes) : k_rewind;
-  const int64_t wrap_delta = k_rewind - k_step;        // added when the K range of a tile ends
-  const int64_t advance_delta = tile_jump - k_rewind;  // added on top when the stager moves on to the next tile
-  const char* st_ptr = is_a ? corpus + (size_t)((ABL & 4) ? 0 : r_begin) * row_bytes : qbase;
-  int64_t st_last_row = is_a ? (p.rows - 1 - r_begin) : 255;  // last valid row of the staged tile, relative to its row 0
-  int st_tiles_left = is_a ? n_tiles - 1 : 0;
-  int st_kt = 0, st_slot = 0;
-
-  auto stage_next = [&]() {
-    const char* g = sgpr_ptr(st_ptr);
-    // rows past the end of the corpus are clamped to its last row (they are masked in the epilogue)
-    const uint32_t max_rowoff = (uint32_t)(st_last_row < 255 ? st_last_row : 255) * row_bytes;
-    unsigned char* l = smem + ring_base + (uint32_t)st_slot * SLOT;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t off = (st_rowoff[j] < max_rowoff ? st_rowoff[j] : max_rowoff) + st_slotoff[j];
-      __builtin_amdgcn_global_load_lds((global_void*)(g + (size_t)off), (lds_void*)(l + j * 1024), 16, 0, 0);
-    }
-    st_slot = (st_slot + 1 == ring_n) ? 0 : st_slot + 1;
-    const bool wrap = (st_kt + 1 == steps_per_tile);
-    const bool advance = wrap && st_tiles_left > 0 && (ABL & 4) == 0;
-    st_kt = wrap ? 0 : st_kt + 1;
-    // arithmetic instead of a nested select: the compiler turns a select tree over run-time 64-bit values
-    // into a scratch-resident lookup table, which drags the whole stager state into scratch memory
-    st_ptr += k_step + (int64_t)wrap * wrap_delta + (int64_t)advance * advance_delta;
-    st_last_row -= advance ? BM : 0;
-    st_tiles_left -= advance ? 1 : 0;
-  };
-
-  const int frag_row = lane & 31;
-  const uint32_t frag_x = (uint32_t)(((lane >> 5) ^ ((frag_row >> 2) & 3)) << 4);
-  const uint32_t a_lane = (uint32_t)((wm * 128 + frag_row) * 64);
-  const uint32_t b_lane = (uint32_t)(B_RING + (wn * 64 + frag_row) * 64);
-
-  auto read_frags = [&](f16x8(&af)[2][4], f16x8(&bf)[2][2], int slot_a, int slot_b) {
-    const unsigned char* abase = smem + slot_a * SLOT;
-    const unsigned char* bbase = smem + slot_b * SLOT;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const uint32_t kx = (uint32_t)(kk << 5) ^ frag_x;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[kk][mi] = *reinterpret_cast<const f16x8*>(abase + (a_lane + kx) + mi * 2048);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bf[kk][ni] = *reinterpret_cast<const f16x8*>(bbase + (b_lane + kx) + ni * 2048);
-    }
-  };
-
-  // ---- prologue: fill both rings completely, wait for step 0, read its fragments
-  if (is_a) {
-#pragma unroll 1
-    for (int i = 0; i < NA; ++i) stage_next();
-    wait_vmcnt<4 * (NA - 1)>();
-  } else {
-#pragma unroll 1
-    for (int i = 0; i < NB; ++i) stage_next();
-    wait_vmcnt<4 * (NB - 1)>();
-  }
-  TAVB_BARRIER();
-  f16x8 af0[2][4], bf0[2][2], af1[2][4], bf1[2][2];
-  read_frags(af0, bf0, 0, 0);
-  int rd_a = 1, rd_b = 1;  // ring slots of the step whose fragments are read next
-
-  f32x16 acc[4][2];
-
-  // one K step: MFMAs on (fu_a, fu_b), prefetch the next step's fragments into (fl_a, fl_b)
-  auto step = [&](f16x8(&fu_a)[2][4], f16x8(&fu_b)[2][2], f16x8(&fl_a)[2][4], f16x8(&fl_b)[2][2], bool sync) {
-    if (sync) {
-    if (is_a)
-      wait_vmcnt<4 * (NA - 2)>();  // the next step's A slab has landed
-    else
-      wait_vmcnt<4 * (NB - 2)>();  // the next step's B slab has landed
-    // this step's fragments are in registers, so its ring slot is free.  The builtin (not inline asm) so
-    // that the compiler's own wait-count bookkeeping sees it and does not put a second lgkmcnt(0) -- one
-    // that would also drain the reads issued below -- in front of the first MFMA.
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt/expcnt untouched
-    TAVB_BARRIER();
-    }
-    if constexpr ((ABL & 32) == 0) read_frags(fl_a, fl_b, rd_a, rd_b);
-    if constexpr ((ABL & 2) == 0) stage_next();
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          if constexpr ((ABL & 1) == 0)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fu_a[kk][mi], fu_b[kk][ni], acc[mi][ni], 0, 0, 0);
-          else
-            asm volatile("" ::"v"(fu_a[kk][mi]), "v"(fu_b[kk][ni]));
-        }
-    // interleave: one LDS read after each of the first 12 MFMAs, one LDS-DMA after each of the last 4
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-    rd_a = (rd_a + 1 == NA) ? 0 : rd_a + 1;
-    rd_b = (rd_b + 1 == NB) ? 0 : rd_b + 1;
-  };
-
-  for (int tile = 0; tile < n_tiles; ++tile) {
-    const int64_t row0 = r_begin + (int64_t)tile * BM;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-#pragma unroll 1
-    for (int kt = 0; kt < steps_per_tile; kt += 2) {
-      step(af0, bf0, af1, bf1, (ABL & 16) ? (kt & 3) == 0 : true);
-      step(af1, bf1, af0, bf0, (ABL & 24) ? false : true);
-    }
-
-    // ---- epilogue: score, admission test, append
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int ql = wn * 64 + ni * 32 + (lane & 31);
-      const float thr = thr_lds[ql];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        bool any = false;
-        float sc[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
-          any = any || ((ABL == 0 || ABL == 512) && sc[r] > thr);
-        }
-        if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi][ni]));
-        if constexpr (ABL == 512) asm volatile("" ::"s"(__builtin_amdgcn_ballot_w64(any)));
-        if (ABL != 512 && __builtin_amdgcn_ballot_w64(any) != 0ull) {
-          // slow path, taken by the whole wave when any lane admits something: every lane builds the
-          // bit mask of its admitted rows, reserves that many buffer slots with ONE LDS atomic (the
-          // latency of the returning atomic is paid once per 32x32 block, not once per key), then
-          // stores its keys with predicated stores.
-          const int64_t row_base = row0 + wm * 128 + mi * 32 + 4 * (lane >> 5);
-          unsigned admit = 0;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float s = sc[r];
-            s = (s > 0.0f) ? s : 0.0f;
-            s = (s > 1.0f) ? 1.0f : s;
-            const bool ok = (sc[r] > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s >= p.min_score);
-            admit |= ok ? (1u << r) : 0u;
-          }
-          const int n_adm = __popc(admit);
-          int pos = 0;
-          if (n_adm > 0) {
-            pos = lds_add_rtn(&cnt_lds[ql], n_adm);
-            if (pos + n_adm > CAP - BM) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if ((admit >> r) & 1u) {
-              float s = sc[r];
-              s = (s > 0.0f) ? s : 0.0f;
-              s = (s > 1.0f) ? 1.0f : s;
-              if (pos < CAP)
-                my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
-              ++pos;
-            }
-          }
-        }
-      }
-    }
-    // Compaction is rare (O(log rows) times per query).  Only then do the appended keys have to be in
-    // memory for another wave to read, so only then does the workgroup pay a drain of its (otherwise
-    // still flying) LDS-DMA queues; normally the epilogue ends at this barrier.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    if (*need_compact != 0) {  // workgroup-uniform: read after the barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    for (int q = wave; q < BN; q += NTHREADS / 64) {
-      const int n = cnt_lds[q];
-      if (n > CAP - BM) {
-        u64* buf = my_cand + (size_t)q * CAP;
-        const WaveTopK<1> best = best_of_buffer(buf, n < CAP ? n : CAP, lane);
-        if (lane < p.k) buf[lane] = best.key[0];
-        const int kept = __popcll(__ballot(best.key[0] != 0ull && lane < p.k));
-        const u64 kth = best.at(p.k - 1);
-        if (lane == 0) {
-          cnt_lds[q] = kept;
-          const float kth_score = __uint_as_float((uint32_t)(kth >> 32));
-          if (kth != 0ull && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    if (tid == 0) *need_compact = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead LDS-DMA before the block retires
-  __syncthreads();
-
-  for (int q = wave; q < BN; q += NTHREADS / 64) {
-    const int qg = qtile * BN + q;
-    if (qg >= p.nq) continue;
-    const int n = cnt_lds[q];
-    const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane);
-    u64* out = p.lists + ((size_t)qg * p.list_stride + split) * (size_t)p.k;
-    if (lane < p.k) out[lane] = best.key[0];
-  }
+// index of the staging piece issued behind MFMA `i` of quarter `q` (-1: none): n pieces spread evenly over the 20 MFMAs
+template <int N3, int N0, int N1>
+constexpr int v6_piece_at(int q, int i) {
+  const int n = q == 3 ? N3 : q == 0 ? N0 : q == 1 ? N1 : 0;
+  const int base = q == 3 ? 0 : q == 0 ? N3 : N3 + N0;
+  for (int j = 0; j < n; ++j)
+    if ((j * 20 + 10) / n == i) return base + j;
+  return -1;
 }
 
- 
-// ---------------------------------------------------------------------------------------------
-// VARIANT 5: fewer operand bytes per flop.  Variants 1-4 sit on the machine balance between the
-// L2 -> CU fabric and the matrix pipe (profiles/r01_cfg3_operand_path.md): a 256 x 256 tile pulls
-// 32 KiB through L2 per 1024 MFMA cycles.  Here the tile is 384 corpus rows x 256 queries held by
-// FOUR waves (2 x 2), one per SIMD, each with the whole 512-register budget: a 192 x 128 sub-tile =
-// 6 x 4 MFMA tiles = 384 accumulator registers + two 40-register fragment sets.  hipcc selects the AGPR or the
-// VGPR form of an MFMA builtin per FUNCTION, so 384 accumulators cannot be split over the two files through
-// the builtin (600 spills); the MFMAs are therefore inline asm with explicit register classes: 16 tiles
-// accumulate in AGPRs ("+a"), 8 in VGPRs ("+v").  A volatile asm is ordered against memory operations, so
-// the program order below -- MFMA, LDS read, MFMA, ..., MFMA, LDS-DMA -- IS the schedule (no
-// sched_group_barrier needed).  Per flop
-// that is 17 % fewer L2 -> LDS bytes and LDS-DMA instructions, 44 % fewer LDS fragment-read bytes
-// and a third fewer barriers than the 8-wave tile.
-//   * K advances in steps of 32 halves; a step is two half-steps (k16 slices) of 24 MFMAs each.
-//   * one ring of 3 slots per operand (A: 24 KiB per slot, B: 16 KiB); every wave stages
-//     6 A pieces + 4 B pieces (1 KiB each) per step, five per half-step, so its vmcnt queue has
-//     the same shape in every wave and one counted wait serves both operands.
-//   * software pipeline of one wave (no partner wave on the SIMD to hide anything):
-//       (S,0): MFMAs on frag set 0 (step S, k 0-15)  | read set 1 <- slot S, k 16-31   | stage 2nd half of step S+2
-//       ---- vmcnt(10): step S+1 landed in this wave; lgkmcnt(0); s_barrier (the only one per step) ----
-//       (S,1): MFMAs on frag set 1                   | read set 0 <- slot S+1, k 0-15  | stage 1st half of step S+3
-//     Slot S is last read in (S,0), so after the barrier it takes step S+3; slot S+1 is first read
-//     after the barrier that follows the wait for its loads; loads have >= 1.5 steps to land.
-//   * the step stream runs across tile boundaries; the epilogue (admission test on the raw dot
-//     products, appends, rare compaction) is as in variant 3.
-// ---------------------------------------------------------------------------------------------
-constexpr int BM5 = 384;
-constexpr int NT5 = 256;
-constexpr int SLOT_A5 = BM5 * 64;   // 24 KiB
-constexpr int SLOT_B5 = BN * 64;    // 16 KiB
-constexpr int RING_A5 = 3;  // (a fourth A slot with the corpus stream one step further ahead measured no gain)
-constexpr int RING_B5 = 3;
-constexpr int B_RING5 = RING_A5 * SLOT_A5;
-constexpr int CTRL5 = RING_A5 * SLOT_A5 + RING_B5 * SLOT_B5;
-constexpr int LDS5 = CTRL5 + BN * 8 + 16;
-
-template <int ABL>
-__global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParams p) {
+template <int ABL, int N3, int N0, int N1>
+__global__ void __launch_bounds__(NT6) mfma_scan_kernel_v6(const MfmaDeviceParams p) {
+  static_assert(N3 + N0 + N1 == PIECES6, "every piece of a step is issued exactly once");
   extern __shared__ __align__(16) unsigned char smem[];
-  float* thr_lds = reinterpret_cast<float*>(smem + CTRL5);
-  int* cnt_lds = reinterpret_cast<int*>(smem + CTRL5 + BN * 4);
+  float* thr_lds = reinterpret_cast<float*>(smem + CTRL6);
+  int* cnt_lds = reinterpret_cast<int*>(smem + CTRL6 + BN * 4);
   typedef __attribute__((address_space(3))) volatile int lds_flag;
-  lds_flag* need_compact = (lds_flag*)(smem + CTRL5 + BN * 8);  // explicit LDS pointer: the generic-pointer form miscompiles in this kernel
+  lds_flag* need_compact = (lds_flag*)(smem + CTRL6 + BN * 8);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1;  // rows wm * 192 ..
+  const int wm = wave >> 1;  // rows wm * 160 ..
   const int wn = wave & 1;   // queries wn * 128 ..
 
   const int b = blockIdx.x;
@@ -1122,7 +554,7 @@ __global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParam
   u64* my_cand = p.cand + (size_t)logical_block * BN * CAP;
 
   const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
-  for (int i = tid; i < BN; i += NT5) {
+  for (int i = tid; i < BN; i += NT6) {
     float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
     const int qg0 = qtile * BN + i;
     if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
@@ -1133,275 +565,233 @@ __global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParam
   if (tid == 0) *need_compact = 0;
 
   const int D = p.dim;
-  const int steps_per_tile = D / 32;
+  const int steps_per_tile = D / 64;
   const uint32_t row_bytes = (uint32_t)D * 2u;
   const char* corpus = reinterpret_cast<const char*>(p.corpus);
   const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * BN * row_bytes;
-  const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BM5 - 1) / BM5) : 0;
+  const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BM6 - 1) / BM6) : 0;
   if (n_tiles == 0) {
-    for (int q = wave; q < BN; q += NT5 / 64) {
+    for (int q = wave; q < BN; q += NT6 / 64) {
       const int qg = qtile * BN + q;
       if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.list_stride + split) * (size_t)p.k + lane] = 0ull;
     }
     return;
   }
 
-  // ---- stager.  Piece = 16 operand rows x 64 bytes -> 1 KiB of LDS, lane l = row l >> 2, 16-byte slot l & 3 of that
-  //      row, fetched from the XOR-swizzled source slot.  Wave w stages A pieces 6w .. 6w+5 and B pieces 4w .. 4w+3.
-  // The five per-lane constants of the K loop: two staging offsets, three fragment-address terms.
-  int a_off0, b_off0;
+  // ---- per-lane constants of the K loop: two staging offsets (even / odd piece), three fragment-address terms.
+  //      Staging: lane l = row l >> 3 of an 8-row piece, PHYSICAL 16-byte slot l & 7, which holds logical slot
+  //      (l & 7) ^ ((row >> 1) & 7); with row = 8 * piece + (l >> 3) that is (l & 7) ^ (4 * (piece & 1) + (l >> 4)).
+  int st_even, st_odd;
   uint32_t frag_x, a_lane, b_lane;
-  auto set_lane_constants = [&]() {
+  {
     int zero = 0;
     asm volatile("" : "+v"(zero));
     const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero));
-    const uint32_t lane_row = (uint32_t)(ln >> 2);
-    const uint32_t lane_slot = (uint32_t)(((ln & 3) ^ ((ln >> 4) & 3)) * 16);
-    a_off0 = (int)(((uint32_t)wave * 96u + lane_row) * row_bytes + lane_slot);
-    b_off0 = (int)(((uint32_t)wave * 64u + lane_row) * row_bytes + lane_slot);
+    const uint32_t lane_row = (uint32_t)(ln >> 3);
+    st_even = (int)(lane_row * row_bytes + (uint32_t)(((ln & 7) ^ (ln >> 4)) * 16));
+    st_odd = (int)(lane_row * row_bytes + (uint32_t)(((ln & 7) ^ (4 + (ln >> 4))) * 16));
     const int frag_row = ln & 31;
-    frag_x = (uint32_t)(((ln >> 5) ^ ((frag_row >> 2) & 3)) << 4);
-    a_lane = (uint32_t)((wm * 192 + frag_row) * 64);            // + mi * 2048
-    b_lane = (uint32_t)(B_RING5 + (wn * 128 + frag_row) * 64);  // + ni * 2048
-  };
-  set_lane_constants();
-  // Staging goes through buffer descriptors (`buffer_load_dwordx4 ... lds`): the per-lane part of an address is ONE
-  // persistent 32-bit VGPR offset per operand, the piece (16 rows apart) and the K step are the scalar offset, the tile is
-  // the descriptor base, and rows past the end of the corpus are cut off by the descriptor's size (they read as zero; the
-  // epilogue masks them anyway).  A per-piece VGPR address temp -- what the flat form needs once a clamp is involved --
-  // would be overwritten while its LDS-DMA is in flight, which hipcc guards with `s_waitcnt vmcnt(0)` inside the K loop.
+    frag_x = (uint32_t)(((ln >> 5) ^ ((frag_row >> 1) & 7)) << 4);  // byte (k16 << 5) ^ frag_x within the 128-byte row
+    a_lane = (uint32_t)((wm * 160 + frag_row) * 128);              // + mi * 4096
+    b_lane = (uint32_t)(B_RING6 + (wn * 128 + frag_row) * 128);    // + ni * 4096
+  }
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sgpr_ptr(qbase)), 0, (int)(BN * row_bytes), 0x00020000);
-  // Separate A / B stager state (the two streams could run at different depths; they run at the same one).
-  int sa_kt = 0, sa_tile = 0, sa_slot = 0;  // next A step to stage: K step, tile, ring slot (of RING_A5)
-  int sb_kt = 0, sb_slot = 0;               // next B step to stage
-  auto stage_a_piece = [&](auto aj_tag) {
-    constexpr int AJ = decltype(aj_tag)::value;
-    const int tile = sa_tile < n_tiles ? sa_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
-    const int64_t row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM5;
-    const int64_t left = p.rows - row0;
-    const int valid = (int)(left < BM5 ? left : BM5);
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(sgpr_ptr(corpus + (size_t)row0 * row_bytes)), 0, __builtin_amdgcn_readfirstlane(valid * (int)row_bytes), 0x00020000);
-    unsigned char* la = smem + sa_slot * SLOT_A5 + wave * 6144;
-    const int soff = __builtin_amdgcn_readfirstlane(sa_kt * 64 + AJ * 16 * (int)row_bytes);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(la + AJ * 1024), 16, a_off0, soff, 0, 0);
-    if constexpr (AJ == 5) {
-      sa_slot = (sa_slot + 1 == RING_A5) ? 0 : sa_slot + 1;
-      const bool wrap = (sa_kt + 1 == steps_per_tile);
-      sa_kt = wrap ? 0 : sa_kt + 1;
-      sa_tile += wrap ? 1 : 0;
+
+  // ---- stager: piece IDX of the step being staged (0 .. 9 corpus pieces, 10 .. 17 query pieces of this wave)
+  int st_kt = 0, st_tile = 0, st_slot = 0;
+  auto stage_piece = [&](auto idx_tag) {
+    constexpr int IDX = decltype(idx_tag)::value;
+    if constexpr (IDX < PIECES_A6) {
+      const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
+      const int64_t row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM6;
+      const int64_t left = p.rows - row0;
+      const int valid = (int)(left < BM6 ? left : BM6);  // rows past the end of the corpus read as zero (masked in the epilogue)
+      const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(sgpr_ptr(corpus + (size_t)row0 * row_bytes)), 0, __builtin_amdgcn_readfirstlane(valid * (int)row_bytes), 0x00020000);
+      const int pc = wave * PIECES_A6 + IDX;
+      unsigned char* la = smem + st_slot * SLOT_A6 + pc * 1024;
+      const int soff = __builtin_amdgcn_readfirstlane(st_kt * 128 + pc * 8 * (int)row_bytes);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)la, 16, (IDX & 1) ? st_odd : st_even, soff, 0, 0);
+    } else {
+      constexpr int BJ = IDX - PIECES_A6;
+      const int pc = wave * PIECES_B6 + BJ;
+      unsigned char* lb = smem + B_RING6 + st_slot * SLOT_B6 + pc * 1024;
+      const int soff = __builtin_amdgcn_readfirstlane(((ABL & 8) ? 0 : st_kt * 128) + pc * 8 * (int)row_bytes);  // ablation 8: the query operand's K step 0 every time (cache resident)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void*)lb, 16, (BJ & 1) ? st_odd : st_even, soff, 0, 0);
+    }
+    if constexpr (IDX == PIECES6 - 1) {
+      st_slot ^= 1;
+      const bool wrap = (st_kt + 1 == steps_per_tile);
+      st_kt = wrap ? 0 : st_kt + 1;
+      st_tile += wrap ? 1 : 0;
     }
   };
-  auto stage_b_piece = [&](auto bj_tag) {
-    constexpr int BJ = decltype(bj_tag)::value;
-    unsigned char* lb = smem + B_RING5 + sb_slot * SLOT_B5 + wave * 4096;
-    const int soff = __builtin_amdgcn_readfirstlane(sb_kt * 64 + BJ * 16 * (int)row_bytes);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void*)(lb + BJ * 1024), 16, b_off0, soff, 0, 0);
-    if constexpr (BJ == 3) {
-      sb_slot = (sb_slot + 1 == RING_B5) ? 0 : sb_slot + 1;
-      sb_kt = (sb_kt + 1 == steps_per_tile) ? 0 : sb_kt + 1;
-    }
-  };
-  // piece J of stage half HALF: HALF 0 = A pieces 0-4; HALF 1 = A piece 5, then B pieces 0-3
-  auto stage_piece = [&](auto half_tag, auto j_tag) {
-    constexpr int HALF = decltype(half_tag)::value;
-    constexpr int J = decltype(j_tag)::value;
-    if constexpr (HALF == 0)
-      stage_a_piece(std::integral_constant<int, J>{});
-    else if constexpr (J == 0)
-      stage_a_piece(std::integral_constant<int, 5>{});
-    else
-      stage_b_piece(std::integral_constant<int, J - 1>{});
-  };
-  using J0 = std::integral_constant<int, 0>;
-  using J1 = std::integral_constant<int, 1>;
-  using J2 = std::integral_constant<int, 2>;
-  using J3 = std::integral_constant<int, 3>;
-  using J4 = std::integral_constant<int, 4>;
-  auto stage_half = [&](auto half_tag) {  // prologue only: a whole half at once
-    stage_piece(half_tag, J0{});
-    stage_piece(half_tag, J1{});
-    stage_piece(half_tag, J2{});
-    stage_piece(half_tag, J3{});
-    stage_piece(half_tag, J4{});
-  };
-  using H0 = std::integral_constant<int, 0>;
-  using H1 = std::integral_constant<int, 1>;
+  auto stage_range = [&]<int... I>(std::integer_sequence<int, I...>) { (stage_piece(std::integral_constant<int, I>{}), ...); };
 
-  // ---- fragment reads: row (lane & 31) of a 32-row block, logical 16-byte slot 2 * kk + (lane >> 5)
-  auto read_frags = [&](f16x8(&af)[6], f16x8(&bf)[4], int slot_a, int slot_b, int kk) {
-    const uint32_t kx = (uint32_t)(kk << 5) ^ frag_x;
-    const unsigned char* abase = smem + slot_a * SLOT_A5 + (a_lane + kx);
-    const unsigned char* bbase = smem + slot_b * SLOT_B5 + (b_lane + kx);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bf[ni] = *reinterpret_cast<const f16x8*>(bbase + ni * 2048);
-#pragma unroll
-    for (int mi = 0; mi < 6; ++mi) af[mi] = *reinterpret_cast<const f16x8*>(abase + mi * 2048);
-  };
-
-  // ---- prologue: steps 0 and 1 and the first half of step 2 in flight; wait for step 0 (everything but the last 15
-  //      pieces); read the first fragments
-  stage_half(H0{}); stage_half(H1{});
-  stage_half(H0{}); stage_half(H1{});
-  stage_half(H0{});
-  wait_vmcnt<15>();
+  // ---- prologue: step 0 whole, the first N3 pieces of step 1 (what quarter 3 of a step "-1" would have issued)
+  stage_range(std::make_integer_sequence<int, PIECES6>{});
+  stage_range(std::make_integer_sequence<int, N3>{});
+  wait_vmcnt<N3>();
   __syncthreads();  // step 0 landed everywhere, thresholds initialised (the wait above is counted: nothing is drained)
-  f16x8 a0[6], b0[4], a1[6], b1[4];
-  read_frags(a0, b0, 0, 0, 0);
-  int rd_a = 0, rd_b = 0;  // ring slots of the step being multiplied
 
-  // tile t = mi * 4 + ni.  Fifteen tiles accumulate in AGPRs, nine in VGPRs: the sixteen AGPRs left over are where the
-  // register allocator parks VGPR values during the epilogue (v_accvgpr_write / read, no memory involved); with all 256
-  // AGPRs taken it parks them in scratch instead, and a scratch reload is a VMEM load behind the LDS-DMA queue.
-  constexpr int NA_TILES = 15;
-  f32x16 acc_a[NA_TILES];       // tiles 0 .. 14
-  f32x16 acc_v[24 - NA_TILES];  // tiles 15 .. 23
-  typedef int i32x4 __attribute__((ext_vector_type(4)));  // an <8 x half> asm operand gets repacked with v_perm; 4 x i32 does not
-#define TAVB_MFMA_A(ACC, A, B) \
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  constexpr int NA_TILES = 15;  // tiles 0 .. 14 accumulate in AGPRs, 15 .. 19 in VGPRs (the spare AGPRs are where the allocator parks VGPR values in the epilogue: no scratch)
+  f32x16 acc_a[NA_TILES];
+  f32x16 acc_v[20 - NA_TILES];
+#define TAVB_MFMA6_A(ACC, A, B) \
   asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(__builtin_bit_cast(i32x4, A)), "v"(__builtin_bit_cast(i32x4, B)))
-#define TAVB_MFMA_V(ACC, A, B) \
+#define TAVB_MFMA6_V(ACC, A, B) \
   asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(__builtin_bit_cast(i32x4, A)), "v"(__builtin_bit_cast(i32x4, B)))
+#define TAVB_MFMA6_A0(ACC, A, B) \
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(ACC) : "v"(__builtin_bit_cast(i32x4, A)), "v"(__builtin_bit_cast(i32x4, B)))
+#define TAVB_MFMA6_V0(ACC, A, B) \
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(__builtin_bit_cast(i32x4, A)), "v"(__builtin_bit_cast(i32x4, B)))
 
-  // One half-step: the 24 MFMAs of k-slice KK of the current step on fragments (fa, fb), with the 10 fragment reads of
-  // the next half-step (into (na, nb), ring slot `nslot`, k-slice NKK) and the five LDS-DMA pieces of stage half SH
-  // slotted between them in program order.
-  auto half_step = [&](f16x8(&fa)[6], f16x8(&fb)[4], f16x8(&na)[6], f16x8(&nb)[4], int nslot_a, int nslot_b, auto nkk_tag, auto sh_tag,
-                       const bool do_read) {
+  f16x8 a0[5], b0[4], a1[5], b1[4];
+  {
+    const unsigned char* abase = smem + (a_lane + frag_x);
+    const unsigned char* bbase = smem + (b_lane + frag_x);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) b0[ni] = *reinterpret_cast<const f16x8*>(bbase + ni * 4096);
+#pragma unroll
+    for (int mi = 0; mi < 5; ++mi) a0[mi] = *reinterpret_cast<const f16x8*>(abase + mi * 4096);
+  }
+  int rd = 0;  // ring slot of the step being multiplied
+
+  // One quarter: the 20 MFMAs of one k16 slice on (fa, fb); behind them, in program order, the 9 fragment reads of the
+  // next quarter (slot `nslot`, slice NKK) into (na, nb) and the staging pieces the schedule puts into quarter Q.
+  auto quarter = [&](auto q_tag, auto first_tag, f16x8(&fa)[5], f16x8(&fb)[4], f16x8(&na)[5], f16x8(&nb)[4], int nslot, auto nkk_tag) {
+    constexpr int Q = decltype(q_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;  // first quarter of a tile: C = 0
     constexpr int NKK = decltype(nkk_tag)::value;
     const uint32_t kx = (uint32_t)(NKK << 5) ^ frag_x;
-    const unsigned char* abase = smem + nslot_a * SLOT_A5 + (a_lane + kx);
-    const unsigned char* bbase = smem + nslot_b * SLOT_B5 + (b_lane + kx);
-    // 24 MFMAs in (mi, ni) order; behind MFMA i: a B read (i = 0..3), an A read (i = 4..9), and one staging piece
-    // behind MFMAs 3, 8, 13, 18, 23.
+    const unsigned char* abase = smem + nslot * SLOT_A6 + (a_lane + kx);
+    const unsigned char* bbase = smem + nslot * SLOT_B6 + (b_lane + kx);
     auto mfma_at = [&](auto i_tag) {
       constexpr int I = decltype(i_tag)::value;
       constexpr int mi = I >> 2, ni = I & 3;
       if constexpr ((ABL & 1) == 0) {
-        if constexpr (I < NA_TILES)
-          TAVB_MFMA_A(acc_a[I], fa[mi], fb[ni]);
-        else
-          TAVB_MFMA_V(acc_v[I - NA_TILES], fa[mi], fb[ni]);
-      }
-      if constexpr ((ABL & 32) == 0) {
-        if (do_read) {  // wave-uniform
-          if constexpr (I < 4) nb[I] = *reinterpret_cast<const f16x8*>(bbase + I * 2048);
-          if constexpr (I >= 4 && I < 10) na[I - 4] = *reinterpret_cast<const f16x8*>(abase + (I - 4) * 2048);
+        if constexpr (FIRST) {
+          if constexpr (I < NA_TILES)
+            TAVB_MFMA6_A0(acc_a[I], fa[mi], fb[ni]);
+          else
+            TAVB_MFMA6_V0(acc_v[I - NA_TILES], fa[mi], fb[ni]);
+        } else {
+          if constexpr (I < NA_TILES)
+            TAVB_MFMA6_A(acc_a[I], fa[mi], fb[ni]);
+          else
+            TAVB_MFMA6_V(acc_v[I - NA_TILES], fa[mi], fb[ni]);
         }
       }
+      if constexpr ((ABL & 32) == 0) {
+        if constexpr (I < 4) nb[I] = *reinterpret_cast<const f16x8*>(bbase + I * 4096);
+        if constexpr (I >= 4 && I < 9) na[I - 4] = *reinterpret_cast<const f16x8*>(abase + (I - 4) * 4096);
+      }
       if constexpr ((ABL & 2) == 0) {
-        if constexpr (I == 3) stage_piece(sh_tag, J0{});
-        if constexpr (I == 8) stage_piece(sh_tag, J1{});
-        if constexpr (I == 13) stage_piece(sh_tag, J2{});
-        if constexpr (I == 18) stage_piece(sh_tag, J3{});
-        if constexpr (I == 23) stage_piece(sh_tag, J4{});
+        constexpr int PC = v6_piece_at<N3, N0, N1>(Q, I);
+        if constexpr (PC >= 0) stage_piece(std::integral_constant<int, PC>{});
       }
     };
     [&]<int... I>(std::integer_sequence<int, I...>) { (mfma_at(std::integral_constant<int, I>{}), ...); }
-    (std::make_integer_sequence<int, 24>{});
-    if constexpr ((ABL & 1) != 0) asm volatile("" ::"v"(fa[0]), "v"(fa[5]), "v"(fb[0]), "v"(fb[3]));
+    (std::make_integer_sequence<int, 20>{});
+    if constexpr ((ABL & 1) != 0) asm volatile("" ::"v"(fa[0]), "v"(fa[4]), "v"(fb[0]), "v"(fb[3]));
   };
-  using K0 = std::integral_constant<int, 0>;
-  using K1 = std::integral_constant<int, 1>;
+  using Q0 = std::integral_constant<int, 0>;
+  using Q1 = std::integral_constant<int, 1>;
+  using Q2 = std::integral_constant<int, 2>;
+  using Q3 = std::integral_constant<int, 3>;
+  auto step = [&](auto first_tag) {
+    quarter(Q0{}, first_tag, a0, b0, a1, b1, rd, Q1{});
+    quarter(Q1{}, std::false_type{}, a1, b1, a0, b0, rd, Q2{});
+    quarter(Q2{}, std::false_type{}, a0, b0, a1, b1, rd, Q3{});
+    // ---- step S+1 has landed in this wave (nothing newer is in flight); slot rd is read out; meet
+    if constexpr ((ABL & 2) == 0) wait_vmcnt<0>();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) through the builtin: visible to the compiler's wait-count pass
+    TAVB_BARRIER();
+    quarter(Q3{}, std::false_type{}, a1, b1, a0, b0, rd ^ 1, Q0{});
+    rd ^= 1;
+  };
 
   for (int tile = 0; tile < n_tiles; ++tile) {
-    const int64_t row0 = r_begin + (int64_t)tile * BM5;
+    const int64_t row0 = r_begin + (int64_t)tile * BM6;
+    if constexpr ((ABL & 1) != 0) {  // MFMAs ablated: give the accumulators a value
 #pragma unroll
-    for (int i = 0; i < NA_TILES; ++i)
+      for (int i = 0; i < NA_TILES; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc_a[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc_a[i][r] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 24 - NA_TILES; ++i)
+      for (int i = 0; i < 20 - NA_TILES; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc_v[i][r] = 0.f;
-
-#pragma unroll 1
-    for (int kt = 0; kt < steps_per_tile; ++kt) {
-      const int rd_a_next = (rd_a + 1 == RING_A5) ? 0 : rd_a + 1;
-      const int rd_b_next = (rd_b + 1 == RING_B5) ? 0 : rd_b + 1;
-      // ---- (S,0): multiply k 0-15 of step S; fetch its k 16-31 fragments; stage the second half of step S+2
-      half_step(a0, b0, a1, b1, rd_a, rd_b, K1{}, H1{}, true);
-      // ---- step S+1 has landed in this wave; slot S is read out; meet
-      if constexpr ((ABL & 2) == 0 && (ABL & 1024) == 0) wait_vmcnt<10>();
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) through the builtin: visible to the compiler's wait-count pass
-      if constexpr ((ABL & 2048) == 0) TAVB_BARRIER();
-      // ---- (S,1): multiply k 16-31; fetch k 0-15 of step S+1 (across the tile boundary too); stage the first half of S+3.
-      //      (Skipping the fetch on a tile's last step -- to free its 40 registers for the epilogue -- needs a run-time
-      //      predicate on the reads, whose branches between the MFMAs cost the K loop 30 %.)
-      half_step(a1, b1, a0, b0, rd_a_next, rd_b_next, K0{}, H0{}, true);
-      rd_a = rd_a_next;
-      rd_b = rd_b_next;
+        for (int r = 0; r < 16; ++r) acc_v[i][r] = 0.f;
     }
+    step(std::true_type{});
+#pragma unroll 1
+    for (int kt = 1; kt < steps_per_tile; ++kt) step(std::false_type{});
 
-    // ---- epilogue: admission test on the raw dot products, append.  The asm MFMAs are invisible to the compiler's
-    //      hazard recognizer: a 32x32x16 MFMA needs 18 wait states before its result may be read.
+    // ---- epilogue: admission test on the raw dot products, append (see variant 3).  The asm MFMAs are invisible
+    //      to the compiler's hazard recognizer: a 32x32x16 MFMA needs 18 wait states before its result may be read.
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    // Everything the epilogue derives from the lane id is derived HERE, from a laundered copy: hoisted out of the tile
-    // loop these per-lane constants (candidate-buffer pointers, LDS addresses, exchange masks) do not fit next to 384
-    // accumulators and would be spilled -- and a spill reload is a VMEM load queued behind the whole in-flight LDS-DMA.
     int zero_e = 0;
-    asm volatile("" : "+v"(zero_e));  // (the lane id proper sits in a spill slot by now: recompute it from nothing)
+    asm volatile("" : "+v"(zero_e));
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_e));
-    // The VGPR-resident tiles go first: once tested they are dead, and their registers are what the AGPR-resident
-    // tiles' copies then live in (interleaved, the allocator runs out and spills).
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int ql = wn * 128 + ni * 32 + (lane_e & 31);
-      const float thr = thr_lds[ql];
-      const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;  // score > thr implies dot > thr_pre (see variant 3)
+      for (int ni = 0; ni < 4; ++ni) {
+        const int ql = wn * 128 + ni * 32 + (lane_e & 31);
+        const float thr = thr_lds[ql];
+        const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;  // score > thr implies dot > thr_pre (see variant 3)
 #pragma unroll
-      for (int mi = 0; mi < 6; ++mi) {
-        if ((mi * 4 + ni >= NA_TILES) != (pass == 0)) continue;  // pass 0: VGPR tiles, pass 1: AGPR tiles
-        const f32x16 dots = (mi * 4 + ni < NA_TILES) ? acc_a[mi * 4 + ni] : acc_v[mi * 4 + ni - NA_TILES];
-        float top = dots[0];
+        for (int mi = 0; mi < 5; ++mi) {
+          if ((mi * 4 + ni >= NA_TILES) != (pass == 0)) continue;  // pass 0: VGPR tiles, pass 1: AGPR tiles
+          const f32x16 dots = (mi * 4 + ni < NA_TILES) ? acc_a[mi * 4 + ni] : acc_v[mi * 4 + ni - NA_TILES];
+          float top = dots[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, dots[r]);
-        TAVB_SB();  // one block at a time: the scheduler would otherwise pull several blocks' accumulator reads forward (spills)
-        const bool any = (ABL == 0 || ABL == 512) && (top > thr_pre);
-        if constexpr (ABL == 512) asm volatile("" ::"s"(__builtin_amdgcn_ballot_w64(any)));  // test computed, slow path never taken
-        if (ABL != 512 && __builtin_amdgcn_ballot_w64(any) != 0ull) {
-          // (scores are recomputed where they are used: sixteen more live registers here would be spilled, and a spill
-          //  reload is a VMEM load behind the whole in-flight LDS-DMA queue)
-          const int64_t row_base = row0 + wm * 192 + mi * 32 + 4 * (lane_e >> 5);
-          unsigned admit = 0;
+          for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, dots[r]);
+          TAVB_SB();  // one block at a time
+          const bool any = (ABL == 0 || ABL == 512) && (top > thr_pre);
+          if constexpr (ABL == 512) asm volatile("" ::"s"(__builtin_amdgcn_ballot_w64(any)));
+          if constexpr (ABL != 0 && ABL != 512) asm volatile("" ::"v"(top));
+          if (ABL != 512 && __builtin_amdgcn_ballot_w64(any) != 0ull) {
+            const int64_t row_base = row0 + wm * 160 + mi * 32 + 4 * (lane_e >> 5);
+            unsigned admit = 0;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float sc = fmaf(dots[r], 0.5f, 0.5f);
-            float s1 = (sc > 0.0f) ? sc : 0.0f;
-            s1 = (s1 > 1.0f) ? 1.0f : s1;
-            const bool ok = (sc > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s1 >= p.min_score);
-            admit |= ok ? (1u << r) : 0u;
-          }
-          const int n_adm = __popc(admit);
-          int pos = 0;
-          if (n_adm > 0) {
-            pos = lds_add_rtn(&cnt_lds[ql], n_adm);
-            if (pos + n_adm > CAP - BM5) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            TAVB_SB();  // one key at a time (sixteen keys and addresses in flight would not fit)
-            if ((admit >> r) & 1u) {
+            for (int r = 0; r < 16; ++r) {
               const float sc = fmaf(dots[r], 0.5f, 0.5f);
               float s1 = (sc > 0.0f) ? sc : 0.0f;
               s1 = (s1 > 1.0f) ? 1.0f : s1;
-              if (pos < CAP)
-                my_cand[(size_t)ql * CAP + pos] = make_key(s1, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
-              ++pos;
+              const bool ok = (sc > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s1 >= p.min_score);
+              admit |= ok ? (1u << r) : 0u;
+            }
+            const int n_adm = __popc(admit);
+            int pos = 0;
+            if (n_adm > 0) {
+              pos = lds_add_rtn(&cnt_lds[ql], n_adm);
+              if (pos + n_adm > CAP - BM6) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              TAVB_SB();
+              if ((admit >> r) & 1u) {
+                const float sc = fmaf(dots[r], 0.5f, 0.5f);
+                float s1 = (sc > 0.0f) ? sc : 0.0f;
+                s1 = (s1 > 1.0f) ? 1.0f : s1;
+                if (pos < CAP)
+                  my_cand[(size_t)ql * CAP + pos] = make_key(s1, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
+                ++pos;
+              }
             }
           }
         }
       }
-    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     TAVB_BARRIER();
     if (*need_compact != 0) {  // workgroup-uniform: read after the barrier
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       TAVB_BARRIER();
-      for (int q = wave; q < BN; q += NT5 / 64) {
+      for (int q = wave; q < BN; q += NT6 / 64) {
         const int n = cnt_lds[q];
-        if (n > CAP - BM5) {
+        if (n > CAP - BM6) {
           u64* buf = my_cand + (size_t)q * CAP;
           const WaveTopK<1> best = best_of_buffer(buf, n < CAP ? n : CAP, lane_e);
           if (lane_e < p.k) buf[lane_e] = best.key[0];
@@ -1425,7 +815,7 @@ __global__ void __launch_bounds__(NT5) mfma_scan_kernel_v5(const MfmaDeviceParam
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead LDS-DMA before the block retires
   __syncthreads();
 
-  for (int q = wave; q < BN; q += NT5 / 64) {
+  for (int q = wave; q < BN; q += NT6 / 64) {
     const int qg = qtile * BN + q;
     if (qg >= p.nq) continue;
     const int n = cnt_lds[q];
@@ -1782,10 +1172,7 @@ static size_t mfma_cand_bytes(int n_splits, int nq_padded) {
   return (size_t)n_splits * (size_t)nq_padded * CAP * sizeof(u64);  // nq_padded = tiles x queries per tile (256 or 32)
 }
 
-size_t mfma_workspace_bytes(int n_splits, int nq_padded) {
-  // candidate buffers, then one rendezvous counter per row range (padded to 256 bytes)
-  return mfma_cand_bytes(n_splits, nq_padded) + (((size_t)n_splits * sizeof(int) + 255) & ~(size_t)255);
-}
+size_t mfma_workspace_bytes(int n_splits, int nq_padded) { return mfma_cand_bytes(n_splits, nq_padded); }
 
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   if (!mfma_supported(p.dim, p.k) || p.nq_padded % BN != 0 || p.n_splits < 1) return hipErrorInvalidValue;
@@ -1802,106 +1189,43 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.k = p.k;
   d.index_base = p.index_base;
   d.min_score = p.min_score;
-  d.group_sel = p.group_sel;
-  d.a_tiled = p.a_tiled;
   d.thr_in = p.thr_in;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
-  const int bm = (p.variant == 5) ? BM5 : BM;
+  const int bm = (p.variant == 6) ? BM6 : BM;
   d.rows_per_split = ((per + bm - 1) / bm) * bm;
   if (!p.workspace) return hipErrorInvalidValue;
   d.cand = p.workspace;
-  d.sync = nullptr;
-  if (p.rendezvous && p.variant == 3 && d.n_qtiles > 1) {
-    d.sync = reinterpret_cast<int*>(reinterpret_cast<char*>(p.workspace) + mfma_cand_bytes(p.n_splits, p.nq_padded));
-    hipError_t e = hipMemsetAsync(d.sync, 0, (size_t)p.n_splits * sizeof(int), stream);
-    if (e != hipSuccess) return e;
-  }
+  // grid: groups of 8 consecutive block ids = 8 different row ranges (one per XCD)
   const int groups = (p.n_splits + 7) / 8;
   const int grid = groups * d.n_qtiles * 8;
-  auto go = [&](auto kern) -> hipError_t {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  auto go = [&](auto kern, int threads, int lds) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS_BYTES, stream, d);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, d);
     return hipGetLastError();
   };
-  // grid: groups of 8 consecutive block ids = 8 different row ranges (one per XCD)
-  if (p.variant == 4) {
-    constexpr int NA4 = 6, NB4 = 3;
-    constexpr int LDS4 = (NA4 + NB4) * 16384 + BN * 8 + 16;
-    auto go4 = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS4, stream, d);
-      return hipGetLastError();
-    };
+  // `ablate` modes exist to time parts of a kernel (results are garbage): see profiles/r02_cfg3_ablation.md
+  if (p.variant == 6) {
+    if (p.dim % 64 != 0) return hipErrorInvalidValue;
     switch (p.ablate) {
-      case 1: return go4(mfma_scan_kernel_v4<NA4, NB4, 1>);
-      case 2: return go4(mfma_scan_kernel_v4<NA4, NB4, 2>);
-      case 3: return go4(mfma_scan_kernel_v4<NA4, NB4, 3>);
-      case 4: return go4(mfma_scan_kernel_v4<NA4, NB4, 4>);
-      case 512: return go4(mfma_scan_kernel_v4<NA4, NB4, 512>);  // admission test computed, slow path never taken
-      case 256: return go4(mfma_scan_kernel_v4<NA4, NB4, 256>);  // everything except the admission test / appends
-      case 34: return go4(mfma_scan_kernel_v4<NA4, NB4, 34>);  // MFMAs + barriers only
-      case 32: return go4(mfma_scan_kernel_v4<NA4, NB4, 32>);  // MFMAs + LDS-DMA, no fragment reads
-      case 36: return go4(mfma_scan_kernel_v4<NA4, NB4, 36>);  // same, corpus tile 0 only (L2 resident)
-      case 33: return go4(mfma_scan_kernel_v4<NA4, NB4, 33>);  // LDS-DMA + barriers only
-      case 37: return go4(mfma_scan_kernel_v4<NA4, NB4, 37>);  // same, L2 resident
-      case 10: return go4(mfma_scan_kernel_v4<NA4, NB4, 10>);  // no LDS-DMA, barrier every 2nd step
-      case 18: return go4(mfma_scan_kernel_v4<NA4, NB4, 18>);  // no LDS-DMA, barrier every 4th step
-      default: return go4(mfma_scan_kernel_v4<NA4, NB4, 0>);
+      case 256: return go(mfma_scan_kernel_v6<256, 8, 6, 4>, NT6, LDS6);  // everything except admissions
+      case 260: return go(mfma_scan_kernel_v6<260, 8, 6, 4>, NT6, LDS6);  // same, corpus tile 0 re-read by every block (L2 resident)
+      case 264: return go(mfma_scan_kernel_v6<264, 8, 6, 4>, NT6, LDS6);  // same as 256, query operand K step 0 re-read (cache resident)
+      case 268: return go(mfma_scan_kernel_v6<268, 8, 6, 4>, NT6, LDS6);  // both operands cache resident
+      case 258: return go(mfma_scan_kernel_v6<258, 8, 6, 4>, NT6, LDS6);  // no LDS-DMA, no admissions
+      default: break;
+    }
+    switch (p.sched) {  // staging pieces per quarter (q3, q0, q1): measurement
+      case 1: return go(mfma_scan_kernel_v6<0, 10, 8, 0>, NT6, LDS6);
+      case 2: return go(mfma_scan_kernel_v6<0, 6, 6, 6>, NT6, LDS6);
+      default: return go(mfma_scan_kernel_v6<0, 8, 6, 4>, NT6, LDS6);
     }
   }
-  if (p.variant == 5) {
-    if (p.a_tiled) return hipErrorInvalidValue;  // row-major operand only
-    auto go5 = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(NT5), LDS5, stream, d);
-      return hipGetLastError();
-    };
-    switch (p.ablate) {
-      case 1: return go5(mfma_scan_kernel_v5<1>);      // no MFMAs
-      case 2: return go5(mfma_scan_kernel_v5<2>);      // no LDS-DMA after the prologue
-      case 256: return go5(mfma_scan_kernel_v5<256>);  // everything except admissions
-      case 260: return go5(mfma_scan_kernel_v5<260>);  // same, corpus tile 0 re-read by every block (L2 resident)
-      case 288: return go5(mfma_scan_kernel_v5<288>);  // same as 256 without the fragment reads
-      case 512: return go5(mfma_scan_kernel_v5<512>);  // admission test computed, slow path never taken
-      case 1280: return go5(mfma_scan_kernel_v5<1280>);  // 256 without the counted vmcnt wait (garbage: timing only)
-      case 3328: return go5(mfma_scan_kernel_v5<3328>);  // ... and without the barrier
-      default: return go5(mfma_scan_kernel_v5<0>);
-    }
-  }
-  if (p.variant == 3) {
-    constexpr int NA3 = 6, NB3 = 3;
-    constexpr int LDS3 = (NA3 + NB3) * 16384 + BN * 8 + 16;
-    auto go3 = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), LDS3, stream, d);
-      return hipGetLastError();
-    };
-    switch (p.ablate) {
-      case 1: return go3(mfma_scan_kernel_v3<NA3, NB3, 1>);
-      case 4: return go3(mfma_scan_kernel_v3<NA3, NB3, 4>);
-      case 5: return go3(mfma_scan_kernel_v3<NA3, NB3, 5>);
-      case 256: return go3(mfma_scan_kernel_v3<NA3, NB3, 256>);  // everything except admissions
-      case 2: return go3(mfma_scan_kernel_v3<NA3, NB3, 2>);
-      case 3: return go3(mfma_scan_kernel_v3<NA3, NB3, 3>);
-      default: return p.a_nt ? go3(mfma_scan_kernel_v3<NA3, NB3, 0, 2>) : go3(mfma_scan_kernel_v3<NA3, NB3, 0>);
-    }
-  }
-  if (p.variant == 1) return go(mfma_scan_kernel<1, 0, 0>);
-  const int sel = p.ablate * 4 + p.prio;
-  switch (sel) {
-    case 0 * 4 + 0: return go(mfma_scan_kernel<2, 0, 0>);
-    case 0 * 4 + 1: return go(mfma_scan_kernel<2, 0, 1>);
-    case 0 * 4 + 2: return go(mfma_scan_kernel<2, 0, 2>);
-    case 1 * 4 + 0: return go(mfma_scan_kernel<2, 1, 0>);
-    case 2 * 4 + 0: return go(mfma_scan_kernel<2, 2, 0>);
-    case 2 * 4 + 1: return go(mfma_scan_kernel<2, 2, 1>);
-    case 2 * 4 + 2: return go(mfma_scan_kernel<2, 2, 2>);
-    case 3 * 4 + 0: return go(mfma_scan_kernel<2, 3, 0>);
-    default: return go(mfma_scan_kernel<2, 0, 0>);
+  constexpr int NA3 = 6, NB3 = 3;
+  constexpr int LDS3 = (NA3 + NB3) * 16384 + BN * 8 + 16;
+  switch (p.ablate) {
+    case 256: return go(mfma_scan_kernel_v3<NA3, NB3, 256>, NTHREADS, LDS3);  // everything except admissions
+    default: return go(mfma_scan_kernel_v3<NA3, NB3, 0>, NTHREADS, LDS3);
   }
 }
 
@@ -1943,7 +1267,6 @@ hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
   d.min_score = p.min_score;
   d.thr_in = p.thr_in;
   d.cand = p.workspace;
-  d.sync = nullptr;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
   d.rows_per_split = ((per + BM - 1) / BM) * BM;
   const int groups = (p.n_splits + 7) / 8;

@@ -216,58 +216,4 @@ hipError_t launch_f32_split_f16(const float* in, void* hi, void* lo, int64_t cou
   return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------
-// Row-major [rows, dim] (f32 or f16) -> "K-blocked" fp16 image for the MFMA kernel:
-//   for each tile of 256 rows, for each K step of 32 halves: one 16 KiB block holding the 256 rows'
-//   64-byte pieces back to back, the four 16-byte slots of each piece XOR-swizzled with (row >> 2) & 3.
-// That is byte for byte the LDS image the MFMA kernel wants, so its LDS-DMA instructions read 1 KiB of
-// contiguous memory each (instead of sixteen 64-byte row pieces 2*dim bytes apart).  Rows past the end
-// of the corpus are zero.  One thread per 16-byte output slot; writes are fully coalesced.
-// ---------------------------------------------------------------------------
-template <typename SrcT>
-__global__ void __launch_bounds__(256) pack_tiled_kernel(const SrcT* __restrict__ src, _Float16* __restrict__ dst,
-                                                         int64_t rows, int dim, int64_t total_slots) {
-  const int steps = dim / 32;
-  for (int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; sidx < total_slots;
-       sidx += (int64_t)gridDim.x * blockDim.x) {
-    const int phys = (int)(sidx & 3);
-    const int row = (int)((sidx >> 2) & 255);
-    const int64_t blk = sidx >> 10;  // (tile, step)
-    const int step = (int)(blk % steps);
-    const int64_t tile = blk / steps;
-    const int logical = phys ^ ((row >> 2) & 3);
-    const int64_t grow = tile * 256 + row;
-    f16x8 out;
-    if (grow < rows) {
-      const SrcT* p = src + grow * (int64_t)dim + step * 32 + logical * 8;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) out[i] = (_Float16)p[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) out[i] = (_Float16)0.0f;
-    }
-    reinterpret_cast<f16x8*>(dst)[sidx] = out;
-  }
-}
-
-size_t tiled_bytes(int64_t rows, int dim) {
-  const int64_t tiles = (rows + 255) / 256;
-  return (size_t)tiles * 256 * (size_t)dim * 2;
-}
-
-hipError_t launch_pack_tiled(const void* src, int src_dtype, int64_t rows, int dim, void* dst, hipStream_t stream) {
-  if (rows <= 0) return hipSuccess;
-  if (dim % 32 != 0) return hipErrorInvalidValue;
-  const int64_t total_slots = (int64_t)(tiled_bytes(rows, dim) / 16);
-  int64_t blocks = (total_slots + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
-  if (src_dtype == TAVB_F16)
-    hipLaunchKernelGGL(pack_tiled_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const _Float16*>(src), reinterpret_cast<_Float16*>(dst), rows, dim, total_slots);
-  else
-    hipLaunchKernelGGL(pack_tiled_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const float*>(src), reinterpret_cast<_Float16*>(dst), rows, dim, total_slots);
-  return hipGetLastError();
-}
-
 }  // namespace tavb
