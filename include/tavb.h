@@ -74,7 +74,7 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "scan_nt"       1 = non-temporal corpus loads (default 1)
  *   "scan_pipe"     1 = software-prefetch next rows before reducing current ones
  *   "force_tier"    0 = auto, 1 = fixed-D kernel, 2 = vector kernel, 3 = scalar kernel
- *   "mfma_min_batch" smallest batch routed to the 256-query MFMA tile on f16 corpora (default 65)
+ *   "mfma_min_batch" smallest batch routed to the 256-query MFMA tile on f16 corpora (default 65; needs k <= 48, dim % 64 == 0)
  *   "skinny_min_batch_f32" / "skinny_min_batch_f16"  smallest batch routed to the 32/64-query MFMA tile on fp32 / fp16
  *                   corpora (defaults 5 / 3, the measured break-even; fp32 corpora have no other matrix-core path, fp16 ones use it up to
  *                   mfma_min_batch - 1); smaller batches use the streaming tiers
@@ -82,8 +82,10 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "mfma_variant"  K loop of the 256-query tile: 0 = auto (6 for ladder phases of at least "mfma_v6_min_rows" rows, else 3),
  *                   3 / 6 = that K loop for every phase
  *   "mfma_splits", "mfma_sched", "mfma_ablate"  measurement knobs, see DESIGN.md
- *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile,
- *                   5 = 32-query MFMA tile
+ *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile (exact
+ *                   filter + fp32-query rescoring of its candidates), 5 = 32/64-query MFMA tile
+ *   "last_flagged" (read only; synchronises) queries of the last 256-query-tile lookup whose candidate set could not be
+ *                   proven complete and were re-run on the exact 64-query tile (0 on ordinary data)
  */
 int tavb_set_option(tavb_ctx* ctx, const char* name, int64_t value);
 int tavb_get_option(tavb_ctx* ctx, const char* name, int64_t* out_value);
@@ -96,6 +98,12 @@ int tavb_get_option(tavb_ctx* ctx, const char* name, int64_t* out_value);
  * added to every returned ordinal (row-sharded corpora: the shard's first row). */
 int tavb_set_corpus(tavb_ctx* ctx, const void* dev_rows, int64_t rows, int32_t dim, int32_t dtype,
                     int64_t ordinal_base);
+
+/* Tell the library that rows [first_row, rows) of the borrowed corpus buffer were rewritten in place (e.g. an append into
+ * spare capacity followed by tavb_set_corpus with the new row count, or a re-upload after the host matrix was edited):
+ * per-corpus quantities it caches (the largest row norm, used by the batched fp16 path's exactness proof) are refreshed
+ * on the next lookup.  tavb_set_corpus with a different pointer / shape / dtype implies it. */
+int tavb_corpus_modified(tavb_ctx* ctx, int64_t first_row);
 
 /* K1: rows / ||row||_2 in float32, zero rows unchanged
  * (model_adapters.py:181-183; tools/benchmark_vectorbase.py:85-86).  in == out allowed. */

@@ -38,6 +38,7 @@ _SIGNATURES = [
     ("tavb_set_option", c_int, [c_void_p, c_char_p, c_int64]),
     ("tavb_get_option", c_int, [c_void_p, c_char_p, POINTER(c_int64)]),
     ("tavb_set_corpus", c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64]),
+    ("tavb_corpus_modified", c_int, [c_void_p, c_int64]),
     ("tavb_normalize_rows_f32", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
     ("tavb_convert_f32_to_f16", c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     ("tavb_search", c_int, [c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, POINTER(c_int32)]),
@@ -255,6 +256,7 @@ class Engine:
                 src = src.astype(np.float16)  # round-to-nearest-even, same as v_cvt_f16_f32
             self.corpus[start:n_new].copy_(torch.from_numpy(src))
         self.set_corpus_tensor(self.corpus, rows=n_new, ordinal_base=self.ordinal_base)
+        _check(self.lib, self.lib.tavb_corpus_modified(self._h, int(start)))  # rows [start, n_new) were (re)written
 
     def clear(self) -> None:
         if self.corpus is not None:

@@ -111,6 +111,8 @@ struct tavb_ctx {
   int64_t mfma_ladder = 4;            // each further phase scans this many times the rows scanned so far (0 = seed once)
 
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand, d_thr, d_sample_keys;
+  Buffer d_delta, d_approx, d_flag, d_fb_queries, d_norm;  // exact rescoring of the 256-query tile (tavb_rescore.hip)
+  int64_t norm_rows = 0;  // rows of the corpus covered by the cached maximum row norm (d_norm)
   Buffer h_stage{nullptr, 0, true};
   Buffer h_out{nullptr, 0, true};  // pinned + device-visible: the last kernel of a synchronous lookup writes its keys straight here
 
@@ -339,6 +341,11 @@ int tavb_destroy(tavb_ctx* c) {
   c->d_cand.release();
   c->d_thr.release();
   c->d_sample_keys.release();
+  c->d_delta.release();
+  c->d_approx.release();
+  c->d_flag.release();
+  c->d_fb_queries.release();
+  c->d_norm.release();
   c->h_stage.release();
   c->h_out.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -428,6 +435,16 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "mfma_variant") *out = c->mfma_variant;
   else if (n == "compute_units") *out = c->n_cu;
   else if (n == "last_tier") *out = c->last_tier;
+  else if (n == "last_flagged") {  // queries of the last 256-query-tile lookup that were re-run on the exact tile (synchronises)
+    *out = 0;
+    if (c->d_flag.ptr) {
+      DeviceGuard guard(c->device);
+      int v = 0;
+      TAVB_HIP(hipStreamSynchronize(c->stream));
+      TAVB_HIP(hipMemcpy(&v, c->d_flag.ptr, sizeof v, hipMemcpyDeviceToHost));
+      *out = v;
+    }
+  }
   else return fail(TAVB_E_INVALID, "unknown option '%s'", name);
   return TAVB_OK;
 }
@@ -440,11 +457,19 @@ int tavb_set_corpus(tavb_ctx* c, const void* dev_rows, int64_t rows, int32_t dim
   if (rows > 0 && !dev_rows) return fail(TAVB_E_INVALID, "null corpus pointer with rows > 0");
   if (rows >= 0x7FFFFFFFll) return fail(TAVB_E_UNSUPPORTED, "at most 2^31-2 rows per device shard (got %lld)", (long long)rows);
   if (ordinal_base < 0) return fail(TAVB_E_INVALID, "ordinal_base must be >= 0");
+  if (dev_rows != c->corpus || dim != c->dim || dtype != c->dtype || rows < c->norm_rows) c->norm_rows = 0;  // cached row-norm maximum: keep it across appends only
   c->corpus = dev_rows;
   c->rows = rows;
   c->dim = dim;
   c->dtype = dtype;
   c->ordinal_base = ordinal_base;
+  return TAVB_OK;
+}
+
+int tavb_corpus_modified(tavb_ctx* c, int64_t first_row) {
+  if (int rc = check_ctx(c)) return rc;
+  if (first_row < 0) return fail(TAVB_E_INVALID, "first_row must be >= 0");
+  if (first_row < c->norm_rows) c->norm_rows = 0;  // the cached row-norm maximum may be stale: recompute on the next batched lookup
   return TAVB_OK;
 }
 
@@ -668,126 +693,240 @@ int tavb_profile_read(tavb_ctx* c, int32_t kernel_id, double* out_total_ms, int6
 
 }  // extern "C"
 
-// Routes a device-resident query batch to the streaming scan or (f16 corpus, large
-// batch) the MFMA kernel.  Not part of the public ABI.
+// ---------------------------------------------------------------------------------------------------------------
+// Tile kernels (tavb_mfma.hip) behind the threshold ladder.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct TileRun {
+  bool skinny;            // 32/64-query tile (fp32 or split-fp16 queries) instead of the 256-query fp16 tile
+  bool q32;               // skinny tile on an fp32 corpus
+  int qt;                 // queries per tile
+  int nq, nq_pad, k;
+  uint32_t index_base;
+  float kernel_min_score; // uniform threshold applied inside the kernel
+  const float* floor;     // optional device [nq_pad]: per-query exclusive admission thresholds valid from the first row on
+  const void* queries;    // operand in the kernel's layout
+  const int* active;      // optional device-side live-query count (fixed-shape launch over a work list)
+  bool ladder;            // scan in phases of growing size (else one phase)
+};
+
+// Threshold ladder.  The corpus is scanned in phases of growing size -- the first `mfma_sample_rows` rows, then
+// `mfma_ladder` times everything scanned so far, ..., then the rest -- every row exactly once.  After each phase the
+// exact top-k so far is merged; its k-th best score is a valid admission threshold for every later row (the k-th best
+// of a subset never exceeds the k-th best of the whole corpus), so each phase starts selective instead of admitting
+// whatever comes first and compacting, and the running top-k rides along as one more list of the next phase's merge.
+// Expected admissions per query drop from k * rows / sample (one seeding phase) to ~k * ladder per phase.  Results do
+// not depend on the phase boundaries.  Output: sorted key lists [nq, k] at `d_out` (or, with `scatter`, rows
+// scatter[slot] of it for the slots below *active).
+int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scatter) {
+  auto pick_splits = [&](int64_t rows) {
+    return r.skinny ? tavb::skinny_pick_splits(rows, r.nq_pad, r.qt, c->n_cu) : tavb::mfma_pick_splits(rows, r.nq_pad, c->n_cu);
+  };
+  auto launch = [&](const tavb::MfmaParams& q) { return r.skinny ? tavb::launch_skinny_scan(q, c->stream) : tavb::launch_mfma_scan(q, c->stream); };
+  const int nq = r.nq, k = r.k;
+  const int splits = c->mfma_splits > 0 ? (int)c->mfma_splits : pick_splits(c->rows);
+  if (int rc = c->d_lists.reserve((size_t)nq * (splits + 1) * k * sizeof(u64_t))) return rc;  // + the carried-over top-k
+  if (int rc = c->d_cand.reserve(tavb::mfma_workspace_bytes(splits, r.nq_pad))) return rc;
+  tavb::MfmaParams p{};
+  p.corpus = c->corpus;
+  p.queries = r.queries;
+  p.lists = reinterpret_cast<u64_t*>(c->d_lists.ptr);
+  p.workspace = reinterpret_cast<u64_t*>(c->d_cand.ptr);
+  p.rows = c->rows;
+  p.dim = c->dim;
+  p.nq = nq;
+  p.nq_padded = r.nq_pad;
+  p.k = k;
+  p.index_base = r.index_base;
+  p.min_score = r.kernel_min_score;
+  p.n_splits = splits;
+  p.variant = c->mfma_variant == 0 ? 3 : (int)c->mfma_variant;  // auto: decided per phase below
+  p.ablate = (int)c->mfma_ablate;
+  p.sched = (int)c->mfma_sched;
+  p.f32 = r.q32 ? 1 : 0;
+  p.skinny_tile = r.skinny ? r.qt : 0;
+  p.active = r.active;
+  std::vector<int64_t> bounds;  // phase i scans rows [bounds[i], bounds[i+1])
+  bounds.push_back(0);
+  const int64_t sample = (c->mfma_sample_rows + 255) / 256 * 256;
+  if (r.ladder && sample > 0 && c->rows >= 8 * sample) {
+    int64_t done = sample;
+    bounds.push_back(done);
+    const int64_t growth = c->mfma_ladder;
+    while (growth > 0 && done * (growth + 1) * 2 <= c->rows && bounds.size() < 8) {
+      done += done * growth;
+      bounds.push_back(done);
+    }
+  }
+  bounds.push_back(c->rows);
+  const int n_phases = (int)bounds.size() - 1;
+  if (n_phases > 1) {
+    if (int rc = c->d_thr.reserve((size_t)r.nq_pad * sizeof(float))) return rc;
+    if (int rc = c->d_sample_keys.reserve((size_t)nq * k * sizeof(u64_t))) return rc;
+  }
+  const size_t row_bytes = (size_t)c->dim * (r.q32 ? 4 : 2);  // of the corpus operand
+  for (int ph = 0; ph < n_phases; ++ph) {
+    const bool last = (ph == n_phases - 1);
+    tavb::MfmaParams pp = p;
+    pp.corpus = reinterpret_cast<const char*>(p.corpus) + (size_t)bounds[ph] * row_bytes;
+    pp.rows = bounds[ph + 1] - bounds[ph];
+    pp.index_base = r.index_base + (uint32_t)bounds[ph];
+    pp.n_splits = pick_splits(pp.rows);
+    if (!r.skinny && c->mfma_variant == 0)  // the 4-wave whole-line tile needs enough tiles per workgroup to amortise its longer prologue
+      pp.variant = (pp.rows >= c->mfma_v6_min_rows) ? 6 : 3;
+    if (c->mfma_splits > 0 || pp.n_splits > splits) pp.n_splits = splits;  // lists / candidate buffers are sized for `splits`
+    const int carried = ph > 0 ? 1 : 0;  // the running top-k of the earlier phases occupies one more list slot
+    pp.list_stride = pp.n_splits + carried;
+    pp.thr_in = ph > 0 ? reinterpret_cast<const float*>(c->d_thr.ptr) : r.floor;
+    if (carried) {
+      TAVB_HIP(hipMemcpy2DAsync(pp.lists + (size_t)pp.n_splits * k, (size_t)pp.list_stride * k * sizeof(u64_t), c->d_sample_keys.ptr,
+                                (size_t)k * sizeof(u64_t), (size_t)k * sizeof(u64_t), (size_t)nq, hipMemcpyDeviceToDevice, c->stream));
+    }
+    {
+      Timed t(c, r.active ? TAVB_KERNEL_RESCORE : !last ? TAVB_KERNEL_MFMA_SAMPLE : (r.skinny ? TAVB_KERNEL_SKINNY : TAVB_KERNEL_MFMA));
+      hipError_t e = launch(pp);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "mfma scan launch failed (phase %d): %s", ph, hipGetErrorString(e));
+    }
+    if (last) {
+      Timed t(c, r.active ? TAVB_KERNEL_RESCORE : TAVB_KERNEL_MERGE);
+      hipError_t e = scatter ? tavb::launch_merge_scatter(pp.lists, pp.list_stride, nq, k, r.active, scatter, d_out, c->stream)
+                             : tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true, d_out, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
+    } else {
+      hipError_t e = tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true,
+                                        reinterpret_cast<u64_t*>(c->d_sample_keys.ptr), c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "phase merge launch failed: %s", hipGetErrorString(e));
+      TAVB_HIP(hipMemsetAsync(c->d_thr.ptr, 0xFF, (size_t)r.nq_pad * sizeof(float), c->stream));  // NaN bits: ignored by `>`
+      e = tavb::launch_sample_thresholds(reinterpret_cast<const u64_t*>(c->d_sample_keys.ptr), nq, k, r.floor,
+                                         reinterpret_cast<float*>(c->d_thr.ptr), c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "threshold launch failed: %s", hipGetErrorString(e));
+    }
+  }
+  return TAVB_OK;
+}
+
+// The 256-query fp16 tile as an exact filter + fp32-query rescoring of its candidates (tavb_rescore.hip).
+int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_score, uint32_t index_base, u64_t* d_out) {
+  constexpr int KC = 64;  // candidates per query
+  const int qt = tavb::mfma_query_tile();
+  const int nq_pad = ((nq + qt - 1) / qt) * qt;
+  const int cap = ((nq + 63) / 64) * 64;  // slots of the work list of queries that need the exact tile
+  const size_t q16_bytes = (size_t)nq_pad * c->dim * 2;
+  if (int rc = c->d_queries_f16.reserve(q16_bytes)) return rc;
+  if (int rc = c->d_delta.reserve((size_t)nq_pad * 2 * sizeof(float))) return rc;  // delta, then the relaxed thresholds
+  if (int rc = c->d_approx.reserve((size_t)nq * KC * sizeof(u64_t))) return rc;
+  if (int rc = c->d_flag.reserve((size_t)(cap + 64) * sizeof(int))) return rc;
+  if (int rc = c->d_fb_queries.reserve((size_t)2 * cap * c->dim * 2 + (size_t)cap * sizeof(float))) return rc;
+  if (int rc = c->d_norm.reserve(256)) return rc;
+  float* d_norm = reinterpret_cast<float*>(c->d_norm.ptr);
+  float* d_delta = reinterpret_cast<float*>(c->d_delta.ptr);
+  float* d_floor = d_delta + nq_pad;
+  int* d_nflag = reinterpret_cast<int*>(c->d_flag.ptr);
+  int* d_flagged = d_nflag + 64;
+  {
+    Timed t(c, TAVB_KERNEL_RESCORE);
+    if (c->norm_rows > c->rows || c->norm_rows == 0) {  // first use on this corpus (or it shrank: the old maximum is still an upper bound, but start over)
+      TAVB_HIP(hipMemsetAsync(d_norm, 0, sizeof(float), c->stream));
+      c->norm_rows = 0;
+    }
+    if (c->norm_rows < c->rows) {  // rows appended since: extend the maximum
+      hipError_t e = tavb::launch_corpus_max_norm(reinterpret_cast<const char*>(c->corpus) + (size_t)c->norm_rows * c->dim * 2,
+                                                  c->rows - c->norm_rows, c->dim, d_norm, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "corpus norm launch failed: %s", hipGetErrorString(e));
+      c->norm_rows = c->rows;
+    }
+    TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16_bytes, c->stream));  // padding queries
+    hipError_t e = tavb::launch_query_prepare(d_q, nq, c->dim, min_score, d_norm, c->d_queries_f16.ptr, d_delta, d_floor, c->stream);
+    if (e != hipSuccess) return fail(TAVB_E_HIP, "query prepare launch failed: %s", hipGetErrorString(e));
+  }
+  TileRun filt{};
+  filt.skinny = false;
+  filt.qt = qt;
+  filt.nq = nq;
+  filt.nq_pad = nq_pad;
+  filt.k = KC;
+  filt.index_base = index_base;
+  filt.kernel_min_score = (min_score > 0.0f) ? 0.0f : min_score;  // the per-query relaxed thresholds (floor) do the filtering; NaN stays NaN
+  filt.floor = d_floor;
+  filt.queries = c->d_queries_f16.ptr;
+  filt.ladder = true;
+  if (int rc = run_tile_ladder(c, filt, reinterpret_cast<u64_t*>(c->d_approx.ptr), nullptr)) return rc;
+  {
+    Timed t(c, TAVB_KERNEL_RESCORE);
+    hipError_t e = tavb::launch_rescore(c->corpus, c->dim, index_base, d_q, reinterpret_cast<const u64_t*>(c->d_approx.ptr), d_delta, min_score, nq, k,
+                                        d_out, d_nflag, d_flagged, c->stream);
+    if (e != hipSuccess) return fail(TAVB_E_HIP, "rescore launch failed: %s", hipGetErrorString(e));
+    char* fb = reinterpret_cast<char*>(c->d_fb_queries.ptr);
+    float* fb_thr = reinterpret_cast<float*>(fb + (size_t)2 * cap * c->dim * 2);
+    e = tavb::launch_gather_flagged(d_q, c->dim, min_score, d_nflag, d_flagged, cap, fb, fb + (size_t)cap * c->dim * 2, fb_thr, c->stream);
+    if (e != hipSuccess) return fail(TAVB_E_HIP, "gather launch failed: %s", hipGetErrorString(e));
+    // the exact tile over the work list: returns at once when the list is empty (the normal case)
+    TileRun ex{};
+    ex.skinny = true;
+    ex.q32 = false;
+    ex.qt = 64;
+    ex.nq = cap;
+    ex.nq_pad = cap;
+    ex.k = k;
+    ex.index_base = index_base;
+    ex.kernel_min_score = min_score;
+    ex.floor = fb_thr;
+    ex.queries = fb;
+    ex.active = d_nflag;
+    ex.ladder = false;
+    if (int rc = run_tile_ladder(c, ex, d_out, d_flagged)) return rc;
+  }
+  return TAVB_OK;
+}
+
+}  // namespace
+
+// Routes a device-resident query batch: streaming scan (few queries), 32/64-query tile (small batches; every batch on
+// fp32 corpora), or the 256-query fp16 tile with exact rescoring (large batches on fp16 corpora).  Not part of the public ABI.
 int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores,
                                 uint32_t index_base, u64_t* d_out) {
   bool uniform_thr = true;
   for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (min_scores[i] == min_scores[0]);
   const bool f16c = (c->dtype == TAVB_F16);
-  const bool wide = f16c && c->corpus && nq >= c->mfma_min_batch && uniform_thr && tavb::mfma_supported(c->dim, k) && c->rows > 0;
-  // 32-query tiles at HBM speed: small batches on fp16 corpora, every batch from `skinny_min_batch_f32` up on fp32 ones
+  // the filter keeps 64 candidates per query: k up to 48 leaves the slack the completeness proof needs
+  const bool wide = f16c && c->corpus && nq >= c->mfma_min_batch && uniform_thr && tavb::mfma_supported(c->dim, 64) && k <= 48 && c->rows > 0 &&
+                    tavb::skinny_supported(c->dim, k, false);
+  // 32/64-query tiles at HBM speed: small batches on fp16 corpora, every batch from `skinny_min_batch_f32` up on fp32 ones
   const bool skinny = !wide && c->corpus && uniform_thr && c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c) &&
                       nq >= (f16c ? c->skinny_min_batch_f16 : c->skinny_min_batch_f32);
-  if (wide || skinny) {
-    const int qt = skinny ? tavb::skinny_query_tile(nq) : tavb::mfma_query_tile();
+  if (wide) {
+    c->last_tier = 4;  // 1-3 = streaming tiers, 4 = 256-query MFMA tile, 5 = 32/64-query MFMA tile
+    return search_wide_exact(c, d_q, nq, k, min_scores[0], index_base, d_out);
+  }
+  if (skinny) {
+    const int qt = tavb::skinny_query_tile(nq);
     const int nq_pad = ((nq + qt - 1) / qt) * qt;
-    const bool q32 = skinny && !f16c;  // the skinny kernel on an fp32 corpus multiplies fp32 queries
-    const bool split = skinny && f16c;  // ... and on an fp16 corpus fp32 queries split into fp16 high + low planes
+    const bool q32 = !f16c;  // on an fp32 corpus the tile multiplies fp32 queries, on an fp16 one fp32 queries split into fp16 high + low planes
     const size_t plane = (size_t)nq_pad * c->dim * (q32 ? 4 : 2);
-    const size_t qbytes = plane * (split ? 2 : 1);
+    const size_t qbytes = plane * (q32 ? 1 : 2);
     if (int rc = c->d_queries_f16.reserve(qbytes)) return rc;
     TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, qbytes, c->stream));
     if (q32) {
       TAVB_HIP(hipMemcpyAsync(c->d_queries_f16.ptr, d_q, (size_t)nq * c->dim * 4, hipMemcpyDeviceToDevice, c->stream));
-    } else if (split) {
+    } else {
       hipError_t e = tavb::launch_f32_split_f16(d_q, c->d_queries_f16.ptr, reinterpret_cast<char*>(c->d_queries_f16.ptr) + plane,
                                                 (int64_t)nq * c->dim, c->stream);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "query split launch failed: %s", hipGetErrorString(e));
-    } else {
-      hipError_t e = tavb::launch_f32_to_f16(d_q, c->d_queries_f16.ptr, (int64_t)nq * c->dim, c->stream);
-      if (e != hipSuccess) return fail(TAVB_E_HIP, "query convert launch failed: %s", hipGetErrorString(e));
     }
-    auto pick_splits = [&](int64_t rows) {
-      return skinny ? tavb::skinny_pick_splits(rows, nq_pad, qt, c->n_cu) : tavb::mfma_pick_splits(rows, nq_pad, c->n_cu);
-    };
-    auto launch = [&](const tavb::MfmaParams& q) { return skinny ? tavb::launch_skinny_scan(q, c->stream) : tavb::launch_mfma_scan(q, c->stream); };
-    c->last_tier = skinny ? 5 : 4;  // 1-3 = streaming tiers, 4 = 256-query MFMA tile, 5 = 32-query MFMA tile
-    const int splits = c->mfma_splits > 0 ? (int)c->mfma_splits : pick_splits(c->rows);
-    if (int rc = c->d_lists.reserve((size_t)nq * (splits + 1) * k * sizeof(u64_t))) return rc;  // + the carried-over top-k
-    if (int rc = c->d_cand.reserve(tavb::mfma_workspace_bytes(splits, nq_pad))) return rc;
-    tavb::MfmaParams p{};
-    p.corpus = c->corpus;
-    p.queries = c->d_queries_f16.ptr;
-    p.lists = reinterpret_cast<u64_t*>(c->d_lists.ptr);
-    p.workspace = reinterpret_cast<u64_t*>(c->d_cand.ptr);
-    p.rows = c->rows;
-    p.dim = c->dim;
-    p.nq = nq;
-    p.nq_padded = nq_pad;
-    p.k = k;
-    p.index_base = index_base;
-    p.min_score = min_scores[0];
-    p.n_splits = splits;
-    p.variant = c->mfma_variant == 0 ? 3 : (int)c->mfma_variant;  // auto: decided per phase below
-    p.ablate = (int)c->mfma_ablate;
-    p.sched = (int)c->mfma_sched;
-    p.f32 = q32 ? 1 : 0;
-    p.skinny_tile = skinny ? qt : 0;
-    p.thr_in = nullptr;
-    // Threshold ladder.  The corpus is scanned in phases of growing size -- the first `mfma_sample_rows` rows, then
-    // `mfma_ladder` times everything scanned so far, ..., then the rest -- every row exactly once.  After each
-    // phase the exact top-k so far is merged; its k-th best score is a valid admission threshold for every later row
-    // (the k-th best of a subset never exceeds the k-th best of the whole corpus), so each phase starts selective
-    // instead of admitting whatever comes first and compacting, and the running top-k rides along as one more list
-    // of the next phase's merge.  Expected admissions per query drop from k * rows / sample (one seeding phase)
-    // to ~k * ladder per phase.  Results do not depend on the phase boundaries.
-    std::vector<int64_t> bounds;  // phase i scans rows [bounds[i], bounds[i+1])
-    bounds.push_back(0);
-    const int64_t sample = (c->mfma_sample_rows + 255) / 256 * 256;
-    if (sample > 0 && c->rows >= 8 * sample) {
-      int64_t done = sample;
-      bounds.push_back(done);
-      const int64_t growth = c->mfma_ladder;
-      while (growth > 0 && done * (growth + 1) * 2 <= c->rows && bounds.size() < 8) {
-        done += done * growth;
-        bounds.push_back(done);
-      }
-    }
-    bounds.push_back(c->rows);
-    const int n_phases = (int)bounds.size() - 1;
-    if (n_phases > 1) {
-      if (int rc = c->d_thr.reserve((size_t)nq_pad * sizeof(float))) return rc;
-      if (int rc = c->d_sample_keys.reserve((size_t)nq * k * sizeof(u64_t))) return rc;
-    }
-    const size_t row_bytes = (size_t)c->dim * (q32 ? 4 : 2);  // of the corpus operand
-    for (int ph = 0; ph < n_phases; ++ph) {
-      const bool last = (ph == n_phases - 1);
-      tavb::MfmaParams pp = p;
-      pp.corpus = reinterpret_cast<const char*>(p.corpus) + (size_t)bounds[ph] * row_bytes;
-      pp.rows = bounds[ph + 1] - bounds[ph];
-      pp.index_base = index_base + (uint32_t)bounds[ph];
-      pp.n_splits = pick_splits(pp.rows);
-      if (!skinny && c->mfma_variant == 0)  // the 4-wave whole-line tile needs dim % 64 == 0 and enough tiles per workgroup to amortise its longer prologue
-        pp.variant = (c->dim % 64 == 0 && pp.rows >= c->mfma_v6_min_rows) ? 6 : 3;
-      if (c->mfma_splits > 0 || pp.n_splits > splits) pp.n_splits = splits;  // lists / candidate buffers are sized for `splits`
-      const int carried = ph > 0 ? 1 : 0;  // the running top-k of the earlier phases occupies one more list slot
-      pp.list_stride = pp.n_splits + carried;
-      pp.thr_in = ph > 0 ? reinterpret_cast<const float*>(c->d_thr.ptr) : nullptr;
-      if (carried) {
-        TAVB_HIP(hipMemcpy2DAsync(pp.lists + (size_t)pp.n_splits * k, (size_t)pp.list_stride * k * sizeof(u64_t), c->d_sample_keys.ptr,
-                                  (size_t)k * sizeof(u64_t), (size_t)k * sizeof(u64_t), (size_t)nq, hipMemcpyDeviceToDevice, c->stream));
-      }
-      {
-        Timed t(c, !last ? TAVB_KERNEL_MFMA_SAMPLE : (skinny ? TAVB_KERNEL_SKINNY : TAVB_KERNEL_MFMA));
-        hipError_t e = launch(pp);
-        if (e != hipSuccess) return fail(TAVB_E_HIP, "mfma scan launch failed (phase %d): %s", ph, hipGetErrorString(e));
-      }
-      if (last) {
-        Timed t(c, TAVB_KERNEL_MERGE);
-        hipError_t e = tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true, d_out, c->stream);
-        if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
-      } else {
-        hipError_t e = tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true,
-                                          reinterpret_cast<u64_t*>(c->d_sample_keys.ptr), c->stream);
-        if (e != hipSuccess) return fail(TAVB_E_HIP, "phase merge launch failed: %s", hipGetErrorString(e));
-        TAVB_HIP(hipMemsetAsync(c->d_thr.ptr, 0xFF, (size_t)nq_pad * sizeof(float), c->stream));  // NaN bits: ignored by `>`
-        e = tavb::launch_sample_thresholds(reinterpret_cast<const u64_t*>(c->d_sample_keys.ptr), nq, k,
-                                           reinterpret_cast<float*>(c->d_thr.ptr), c->stream);
-        if (e != hipSuccess) return fail(TAVB_E_HIP, "threshold launch failed: %s", hipGetErrorString(e));
-      }
-    }
-    return TAVB_OK;
+    c->last_tier = 5;
+    TileRun r{};
+    r.skinny = true;
+    r.q32 = q32;
+    r.qt = qt;
+    r.nq = nq;
+    r.nq_pad = nq_pad;
+    r.k = k;
+    r.index_base = index_base;
+    r.kernel_min_score = min_scores[0];
+    r.queries = c->d_queries_f16.ptr;
+    r.ladder = true;
+    return run_tile_ladder(c, r, d_out, nullptr);
   }
   return search_device_impl(c, d_q, nq, k, min_scores, nullptr, c->rows, index_base, d_out);
 }

@@ -212,6 +212,42 @@ struct WaveTopK {
   }
 };
 
+// ascending bitonic sort of one key per lane (lane 63 ends up with the largest)
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ u64 sort_stage(u64 key, int lane) {
+  const u64 other = xor_lane_u64<STRIDE>(key, lane);
+  const bool asc_block = (lane & SIZE) == 0 || SIZE == 64;
+  const bool lower = (lane & STRIDE) == 0;
+  const bool keep_min = (lower == asc_block);
+  const bool mine_small = key < other;
+  return (keep_min == mine_small) ? key : other;
+}
+
+__device__ __forceinline__ u64 sort64_ascending(u64 k, int lane) {
+  k = sort_stage<2, 1>(k, lane);
+  k = sort_stage<4, 2>(k, lane);
+  k = sort_stage<4, 1>(k, lane);
+  k = sort_stage<8, 4>(k, lane);
+  k = sort_stage<8, 2>(k, lane);
+  k = sort_stage<8, 1>(k, lane);
+  k = sort_stage<16, 8>(k, lane);
+  k = sort_stage<16, 4>(k, lane);
+  k = sort_stage<16, 2>(k, lane);
+  k = sort_stage<16, 1>(k, lane);
+  k = sort_stage<32, 16>(k, lane);
+  k = sort_stage<32, 8>(k, lane);
+  k = sort_stage<32, 4>(k, lane);
+  k = sort_stage<32, 2>(k, lane);
+  k = sort_stage<32, 1>(k, lane);
+  k = sort_stage<64, 32>(k, lane);
+  k = sort_stage<64, 16>(k, lane);
+  k = sort_stage<64, 8>(k, lane);
+  k = sort_stage<64, 4>(k, lane);
+  k = sort_stage<64, 2>(k, lane);
+  k = sort_stage<64, 1>(k, lane);
+  return k;
+}
+
 // Merge the sorted lists of all waves of a workgroup into wave 0's list through
 // LDS (`scratch`: (waves/2) * 64*KPL keys).  Every wave must call this.
 template <int KPL>

@@ -39,6 +39,18 @@ hipError_t launch_scan(const ScanParams& p, const ScanGeometry& g, hipStream_t s
 // lists: [n_lists, nq, k] (list-major) or [nq, n_lists, k] (query-major) sorted keys -> out [nq, k]
 hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, int k, bool query_major,
                         unsigned long long* out, hipStream_t stream);
+// the same over a device-side work list: query slot s is merged only if s < *active, into out[scatter[s]]
+hipError_t launch_merge_scatter(const unsigned long long* lists, int n_lists, int nq, int k, const int* active, const int* scatter,
+                                unsigned long long* out, hipStream_t stream);
+
+// exact fp32-query semantics for the 256-query tile (tavb_rescore.hip)
+hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, float* out_sq, hipStream_t stream);
+hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, const float* max_norm_sq, void* q16, float* delta, float* thr,
+                                hipStream_t stream);
+hipError_t launch_rescore(const void* corpus_f16, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx, const float* delta,
+                          float min_score, int nq, int k, unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream);
+hipError_t launch_gather_flagged(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, void* hi, void* lo,
+                                 float* thr, hipStream_t stream);
 
 hipError_t launch_normalize_f32(const float* in, float* out, int64_t rows, int dim, hipStream_t stream);
 hipError_t launch_f32_to_f16(const float* in, void* out, int64_t count, hipStream_t stream);
@@ -64,11 +76,12 @@ struct MfmaParams {
   int32_t sched;     // variant 6: staging schedule (measurement)
   int32_t ablate;    // measurement only (garbage results): see launch_mfma_scan
   const float* thr_in;  // optional per-query admission thresholds (device, [nq_padded]) from the earlier ladder phases
+  const int* active;    // skinny kernel only, optional: device-side count of live queries (query tiles past it return at once)
   int32_t f32;          // skinny kernel only: corpus and queries are fp32 (else fp16)
   int32_t skinny_tile;  // skinny kernel only: queries per tile, 32 or 64
 };
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
-hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, float* thr, hipStream_t stream);
+hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, const float* floor, float* thr, hipStream_t stream);
 int mfma_query_tile();                    // queries per workgroup tile
 int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu);
 bool mfma_supported(int dim, int k);

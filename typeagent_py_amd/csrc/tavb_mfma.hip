@@ -79,6 +79,7 @@ struct MfmaDeviceParams {
   uint32_t index_base;
   float min_score;
   const float* thr_in;  // optional [nq_padded] admission thresholds from a sample pass (exclusive bound)
+  const int* active;    // optional: number of live queries, read on the device; query tiles past it return at once
 };
 
 // Pin a wave-uniform pointer into SGPRs.  Without this the compiler strength-reduces the eight
@@ -89,42 +90,6 @@ __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
   return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
-}
-
-// ascending bitonic sort of one key per lane (lane 63 ends up with the largest)
-template <int SIZE, int STRIDE>
-__device__ __forceinline__ u64 sort_stage(u64 key, int lane) {
-  const u64 other = xor_lane_u64<STRIDE>(key, lane);
-  const bool asc_block = (lane & SIZE) == 0 || SIZE == 64;
-  const bool lower = (lane & STRIDE) == 0;
-  const bool keep_min = (lower == asc_block);
-  const bool mine_small = key < other;
-  return (keep_min == mine_small) ? key : other;
-}
-
-__device__ __forceinline__ u64 sort64_ascending(u64 k, int lane) {
-  k = sort_stage<2, 1>(k, lane);
-  k = sort_stage<4, 2>(k, lane);
-  k = sort_stage<4, 1>(k, lane);
-  k = sort_stage<8, 4>(k, lane);
-  k = sort_stage<8, 2>(k, lane);
-  k = sort_stage<8, 1>(k, lane);
-  k = sort_stage<16, 8>(k, lane);
-  k = sort_stage<16, 4>(k, lane);
-  k = sort_stage<16, 2>(k, lane);
-  k = sort_stage<16, 1>(k, lane);
-  k = sort_stage<32, 16>(k, lane);
-  k = sort_stage<32, 8>(k, lane);
-  k = sort_stage<32, 4>(k, lane);
-  k = sort_stage<32, 2>(k, lane);
-  k = sort_stage<32, 1>(k, lane);
-  k = sort_stage<64, 32>(k, lane);
-  k = sort_stage<64, 16>(k, lane);
-  k = sort_stage<64, 8>(k, lane);
-  k = sort_stage<64, 4>(k, lane);
-  k = sort_stage<64, 2>(k, lane);
-  k = sort_stage<64, 1>(k, lane);
-  return k;
 }
 
 // LDS read-modify-write / store that the compiler cannot see as LDS traffic.  hipcc's wait-count pass orders every LDS
@@ -895,6 +860,7 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
   if (split >= p.n_splits) return;
   const int64_t r_begin = (int64_t)split * p.rows_per_split;
   const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
+  if (p.active != nullptr && qtile * SQ >= *p.active) return;  // fixed-shape launch over a device-side work list (tavb_rescore.hip)
   const int logical_block = split * p.n_qtiles + qtile;
   u64* my_cand = p.cand + (size_t)logical_block * SQ * CAP;
 
@@ -1135,7 +1101,8 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
 
 // thr[q] = the largest float below the k-th best score of the sample pass (so that `score > thr` admits
 // every row scoring >= that k-th best), or -inf when the sample did not yield k hits.
-__global__ void sample_threshold_kernel(const u64* __restrict__ keys, int nq, int k, float* __restrict__ thr) {
+// `floor` (optional, [nq]): per-query thresholds that hold from the start (the relaxed min_score of the filter pass).
+__global__ void sample_threshold_kernel(const u64* __restrict__ keys, int nq, int k, const float* __restrict__ floor, float* __restrict__ thr) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   const u64 kth = keys[(size_t)q * k + (k - 1)];
@@ -1144,11 +1111,12 @@ __global__ void sample_threshold_kernel(const u64* __restrict__ keys, int nq, in
     const uint32_t bits = (uint32_t)(kth >> 32);
     t = bits ? __uint_as_float(bits - 1u) : -__builtin_inff();
   }
+  if (floor != nullptr && floor[q] > t) t = floor[q];
   thr[q] = t;
 }
 
-hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, float* thr, hipStream_t stream) {
-  hipLaunchKernelGGL(sample_threshold_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, keys, nq, k, thr);
+hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, const float* floor, float* thr, hipStream_t stream) {
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, keys, nq, k, floor, thr);
   return hipGetLastError();
 }
 
@@ -1266,6 +1234,7 @@ hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
   d.index_base = p.index_base;
   d.min_score = p.min_score;
   d.thr_in = p.thr_in;
+  d.active = p.active;
   d.cand = p.workspace;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
   d.rows_per_split = ((per + BM - 1) / BM) * BM;

@@ -15,13 +15,15 @@ namespace tavb {
 // ---------------------------------------------------------------------------
 template <int KPL>
 __global__ void __launch_bounds__(1024) merge_kernel(const u64* __restrict__ lists, int n_lists, int nq, int k,
-                                                     int query_major, u64* __restrict__ out) {
+                                                     int query_major, u64* __restrict__ out, const int* __restrict__ active,
+                                                     const int* __restrict__ scatter) {
   extern __shared__ __align__(16) unsigned char smem[];
   u64* scratch = reinterpret_cast<u64*>(smem);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_waves = blockDim.x >> 6;
   const int q = blockIdx.x;
+  if (active != nullptr && q >= *active) return;  // device-side work list: slot not in use
   WaveTopK<KPL> mine;
   mine.clear();
   auto list_ptr = [&](int m) {
@@ -44,7 +46,7 @@ __global__ void __launch_bounds__(1024) merge_kernel(const u64* __restrict__ lis
     mine.merge_reversed(other, lane);
   }
   block_merge<KPL>(mine, scratch, wave, n_waves, lane);
-  if (wave == 0) mine.store(out + (size_t)q * k, k, lane);
+  if (wave == 0) mine.store(out + (size_t)(scatter != nullptr ? scatter[q] : q) * k, k, lane);
 }
 
 hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, int k, bool query_major,
@@ -56,10 +58,20 @@ hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, in
   const size_t lds = (size_t)((waves + 1) / 2) * 64 * kpl * sizeof(u64);
   if (kpl == 1)
     hipLaunchKernelGGL(merge_kernel<1>, dim3(nq), dim3(waves * 64), lds, stream, lists, n_lists, nq, k,
-                       query_major ? 1 : 0, out);
+                       query_major ? 1 : 0, out, nullptr, nullptr);
   else
     hipLaunchKernelGGL(merge_kernel<4>, dim3(nq), dim3(waves * 64), lds, stream, lists, n_lists, nq, k,
-                       query_major ? 1 : 0, out);
+                       query_major ? 1 : 0, out, nullptr, nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_merge_scatter(const unsigned long long* lists, int n_lists, int nq, int k, const int* active, const int* scatter,
+                                unsigned long long* out, hipStream_t stream) {
+  if (n_lists < 1 || nq < 1 || k < 1 || k > 64 || !active || !scatter) return hipErrorInvalidValue;
+  int waves = 16;
+  while (waves > 1 && waves / 2 >= n_lists) waves /= 2;
+  const size_t lds = (size_t)((waves + 1) / 2) * 64 * sizeof(u64);
+  hipLaunchKernelGGL(merge_kernel<1>, dim3(nq), dim3(waves * 64), lds, stream, lists, n_lists, nq, k, 1, out, active, scatter);
   return hipGetLastError();
 }
 

@@ -1,0 +1,218 @@
+// Exact fp32-query semantics for the 256-query MFMA tile.
+//
+// `fuzzy_lookup_embeddings(E)` must equal `[fuzzy_lookup_embedding(e) for e in E]` (vectorbase.py:163-190 per query):
+// fp32 query x corpus row, fp32 accumulation.  The 256-query tile multiplies fp16 x fp16, so it sees the queries ROUNDED to
+// fp16 -- up to ~2e-5 off in score, above the 1e-5 bar.  Instead of paying a second (low-plane) MFMA pass over the
+// corpus, the tile is used as an exact FILTER:
+//
+//   1. query_prepare_kernel: q16 = fp16(q); delta_q = a rigorous bound on |score_fp16query(x) - score_fp32query(x)| over
+//      every corpus row x:   |x.(q - q16)| <= ||x|| ||q - q16||   (Cauchy-Schwarz), ||x|| <= R = the largest row norm of
+//      the corpus (corpus_max_norm_kernel, cached per corpus), plus the fp32 summation slack of the two dot products.
+//   2. the tile selects the best K' = 64 rows per query by APPROXIMATE score, admitting down to min_score - 2 delta_q.
+//   3. rescore_kernel: the 64 candidates are scored exactly (fp32 query, fp16 row widened, fp32 accumulate -- the
+//      arithmetic of the streaming kernels), filtered by the exact min_score, sorted, and the best k are the answer --
+//      PROVIDED the candidate set provably contains the exact top-k:  fewer than 64 candidates (then it holds every row
+//      with approximate score >= min_score - 2 delta, hence every row whose exact score passes), or
+//           approx(rank 63)  <  approx(rank k-1) - 2 delta_q
+//      (a row outside the set has approx <= approx(rank 63), so exact <= that + delta < approx(rank k-1) - delta <= the
+//      exact score of each of the k rows that lead the approximate ranking: it cannot be in the exact top-k).
+//   4. a query that fails the test (near-duplicate rows around rank k; never on gaussian data: the gap between ranks
+//      32 and 64 of 10M rows is ~8x the bound) is appended to a device-side list; one fixed-shape launch of the
+//      64-query tile with split hi/lo query planes (exact by construction, tavb_mfma.hip) serves the list and returns
+//      at once when it is empty.  No host round trip anywhere: the asynchronous device-resident form stays asynchronous.
+
+#include <hip/hip_runtime.h>
+
+#include "tavb_device.h"
+#include "tavb_internal.h"
+
+namespace tavb {
+
+namespace {
+
+__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
+  // non-negative floats (and +inf) order like their bit patterns
+  atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+// max over rows of sum(x^2), rows fp16; a row whose sum is not finite makes the result +inf (the bound is then
+// useless and every query takes the exact path).  One wave per row, 16-byte loads.
+__global__ void __launch_bounds__(256) corpus_max_norm_kernel(const _Float16* __restrict__ rows, int64_t n, int dim, float* __restrict__ out_sq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int n8 = dim / 8;
+  float best = 0.f;
+  for (int64_t r = wave; r < n; r += n_waves) {
+    const f16x8* x = reinterpret_cast<const f16x8*>(rows + r * (int64_t)dim);
+    float ss = 0.f;
+    for (int i = lane; i < n8; i += 64) {
+      const f16x8 v = __builtin_nontemporal_load(x + i);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss = fmaf((float)v[e], (float)v[e], ss);
+    }
+    ss = wave_sum(ss);
+    if (!(ss < __builtin_inff())) ss = __builtin_inff();  // NaN / inf rows
+    best = fmaxf(best, ss);
+  }
+  if (lane == 0) atomic_max_nonneg(out_sq, best);
+}
+
+// One wave per query.  q16 <- fp16(q); delta <- score-units bound described above; thr <- the exclusive admission
+// threshold of the approximate pass (just below min_score - 2 delta; -inf when every row qualifies; +inf for NaN).
+__global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restrict__ q, int nq, int dim, float min_score,
+                                                            const float* __restrict__ max_norm_sq, _Float16* __restrict__ q16,
+                                                            float* __restrict__ delta, float* __restrict__ thr) {
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (qi >= nq) return;
+  const float* src = q + (size_t)qi * dim;
+  _Float16* dst = q16 + (size_t)qi * dim;
+  float err = 0.f, qq = 0.f;
+  for (int i = lane; i < dim; i += 64) {
+    const float v = src[i];
+    const _Float16 h = (_Float16)v;
+    dst[i] = h;
+    const float d = v - (float)h;
+    err = fmaf(d, d, err);
+    qq = fmaf(v, v, qq);
+  }
+  err = wave_sum(err);
+  qq = wave_sum(qq);
+  if (lane == 0) {
+    const float R = sqrtf(*max_norm_sq);
+    // rounding of the query + summation slack of two fp32 dot products (blocked accumulation: dim / 8 effective terms)
+    float d = 0.5f * (sqrtf(err) * R * 1.0001f + 2.0f * (float)(dim / 8 + 8) * 5.9604645e-8f * R * sqrtf(qq)) + 1.2e-7f;
+    if (!(d < __builtin_inff())) d = __builtin_inff();  // inf / NaN query or corpus: nothing can be proven
+    delta[qi] = d;
+    float t;
+    if (min_score != min_score) {
+      t = __builtin_inff();
+    } else {
+      const float lo = min_score - 2.0f * d;
+      t = (lo > 0.0f) ? __uint_as_float(__float_as_uint(lo) - 1u) : -__builtin_inff();
+    }
+    thr[qi] = t;
+  }
+}
+
+// One workgroup (4 waves) per query: exact scores of its K' = 64 candidates, exact threshold, sort, completeness test.
+__global__ void __launch_bounds__(256) rescore_kernel(const _Float16* __restrict__ corpus, int dim, uint32_t index_base,
+                                                      const float* __restrict__ queries, const u64* __restrict__ approx /*[nq, 64]*/,
+                                                      const float* __restrict__ delta, float min_score, int k,
+                                                      u64* __restrict__ out /*[nq, k]*/, int* __restrict__ n_flagged,
+                                                      int* __restrict__ flagged) {
+  __shared__ u64 exact[64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int qi = blockIdx.x;
+  const u64* cand = approx + (size_t)qi * 64;
+  const float* q = queries + (size_t)qi * dim;
+  const int n8 = dim / 8;
+  for (int c = wave; c < 64; c += 4) {
+    const u64 key = cand[c];  // wave-uniform
+    u64 out_key = 0ull;
+    if (key != 0ull) {
+      const uint32_t ord = 0xFFFFFFFFu - (uint32_t)key;
+      const f16x8* x = reinterpret_cast<const f16x8*>(corpus + (size_t)(ord - index_base) * dim);
+      float dot = 0.f;
+      for (int i = lane; i < n8; i += 64) {
+        const f16x8 v = x[i];
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(q + i * 8);
+        const f32x4 qb = *reinterpret_cast<const f32x4*>(q + i * 8 + 4);
+        dot = fmaf((float)v[0], qa.x, dot);
+        dot = fmaf((float)v[1], qa.y, dot);
+        dot = fmaf((float)v[2], qa.z, dot);
+        dot = fmaf((float)v[3], qa.w, dot);
+        dot = fmaf((float)v[4], qb.x, dot);
+        dot = fmaf((float)v[5], qb.y, dot);
+        dot = fmaf((float)v[6], qb.z, dot);
+        dot = fmaf((float)v[7], qb.w, dot);
+      }
+      dot = wave_sum(dot);
+      const float s = cosine_to_score(dot);
+      if (s >= min_score) out_key = make_key(s, ord);  // NaN fails, like numpy's >=
+    }
+    if (lane == 0) exact[c] = out_key;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  u64 mine = sort64_ascending(exact[lane], lane);  // lane 63 = best
+  const u64 best_first = shfl_u64(mine, 63 - lane);
+  if (lane < k) out[(size_t)qi * k + lane] = best_first;
+  // completeness of the candidate set
+  const u64 a_last = cand[63];
+  bool ok = true;
+  if (a_last != 0ull) {  // 64 candidates: the set was cut
+    const float a63 = __uint_as_float((uint32_t)(a_last >> 32));
+    const float ak = __uint_as_float((uint32_t)(cand[k - 1] >> 32));
+    const float d = delta[qi];
+    ok = (a63 < ak - 2.0f * d);  // false for d = inf / NaN
+  }
+  if (!ok && lane == 0) {
+    const int slot = atomicAdd(n_flagged, 1);
+    flagged[slot] = qi;
+  }
+}
+
+// Compact the flagged queries into the operand of the exact 64-query tile: split hi / lo fp16 planes [2, cap, dim]
+// (unused slots zero) and per-slot exclusive thresholds (+inf for unused slots: they admit nothing).
+__global__ void __launch_bounds__(256) gather_flagged_kernel(const float* __restrict__ queries, int dim, float min_score,
+                                                             const int* __restrict__ n_flagged, const int* __restrict__ flagged, int cap,
+                                                             _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* __restrict__ thr) {
+  const int n = *n_flagged;
+  if (n == 0) return;  // the common case: nothing to do, nothing written
+  const int slot = blockIdx.x;
+  if (slot >= cap) return;
+  const bool used = slot < n;
+  const float thr0 = (min_score > 0.0f) ? __uint_as_float(__float_as_uint(min_score) - 1u) : -__builtin_inff();
+  if (threadIdx.x == 0) thr[slot] = used ? ((min_score != min_score) ? __builtin_inff() : thr0) : __builtin_inff();
+  const float* src = used ? queries + (size_t)flagged[slot] * dim : nullptr;
+  for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+    _Float16 h = (_Float16)0.0f, l = (_Float16)0.0f;
+    if (used) {
+      const float v = src[i];
+      h = (_Float16)v;
+      const float hf = (float)h;
+      l = (hf - hf == 0.0f) ? (_Float16)(v - hf) : (_Float16)0.0f;
+    }
+    hi[(size_t)slot * dim + i] = h;
+    lo[(size_t)slot * dim + i] = l;
+  }
+}
+
+__global__ void zero_int_kernel(int* p) { *p = 0; }
+
+}  // namespace
+
+hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, float* out_sq, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int64_t blocks = (n + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(corpus_max_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(rows_f16), n, dim, out_sq);
+  return hipGetLastError();
+}
+
+hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, const float* max_norm_sq, void* q16, float* delta, float* thr,
+                                hipStream_t stream) {
+  hipLaunchKernelGGL(query_prepare_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, q, nq, dim, min_score, max_norm_sq,
+                     reinterpret_cast<_Float16*>(q16), delta, thr);
+  return hipGetLastError();
+}
+
+hipError_t launch_rescore(const void* corpus_f16, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx, const float* delta,
+                          float min_score, int nq, int k, unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream) {
+  hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, stream, n_flagged);
+  hipLaunchKernelGGL(rescore_kernel, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(corpus_f16), dim, index_base, queries, approx,
+                     delta, min_score, k, out, n_flagged, flagged);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_flagged(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, void* hi, void* lo,
+                                 float* thr, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_flagged_kernel, dim3(cap), dim3(256), 0, stream, queries, dim, min_score, n_flagged, flagged, cap,
+                     reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo), thr);
+  return hipGetLastError();
+}
+
+}  // namespace tavb
