@@ -112,6 +112,10 @@ int tavb_normalize_rows_f32(tavb_ctx* ctx, const float* dev_in, float* dev_out, 
 /* float32 -> float16 (round to nearest even), used to build f16 corpora on device. */
 int tavb_convert_f32_to_f16(tavb_ctx* ctx, const float* dev_in, void* dev_out, int64_t count);
 
+/* A packed result key: (float32 score bits << 32) | (0xFFFFFFFF - ordinal); 0 = empty
+ * slot.  Bigger key = better hit, so per-shard lists merge with integer compares. */
+typedef uint64_t tavb_key;
+
 /* ---- synchronous lookups (host in, host out) ---------------------------------- */
 /* fuzzy_lookup_embedding without predicate (vectorbase.py:163-190):
  * up to k best rows with score >= min_score.  out_* hold k entries; *out_count = M. */
@@ -132,6 +136,35 @@ int tavb_search_subset(tavb_ctx* ctx, const float* query_host, const int64_t* ro
 int tavb_search_batch(tavb_ctx* ctx, const float* queries_host, int32_t nq, int32_t k, const float* min_scores,
                       int64_t* out_ordinals, float* out_scores, int32_t* out_counts);
 
+/* ---- message re-rank on the device (the step right after the lookup in both providers) -------- */
+/* Chunk row -> message ordinal map of the corpus: device int32 [rows], borrowed like the corpus (-1 = the row belongs to
+ * no message).  n_messages bounds the ordinals (size of the accept bitmap). */
+int tavb_set_row_messages(tavb_ctx* ctx, const int32_t* dev_row_to_msg, int64_t rows, int64_t n_messages);
+
+/* SqliteMessageTextIndex.lookup_by_embedding / lookup_in_subset_by_embedding (storage/sqlite/messageindex.py:296-326,
+ * 182-257) in one submission: the best k chunk rows with score >= min_score over the WHOLE corpus, THEN the
+ * set-membership filter on their message ordinals (accept_msgs_host: n_accept ordinals, the provider's
+ * `ordinals_set`; n_accept = -1: no filter), THEN the best score per message, sorted by score (stable: ties keep hit
+ * order), cut at max_messages -- the provider's order of operations, so it returns exactly what the provider returns
+ * (possibly fewer than max_messages).  out_* hold k entries. */
+int tavb_search_messages(tavb_ctx* ctx, const float* query_host, int32_t k, float min_score, const int32_t* accept_msgs_host, int64_t n_accept,
+                         int32_t max_messages, int64_t* out_messages, float* out_scores, int32_t* out_count);
+
+/* The in-memory provider's form (storage/memory/messageindex.py:173-207 via knowpro/textlocindex.py:164-177): a true
+ * subset gather (rows_host: corpus row per subset position, as tavb_search_subset), then the same aggregation. */
+int tavb_search_messages_subset(tavb_ctx* ctx, const float* query_host, const int64_t* rows_host, int64_t n_subset, int32_t k, float min_score,
+                                int32_t max_messages, int64_t* out_messages, float* out_scores, int32_t* out_count);
+
+/* Split form of tavb_search_batch for a caller that drives SEVERAL contexts (one per GPU, row shards of one corpus) from
+ * one thread: tavb_search_begin copies the queries and enqueues the kernels on the context's stream, tavb_search_end
+ * waits for them and returns nq sorted lists of k keys.  Keys carry ordinal_base + row (must stay below 2^32 - 1), so the
+ * lists of the shards merge with tavb_merge_keys_host (lists [n_lists, nq, k] -> out [nq, k]; a pure host helper) and
+ * decode with tavb_decode_keys.  `cursor` (optional, nq == 1): only hits strictly AFTER that key in the result order,
+ * i.e. the paging cursor of tavb_search_after as a key -- the same key on every shard. */
+int tavb_search_begin(tavb_ctx* ctx, const float* queries_host, int32_t nq, int32_t k, const float* min_scores, const tavb_key* cursor);
+int tavb_search_end(tavb_ctx* ctx, int32_t nq, int32_t k, tavb_key* out_keys_host);
+int tavb_merge_keys_host(const tavb_key* lists, int32_t n_lists, int32_t nq, int32_t k, tavb_key* out);
+
 /* Continuation ("cursor") forms: the next k hits strictly AFTER the hit
  * (after_score, after_ordinal) in the (score descending, ordinal ascending) order.
  * Feeding the last hit of one page as the cursor of the next enumerates every row
@@ -145,11 +178,8 @@ int tavb_search_subset_after(tavb_ctx* ctx, const float* query_host, const int64
                              int32_t k, float min_score, float after_score, int64_t after_position,
                              int64_t* out_positions, float* out_scores, int32_t* out_count);
 
-/* ---- asynchronous device-resident lookups (sharding, benchmarking) -------------- */
-/* A packed result key: (float32 score bits << 32) | (0xFFFFFFFF - ordinal); 0 = empty
- * slot.  Bigger key = better hit, so per-shard lists merge with integer compares. */
-typedef uint64_t tavb_key;
 
+/* ---- asynchronous device-resident lookups (sharding, benchmarking) -------------- */
 /* Queries already on the device (float32 [nq, dim]); writes nq sorted lists of k keys to
  * dev_out_keys [nq, k] on the context's stream and returns without synchronising.
  * Keys carry ordinal_base + row (must stay below 2^32 - 1). */

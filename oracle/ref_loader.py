@@ -60,8 +60,12 @@ class NullEmbeddingModel:
         raise RuntimeError("oracle does not generate embeddings")
 
 
-def _install_stubs() -> None:
+def _install_stubs() -> list[str]:
+    """Register the stand-in sibling modules; returns the names this call added (the caller removes them again)."""
+    added: list[str] = []
+
     def _mod(name: str, is_pkg: bool) -> types.ModuleType:
+        added.append(name)
         m = types.ModuleType(name)
         if is_pkg:
             m.__path__ = []  # type: ignore[attr-defined]
@@ -85,6 +89,7 @@ def _install_stubs() -> None:
 
         ma.create_embedding_model = create_embedding_model
         sys.modules["typeagent.aitools.model_adapters"] = ma
+    return added
 
 
 _cached = None
@@ -99,7 +104,7 @@ def load_reference_vectorbase():
         raise FileNotFoundError(
             f"{_REF_FILE} not found: the verbatim reference is only available in the build container"
         )
-    _install_stubs()
+    added = _install_stubs()
     spec = importlib.util.spec_from_file_location(_MODNAME, _REF_FILE)
     assert spec is not None and spec.loader is not None
     mod = importlib.util.module_from_spec(spec)
@@ -114,6 +119,10 @@ def load_reference_vectorbase():
             sys.modules[_MODNAME] = saved
         else:
             del sys.modules[_MODNAME]
+        # ... and no stub `typeagent` package either: a later `typeagent_py_amd.install()` in this process must see the
+        # interpreter as it was (the loaded module keeps its own references to the stubs it imported)
+        for name in added:
+            sys.modules.pop(name, None)
     _cached = mod
     return mod
 

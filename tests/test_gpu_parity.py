@@ -400,31 +400,52 @@ def test_lookup_texts_batched_equals_sequential_fuzzy_lookup():
     assert asyncio.run(lookup_texts_batched(vb, [])) == []
 
 
-def test_message_lookup_adapters_match_provider_semantics():
-    """chunk rows -> message ordinals, in the order of operations of each provider."""
+def test_message_rerank_on_device_matches_provider_semantics():
+    """chunk rows -> message ordinals ON THE DEVICE (lookup + accept bitmap + per-message reduction in one
+    submission), in the order of operations of each provider.  The expectation is oracle/messages_oracle.py, which is pinned
+    to the verbatim `SqliteMessageTextIndex` in tests/test_reference_consumers.py."""
+    from oracle import messages_oracle as mo
     from typeagent_py_amd.adapters import lookup_messages_by_embedding, lookup_messages_in_subset
 
-    v, q = make_corpus(6000, 384, 9400)
-    row_to_msg = (np.arange(6000) // 3).tolist()  # three chunks per message
+    n = 30_000
+    v, q = make_corpus(n, 384, 9400)
+    rng = np.random.default_rng(9401)
+    row_to_msg = np.sort(rng.integers(0, 9_000, size=n)).astype(np.int64)  # 1 .. ~10 chunks per message, some ordinals unused
+    row_to_msg[rng.choice(n, size=200, replace=False)] = -1  # rows without a message (the SQL lookup finds nothing for them)
     vb = new_vb(v)
-    sc = vo.scores_full(v, q)
-    # sqlite style: top-25 chunks of the whole corpus, then the message filter, then max per message
-    got = lookup_messages_by_embedding(vb, q, row_to_msg, max_matches=25, threshold_score=0.5, accept=lambda m: m % 2 == 0)
-    top = sorted(range(6000), key=lambda i: (-sc[i], i))[:25]
-    want: dict[int, float] = {}
-    for i in top:
-        if sc[i] >= np.float32(0.5) and (i // 3) % 2 == 0:
-            want[i // 3] = max(want.get(i // 3, 0.0), float(sc[i]))
-    want_sorted = sorted(want.items(), key=lambda t: -t[1])
-    assert [h.item for h in got] == [m for m, _ in want_sorted]
-    np.testing.assert_allclose([h.score for h in got], [s for _, s in want_sorted], atol=SCORE_TOL, rtol=0)
-    # memory style: gather the subset rows, then max per message
-    subset = list(range(100, 400))
-    got = lookup_messages_in_subset(vb, q, subset, row_to_msg, max_matches=10, threshold_score=0.0)
-    best: dict[int, float] = {}
-    for i in sorted(subset, key=lambda i: (-sc[i], i))[:10]:
-        best[i // 3] = max(best.get(i // 3, 0.0), float(sc[i]))
-    assert [h.item for h in got] == [m for m, _ in sorted(best.items(), key=lambda t: -t[1])]
+    look = lambda e, k, t: vo.lookup(v, e, k, t)
+    qs = [q] + list(make_queries(4, 384, 9402))
+    # near-duplicates of one query inside one message, so that "best score per message" has something to do
+    big = int(row_to_msg[np.flatnonzero(row_to_msg >= 0)[500]])
+    rows_big = np.flatnonzero(row_to_msg == big)
+    for r in rows_big:
+        w = qs[1] + 0.5 * rng.standard_normal(384).astype(np.float32) / np.sqrt(384)
+        v[r] = w / np.linalg.norm(w)
+    vb = new_vb(v)
+    for qi, e in enumerate(qs):
+        for k, t, subset in ((25, 0.5, None), (None, None, None), (200, 0.0, None), (25, 0.0, list(range(0, 9_000, 2))), (40, 0.45, [big, 7, 7, 8999, 12345678]),
+                             (10, 0.0, [])):
+            want = mo.sqlite_lookup_by_embedding(look, e, row_to_msg, k, t, subset)
+            got = lookup_messages_by_embedding(vb, e, row_to_msg, max_matches=k, threshold_score=t, accept=subset)
+            assert [h.item for h in got] == [m for m, _ in want], (qi, k, t)
+            np.testing.assert_allclose([h.score for h in got], [s for _, s in want], atol=SCORE_TOL, rtol=0)
+    got = lookup_messages_by_embedding(vb, qs[1], row_to_msg, max_matches=25, threshold_score=0.0)
+    assert got[0].item == big and sum(1 for h in got if h.item == big) == 1 and len(got) < 25  # several chunks of `big` collapsed
+    # an arbitrary callable predicate: lookup on the device, aggregation on the host, same answer as the collection form
+    even = lookup_messages_by_embedding(vb, qs[0], row_to_msg, 25, 0.0, accept=lambda m: m % 2 == 0)
+    assert [h.item for h in even] == [h.item for h in lookup_messages_by_embedding(vb, qs[0], row_to_msg, 25, 0.0, accept=list(range(0, 9_000, 2)))]
+    # memory provider: true subset gather over index positions, then best score per message (no -1 rows there)
+    rtm = np.where(row_to_msg < 0, 0, row_to_msg)
+    subset = list(range(100, 4000)) + rows_big.tolist()
+    for e in qs[:3]:
+        hits = vo.lookup_in_subset(v, e, subset, 10, 0.0)
+        want = mo.memory_messages_from_hits(hits, rtm)
+        got = lookup_messages_in_subset(vb, e, subset, rtm, max_matches=10, threshold_score=0.0)
+        assert [h.item for h in got] == [m for m, _ in want]
+    # the map must cover the index
+    vb.add_embeddings(None, v[:3])
+    with pytest.raises(ValueError, match="covers"):
+        vb.lookup_messages_by_embedding(qs[0], 5, 0.0)
 
 
 def test_subset_semantics_from_reference_tests():

@@ -1,0 +1,170 @@
+"""One VectorBase over several devices from one process (typeagent_py_amd/multidevice.py).
+
+CPU part: the host logic of `DeviceGroup` (shard layout, appends, re-sharding, key merging, subset cursors) against the
+oracle, with a numpy stand-in for the per-device engine (test infrastructure: it computes a shard's answer with the
+oracle and packs it into result keys exactly like the kernels do).
+GPU part (`-m gpu`): the real thing, several contexts on the visible GPU(s), through the drop-in VectorBase API.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import vectorbase_oracle as vo
+from tests.fake_engine import FakeEngine
+from tests.fakes import NullModel
+from tests.synth import make_corpus, make_queries, subset_choice
+from typeagent_py_amd import TextEmbeddingIndexSettings, VectorBase, _native, multidevice
+
+
+@pytest.fixture
+def fake_group(monkeypatch):
+    FakeEngine.instances = []
+    monkeypatch.setattr(multidevice._native, "Engine", FakeEngine)
+    yield
+    FakeEngine.instances = []
+
+
+def _vb(devices):
+    return VectorBase(TextEmbeddingIndexSettings(NullModel()), devices=devices)
+
+
+def _check(vb, v, q, k, ms):
+    res = vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=ms)
+    rep = vo.check_topk_parity(vo.scores_full(v, q), [r.item for r in res], [r.score for r in res], k, ms)
+    assert rep.ordinals_bit_exact
+    return res
+
+
+def test_group_lookup_batch_and_layout_on_fake_devices(fake_group):
+    v, q = make_corpus(1003, 48, 11)
+    vb = _vb([0, 1, 2])
+    vb.add_embeddings(None, v)
+    _check(vb, v, q, 32, 0.0)
+    g = vb.engine
+    assert g.bounds == [0, 335, 670, 1003] and [e.ordinal_base for e in g.engines] == [0, 335, 670]
+    qs = make_queries(9, 48, 12)
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=10, min_score=0.5)
+    for qi in range(9):
+        ref = vo.lookup(v, qs[qi], 10, 0.5)
+        assert [r.item for r in out[qi]] == [i for i, _ in ref]
+    # ties across shards resolve to the smaller global ordinal
+    v2 = np.concatenate([v, v[:5]])
+    vb2 = _vb([0, 1])
+    vb2.add_embeddings(None, v2)
+    res = vb2.fuzzy_lookup_embedding(v[3], max_hits=2, min_score=0.0)
+    assert [r.item for r in res] == [3, 1006]
+
+
+def test_group_appends_go_to_the_last_shard_until_it_doubles(fake_group):
+    v, q = make_corpus(900, 32, 21)
+    vb = _vb([0, 1, 2])
+    vb.add_embeddings(None, v[:300])
+    _check(vb, v[:300], q, 10, 0.0)
+    e0, e1, e2 = vb.engine.engines
+    n0 = (len(e0.uploads), len(e1.uploads))
+    vb.add_embeddings(None, v[300:350])  # fits the last shard: only it is touched
+    _check(vb, v[:350], q, 10, 0.0)
+    assert (len(e0.uploads), len(e1.uploads)) == n0 and e2.uploads[-1] == (100, 50)
+    vb.add_embeddings(None, v[350:])  # 900 rows > 4 blocks of 100: re-shard from scratch
+    _check(vb, v, q, 10, 0.0)
+    assert vb.engine.bounds == [0, 300, 600, 900]
+    vb.add_embedding(None, v[0])
+    assert _check(vb, np.concatenate([v, v[:1]]), v[0], 2, 0.0)[0].item == 0
+
+
+def test_group_subset_paging_and_predicate_on_fake_devices(fake_group):
+    v, q = make_corpus(700, 32, 31)
+    vb = _vb([0, 1, 2, 3])
+    vb.add_embeddings(None, v)
+    sub = subset_choice(700, 200, 32) + [5, 5, -3]
+    res = vb.fuzzy_lookup_embedding_in_subset(q, sub, max_hits=20, min_score=0.0)
+    ref = vo.lookup_in_subset(v, q, sub, 20, 0.0)
+    assert [(r.item, r.score) for r in res] == [(i, pytest.approx(s, abs=1e-6)) for i, s in ref]
+    # paged paths: more hits than one page, all survivors, predicate
+    big = vb.fuzzy_lookup_embedding(q, max_hits=600, min_score=0.0)
+    ref = vo.lookup(v, q, 600, 0.0)
+    assert [r.item for r in big] == [i for i, _ in ref]
+    allhits = vb.fuzzy_lookup_embedding(q, max_hits=0, min_score=0.5)
+    assert [r.item for r in allhits] == [i for i, _ in vo.lookup(v, q, 0, 0.5)]
+    pred = vb.fuzzy_lookup_embedding(q, max_hits=7, min_score=0.0, predicate=lambda i: i % 3 == 0)
+    assert [r.item for r in pred] == [i for i, _ in vo.lookup(v, q, 7, 0.0, predicate=lambda i: i % 3 == 0)]
+    sub_all = vb.fuzzy_lookup_embedding_in_subset(q, sub, max_hits=0, min_score=0.0)  # paged subset search across shards
+    ref_all = vo.lookup_in_subset(v, q, sub, 0, 0.0)
+    assert sorted((r.item, round(r.score, 6)) for r in sub_all) == sorted((i, round(s, 6)) for i, s in ref_all)
+    assert [r.score for r in sub_all] == sorted((r.score for r in sub_all), reverse=True)
+
+
+def test_merge_keys_host_helper():
+    rng = np.random.default_rng(5)
+    lists = np.sort(rng.integers(1, 1 << 62, size=(5, 7, 9), dtype=np.uint64), axis=2)[:, :, ::-1].copy()
+    lists[2, 3, 4:] = 0  # a short list
+    got = _native.merge_keys(lists)
+    for q in range(7):
+        want = np.sort(lists[:, q, :].reshape(-1))[::-1][:9]
+        np.testing.assert_array_equal(got[q], want)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU: several contexts on the visible device(s)
+# ------------------------------------------------------------------------------------------------------------------
+def _device_list(n):
+    have = _native.device_count()
+    return [i % max(have, 1) for i in range(n)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_gpu_device_group_matches_oracle_through_the_vectorbase_api(dtype):
+    v, q = make_corpus(50_021, 1536, 41)
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), devices=_device_list(3), corpus_dtype=dtype)
+    vb.add_embeddings(None, v)
+    vv = v.astype(np.float16).astype(np.float32) if dtype == "fp16" else v
+    res = vb.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
+    assert vo.check_topk_parity(vo.scores_full(vv, q), [r.item for r in res], [r.score for r in res], 32, 0.0).ordinals_bit_exact
+    assert max(r.item for r in res) > 16_674  # hits from the later shards carry global ordinals
+    for nq in (7, 40, 300):  # streaming tier, 64-query tile, 256-query tile + rescoring: per shard, merged on the host
+        qs = make_queries(nq, 1536, 42 + nq)
+        out = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+        for qi in range(0, nq, max(1, nq // 12)):
+            rep = vo.check_topk_parity(vo.scores_full(vv, qs[qi]), [r.item for r in out[qi]], [r.score for r in out[qi]], 32, 0.0)
+            assert rep.ordinals_bit_exact
+    sub = subset_choice(50_021, 3000, 43) + [7, 7, -1]
+    res = vb.fuzzy_lookup_embedding_in_subset(q, sub, max_hits=25, min_score=0.0)
+    ref = vo.lookup_in_subset(vv, q, sub, 25, 0.0)
+    assert [r.item for r in res] == [i for i, _ in ref]
+    big = vb.fuzzy_lookup_embedding(q, max_hits=700, min_score=0.0)  # paged across shards
+    assert [r.item for r in big] == [i for i, _ in vo.lookup(vv, q, 700, 0.0)]
+    pred = vb.fuzzy_lookup_embedding(q, max_hits=9, min_score=0.0, predicate=lambda i: i % 5 == 1)
+    assert [r.item for r in pred] == [i for i, _ in vo.lookup(vv, q, 9, 0.0, predicate=lambda i: i % 5 == 1)]
+    vb.add_embeddings(None, v[:100])  # append into the last shard
+    res = vb.fuzzy_lookup_embedding(v[5], max_hits=2, min_score=0.0)
+    assert [r.item for r in res] == [5, 50_026]
+
+
+@pytest.mark.gpu
+def test_gpu_device_group_adopts_one_tensor_per_device():
+    import torch
+
+    v, q = make_corpus(9_001, 1536, 51)
+    devs = _device_list(2)
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), devices=devs)
+    parts = [torch.from_numpy(v[:4000]).to(f"cuda:{devs[0]}"), torch.from_numpy(v[4000:]).to(f"cuda:{devs[1]}")]
+    vb.adopt_device_corpus(parts)
+    assert len(vb) == 9_001
+    res = vb.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
+    assert vo.check_topk_parity(vo.scores_full(v, q), [r.item for r in res], [r.score for r in res], 32, 0.0).ordinals_bit_exact
+    np.testing.assert_array_equal(vb.serialize(), v)
+
+
+@pytest.mark.gpu
+def test_gpu_two_real_devices_when_present():
+    if _native.device_count() < 2:
+        pytest.skip("one GPU visible")
+    v, q = make_corpus(200_003, 1536, 61)
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), devices=[0, 1], corpus_dtype="fp16")
+    vb.add_embeddings(None, v)
+    vv = v.astype(np.float16).astype(np.float32)
+    qs = make_queries(130, 1536, 62)
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    for qi in range(0, 130, 13):
+        assert vo.check_topk_parity(vo.scores_full(vv, qs[qi]), [r.item for r in out[qi]], [r.score for r in out[qi]], 32, 0.0).ordinals_bit_exact

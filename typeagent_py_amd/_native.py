@@ -45,6 +45,13 @@ _SIGNATURES = [
     ("tavb_search_subset", c_int,
      [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, POINTER(c_int32)]),
     ("tavb_search_batch", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("tavb_set_row_messages", c_int, [c_void_p, c_void_p, c_int64, c_int64]),
+    ("tavb_search_messages", c_int, [c_void_p, c_void_p, c_int32, c_float, c_void_p, c_int64, c_int32, c_void_p, c_void_p, POINTER(c_int32)]),
+    ("tavb_search_messages_subset", c_int,
+     [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_int32, c_void_p, c_void_p, POINTER(c_int32)]),
+    ("tavb_search_begin", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    ("tavb_search_end", c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    ("tavb_merge_keys_host", c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     ("tavb_search_after", c_int,
      [c_void_p, c_void_p, c_int32, c_float, c_float, c_int64, c_void_p, c_void_p, POINTER(c_int32)]),
     ("tavb_search_subset_after", c_int,
@@ -257,6 +264,7 @@ class Engine:
             self.corpus[start:n_new].copy_(torch.from_numpy(src))
         self.set_corpus_tensor(self.corpus, rows=n_new, ordinal_base=self.ordinal_base)
         _check(self.lib, self.lib.tavb_corpus_modified(self._h, int(start)))  # rows [start, n_new) were (re)written
+        return True
 
     def clear(self) -> None:
         if self.corpus is not None:
@@ -349,6 +357,57 @@ class Engine:
         _check(self.lib, rc)
         return ords, scs, cnts
 
+    # message re-rank on the device ---------------------------------------------
+    def set_row_messages(self, row_to_message: np.ndarray) -> None:
+        """int array [rows]: chunk row -> message ordinal (-1 = none); kept on the device next to the corpus."""
+        torch = self._torch
+        m = np.ascontiguousarray(row_to_message, dtype=np.int32)
+        if m.ndim != 1:
+            raise ValueError("row_to_message must be 1-D")
+        self.row_messages = torch.from_numpy(m).to(torch.device("cuda", self.device))
+        torch.cuda.current_stream(self.device).synchronize()
+        n_messages = int(m.max()) + 1 if m.size else 0
+        _check(self.lib, self.lib.tavb_set_row_messages(self._h, c_void_p(self.row_messages.data_ptr()), m.shape[0], max(n_messages, 0)))
+
+    def search_messages(self, q, k: int, thr: np.float32, max_messages: int, accept=None, subset_rows=None):
+        """-> (message ordinals int64[m], scores float32[m]).  accept: int array of accepted message ordinals (sqlite
+        provider's subset form) or None; subset_rows: int64 corpus rows (memory provider's subset gather) or None."""
+        a = self._query(q)
+        msgs = np.empty(k, dtype=np.int64)
+        scs = np.empty(k, dtype=np.float32)
+        cnt = c_int32(0)
+        with self._lock:
+            if subset_rows is not None:
+                r = np.ascontiguousarray(subset_rows, dtype=np.int64)
+                rc = self.lib.tavb_search_messages_subset(self._h, a.ctypes.data_as(c_void_p), r.ctypes.data_as(c_void_p), r.shape[0], k, c_float(float(thr)),
+                                                          int(max_messages), msgs.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt))
+            else:
+                acc = None if accept is None else np.ascontiguousarray(accept, dtype=np.int32)
+                rc = self.lib.tavb_search_messages(self._h, a.ctypes.data_as(c_void_p), k, c_float(float(thr)),
+                                                   acc.ctypes.data_as(c_void_p) if acc is not None and acc.size else None,
+                                                   -1 if acc is None else acc.shape[0], int(max_messages),
+                                                   msgs.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt))
+        _check(self.lib, rc)
+        m = int(cnt.value)
+        return msgs[:m], scs[:m]
+
+    # split form (several contexts driven from one thread) --------------------
+    def search_begin(self, queries: np.ndarray, k: int, thrs: np.ndarray, cursor_key: int | None = None) -> None:
+        """queries f32 [nq, dim] (contiguous), thrs f32 [nq]: enqueue; pair with search_end(nq, k)."""
+        cur = None
+        if cursor_key is not None:
+            cur = (c_uint64 * 1)(int(cursor_key))
+        with self._lock:
+            rc = self.lib.tavb_search_begin(self._h, queries.ctypes.data_as(c_void_p), queries.shape[0], k, thrs.ctypes.data_as(c_void_p),
+                                            ctypes.cast(cur, c_void_p) if cur is not None else None)
+        _check(self.lib, rc)
+
+    def search_end(self, nq: int, k: int, out_keys: np.ndarray) -> None:
+        """out_keys: uint64 [nq, k] (contiguous) <- sorted key lists with global ordinals."""
+        with self._lock:
+            rc = self.lib.tavb_search_end(self._h, nq, k, out_keys.ctypes.data_as(c_void_p))
+        _check(self.lib, rc)
+
     # device-resident forms ---------------------------------------------------
     def search_device(self, dev_queries, k: int, thr: float, out_keys=None):
         """dev_queries: torch f32 [nq, dim] on this device -> torch int64 [nq, k] of packed keys (async)."""
@@ -387,6 +446,22 @@ class Engine:
             rc = self.lib.tavb_merge_device(self._h, c_void_p(dev_lists.data_ptr()), n_lists, nq, k, c_void_p(out_keys.data_ptr()))
         _check(self.lib, rc)
         return out_keys
+
+
+def make_key(score: float, ordinal: int) -> int:
+    """The packed key of (score, ordinal): (float32 bits << 32) | (0xFFFFFFFF - ordinal)."""
+    bits = int(np.float32(score).view(np.uint32))
+    return (bits << 32) | (0xFFFFFFFF - int(ordinal))
+
+
+def merge_keys(lists: np.ndarray) -> np.ndarray:
+    """uint64 [n_lists, nq, k] sorted key lists -> uint64 [nq, k] (host k-way merge in libtavb)."""
+    lib = load_library(preload_torch=False)
+    a = np.ascontiguousarray(lists, dtype=np.uint64)
+    n_lists, nq, k = a.shape
+    out = np.empty((nq, k), dtype=np.uint64)
+    _check(lib, lib.tavb_merge_keys_host(a.ctypes.data_as(c_void_p), n_lists, nq, k, out.ctypes.data_as(c_void_p)))
+    return out
 
 
 def decode_keys(keys: np.ndarray):

@@ -45,35 +45,48 @@ async def lookup_texts_batched(
     return vector_base.fuzzy_lookup_embeddings(np.asarray(embeddings, dtype=np.float32), max_hits=max_hits, min_score=min_score)
 
 
-def install_batched_lookup_terms() -> list[str]:
-    """When typeagent is importable, replace the two sequential `lookup_terms` bodies by the batched
-    form above.  Returns the names of the classes that were patched (empty here: typeagent needs
-    Python >= 3.12 and its provider dependencies)."""
-    patched: list[str] = []
+_patched: list[tuple[type, str, object]] = []
+
+
+def install_batched_lookup_terms() -> dict:
+    """When typeagent's related-terms indexes are importable, replace their two sequential `lookup_terms` bodies
+    (storage/memory/reltermsindex.py:320-332, storage/sqlite/reltermsindex.py:259-271) by the batched form above.
+    Returns {"patched": [class names], "skipped": {module name: reason}} -- a module that cannot be imported is reported,
+    never silently ignored; any other failure propagates.  `uninstall_batched_lookup_terms()` restores the originals."""
+    report: dict = {"patched": [], "skipped": {}}
     try:
         from typeagent.storage.memory import reltermsindex as mem  # type: ignore
-
+    except ImportError as exc:
+        report["skipped"]["typeagent.storage.memory.reltermsindex"] = f"{type(exc).__name__}: {exc}"
+    else:
         async def lookup_terms(self, texts, max_hits=None, min_score=None):
             matches = await lookup_texts_batched(self._vectorbase, texts, max_hits, min_score)
             return [self.matches_to_terms(m) for m in matches]
 
+        _patched.append((mem.TermEmbeddingIndex, "lookup_terms", mem.TermEmbeddingIndex.lookup_terms))
         mem.TermEmbeddingIndex.lookup_terms = lookup_terms
-        patched.append("typeagent.storage.memory.reltermsindex.TermEmbeddingIndex")
-    except Exception:
-        pass
+        report["patched"].append("typeagent.storage.memory.reltermsindex.TermEmbeddingIndex")
     try:
         from typeagent.knowpro import interfaces  # type: ignore
         from typeagent.storage.sqlite import reltermsindex as sql  # type: ignore
-
+    except ImportError as exc:
+        report["skipped"]["typeagent.storage.sqlite.reltermsindex"] = f"{type(exc).__name__}: {exc}"
+    else:
         async def lookup_terms_sql(self, texts, max_hits=None, min_score=None):
+            # == [await self.lookup_term(t, max_hits, min_score) for t in texts] (:259-271 over :158-179)
             matches = await lookup_texts_batched(self._vector_base, texts, max_hits, min_score)
             return [[interfaces.Term(self._terms_list[m.item], m.score) for m in ms if m.item < len(self._terms_list)] for ms in matches]
 
+        _patched.append((sql.SqliteRelatedTermsFuzzy, "lookup_terms", sql.SqliteRelatedTermsFuzzy.lookup_terms))
         sql.SqliteRelatedTermsFuzzy.lookup_terms = lookup_terms_sql
-        patched.append("typeagent.storage.sqlite.reltermsindex.SqliteRelatedTermsFuzzy")
-    except Exception:
-        pass
-    return patched
+        report["patched"].append("typeagent.storage.sqlite.reltermsindex.SqliteRelatedTermsFuzzy")
+    return report
+
+
+def uninstall_batched_lookup_terms() -> None:
+    while _patched:
+        cls, name, original = _patched.pop()
+        setattr(cls, name, original)
 
 
 def best_score_per_message(
@@ -104,12 +117,23 @@ def lookup_messages_by_embedding(
     row_to_message,
     max_matches: int | None = None,
     threshold_score: float | None = None,
-    accept: Callable[[int], bool] | None = None,
+    accept: Callable[[int], bool] | Sequence[int] | set | None = None,
 ) -> list[ScoredInt]:
     """`SqliteMessageTextIndex.lookup_by_embedding` / `lookup_in_subset_by_embedding` restated on the device
     path (storage/sqlite/messageindex.py:296-326): ONE full-corpus top-`max_matches` chunk lookup, THEN the
     message-ordinal filter, THEN best score per message, THEN the cut -- in that order, so that it returns
-    exactly what the sqlite provider returns (possibly fewer than `max_matches` messages)."""
+    exactly what the sqlite provider returns (possibly fewer than `max_matches` messages).
+    `accept`: the provider's `ordinals_set` as a collection of message ordinals -> the whole thing is one device
+    submission (`VectorBase.lookup_messages_by_embedding`: lookup + bitmap filter + per-message reduction kernels); an
+    arbitrary callable -> lookup on the device, aggregation on the host."""
+    if accept is None or not callable(accept):
+        if not callable(row_to_message):
+            if getattr(vector_base, "_row_messages_src", None) is not row_to_message:
+                vector_base.set_row_messages(row_to_message)
+            return vector_base.lookup_messages_by_embedding(embedding, max_matches, threshold_score, accept_ordinals=accept)
+        if accept is not None:
+            members = set(int(x) for x in accept)
+            accept = members.__contains__
     hits = vector_base.fuzzy_lookup_embedding(embedding, max_hits=max_matches, min_score=threshold_score)
     return best_score_per_message(hits, row_to_message, max_matches, accept)
 
@@ -123,7 +147,13 @@ def lookup_messages_in_subset(
     threshold_score: float | None = None,
 ) -> list[ScoredInt]:
     """The memory provider's form (storage/memory/messageindex.py:173-207 via knowpro/textlocindex.py:164-177):
-    a true subset gather on the device, then best score per message and the cut."""
+    a true subset gather on the device, then best score per message and the cut (one device submission when
+    `row_to_message` is an array)."""
+    if not callable(row_to_message):
+        if getattr(vector_base, "_row_messages_src", None) is not row_to_message:
+            vector_base.set_row_messages(row_to_message)
+        out = vector_base.lookup_messages_in_subset_by_embedding(embedding, list(rows_of_subset), max_matches, threshold_score)
+        return out if max_matches is None else out[:max_matches]
     hits = vector_base.fuzzy_lookup_embedding_in_subset(embedding, list(rows_of_subset), max_hits=max_matches, min_score=threshold_score)
     return best_score_per_message(hits, row_to_message, max_matches)
 

@@ -112,6 +112,9 @@ struct tavb_ctx {
 
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand, d_thr, d_sample_keys;
   Buffer d_delta, d_approx, d_flag, d_fb_queries, d_norm;  // exact rescoring of the 256-query tile (tavb_rescore.hip)
+  Buffer d_accept, d_bits;  // message re-rank: accepted message ordinals, their bitmap
+  const int32_t* row_to_msg = nullptr;  // borrowed device map chunk row -> message ordinal
+  int64_t row_to_msg_rows = 0, n_messages = 0;
   int64_t norm_rows = 0;  // rows of the corpus covered by the cached maximum row norm (d_norm)
   Buffer h_stage{nullptr, 0, true};
   Buffer h_out{nullptr, 0, true};  // pinned + device-visible: the last kernel of a synchronous lookup writes its keys straight here
@@ -123,6 +126,7 @@ struct tavb_ctx {
   std::vector<hipEvent_t> free_events;
 
   int last_tier = 0;
+  int pending_nq = 0, pending_k = 0;  // shape of the lookup enqueued by tavb_search_begin
 };
 
 namespace {
@@ -346,6 +350,8 @@ int tavb_destroy(tavb_ctx* c) {
   c->d_flag.release();
   c->d_fb_queries.release();
   c->d_norm.release();
+  c->d_accept.release();
+  c->d_bits.release();
   c->h_stage.release();
   c->h_out.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -525,6 +531,75 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
   return TAVB_OK;
 }
 
+int tavb_search_begin(tavb_ctx* c, const float* queries_host, int32_t nq, int32_t k, const float* min_scores, const tavb_key* cursor) {
+  if (int rc = check_search_args(c, k)) return rc;
+  if (nq < 1) return fail(TAVB_E_INVALID, "nq must be >= 1");
+  if (!queries_host || !min_scores) return fail(TAVB_E_INVALID, "null argument");
+  if (cursor && nq != 1) return fail(TAVB_E_INVALID, "a cursor goes with exactly one query");
+  if (c->ordinal_base + c->rows >= 0xFFFFFFFFll)
+    return fail(TAVB_E_UNSUPPORTED, "keys hold 32-bit ordinals: ordinal_base + rows must be < 2^32 - 1");
+  DeviceGuard guard(c->device);
+  const size_t qbytes = (size_t)nq * c->dim * sizeof(float);
+  const size_t obytes = (size_t)nq * k * sizeof(u64_t);
+  if (int rc = c->h_stage.reserve(qbytes)) return rc;
+  if (int rc = c->h_out.reserve(obytes)) return rc;
+  if (int rc = c->d_queries.reserve(qbytes)) return rc;
+  c->pending_nq = c->pending_k = 0;
+  if (c->rows == 0) {
+    memset(c->h_out.ptr, 0, obytes);
+  } else {
+    memcpy(c->h_stage.ptr, queries_host, qbytes);
+    TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
+    int rc;
+    if (cursor)
+      rc = search_device_impl(c, reinterpret_cast<const float*>(c->d_queries.ptr), 1, k, min_scores, nullptr, c->rows, (uint32_t)c->ordinal_base,
+                              reinterpret_cast<u64_t*>(c->h_out.ptr), (u64_t)*cursor);
+    else
+      rc = tavb_search_device_dispatch(c, reinterpret_cast<const float*>(c->d_queries.ptr), nq, k, min_scores, (uint32_t)c->ordinal_base,
+                                       reinterpret_cast<u64_t*>(c->h_out.ptr));
+    if (rc) return rc;
+  }
+  c->pending_nq = nq;
+  c->pending_k = k;
+  return TAVB_OK;
+}
+
+int tavb_search_end(tavb_ctx* c, int32_t nq, int32_t k, tavb_key* out_keys_host) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!out_keys_host) return fail(TAVB_E_INVALID, "null argument");
+  if (nq != c->pending_nq || k != c->pending_k || nq < 1) return fail(TAVB_E_INVALID, "tavb_search_end does not match the pending tavb_search_begin");
+  DeviceGuard guard(c->device);
+  TAVB_HIP(hipStreamSynchronize(c->stream));
+  memcpy(out_keys_host, c->h_out.ptr, (size_t)nq * k * sizeof(u64_t));
+  c->pending_nq = c->pending_k = 0;
+  return TAVB_OK;
+}
+
+int tavb_merge_keys_host(const tavb_key* lists, int32_t n_lists, int32_t nq, int32_t k, tavb_key* out) {
+  if (n_lists < 1 || nq < 0 || k < 1) return fail(TAVB_E_INVALID, "bad merge shape");
+  if (nq == 0) return TAVB_OK;
+  if (!lists || !out) return fail(TAVB_E_INVALID, "null argument");
+  std::vector<int> head((size_t)n_lists);
+  for (int q = 0; q < nq; ++q) {
+    std::fill(head.begin(), head.end(), 0);
+    for (int i = 0; i < k; ++i) {
+      int best = -1;
+      u64_t best_key = 0;
+      for (int l = 0; l < n_lists; ++l) {
+        if (head[l] >= k) continue;
+        const u64_t key = lists[((size_t)l * nq + q) * k + head[l]];
+        if (key > best_key) {
+          best_key = key;
+          best = l;
+        }
+      }
+      out[(size_t)q * k + i] = best_key;  // 0 once every list is exhausted
+      if (best >= 0) ++head[best];
+    }
+  }
+  return TAVB_OK;
+}
+
 int tavb_search(tavb_ctx* c, const float* query_host, int32_t k, float min_score, int64_t* out_ordinals,
                 float* out_scores, int32_t* out_count) {
   return tavb_search_batch(c, query_host, 1, k, &min_score, out_ordinals, out_scores, out_count);
@@ -573,6 +648,109 @@ static int search_subset_impl(tavb_ctx* c, const float* query_host, const int64_
   TAVB_HIP(hipStreamSynchronize(c->stream));
   decode(reinterpret_cast<const u64_t*>(c->h_out.ptr), 1, k, 0, out_positions, out_scores, out_count);
   return TAVB_OK;
+}
+
+int tavb_set_row_messages(tavb_ctx* c, const int32_t* dev_row_to_msg, int64_t rows, int64_t n_messages) {
+  if (int rc = check_ctx(c)) return rc;
+  if (rows < 0 || n_messages < 0) return fail(TAVB_E_INVALID, "bad shape");
+  if (rows > 0 && !dev_row_to_msg) return fail(TAVB_E_INVALID, "null map with rows > 0");
+  if (n_messages >= 0xFFFFFFFFll) return fail(TAVB_E_UNSUPPORTED, "message ordinals must stay below 2^32 - 1");
+  c->row_to_msg = dev_row_to_msg;
+  c->row_to_msg_rows = rows;
+  c->n_messages = n_messages;
+  return TAVB_OK;
+}
+
+// hits (device keys [k]) -> message keys in pinned host memory -> caller's arrays
+static int rerank_and_return(tavb_ctx* c, const u64_t* d_hits, int k, const int32_t* d_pos_to_row, const int32_t* accept_msgs_host, int64_t n_accept,
+                             bool filtered, int32_t max_messages, int64_t* out_messages, float* out_scores, int32_t* out_count) {
+  const uint32_t* d_bits = nullptr;
+  if (filtered) {
+    const size_t words = (size_t)((c->n_messages + 31) / 32) + 1;
+    if (int rc = c->d_bits.reserve(words * 4)) return rc;
+    TAVB_HIP(hipMemsetAsync(c->d_bits.ptr, 0, words * 4, c->stream));
+    if (n_accept > 0) {
+      if (int rc = c->d_accept.reserve((size_t)n_accept * 4)) return rc;
+      // (pageable source: the copy is staged by the runtime before the call returns)
+      TAVB_HIP(hipMemcpyAsync(c->d_accept.ptr, accept_msgs_host, (size_t)n_accept * 4, hipMemcpyHostToDevice, c->stream));
+      hipError_t e = tavb::launch_accept_bitmap(reinterpret_cast<const int32_t*>(c->d_accept.ptr), n_accept, reinterpret_cast<uint32_t*>(c->d_bits.ptr),
+                                                c->n_messages, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "bitmap launch failed: %s", hipGetErrorString(e));
+    }
+    d_bits = reinterpret_cast<const uint32_t*>(c->d_bits.ptr);
+  }
+  hipError_t e = tavb::launch_message_rerank(d_hits, 1, k, 0u, d_pos_to_row, c->row_to_msg, c->row_to_msg_rows, d_bits, c->n_messages, max_messages,
+                                             reinterpret_cast<u64_t*>(c->h_out.ptr), c->stream);
+  if (e != hipSuccess) return fail(TAVB_E_HIP, "re-rank launch failed: %s", hipGetErrorString(e));
+  TAVB_HIP(hipStreamSynchronize(c->stream));
+  decode(reinterpret_cast<const u64_t*>(c->h_out.ptr), 1, k, 0, out_messages, out_scores, out_count);
+  return TAVB_OK;
+}
+
+static int check_message_args(tavb_ctx* c, int k, int32_t max_messages) {
+  if (int rc = check_search_args(c, k)) return rc;
+  if (!c->row_to_msg && c->rows > 0) return fail(TAVB_E_NO_CORPUS, "no row -> message map set (call tavb_set_row_messages first)");
+  if (c->row_to_msg_rows < c->rows) return fail(TAVB_E_INVALID, "the row -> message map covers %lld rows, the corpus has %lld", (long long)c->row_to_msg_rows, (long long)c->rows);
+  if (max_messages < 0) return fail(TAVB_E_INVALID, "max_messages must be >= 0");
+  return TAVB_OK;
+}
+
+int tavb_search_messages(tavb_ctx* c, const float* query_host, int32_t k, float min_score, const int32_t* accept_msgs_host, int64_t n_accept,
+                         int32_t max_messages, int64_t* out_messages, float* out_scores, int32_t* out_count) {
+  if (int rc = check_message_args(c, k, max_messages)) return rc;
+  if (!query_host || !out_messages || !out_scores || !out_count) return fail(TAVB_E_INVALID, "null argument");
+  if (n_accept < -1 || (n_accept > 0 && !accept_msgs_host)) return fail(TAVB_E_INVALID, "bad accept list");
+  *out_count = 0;
+  if (c->rows == 0) return TAVB_OK;
+  DeviceGuard guard(c->device);
+  const size_t qbytes = (size_t)c->dim * sizeof(float);
+  const size_t obytes = (size_t)k * sizeof(u64_t);
+  if (int rc = c->h_stage.reserve(qbytes)) return rc;
+  if (int rc = c->h_out.reserve(obytes)) return rc;
+  if (int rc = c->d_queries.reserve(qbytes)) return rc;
+  if (int rc = c->d_out.reserve(obytes)) return rc;
+  memcpy(c->h_stage.ptr, query_host, qbytes);
+  TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
+  // keys carry LOCAL rows here (index_base 0): they only index the map
+  if (int rc = search_device_impl(c, reinterpret_cast<const float*>(c->d_queries.ptr), 1, k, &min_score, nullptr, c->rows, 0u,
+                                  reinterpret_cast<u64_t*>(c->d_out.ptr)))
+    return rc;
+  return rerank_and_return(c, reinterpret_cast<const u64_t*>(c->d_out.ptr), k, nullptr, accept_msgs_host, n_accept, n_accept >= 0, max_messages, out_messages,
+                           out_scores, out_count);
+}
+
+int tavb_search_messages_subset(tavb_ctx* c, const float* query_host, const int64_t* rows_host, int64_t n_subset, int32_t k, float min_score,
+                                int32_t max_messages, int64_t* out_messages, float* out_scores, int32_t* out_count) {
+  if (int rc = check_message_args(c, k, max_messages)) return rc;
+  if (!query_host || !out_messages || !out_scores || !out_count) return fail(TAVB_E_INVALID, "null argument");
+  if (n_subset < 0 || n_subset >= 0x7FFFFFFFll) return fail(TAVB_E_INVALID, "bad subset length");
+  *out_count = 0;
+  if (n_subset == 0 || c->rows == 0) return TAVB_OK;
+  if (!rows_host) return fail(TAVB_E_INVALID, "null rows_host");
+  DeviceGuard guard(c->device);
+  const size_t qbytes = (size_t)c->dim * sizeof(float);
+  const size_t rbytes = (size_t)n_subset * sizeof(int32_t);
+  const size_t obytes = (size_t)k * sizeof(u64_t);
+  const size_t qoff = (rbytes + 255) & ~(size_t)255;
+  if (int rc = c->h_stage.reserve(qoff + qbytes)) return rc;
+  if (int rc = c->h_out.reserve(obytes)) return rc;
+  if (int rc = c->d_queries.reserve(qbytes)) return rc;
+  if (int rc = c->d_rows.reserve(rbytes)) return rc;
+  if (int rc = c->d_out.reserve(obytes)) return rc;
+  int32_t* r32 = reinterpret_cast<int32_t*>(c->h_stage.ptr);
+  for (int64_t i = 0; i < n_subset; ++i) {
+    const int64_t r = rows_host[i];
+    if (r < 0 || r >= c->rows) return fail(TAVB_E_INVALID, "subset row %lld out of range [0, %lld)", (long long)r, (long long)c->rows);
+    r32[i] = (int32_t)r;
+  }
+  memcpy(reinterpret_cast<char*>(c->h_stage.ptr) + qoff, query_host, qbytes);
+  TAVB_HIP(hipMemcpyAsync(c->d_rows.ptr, c->h_stage.ptr, rbytes, hipMemcpyHostToDevice, c->stream));
+  TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, reinterpret_cast<char*>(c->h_stage.ptr) + qoff, qbytes, hipMemcpyHostToDevice, c->stream));
+  if (int rc = search_device_impl(c, reinterpret_cast<const float*>(c->d_queries.ptr), 1, k, &min_score, reinterpret_cast<const int32_t*>(c->d_rows.ptr),
+                                  n_subset, 0u, reinterpret_cast<u64_t*>(c->d_out.ptr)))
+    return rc;
+  return rerank_and_return(c, reinterpret_cast<const u64_t*>(c->d_out.ptr), k, reinterpret_cast<const int32_t*>(c->d_rows.ptr), nullptr, 0, false,
+                           max_messages, out_messages, out_scores, out_count);
 }
 
 int tavb_search_subset(tavb_ctx* c, const float* query_host, const int64_t* rows_host, int64_t n_subset, int32_t k,

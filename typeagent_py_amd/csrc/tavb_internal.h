@@ -43,6 +43,12 @@ hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, in
 hipError_t launch_merge_scatter(const unsigned long long* lists, int n_lists, int nq, int k, const int* active, const int* scatter,
                                 unsigned long long* out, hipStream_t stream);
 
+// chunk-row hits -> message hits (tavb_misc.hip)
+hipError_t launch_accept_bitmap(const int32_t* msgs, int64_t n, uint32_t* bits, int64_t n_bits, hipStream_t stream);
+hipError_t launch_message_rerank(const unsigned long long* hits, int nq, int k, uint32_t index_base, const int32_t* pos_to_row, const int32_t* row_to_msg,
+                                 int64_t n_rows, const uint32_t* accept_bits, int64_t n_bits, int max_messages, unsigned long long* out,
+                                 hipStream_t stream);
+
 // exact fp32-query semantics for the 256-query tile (tavb_rescore.hip)
 hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, float* out_sq, hipStream_t stream);
 hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, const float* max_norm_sq, void* q16, float* delta, float* thr,

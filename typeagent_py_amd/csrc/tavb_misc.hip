@@ -228,4 +228,70 @@ hipError_t launch_f32_split_f16(const float* in, void* hi, void* lo, int64_t cou
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Message re-rank: chunk-row hits -> message hits, on the device (the step right after the lookup in both providers:
+// storage/sqlite/messageindex.py:182-257, 296-326; storage/memory/messageindex.py:185-207).
+//   hits (sorted by score desc, row asc) -> msg = row_to_msg[row] (rows without a message, -1, are skipped: the SQL
+//   `WHERE index_position IN (...)` finds nothing for them) -> optional set-membership filter on msg (the provider's
+//   predicate / `ordinals_set`) -> best score per message -> sort by score desc (stable) -> first max_messages.
+// Because the hits arrive best first, "best score per message" is the FIRST accepted hit of each message and the stable
+// sort leaves that subsequence as it is: the result is the accepted first occurrences, in hit order, cut at
+// max_messages.  Output: keys (score bits << 32 | 0xFFFFFFFF - msg), 0-terminated, like every other result list.
+// One workgroup per query; k <= 256 hits.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) accept_bitmap_kernel(const int32_t* __restrict__ msgs, int64_t n, uint32_t* __restrict__ bits, int64_t n_bits) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = msgs[i];
+    if (m >= 0 && m < n_bits) atomicOr(&bits[m >> 5], 1u << (m & 31));
+  }
+}
+
+__global__ void __launch_bounds__(256) message_rerank_kernel(const u64* __restrict__ hits /*[nq, k]*/, int k, uint32_t index_base,
+                                                             const int32_t* __restrict__ pos_to_row /*optional: subset position -> row*/,
+                                                             const int32_t* __restrict__ row_to_msg, int64_t n_rows,
+                                                             const uint32_t* __restrict__ accept_bits /*optional*/, int64_t n_bits, int max_messages,
+                                                             u64* __restrict__ out /*[nq, k]*/) {
+  __shared__ int msg_of[256];
+  __shared__ unsigned char keep[256];
+  const int i = threadIdx.x;
+  const u64* h = hits + (size_t)blockIdx.x * k;
+  u64* o = out + (size_t)blockIdx.x * k;
+  u64 key = (i < k) ? h[i] : 0ull;
+  int msg = -1;
+  if (key != 0ull) {
+    int64_t row = (int64_t)(0xFFFFFFFFu - (uint32_t)key) - (int64_t)index_base;
+    if (pos_to_row != nullptr) row = pos_to_row[row];
+    if (row >= 0 && row < n_rows) msg = row_to_msg[row];
+    if (msg >= 0 && accept_bits != nullptr && !(msg < n_bits && ((accept_bits[msg >> 5] >> (msg & 31)) & 1u))) msg = -1;
+  }
+  msg_of[i] = msg;
+  __syncthreads();
+  bool first = msg >= 0;
+  for (int j = 0; first && j < i; ++j) first = (msg_of[j] != msg);  // an earlier (better or equal) hit of the same message wins
+  keep[i] = first ? 1 : 0;
+  __syncthreads();
+  int pos = 0;
+  for (int j = 0; j < i; ++j) pos += keep[j];
+  if (i < k) o[i] = 0ull;
+  __syncthreads();
+  if (first && pos < max_messages && pos < k) o[pos] = (key & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - (uint32_t)msg);
+}
+
+hipError_t launch_accept_bitmap(const int32_t* msgs, int64_t n, uint32_t* bits, int64_t n_bits, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(accept_bitmap_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, msgs, n, bits, n_bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_message_rerank(const unsigned long long* hits, int nq, int k, uint32_t index_base, const int32_t* pos_to_row, const int32_t* row_to_msg,
+                                 int64_t n_rows, const uint32_t* accept_bits, int64_t n_bits, int max_messages, unsigned long long* out,
+                                 hipStream_t stream) {
+  if (nq < 1 || k < 1 || k > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(message_rerank_kernel, dim3(nq), dim3(256), 0, stream, hits, k, index_base, pos_to_row, row_to_msg, n_rows, accept_bits, n_bits,
+                     max_messages, out);
+  return hipGetLastError();
+}
+
 }  // namespace tavb

@@ -122,11 +122,16 @@ class VectorBase:
         *,
         device: int | None = None,
         corpus_dtype: str | None = None,
+        devices: list[int] | None = None,
     ):
         self.settings = settings
         self._model = settings.embedding_model
         self._embedding_size = 0
         self._device_index = device if device is not None else (int(os.environ["TYPEAGENT_VB_DEVICE"]) if "TYPEAGENT_VB_DEVICE" in os.environ else None)
+        # several GPUs under ONE object (row shards, one context + stream per device; typeagent_py_amd/multidevice.py)
+        if devices is None and os.environ.get("TYPEAGENT_VB_DEVICES"):
+            devices = [int(x) for x in os.environ["TYPEAGENT_VB_DEVICES"].split(",") if x.strip() != ""]
+        self._devices = list(devices) if devices else None
         if corpus_dtype is None:
             self._dtype = _env_dtype()
         else:
@@ -137,6 +142,8 @@ class VectorBase:
         self._dev_rows = 0  # rows of the host matrix already mirrored on the device
         self._dev_valid = True  # False => the device copy must be rebuilt from row 0
         self._device_only = None  # torch tensor when the corpus lives only on the device
+        self._row_messages: np.ndarray | None = None  # chunk row -> message ordinal (message re-rank on the device)
+        self._row_messages_rows = -1  # rows of the map already on the device
         self.clear()
 
     # ------------------------------------------------------------------ storage
@@ -162,7 +169,10 @@ class VectorBase:
     def _materialize_host(self) -> None:
         t, n = self._device_only, self._count
         self._device_only = None
-        host = t[:n].float().cpu().numpy()
+        if isinstance(t, list):
+            host = np.concatenate([x.float().cpu().numpy() for x in t])[:n]
+        else:
+            host = t[:n].float().cpu().numpy()
         self._host, self._count = host, n  # device copy stays valid: same rows
         if self._dtype == _native.TAVB_F16:
             pass  # host copy holds the fp16 values widened to f32
@@ -238,7 +248,12 @@ class VectorBase:
     # ------------------------------------------------------------------ device mirror
     def _ensure_engine(self) -> _native.Engine:
         if self._engine is None:
-            self._engine = _native.Engine(self._device_index)
+            if self._devices:
+                from .multidevice import DeviceGroup
+
+                self._engine = DeviceGroup(self._devices)
+            else:
+                self._engine = _native.Engine(self._device_index)
         return self._engine
 
     def _sync_device(self) -> _native.Engine:
@@ -253,7 +268,9 @@ class VectorBase:
             self._dev_rows = 0
         if self._dev_rows < n or eng.rows != n or eng.dim != self._embedding_size:
             start = self._dev_rows if (eng.corpus is not None and eng.dim == self._embedding_size and eng.dtype == self._dtype) else 0
-            eng.upload_rows(self._host[start:n], start, self._dtype, capacity_hint=self._host.shape[0] if start == 0 else 0)
+            done = eng.upload_rows(self._host[start:n], start, self._dtype, capacity_hint=self._host.shape[0] if start == 0 else 0)
+            if done is False:  # a device group has to re-shard: everything again
+                eng.upload_rows(self._host[:n], 0, self._dtype, capacity_hint=self._host.shape[0])
             self._dev_rows = n
         return eng
 
@@ -265,11 +282,17 @@ class VectorBase:
     def adopt_device_corpus(self, tensor, rows: int | None = None, ordinal_base: int = 0) -> None:
         """Use a float32/float16 torch tensor [N, D] already on the GPU as the corpus
         without a host copy (corpora larger than host RAM).  serialize() will copy
-        it back on demand."""
+        it back on demand.  With `devices=[...]`: a list of tensors, one row shard per device."""
         eng = self._ensure_engine()
         eng.ordinal_base = ordinal_base
-        eng.set_corpus_tensor(tensor, rows=rows, ordinal_base=ordinal_base)
-        self._set_embedding_size(int(tensor.shape[1]))
+        if self._devices:  # one tensor per device, row shards in order
+            tensors = list(tensor) if isinstance(tensor, (list, tuple)) else [tensor]
+            eng.set_shard_tensors(tensors, ordinal_base=ordinal_base)
+            tensor = tensors
+            self._set_embedding_size(int(tensors[0].shape[1]))
+        else:
+            eng.set_corpus_tensor(tensor, rows=rows, ordinal_base=ordinal_base)
+            self._set_embedding_size(int(tensor.shape[1]))
         self._device_only = tensor
         self._count = eng.rows
         self._dtype = eng.dtype
@@ -386,6 +409,95 @@ class VectorBase:
             m = int(cnts[qi])
             out.append([ScoredInt(int(i), float(s)) for i, s in zip(ords[qi, :m].tolist(), scs[qi, :m].tolist())])
         return out
+
+    # ------------------------------------------------------------------ message re-rank (additive)
+    def set_row_messages(self, row_to_message) -> None:
+        """chunk row -> message ordinal for every row of the index (-1: none): what the providers keep as
+        `TextLocation.message_ordinal` per index position (knowpro/textlocindex.py:54-73; the `msg_id` column of
+        storage/sqlite/schema.py:71-81).  Enables `lookup_messages_by_embedding*`, which run the providers' post-lookup
+        aggregation on the device."""
+        self._row_messages_src = row_to_message  # identity of the caller's object: callers that pass it every time do not re-upload
+        self._row_messages = np.ascontiguousarray(row_to_message, dtype=np.int64).reshape(-1)
+        self._row_messages_rows = -1
+
+    def _messages_engine(self):
+        """engine with corpus AND map synced, or None when the aggregation has to run on the host (device group)."""
+        if self._row_messages is None:
+            raise RuntimeError("set_row_messages() first")
+        if len(self._row_messages) < self._count:
+            raise ValueError(f"the row -> message map covers {len(self._row_messages)} rows, the index has {self._count}")
+        eng = self._sync_device()
+        if not isinstance(eng, _native.Engine):
+            return None
+        if self._row_messages_rows != self._count:
+            eng.set_row_messages(self._row_messages[: self._count])
+            self._row_messages_rows = self._count
+        return eng
+
+    def _host_rerank(self, hits, max_matches, accept=None) -> list[ScoredInt]:
+        best: dict[int, float] = {}
+        for h in hits:
+            msg = int(self._row_messages[h.item])
+            if msg < 0 or (accept is not None and msg not in accept):
+                continue
+            if msg not in best:
+                best[msg] = h.score  # hits arrive best first: the first occurrence is the best score
+        out = [ScoredInt(m, sc) for m, sc in best.items()]
+        return out if max_matches is None else out[:max_matches]
+
+    def lookup_messages_by_embedding(
+        self,
+        embedding: NormalizedEmbedding,
+        max_matches: int | None = None,
+        threshold_score: float | None = None,
+        accept_ordinals=None,
+    ) -> list[ScoredInt]:
+        """`SqliteMessageTextIndex.lookup_by_embedding` / `lookup_in_subset_by_embedding`
+        (storage/sqlite/messageindex.py:296-326, 182-257) as ONE device submission: full-corpus top-`max_matches` chunk
+        rows (None -> 10, like `fuzzy_lookup_embedding`), THEN the membership filter on their message ordinals
+        (`accept_ordinals`, the provider's `ordinals_set`), THEN best score per message, THEN the cut -- the provider's
+        order, so the result is the provider's (possibly fewer than `max_matches` messages).  -> [ScoredInt(message, score)]."""
+        max_hits, thr = self._limits(max_matches, threshold_score)
+        if self._count == 0:
+            return []
+        eng = self._messages_engine()
+        cut = max_hits if max_matches is not None else max(max_hits, 1)
+        if eng is None or not (1 <= max_hits <= _PAGE):
+            hits = self.fuzzy_lookup_embedding(embedding, max_hits=max_matches, min_score=threshold_score)
+            return self._host_rerank(hits, max_matches, None if accept_ordinals is None else set(int(x) for x in accept_ordinals))
+        acc = None if accept_ordinals is None else np.fromiter((int(x) for x in accept_ordinals), dtype=np.int64)
+        if acc is not None:
+            acc = acc[(acc >= 0) & (acc < 2**31 - 1)]
+        msgs, scs = eng.search_messages(embedding, max_hits, thr, cut, accept=acc)
+        return [ScoredInt(int(m), float(sc)) for m, sc in zip(msgs.tolist(), scs.tolist())]
+
+    def lookup_messages_in_subset_by_embedding(
+        self,
+        embedding: NormalizedEmbedding,
+        rows_of_subset: list[int],
+        max_matches: int | None = None,
+        threshold_score: float | None = None,
+    ) -> list[ScoredInt]:
+        """The in-memory provider's form (storage/memory/messageindex.py:173-207 via knowpro/textlocindex.py:164-177): a
+        true subset gather over the given index positions, then best score per message, sorted."""
+        max_hits, thr = self._limits(max_matches, threshold_score)
+        if len(rows_of_subset) == 0 or self._count == 0:
+            return []
+        eng = self._messages_engine()
+        if eng is None or not (1 <= max_hits <= _PAGE):
+            hits = self.fuzzy_lookup_embedding_in_subset(embedding, rows_of_subset, max_hits=max_matches, min_score=threshold_score)
+            return self._host_rerank(hits, None)
+        subset = np.asarray(rows_of_subset)
+        if subset.dtype.kind not in "iu":
+            raise IndexError("arrays used as indices must be of integer (or boolean) type")
+        subset = subset.astype(np.int64, copy=False).reshape(-1)
+        n = self._count
+        rows = np.where(subset < 0, subset + n, subset)
+        bad = (rows < 0) | (rows >= n)
+        if bad.any():
+            raise IndexError(f"index {int(subset[np.argmax(bad)])} is out of bounds for axis 0 with size {n}")
+        msgs, scs = eng.search_messages(embedding, max_hits, thr, max_hits, subset_rows=rows)
+        return [ScoredInt(int(m), float(sc)) for m, sc in zip(msgs.tolist(), scs.tolist())]
 
     async def fuzzy_lookup(
         self,
