@@ -99,6 +99,14 @@ int tavb_get_option(tavb_ctx* ctx, const char* name, int64_t* out_value);
 int tavb_set_corpus(tavb_ctx* ctx, const void* dev_rows, int64_t rows, int32_t dim, int32_t dtype,
                     int64_t ordinal_base);
 
+/* Load path (what knowpro/serialization.py:207-221 and the BLOB reload loops of
+ * storage/sqlite/messageindex.py:33-45 / reltermsindex.py:144-156 feed): float32 host rows [n_rows, dim] -> device
+ * memory at dev_dst (inside the caller's capacity-doubling corpus buffer) as dst_dtype.  The rows go through two pinned
+ * 16 MiB staging slots (filled by a few host threads) and asynchronous copies, so the host-side copy of chunk i+1 overlaps
+ * the DMA of chunk i; for TAVB_F16 the conversion (round to nearest even) runs on the device from a scratch slot, the
+ * host never builds an fp16 (or a second fp32) copy.  Returns when the rows are in place. */
+int tavb_upload_rows(tavb_ctx* ctx, const float* rows_host, int64_t n_rows, int32_t dim, void* dev_dst, int32_t dst_dtype);
+
 /* Tell the library that rows [first_row, rows) of the borrowed corpus buffer were rewritten in place (e.g. an append into
  * spare capacity followed by tavb_set_corpus with the new row count, or a re-upload after the host matrix was edited):
  * per-corpus quantities it caches (the largest row norm, used by the batched fp16 path's exactness proof) are refreshed

@@ -1052,6 +1052,63 @@ def test_two_ranks_device_kernels_gloo_exchange():
     assert ret[0][0].max() > 15_001  # hits from the second shard carry their global ordinals
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_device_resident_load_paths_stream_without_a_host_matrix(tmp_path, dtype):
+    """`_embeddings.bin` and SQLite BLOB reloads stream chunk by chunk through the pinned staging ring into the
+    capacity-doubling DEVICE corpus (on-device fp16 conversion); no host matrix is built.  Lookups match the oracle,
+    serialize() copies back on demand (and the index is host-authoritative from then on)."""
+    import sqlite3
+
+    from typeagent_py_amd.adapters import load_embeddings_bin, load_sqlite_embeddings
+
+    rng = np.random.default_rng(77)
+    related, _ = make_corpus(5_003, 384, 7701)
+    messages, q = make_corpus(20_011, 384, 7702)
+    path = tmp_path / "x_embeddings.bin"
+    with open(path, "wb") as f:  # knowpro/serialization.py:84-98: related-term rows, then message rows
+        f.write(related.astype("<f4").tobytes())
+        f.write(messages.astype("<f4").tobytes())
+    rv = VectorBase(TextEmbeddingIndexSettings(NullModel()), corpus_dtype=dtype, keep_host_copy=False)
+    mv = VectorBase(TextEmbeddingIndexSettings(NullModel()), corpus_dtype=dtype, keep_host_copy=False)
+    assert load_embeddings_bin(str(path), 384, len(related), len(messages), rv, mv, chunk_rows=3000) == (len(related), len(messages))
+    assert len(mv) == len(messages) and mv._host.shape[0] == 0 and mv._device_only is not None  # nothing on the host
+    want = messages.astype(np.float16).astype(np.float32) if dtype == "fp16" else messages
+    res = mv.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
+    vo.check_topk_parity(vo.scores_full(want, q), *items_scores(res), 32, 0.0)
+    assert mv._host.shape[0] == 0  # a lookup does not materialise it either
+    np.testing.assert_array_equal(mv.serialize(), want)  # ... serialize() does (fp16 storage: the widened values)
+    mv.add_embeddings(None, related[:5])  # host-authoritative now: appends behave as always
+    assert len(mv) == len(messages) + 5 and mv.fuzzy_lookup_embedding(related[2], max_hits=1)[0].item == len(messages) + 2
+    # SQLite BLOB column, fetched 1000 rows at a time (storage/sqlite/messageindex.py:33-45)
+    db = sqlite3.connect(str(tmp_path / "c.db"))
+    db.execute("CREATE TABLE MessageTextIndex (msg_id INTEGER, chunk_ordinal INTEGER, embedding BLOB NOT NULL, index_position INTEGER)")
+    db.executemany("INSERT INTO MessageTextIndex VALUES (?, ?, ?, ?)", [(i // 2, i % 2, row.tobytes(), i) for i, row in enumerate(related)])
+    db.commit()
+    sv = VectorBase(TextEmbeddingIndexSettings(NullModel()), corpus_dtype=dtype, keep_host_copy=False)
+    load_sqlite_embeddings(db, sv, fetch_rows=1000)
+    assert len(sv) == len(related) and sv._host.shape[0] == 0
+    want_r = related.astype(np.float16).astype(np.float32) if dtype == "fp16" else related
+    vo.check_topk_parity(vo.scores_full(want_r, q), *items_scores(sv.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.0)), 10, 0.0)
+    sv.add_embedding(None, related[0])  # single rows stream too
+    assert len(sv) == len(related) + 1 and sv._host.shape[0] == 0
+
+
+def test_appending_to_an_adopted_tensor_copies_it_first():
+    import torch
+
+    v, q = make_corpus(4_000, 384, 7800)
+    t = torch.from_numpy(np.concatenate([v, np.zeros((100, 384), np.float32)])).cuda()  # spare capacity behind the 4000 rows
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), keep_host_copy=False)
+    vb.adopt_device_corpus(t, rows=4_000)
+    vb.add_embeddings(None, v[:10] * 2.0)
+    assert len(vb) == 4_010 and float(t[4_000:].abs().sum()) == 0.0  # the caller's tensor was not written to
+    assert [r.item for r in vb.fuzzy_lookup_embedding(v[3], max_hits=2, min_score=0.0)] == [3, 4_003]  # the 2x row clips to 1.0 too: a tie, ascending ordinal
+    vb2 = new_vb()
+    vb2.adopt_device_corpus(t, rows=4_000)
+    vb2.add_embedding(None, v[0])  # host-copy mode: materialises, then appends on the host
+    assert len(vb2) == 4_001 and float(t[4_000:].abs().sum()) == 0.0
+
+
 def test_device_only_corpus_and_lazy_host_copy():
     import torch
 

@@ -38,6 +38,7 @@ _SIGNATURES = [
     ("tavb_set_option", c_int, [c_void_p, c_char_p, c_int64]),
     ("tavb_get_option", c_int, [c_void_p, c_char_p, POINTER(c_int64)]),
     ("tavb_set_corpus", c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64]),
+    ("tavb_upload_rows", c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32]),
     ("tavb_corpus_modified", c_int, [c_void_p, c_int64]),
     ("tavb_normalize_rows_f32", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
     ("tavb_convert_f32_to_f16", c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
@@ -170,6 +171,7 @@ class Engine:
         self._h = handle
         self._lock = threading.Lock()
         self.corpus = None  # torch tensor [capacity, dim]
+        self._owns_corpus = False  # True when upload_rows allocated it (a tensor adopted from the caller is never appended into)
         self.rows = 0
         self.dim = 0
         self.dtype = TAVB_F32
@@ -215,7 +217,7 @@ class Engine:
     def torch_dtype(self, dtype: int):
         return self._torch.float16 if dtype == TAVB_F16 else self._torch.float32
 
-    def set_corpus_tensor(self, tensor, rows: int | None = None, ordinal_base: int = 0, sync_torch: bool = True) -> None:
+    def set_corpus_tensor(self, tensor, rows: int | None = None, ordinal_base: int = 0, sync_torch: bool = True, _owned: bool = False) -> None:
         """Adopt a device tensor [>=rows, dim] (f32 or f16, contiguous) as the corpus."""
         torch = self._torch
         if tensor.dim() != 2 or not tensor.is_contiguous():
@@ -236,6 +238,7 @@ class Engine:
             torch.cuda.current_stream(self.device).synchronize()
         _check(self.lib, self.lib.tavb_set_corpus(self._h, c_void_p(tensor.data_ptr()), n, tensor.shape[1], dt, int(ordinal_base)))
         self.corpus, self.rows, self.dim, self.dtype, self.ordinal_base = tensor, n, int(tensor.shape[1]), dt, int(ordinal_base)
+        self._owns_corpus = _owned
 
     def upload_rows(self, host_rows: np.ndarray, start: int, dtype: int, capacity_hint: int = 0) -> None:
         """Make device rows [start, start+len) equal to `host_rows` (f32), growing the
@@ -248,6 +251,7 @@ class Engine:
         dev = torch.device("cuda", self.device)
         need_new = (
             self.corpus is None or self.corpus.shape[1] != dim or self.corpus.dtype != tdt or self.corpus.shape[0] < n_new
+            or not self._owns_corpus  # adopted from the caller: copy into a buffer of our own before writing rows
         )
         if need_new:
             cap = max(n_new, capacity_hint, 2 * (self.corpus.shape[0] if self.corpus is not None and start > 0 else 0), 16)
@@ -258,17 +262,18 @@ class Engine:
                 fresh[:start].copy_(self.corpus[:start])
             self.corpus = fresh
         if host_rows.shape[0]:
+            # pinned double-buffered staging + async H2D + on-device f32 -> f16 (tavb_upload_rows): no fp16 / second fp32 host copy
             src = np.ascontiguousarray(host_rows, dtype=np.float32)
-            if dtype == TAVB_F16:
-                src = src.astype(np.float16)  # round-to-nearest-even, same as v_cvt_f16_f32
-            self.corpus[start:n_new].copy_(torch.from_numpy(src))
-        self.set_corpus_tensor(self.corpus, rows=n_new, ordinal_base=self.ordinal_base)
+            torch.cuda.current_stream(self.device).synchronize()  # the allocation / copy of old rows above ran on torch's stream
+            dst = self.corpus.data_ptr() + start * dim * (2 if dtype == TAVB_F16 else 4)
+            _check(self.lib, self.lib.tavb_upload_rows(self._h, src.ctypes.data_as(c_void_p), src.shape[0], dim, c_void_p(dst), dtype))
+        self.set_corpus_tensor(self.corpus, rows=n_new, ordinal_base=self.ordinal_base, _owned=True)
         _check(self.lib, self.lib.tavb_corpus_modified(self._h, int(start)))  # rows [start, n_new) were (re)written
         return True
 
     def clear(self) -> None:
         if self.corpus is not None:
-            self.set_corpus_tensor(self.corpus, rows=0, ordinal_base=self.ordinal_base)
+            self.set_corpus_tensor(self.corpus, rows=0, ordinal_base=self.ordinal_base, _owned=self._owns_corpus)
         self.rows = 0
 
     # -- K1 / convert --------------------------------------------------------

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "tavb_internal.h"
@@ -113,6 +114,10 @@ struct tavb_ctx {
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand, d_thr, d_sample_keys;
   Buffer d_delta, d_approx, d_flag, d_fb_queries, d_norm;  // exact rescoring of the 256-query tile (tavb_rescore.hip)
   Buffer d_accept, d_bits;  // message re-rank: accepted message ordinals, their bitmap
+  // load path (tavb_upload_rows): two pinned staging slots + two device scratch slots, recycled through events
+  Buffer h_ring[2] = {{nullptr, 0, true}, {nullptr, 0, true}};
+  Buffer d_ring[2];
+  hipEvent_t ring_done[2] = {nullptr, nullptr};
   const int32_t* row_to_msg = nullptr;  // borrowed device map chunk row -> message ordinal
   int64_t row_to_msg_rows = 0, n_messages = 0;
   int64_t norm_rows = 0;  // rows of the corpus covered by the cached maximum row norm (d_norm)
@@ -352,6 +357,11 @@ int tavb_destroy(tavb_ctx* c) {
   c->d_norm.release();
   c->d_accept.release();
   c->d_bits.release();
+  for (int i = 0; i < 2; ++i) {
+    c->h_ring[i].release();
+    c->d_ring[i].release();
+    if (c->ring_done[i]) (void)hipEventDestroy(c->ring_done[i]);
+  }
   c->h_stage.release();
   c->h_out.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -469,6 +479,70 @@ int tavb_set_corpus(tavb_ctx* c, const void* dev_rows, int64_t rows, int32_t dim
   c->dim = dim;
   c->dtype = dtype;
   c->ordinal_base = ordinal_base;
+  return TAVB_OK;
+}
+
+namespace {
+// host -> pinned copy on a few threads: one core moves ~10 GB/s, PCIe Gen5 x16 takes ~50
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+  constexpr size_t kMinPerThread = 2u << 20;
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t n = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), bytes / kMinPerThread);
+  if (n <= 1) {
+    memcpy(dst, src, bytes);
+    return;
+  }
+  const size_t per = ((bytes / n) + 63) & ~(size_t)63;
+  std::vector<std::thread> pool;
+  for (size_t i = 1; i < n; ++i) {
+    const size_t off = i * per;
+    if (off >= bytes) break;
+    const size_t len = std::min(per, bytes - off);
+    pool.emplace_back([=] { memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len); });
+  }
+  memcpy(dst, src, std::min(per, bytes));
+  for (auto& t : pool) t.join();
+}
+}  // namespace
+
+int tavb_upload_rows(tavb_ctx* c, const float* rows_host, int64_t n_rows, int32_t dim, void* dev_dst, int32_t dst_dtype) {
+  if (int rc = check_ctx(c)) return rc;
+  if (n_rows < 0 || dim < 1) return fail(TAVB_E_INVALID, "bad shape");
+  if (dst_dtype != TAVB_F32 && dst_dtype != TAVB_F16) return fail(TAVB_E_INVALID, "dtype must be TAVB_F32 or TAVB_F16");
+  if (n_rows == 0) return TAVB_OK;
+  if (!rows_host || !dev_dst) return fail(TAVB_E_INVALID, "null pointer");
+  DeviceGuard guard(c->device);
+  const size_t row_bytes = (size_t)dim * sizeof(float);
+  constexpr size_t kSlot = 16u << 20;  // 16 MiB per staging slot
+  const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t)(kSlot / row_bytes));
+  const size_t slot_bytes = (size_t)rows_per_chunk * row_bytes;
+  for (int i = 0; i < 2; ++i) {
+    if (int rc = c->h_ring[i].reserve(slot_bytes)) return rc;
+    if (dst_dtype == TAVB_F16)
+      if (int rc = c->d_ring[i].reserve(slot_bytes)) return rc;
+    if (!c->ring_done[i]) TAVB_HIP(hipEventCreateWithFlags(&c->ring_done[i], hipEventDisableTiming));
+  }
+  const size_t dst_elem = dst_dtype == TAVB_F16 ? 2 : 4;
+  int64_t done = 0;
+  for (int chunk = 0; done < n_rows; ++chunk) {
+    const int slot = chunk & 1;
+    const int64_t n = std::min(rows_per_chunk, n_rows - done);
+    const size_t bytes = (size_t)n * row_bytes;
+    if (chunk >= 2) TAVB_HIP(hipEventSynchronize(c->ring_done[slot]));  // the copy (and convert) that used this slot two chunks ago are done
+    parallel_copy(c->h_ring[slot].ptr, reinterpret_cast<const char*>(rows_host) + (size_t)done * row_bytes, bytes);  // overlaps the previous chunk's DMA
+    char* dst = reinterpret_cast<char*>(dev_dst) + (size_t)done * dim * dst_elem;
+    if (dst_dtype == TAVB_F32) {
+      TAVB_HIP(hipMemcpyAsync(dst, c->h_ring[slot].ptr, bytes, hipMemcpyHostToDevice, c->stream));
+    } else {
+      TAVB_HIP(hipMemcpyAsync(c->d_ring[slot].ptr, c->h_ring[slot].ptr, bytes, hipMemcpyHostToDevice, c->stream));
+      Timed t(c, TAVB_KERNEL_CONVERT);
+      hipError_t e = tavb::launch_f32_to_f16(reinterpret_cast<const float*>(c->d_ring[slot].ptr), dst, n * dim, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "convert launch failed: %s", hipGetErrorString(e));
+    }
+    TAVB_HIP(hipEventRecord(c->ring_done[slot], c->stream));
+    done += n;
+  }
+  TAVB_HIP(hipStreamSynchronize(c->stream));  // the caller may free / reuse rows_host and read dev_dst from other streams
   return TAVB_OK;
 }
 

@@ -123,6 +123,7 @@ class VectorBase:
         device: int | None = None,
         corpus_dtype: str | None = None,
         devices: list[int] | None = None,
+        keep_host_copy: bool | None = None,
     ):
         self.settings = settings
         self._model = settings.embedding_model
@@ -132,6 +133,13 @@ class VectorBase:
         if devices is None and os.environ.get("TYPEAGENT_VB_DEVICES"):
             devices = [int(x) for x in os.environ["TYPEAGENT_VB_DEVICES"].split(",") if x.strip() != ""]
         self._devices = list(devices) if devices else None
+        # keep_host_copy=False: rows handed to add_embedding(s) are streamed straight into the device corpus (pinned
+        # staging, async H2D, on-device fp16 conversion) and NOT kept on the host -- the load paths
+        # (adapters.load_embeddings_bin / load_sqlite_embeddings) for corpora that should not exist twice.  serialize() /
+        # get_embedding_at() copy the matrix back on first use, after which the host copy is authoritative again.
+        if keep_host_copy is None:
+            keep_host_copy = os.environ.get("TYPEAGENT_VB_HOST_COPY", "1") not in ("0", "false", "no")
+        self._keep_host = bool(keep_host_copy) or bool(self._devices)
         if corpus_dtype is None:
             self._dtype = _env_dtype()
         else:
@@ -173,6 +181,7 @@ class VectorBase:
             host = np.concatenate([x.float().cpu().numpy() for x in t])[:n]
         else:
             host = t[:n].float().cpu().numpy()
+        self._keep_host = True  # from here on the host matrix is the authoritative copy (like the reference's)
         self._host, self._count = host, n  # device copy stays valid: same rows
         if self._dtype == _native.TAVB_F16:
             pass  # host copy holds the fp16 values widened to f32
@@ -209,11 +218,14 @@ class VectorBase:
             self._set_embedding_size(len(row))
         if len(row) != self._embedding_size:
             raise ValueError(f"Embedding size mismatch: expected {self._embedding_size}, got {len(row)}")
-        if self._device_only is not None:
-            self._materialize_host()
-        self._reserve(1)
-        self._host[self._count] = row.reshape(-1)
-        self._count += 1
+        if self._stream_to_device(row.reshape(1, -1)):
+            pass
+        else:
+            if self._device_only is not None:
+                self._materialize_host()
+            self._reserve(1)
+            self._host[self._count] = row.reshape(-1)
+            self._count += 1
         if key is not None:
             self._model.add_embedding(key, row)
 
@@ -224,15 +236,28 @@ class VectorBase:
             self._set_embedding_size(embeddings.shape[1])
         if embeddings.shape[1] != self._embedding_size:
             raise ValueError(f"Embedding size mismatch: expected {self._embedding_size}, got {embeddings.shape[1]}")
-        if self._device_only is not None:
-            self._materialize_host()
-        n = embeddings.shape[0]
-        self._reserve(n)
-        self._host[self._count : self._count + n] = embeddings
-        self._count += n
+        if not self._stream_to_device(embeddings):
+            if self._device_only is not None:
+                self._materialize_host()
+            n = embeddings.shape[0]
+            self._reserve(n)
+            self._host[self._count : self._count + n] = embeddings
+            self._count += n
         if keys is not None:
             for key, row in zip(keys, embeddings):
                 self._model.add_embedding(key, row)
+
+    def _stream_to_device(self, rows: np.ndarray) -> bool:
+        """keep_host_copy=False: append `rows` to the device corpus only.  False when this index keeps its host matrix."""
+        if self._keep_host or (self._count > 0 and self._device_only is None):
+            return False  # (a host matrix already exists -- e.g. after serialize(): stay host-authoritative)
+        eng = self._ensure_engine()
+        if len(rows):
+            eng.upload_rows(np.ascontiguousarray(rows, dtype=np.float32), self._count, self._dtype)
+            self._count += len(rows)
+            self._device_only = eng.corpus
+            self._dev_rows, self._dev_valid = self._count, True
+        return True
 
     async def add_key(self, key: str, cache: bool = True) -> None:
         embedding = await self.get_embedding(key, cache=cache)
