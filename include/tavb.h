@@ -173,6 +173,16 @@ int tavb_search_begin(tavb_ctx* ctx, const float* queries_host, int32_t nq, int3
 int tavb_search_end(tavb_ctx* ctx, int32_t nq, int32_t k, tavb_key* out_keys_host);
 int tavb_merge_keys_host(const tavb_key* lists, int32_t n_lists, int32_t nq, int32_t k, tavb_key* out);
 
+/* Every row with score >= min_score in ONE pass -- the reference's `np.flatnonzero(scores >= min_score)`
+ * (vectorbase.py:179, 219) -- sorted best first on the host; the first min(total, max_out) are returned, *out_total is the
+ * number of survivors.  This is the candidate set of the predicate path (vectorbase.py:191-201), of max_hits >
+ * TAVB_MAX_FUSED_K and of the max_hits == 0 quirk (`[-0:]`: all survivors, sorted).  Call with max_out = 0 to learn the
+ * count first.  The subset form returns subset POSITIONS (like tavb_search_subset). */
+int tavb_search_all(tavb_ctx* ctx, const float* query_host, float min_score, int64_t max_out, int64_t* out_ordinals, float* out_scores,
+                    int64_t* out_count, int64_t* out_total);
+int tavb_search_subset_all(tavb_ctx* ctx, const float* query_host, const int64_t* rows_host, int64_t n_subset, float min_score, int64_t max_out,
+                           int64_t* out_positions, float* out_scores, int64_t* out_count, int64_t* out_total);
+
 /* Continuation ("cursor") forms: the next k hits strictly AFTER the hit
  * (after_score, after_ordinal) in the (score descending, ordinal ascending) order.
  * Feeding the last hit of one page as the cursor of the next enumerates every row

@@ -68,6 +68,12 @@ class FakeEngine:
             ok &= (sc < np.float32(after[0])) | ((sc == np.float32(after[0])) & (ids > after[1]))
         return _order(sc[ok], ids[ok], k)
 
+    def search_all(self, q, thr, max_out=None, subset_rows=None):
+        if subset_rows is not None:
+            pos, sc = self.search_subset(q, subset_rows, len(subset_rows) if max_out is None else max_out, thr)
+            return pos, sc
+        return self.search(q, self.rows if max_out is None else max_out, thr)
+
     def search_batch(self, queries, k, thrs):
         queries = np.asarray(queries, dtype=np.float32)
         t = np.broadcast_to(np.asarray(thrs, dtype=np.float32), (len(queries),))

@@ -241,6 +241,46 @@ def test_predicate_path():
         assert items == [i for i, _ in ref]
         np.testing.assert_allclose(scores, [s for _, s in ref], atol=SCORE_TOL, rtol=0)
     assert vb.fuzzy_lookup_embedding(q, max_hits=0, min_score=0.0, predicate=lambda i: True) == []
+    # like the reference (:193-199) the predicate sees EVERY survivor, once, in ascending ordinal order
+    seen = []
+    vb.fuzzy_lookup_embedding(q, max_hits=3, min_score=0.5, predicate=lambda i: seen.append(i) or (i % 2 == 0))
+    assert seen == np.flatnonzero(vo.scores_full(v, q) >= np.float32(0.5)).tolist() and len(seen) > 500
+
+
+@pytest.mark.parametrize("dtype,n,d", [("fp32", 300_000, 1536), ("fp16", 120_000, 1536), ("fp32", 5_000, 100), ("fp32", 700, 3)])
+def test_all_survivors_in_one_pass(dtype, n, d):
+    """max_hits beyond the fused selection, max_hits == 0 and the predicate path: ONE emit-all scan (not a scan per 256
+    results), sorted on the host; whole-corpus and subset forms."""
+    v, q = make_corpus(n, d, 7900 + d)
+    vb = new_vb(v, dtype=dtype)
+    vv = _f16(v) if dtype == "fp16" else v
+    sc = vo.scores_full(vv, q)
+    eng = vb.engine
+    eng.profile_enable(True)
+    eng.profile_reset()
+    res = vb.fuzzy_lookup_embedding(q, max_hits=0, min_score=0.0)  # every row survives: n results
+    assert eng.profile_read(_native.KERNEL_SCAN)[1] == 1
+    assert len(res) == n
+    vo.check_topk_parity(sc, *items_scores(res), 0, 0.0)
+    res = vb.fuzzy_lookup_embedding(q, max_hits=3000, min_score=0.0)
+    assert len(res) == min(3000, n)
+    vo.check_topk_parity(sc, *items_scores(res), 3000, 0.0)
+    thr = float(np.sort(sc)[-400]) if n > 1000 else 0.5
+    res = vb.fuzzy_lookup_embedding(q, max_hits=0, min_score=thr)
+    ref = vo.lookup(vv, q, 0, thr)
+    assert len(res) == len(ref)
+    vo.check_topk_parity(sc, *items_scores(res), 0, thr)
+    sub = subset_choice(n, min(n, 2000), 7901) + [0, 0, -1]
+    res = vb.fuzzy_lookup_embedding_in_subset(q, sub, max_hits=0, min_score=0.0)
+    ref = vo.lookup_in_subset(vv, q, sub, 0, 0.0)
+    assert len(res) == len(ref) == len(sub)
+    got_sorted, ref_sorted = sorted((r.item, r.score) for r in res), sorted(ref)
+    assert [i for i, _ in got_sorted] == [i for i, _ in ref_sorted]
+    np.testing.assert_allclose([s_ for _, s_ in got_sorted], [s_ for _, s_ in ref_sorted], atol=SCORE_TOL, rtol=0)
+    assert [r.score for r in res] == sorted((r.score for r in res), reverse=True)
+    res = vb.fuzzy_lookup_embedding_in_subset(q, sub, max_hits=500, min_score=0.0)
+    assert len(res) == min(500, len(sub))
+    eng.profile_enable(False)
 
 
 def test_subset_search_differential():

@@ -53,6 +53,9 @@ _SIGNATURES = [
     ("tavb_search_begin", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     ("tavb_search_end", c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     ("tavb_merge_keys_host", c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    ("tavb_search_all", c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p, POINTER(c_int64), POINTER(c_int64)]),
+    ("tavb_search_subset_all", c_int,
+     [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_int64, c_void_p, c_void_p, POINTER(c_int64), POINTER(c_int64)]),
     ("tavb_search_after", c_int,
      [c_void_p, c_void_p, c_int32, c_float, c_float, c_int64, c_void_p, c_void_p, POINTER(c_int32)]),
     ("tavb_search_subset_after", c_int,
@@ -345,6 +348,26 @@ class Engine:
         _check(self.lib, rc)
         m = int(cnt.value)
         return pos[:m], scs[:m]
+
+    def search_all(self, q, thr: np.float32, max_out: int | None = None, subset_rows=None):
+        """Every row (or subset position) with score >= thr, best first, in one corpus pass; the first `max_out` of them
+        (None: all) -> (ordinals-or-positions int64[m], scores float32[m])."""
+        a = self._query(q)
+        r = None if subset_rows is None else np.ascontiguousarray(subset_rows, dtype=np.int64)
+        cap = (self.rows if r is None else r.shape[0]) if max_out is None else min(int(max_out), self.rows if r is None else r.shape[0])
+        items = np.empty(max(cap, 1), dtype=np.int64)
+        scs = np.empty(max(cap, 1), dtype=np.float32)
+        cnt, total = c_int64(0), c_int64(0)
+        with self._lock:
+            if r is None:
+                rc = self.lib.tavb_search_all(self._h, a.ctypes.data_as(c_void_p), c_float(float(thr)), cap, items.ctypes.data_as(c_void_p),
+                                              scs.ctypes.data_as(c_void_p), byref(cnt), byref(total))
+            else:
+                rc = self.lib.tavb_search_subset_all(self._h, a.ctypes.data_as(c_void_p), r.ctypes.data_as(c_void_p), r.shape[0], c_float(float(thr)), cap,
+                                                     items.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt), byref(total))
+        _check(self.lib, rc)
+        m = int(cnt.value)
+        return items[:m], scs[:m]
 
     def search_batch(self, queries, k: int, thrs):
         """queries f32 [nq, dim]; thrs float32 [nq] -> (ordinals [nq,k], scores [nq,k], counts [nq])."""

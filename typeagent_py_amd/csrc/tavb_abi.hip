@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -114,6 +115,7 @@ struct tavb_ctx {
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand, d_thr, d_sample_keys;
   Buffer d_delta, d_approx, d_flag, d_fb_queries, d_norm;  // exact rescoring of the 256-query tile (tavb_rescore.hip)
   Buffer d_accept, d_bits;  // message re-rank: accepted message ordinals, their bitmap
+  Buffer d_emit;            // survivors of tavb_search_all: a counter, then the keys
   // load path (tavb_upload_rows): two pinned staging slots + two device scratch slots, recycled through events
   Buffer h_ring[2] = {{nullptr, 0, true}, {nullptr, 0, true}};
   Buffer d_ring[2];
@@ -357,6 +359,7 @@ int tavb_destroy(tavb_ctx* c) {
   c->d_norm.release();
   c->d_accept.release();
   c->d_bits.release();
+  c->d_emit.release();
   for (int i = 0; i < 2; ++i) {
     c->h_ring[i].release();
     c->d_ring[i].release();
@@ -722,6 +725,93 @@ static int search_subset_impl(tavb_ctx* c, const float* query_host, const int64_
   TAVB_HIP(hipStreamSynchronize(c->stream));
   decode(reinterpret_cast<const u64_t*>(c->h_out.ptr), 1, k, 0, out_positions, out_scores, out_count);
   return TAVB_OK;
+}
+
+// one pass, every survivor: keys on the device -> host, sorted best first, the first max_out decoded
+static int search_all_impl(tavb_ctx* c, const float* query_host, const int64_t* rows_host, int64_t n_subset, bool subset, float min_score,
+                           int64_t max_out, int64_t* out_items, float* out_scores, int64_t* out_count, int64_t* out_total) {
+  if (int rc = check_ctx(c)) return rc;
+  if (c->dim <= 0 || (!c->corpus && c->rows != 0)) return fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
+  if (!query_host || !out_count || !out_total || max_out < 0 || (max_out > 0 && (!out_items || !out_scores)))
+    return fail(TAVB_E_INVALID, "bad argument");
+  *out_count = 0;
+  *out_total = 0;
+  const int64_t n_pos = subset ? n_subset : c->rows;
+  if (n_pos < 0 || n_pos >= 0x7FFFFFFFll) return fail(TAVB_E_INVALID, "bad subset length");
+  if (n_pos == 0 || c->rows == 0) return TAVB_OK;
+  if (subset && !rows_host) return fail(TAVB_E_INVALID, "null rows_host");
+  DeviceGuard guard(c->device);
+  const size_t qbytes = (size_t)c->dim * sizeof(float);
+  const size_t rbytes = subset ? (size_t)n_subset * sizeof(int32_t) : 0;
+  const size_t qoff = (rbytes + 255) & ~(size_t)255;
+  if (int rc = c->h_stage.reserve(qoff + qbytes)) return rc;
+  if (int rc = c->d_queries.reserve(qbytes)) return rc;
+  if (int rc = c->d_emit.reserve(256 + (size_t)n_pos * sizeof(u64_t))) return rc;
+  if (subset) {
+    if (int rc = c->d_rows.reserve(rbytes)) return rc;
+    int32_t* r32 = reinterpret_cast<int32_t*>(c->h_stage.ptr);
+    for (int64_t i = 0; i < n_subset; ++i) {
+      const int64_t r = rows_host[i];
+      if (r < 0 || r >= c->rows) return fail(TAVB_E_INVALID, "subset row %lld out of range [0, %lld)", (long long)r, (long long)c->rows);
+      r32[i] = (int32_t)r;
+    }
+    TAVB_HIP(hipMemcpyAsync(c->d_rows.ptr, c->h_stage.ptr, rbytes, hipMemcpyHostToDevice, c->stream));
+  }
+  memcpy(reinterpret_cast<char*>(c->h_stage.ptr) + qoff, query_host, qbytes);
+  TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, reinterpret_cast<char*>(c->h_stage.ptr) + qoff, qbytes, hipMemcpyHostToDevice, c->stream));
+  unsigned long long* d_counter = reinterpret_cast<unsigned long long*>(c->d_emit.ptr);
+  u64_t* d_keys = reinterpret_cast<u64_t*>(reinterpret_cast<char*>(c->d_emit.ptr) + 256);
+  TAVB_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long), c->stream));
+  tavb::ScanParams p{};
+  p.corpus = c->corpus;
+  p.row_ids = subset ? reinterpret_cast<const int32_t*>(c->d_rows.ptr) : nullptr;
+  p.queries = reinterpret_cast<const float*>(c->d_queries.ptr);
+  p.n_pos = n_pos;
+  p.dim = c->dim;
+  p.dtype = c->dtype;
+  p.nq = 1;
+  p.k = 1;
+  p.index_base = 0u;
+  p.key_bound = ~0ull;
+  p.min_score[0] = min_score;
+  {
+    Timed t(c, TAVB_KERNEL_SCAN);
+    const int blocks = (int)std::min<int64_t>(c->n_cu, (n_pos + 15) / 16);
+    hipError_t e = tavb::launch_scan_emit(p, std::max(blocks, 1), d_keys, (unsigned long long)n_pos, d_counter, c->stream);
+    if (e != hipSuccess) return fail(TAVB_E_HIP, "emit scan launch failed: %s", hipGetErrorString(e));
+  }
+  unsigned long long total = 0;
+  TAVB_HIP(hipMemcpyAsync(&total, d_counter, sizeof total, hipMemcpyDeviceToHost, c->stream));
+  TAVB_HIP(hipStreamSynchronize(c->stream));
+  *out_total = (int64_t)total;
+  if (total == 0 || max_out == 0) return TAVB_OK;
+  std::vector<u64_t> keys((size_t)total);
+  TAVB_HIP(hipMemcpy(keys.data(), d_keys, (size_t)total * sizeof(u64_t), hipMemcpyDeviceToHost));
+  const size_t want = (size_t)std::min<int64_t>((int64_t)total, max_out);
+  if (want < keys.size())
+    std::partial_sort(keys.begin(), keys.begin() + want, keys.end(), std::greater<u64_t>());
+  else
+    std::sort(keys.begin(), keys.end(), std::greater<u64_t>());
+  const int64_t base = subset ? 0 : c->ordinal_base;
+  for (size_t i = 0; i < want; ++i) {
+    const uint32_t hi = (uint32_t)(keys[i] >> 32), lo = (uint32_t)keys[i];
+    float sc;
+    memcpy(&sc, &hi, sizeof sc);
+    out_items[i] = (int64_t)(0xFFFFFFFFu - lo) + base;
+    out_scores[i] = sc;
+  }
+  *out_count = (int64_t)want;
+  return TAVB_OK;
+}
+
+int tavb_search_all(tavb_ctx* c, const float* query_host, float min_score, int64_t max_out, int64_t* out_ordinals, float* out_scores,
+                    int64_t* out_count, int64_t* out_total) {
+  return search_all_impl(c, query_host, nullptr, 0, false, min_score, max_out, out_ordinals, out_scores, out_count, out_total);
+}
+
+int tavb_search_subset_all(tavb_ctx* c, const float* query_host, const int64_t* rows_host, int64_t n_subset, float min_score, int64_t max_out,
+                           int64_t* out_positions, float* out_scores, int64_t* out_count, int64_t* out_total) {
+  return search_all_impl(c, query_host, rows_host, n_subset, true, min_score, max_out, out_positions, out_scores, out_count, out_total);
 }
 
 int tavb_set_row_messages(tavb_ctx* c, const int32_t* dev_row_to_msg, int64_t rows, int64_t n_messages) {

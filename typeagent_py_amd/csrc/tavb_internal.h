@@ -36,6 +36,10 @@ struct ScanGeometry {
 // returns hipSuccess or the launch error; `*tier_used` reports the kernel family chosen
 hipError_t launch_scan(const ScanParams& p, const ScanGeometry& g, hipStream_t stream, int* tier_used);
 
+// every row with score >= min_score[0] (and key < key_bound), unsorted: out[0 .. *counter) (entries past `capacity` are dropped, still counted)
+hipError_t launch_scan_emit(const ScanParams& p, int blocks, unsigned long long* out, unsigned long long capacity, unsigned long long* counter,
+                            hipStream_t stream);
+
 // lists: [n_lists, nq, k] (list-major) or [nq, n_lists, k] (query-major) sorted keys -> out [nq, k]
 hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, int k, bool query_major,
                         unsigned long long* out, hipStream_t stream);

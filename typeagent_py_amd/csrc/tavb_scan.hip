@@ -355,6 +355,94 @@ __global__ void __launch_bounds__(1024) scan_scalar_kernel(const ScanParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// emit: EVERY row with score >= min_score, unsorted, in one pass (the candidate stream of the predicate path,
+// vectorbase.py:191-201, of max_hits > TAVB_MAX_FUSED_K and of the max_hits == 0 quirk -- the reference's
+// `np.flatnonzero(scores >= min_score)`, :179).  A wave collects the keys of its passing rows across its lanes (slot i in
+// lane i) and appends them 64 at a time: one atomic and one coalesced 512-byte store per 64 survivors.
+// ---------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(1024) scan_emit_kernel(const ScanParams p, u64* __restrict__ out, unsigned long long capacity,
+                                                         unsigned long long* __restrict__ counter) {
+  constexpr int EPL = Elem<T>::EPL;
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* qlds = reinterpret_cast<float*>(smem);  // [D]
+  const int D = p.dim;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_waves = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) qlds[i] = p.queries[i];
+  __syncthreads();
+  const float min_score = p.min_score[0];
+  const char* corpus = reinterpret_cast<const char*>(p.corpus);
+  const int32_t* row_ids = p.row_ids;
+  const int64_t row_bytes = (int64_t)D * sizeof(T);
+  const int n_slices = D / EPL;
+  u64 held = 0ull;  // this lane's slot of the wave's pending keys
+  int pending = 0;  // wave-uniform
+  auto flush = [&]() {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(counter, (unsigned long long)pending);
+    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+    if (lane < pending && base + lane < capacity) out[base + lane] = held;
+    pending = 0;
+  };
+  for (int64_t pos = (int64_t)blockIdx.x * n_waves + wave; pos < p.n_pos; pos += (int64_t)gridDim.x * n_waves) {
+    const int64_t row = row_ids ? (int64_t)row_ids[pos] : pos;
+    const char* rp = corpus + row * row_bytes;
+    float acc = 0.f;
+    if constexpr (VEC) {
+#pragma unroll 4
+      for (int sl = lane; sl < n_slices; sl += 64) {
+        const f32x4 x = ld16<true>(rp + (size_t)sl * 16);
+        float qf[EPL];
+        const f32x4* src = reinterpret_cast<const f32x4*>(qlds + (size_t)sl * EPL);
+#pragma unroll
+        for (int v = 0; v < EPL / 4; ++v) {
+          const f32x4 t = src[v];
+          qf[4 * v + 0] = t.x;
+          qf[4 * v + 1] = t.y;
+          qf[4 * v + 2] = t.z;
+          qf[4 * v + 3] = t.w;
+        }
+        acc = dot_slice<T>(x, qf, acc);
+      }
+    } else {
+      const T* re = reinterpret_cast<const T*>(rp);
+      for (int e = lane; e < D; e += 64) acc = fmaf((float)re[e], qlds[e], acc);
+    }
+    const float s = wave_uniform(cosine_to_score(wave_sum(acc)));
+    if (s >= min_score) {  // wave-uniform; NaN never passes
+      const u64 key = make_key(s, (uint32_t)pos + p.index_base);
+      if (key < p.key_bound) {
+        if (lane == pending) held = key;
+        if (++pending == 64) flush();
+      }
+    }
+  }
+  if (pending) flush();
+}
+
+hipError_t launch_scan_emit(const ScanParams& p, int blocks, u64* out, unsigned long long capacity, unsigned long long* counter, hipStream_t stream) {
+  if (p.dim < 1 || p.n_pos < 0) return hipErrorInvalidValue;
+  const bool f16 = p.dtype == TAVB_F16;
+  const int epl = f16 ? 8 : 4;
+  const bool vec = ((uintptr_t)p.corpus % 16) == 0 && (p.dim % epl) == 0;
+  const size_t lds = (size_t)p.dim * sizeof(float);
+  if (lds > 150 * 1024) return hipErrorInvalidValue;
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, stream, p, out, capacity, counter);
+    return hipGetLastError();
+  };
+  if (f16) return vec ? go(scan_emit_kernel<_Float16, true>) : go(scan_emit_kernel<_Float16, false>);
+  return vec ? go(scan_emit_kernel<float, true>) : go(scan_emit_kernel<float, false>);
+}
+
+// ---------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------
 namespace {

@@ -160,6 +160,30 @@ class DeviceGroup:
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(thrs, dtype=np.float32), (a.shape[0],)))
         return _native.decode_keys(self._gather(a, k, t))
 
+    def search_all(self, q, thr: np.float32, max_out: int | None = None, subset_rows=None):
+        """Every survivor, best first (one emit-all pass per shard, merged on the host)."""
+        a = self._query(q)
+        ids_all, sc_all = [], []
+        rows = None if subset_rows is None else np.ascontiguousarray(subset_rows, dtype=np.int64)
+        for e, lo, hi in self._active():
+            if rows is None:
+                i, s = e.search_all(a, thr, max_out)  # ordinals are global (ordinal_base = the shard's first row)
+            else:
+                idx = np.flatnonzero((rows >= lo) & (rows < hi))
+                if idx.size == 0:
+                    continue
+                p, s = e.search_all(a, thr, max_out, subset_rows=rows[idx] - lo)
+                i = idx[p]
+            ids_all.append(i)
+            sc_all.append(s)
+        if not ids_all:
+            return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.float32)
+        ids, sc = np.concatenate(ids_all), np.concatenate(sc_all)
+        order = np.lexsort((ids, -sc.astype(np.float64)))
+        if max_out is not None:
+            order = order[:max_out]
+        return ids[order], sc[order]
+
     def search_subset(self, q, rows: np.ndarray, k: int, thr: np.float32, after: tuple[float, int] | None = None):
         """rows: int64 global corpus row per subset position -> (positions int64[m], scores float32[m]); the order is
         (score desc, position asc) like one device's."""

@@ -25,8 +25,6 @@ Documented deviations from the reference (none is exercised by its callers):
   * equal float32 scores are ordered by ascending ordinal (the reference's order
     among ties is whatever numpy's introselect leaves, :183-187);
   * a query is converted to float32 (np.dot would promote a float64 query);
-  * `predicate` is called lazily, best score first, until `max_hits` rows are
-    accepted (the reference calls it for every survivor in ordinal order, :195-199);
   * negative `max_hits` raises ValueError (the reference returns slicing artefacts).
 """
 
@@ -50,7 +48,7 @@ MODEL_DEFAULT_MIN_SCORES: dict[str, float] = {
     "text-embedding-ada-002": 0.93,
 }
 
-_PAGE = _native.MAX_FUSED_K  # rows fetched per device pass on the paged paths
+_PAGE = _native.MAX_FUSED_K  # most hits the fused select-while-streaming kernels return; beyond: one emit-all pass + host sort
 
 
 def get_default_min_score(model_name: str) -> float:
@@ -340,27 +338,6 @@ class VectorBase:
             raise ValueError("max_hits must be >= 0")
         return max_hits, _native.f32_threshold(min_score)
 
-    def _paged(self, fetch: Callable[[int, tuple[float, int] | None], tuple[np.ndarray, np.ndarray]], want: int | None,
-               accept: Callable[[int], bool] | None) -> tuple[list[int], list[float]]:
-        """Walk the best-first candidate stream `fetch(k, cursor)` page by page until `want`
-        rows are taken (None = all) or the stream ends."""
-        items: list[int] = []
-        scores: list[float] = []
-        cursor: tuple[float, int] | None = None
-        while want is None or len(items) < want:
-            k = _PAGE if (want is None or accept is not None) else min(_PAGE, want - len(items))
-            ids, scs = fetch(k, cursor)
-            for i, s in zip(ids.tolist(), scs.tolist()):
-                if accept is None or accept(i):
-                    items.append(i)
-                    scores.append(s)
-                    if want is not None and len(items) >= want:
-                        break
-            if len(ids) < k:
-                break
-            cursor = (float(scs[-1]), int(ids[-1]))
-        return items, scores
-
     def fuzzy_lookup_embedding(
         self,
         embedding: NormalizedEmbedding,
@@ -372,16 +349,21 @@ class VectorBase:
         if self._count == 0:
             return []
         eng = self._sync_device()
-        if predicate is None and 1 <= max_hits <= _PAGE:
-            ids, scs = eng.search(embedding, max_hits, thr)
+        if predicate is None:
+            if 1 <= max_hits <= _PAGE:
+                ids, scs = eng.search(embedding, max_hits, thr)  # fused select-while-streaming
+            else:
+                # more hits than the fused selection holds, or max_hits == 0 (every survivor, sorted: the `[-0:]` quirk,
+                # :186-187): ONE pass emits all survivors, the host sorts them
+                ids, scs = eng.search_all(embedding, thr, None if max_hits == 0 else max_hits)
             return [ScoredInt(int(i), float(s)) for i, s in zip(ids.tolist(), scs.tolist())]
-        if predicate is not None and max_hits == 0:
-            return []  # scored_ordinals[:0] (:201)
-        # max_hits == 0 without predicate: every survivor, sorted (the [-0:] quirk, :186-187)
-        want = None if (predicate is None and max_hits == 0) else max_hits
-        items, scores = self._paged(lambda k, cur: eng.search(embedding, k, thr, after=cur), want,
-                                    (lambda i: bool(predicate(int(i)))) if predicate is not None else None)
-        return [ScoredInt(i, s) for i, s in zip(items, scores)]
+        # predicate path (:191-201): threshold on the device (one pass, all survivors), then exactly the reference's steps:
+        # predicate(ordinal) for EVERY survivor in ascending ordinal order, stable sort by score, cut
+        ids, scs = eng.search_all(embedding, thr, None)
+        order = np.lexsort((ids,))  # ascending ordinal: the order of np.flatnonzero (:193)
+        kept = [ScoredInt(int(i), float(s)) for i, s in zip(ids[order].tolist(), scs[order].tolist()) if predicate(int(i))]
+        kept.sort(key=lambda x: x.score, reverse=True)
+        return kept[:max_hits]
 
     def fuzzy_lookup_embedding_in_subset(
         self,
@@ -406,10 +388,9 @@ class VectorBase:
         eng = self._sync_device()
         if 1 <= max_hits <= _PAGE:
             pos, scs = eng.search_subset(embedding, rows, max_hits, thr)
-            return [ScoredInt(int(subset[p]), float(s)) for p, s in zip(pos.tolist(), scs.tolist())]
-        want = None if max_hits == 0 else max_hits
-        positions, scores = self._paged(lambda k, cur: eng.search_subset(embedding, rows, k, thr, after=cur), want, None)
-        return [ScoredInt(int(subset[p]), s) for p, s in zip(positions, scores)]
+        else:
+            pos, scs = eng.search_all(embedding, thr, None if max_hits == 0 else max_hits, subset_rows=rows)
+        return [ScoredInt(int(subset[p]), float(s)) for p, s in zip(pos.tolist(), scs.tolist())]
 
     def fuzzy_lookup_embeddings(
         self,
