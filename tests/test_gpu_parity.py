@@ -522,6 +522,23 @@ def test_appends_between_lookups_keep_device_in_sync():
     vo.check_topk_parity(vo.scores_full(other, q), *items_scores(res), 5, 0.0)
 
 
+def test_in_place_edit_of_the_serialized_matrix_is_noticed():
+    """serialize() hands out the live host matrix (like the reference, :271).  Editing it in place used to leave the device
+    mirror stale without a word; the sampled fingerprint now notices (bulk edits) and mark_dirty() stays the explicit form."""
+    v, q = make_corpus(5000, 256, 4400)
+    vb = new_vb(v)
+    first = vb.fuzzy_lookup_embedding(q, max_hits=5, min_score=0.0)
+    live = vb.serialize()
+    live[:] = np.roll(live, 7, axis=0)  # every row moves 7 places down
+    moved = vb.fuzzy_lookup_embedding(q, max_hits=5, min_score=0.0)
+    assert [r.item for r in moved] == [(r.item + 7) % 5000 for r in first]
+    x = np.ascontiguousarray(v[::-1])
+    vb.deserialize(x)  # kept by reference (:287): the caller still holds x
+    x *= -1.0
+    flipped = vb.fuzzy_lookup_embedding(q, max_hits=3, min_score=0.0)
+    vo.check_topk_parity(vo.scores_full(x, q), *items_scores(flipped), 3, 0.0)
+
+
 def test_wrong_query_size_raises_value_error():
     vb = new_vb(np.ones((4, 8), dtype=np.float32))
     with pytest.raises(ValueError):

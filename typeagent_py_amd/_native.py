@@ -23,7 +23,7 @@ MAX_STREAM_QUERIES = 8
 
 KERNEL_SCAN, KERNEL_MERGE, KERNEL_MFMA, KERNEL_NORMALIZE, KERNEL_CONVERT, KERNEL_MFMA_SAMPLE, KERNEL_SKINNY, KERNEL_RESCORE = range(8)
 
-_LIB_NAME = "libtavb.so"
+_LIB_NAME = os.environ.get("TAVB_LIBRARY", "libtavb.so")  # "libtavb_debug.so": the ASan/UBSan host build (`make -C csrc debug`)
 _lib = None
 _lib_lock = threading.Lock()
 

@@ -147,6 +147,8 @@ class VectorBase:
         self._count = 0
         self._dev_rows = 0  # rows of the host matrix already mirrored on the device
         self._dev_valid = True  # False => the device copy must be rebuilt from row 0
+        self._handed_out = False  # the live host matrix is (or may be) in a caller's hands: watch it for in-place edits
+        self._dev_fingerprint = None
         self._device_only = None  # torch tensor when the corpus lives only on the device
         self._row_messages: np.ndarray | None = None  # chunk row -> message ordinal (message re-rank on the device)
         self._row_messages_rows = -1  # rows of the map already on the device
@@ -157,6 +159,7 @@ class VectorBase:
     def _vectors(self) -> NormalizedEmbeddings:
         if self._device_only is not None:
             self._materialize_host()
+        self._handed_out = True
         if self._embedding_size > 0 and self._host.ndim == 2 and self._count != self._host.shape[0]:
             return self._host[: self._count]  # the filled part of the growth buffer
         return self._host  # exactly the adopted / full matrix (same object every time)
@@ -171,6 +174,7 @@ class VectorBase:
         self._count = len(matrix)
         self._dev_rows = 0
         self._dev_valid = False
+        self._handed_out = True  # the caller keeps a reference to `matrix` (deserialize keeps it by reference, :287)
 
     def _materialize_host(self) -> None:
         t, n = self._device_only, self._count
@@ -284,6 +288,8 @@ class VectorBase:
         if self._device_only is not None:
             return eng
         n = self._count
+        if self._handed_out and self._dev_valid and self._dev_rows == n and n > 0 and self._dev_fingerprint != self._fingerprint():
+            self._dev_valid = False  # the matrix handed out by serialize()/deserialize() was edited in place
         if not self._dev_valid:
             self._dev_rows = 0
             self._dev_valid = True
@@ -295,11 +301,22 @@ class VectorBase:
             if done is False:  # a device group has to re-shard: everything again
                 eng.upload_rows(self._host[:n], 0, self._dtype, capacity_hint=self._host.shape[0])
             self._dev_rows = n
+            self._dev_fingerprint = self._fingerprint() if self._handed_out else None
         return eng
+
+    def _fingerprint(self):
+        """Hash of up to 32 evenly spaced rows of the host matrix (~30 us): a cheap watch on a matrix that a caller holds
+        a reference to.  Whole-matrix edits (re-normalisation, bulk replacement) are caught; an edit confined to rows
+        outside the sample is not -- `mark_dirty()` is the explicit form."""
+        n = self._count
+        if n == 0 or self._host.ndim != 2:
+            return None
+        idx = np.unique(np.linspace(0, n - 1, num=min(n, 32)).astype(np.int64))
+        return hash((n, self._host.shape[1], self._host[idx].tobytes()))
 
     def mark_dirty(self) -> None:
         """Call after mutating the array returned by serialize()/_vectors in place:
-        the device mirror is rebuilt on the next lookup."""
+        the device mirror is rebuilt on the next lookup.  (A sampled fingerprint catches most such edits without it.)"""
         self._dev_valid = False
 
     def adopt_device_corpus(self, tensor, rows: int | None = None, ordinal_base: int = 0) -> None:
