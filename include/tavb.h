@@ -78,9 +78,8 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "skinny_min_batch_f32" / "skinny_min_batch_f16"  smallest batch routed to the 32/64-query MFMA tile on fp32 / fp16
  *                   corpora (defaults 5 / 3, the measured break-even; fp32 corpora have no other matrix-core path, fp16 ones use it up to
  *                   mfma_min_batch - 1); smaller batches use the streaming tiers
- *   "mfma_sample_rows", "mfma_ladder"  phases of the MFMA paths' threshold ladder (rows of the first phase; growth)
- *   "mfma_variant"  K loop of the 256-query tile: 0 = auto (6 for ladder phases of at least "mfma_v6_min_rows" rows, else 3),
- *                   3 / 6 = that K loop for every phase
+ *   "mfma_sample_rows", "mfma_ladder"  phases of the MFMA paths' threshold ladder: rows of the first phase (0 = auto: two
+ *                   tiles per workgroup; -1 = a single phase, no seeding) and the growth factor of the following ones
  *   "mfma_splits", "mfma_sched", "mfma_ablate"  measurement knobs, see DESIGN.md
  *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile (exact
  *                   filter + fp32-query rescoring of its candidates), 5 = 32/64-query MFMA tile

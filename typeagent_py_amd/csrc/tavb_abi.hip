@@ -103,16 +103,15 @@ struct tavb_ctx {
   tavb::ScanGeometry geom{0, 16, 2, 1, 0, 0};
   int64_t mfma_min_batch = 65;  // fp16 corpora: batches from this size up use the 256-query tile (3 .. 64 the 32/64-query tile)
   int64_t mfma_splits = 0;  // 0 = auto
-  int64_t mfma_variant = 0;  // 0 = auto (see tavb_search_device_dispatch); 3, 6 = that K loop for every phase
   int64_t mfma_ablate = 0;
   int64_t mfma_sched = 0;
-  int64_t mfma_v6_min_rows = 400000;  // auto variant: phases of at least this many rows run the whole-line tile (variant 6)
-  int64_t mfma_sample_rows = 131072;  // rows of the first (threshold-seeding) phase (0 = one phase, no seeding)
+  int64_t mfma_sample_rows = 0;  // rows of the first (threshold-seeding) phase: 0 = auto (two tiles per workgroup), -1 = one phase, no seeding
   int64_t skinny_min_batch_f32 = 5;   // fp32 corpus: batches from this size up use the 32-query MFMA tile
   int64_t skinny_min_batch_f16 = 3;   // fp16 corpus: batches from this size up to mfma_min_batch - 1 use it
   int64_t mfma_ladder = 4;            // each further phase scans this many times the rows scanned so far (0 = seed once)
 
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand, d_thr, d_sample_keys;
+  Buffer d_counts;  // 256-query tile: keys left per candidate buffer
   Buffer d_delta, d_approx, d_flag, d_fb_queries, d_norm;  // exact rescoring of the 256-query tile (tavb_rescore.hip)
   Buffer d_accept, d_bits;  // message re-rank: accepted message ordinals, their bitmap
   Buffer d_emit;            // survivors of tavb_search_all: a counter, then the keys
@@ -352,6 +351,7 @@ int tavb_destroy(tavb_ctx* c) {
   c->d_cand.release();
   c->d_thr.release();
   c->d_sample_keys.release();
+  c->d_counts.release();
   c->d_delta.release();
   c->d_approx.release();
   c->d_flag.release();
@@ -402,15 +402,9 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_min_batch") {
     if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch must be >= 1");
     c->mfma_min_batch = v;
-  } else if (n == "mfma_variant") {
-    if (v != 0 && v != 3 && v != 6) return fail(TAVB_E_INVALID, "mfma_variant must be 0 (auto), 3 or 6");
-    c->mfma_variant = v;
   } else if (n == "mfma_sample_rows") {
-    if (v < 0) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= 0");
+    if (v < -1) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= -1");
     c->mfma_sample_rows = v;
-  } else if (n == "mfma_v6_min_rows") {
-    if (v < 0) return fail(TAVB_E_INVALID, "mfma_v6_min_rows must be >= 0");
-    c->mfma_v6_min_rows = v;
   } else if (n == "mfma_sched") {
     if (v < 0 || v > 3) return fail(TAVB_E_INVALID, "mfma_sched must be 0..3");
     c->mfma_sched = v;
@@ -451,7 +445,6 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "skinny_min_batch_f32") *out = c->skinny_min_batch_f32;
   else if (n == "skinny_min_batch_f16") *out = c->skinny_min_batch_f16;
   else if (n == "mfma_sample_rows") *out = c->mfma_sample_rows;
-  else if (n == "mfma_variant") *out = c->mfma_variant;
   else if (n == "compute_units") *out = c->n_cu;
   else if (n == "last_tier") *out = c->last_tier;
   else if (n == "last_flagged") {  // queries of the last 256-query-tile lookup that were re-run on the exact tile (synchronises)
@@ -1068,13 +1061,18 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   auto launch = [&](const tavb::MfmaParams& q) { return r.skinny ? tavb::launch_skinny_scan(q, c->stream) : tavb::launch_mfma_scan(q, c->stream); };
   const int nq = r.nq, k = r.k;
   const int splits = c->mfma_splits > 0 ? (int)c->mfma_splits : pick_splits(c->rows);
-  if (int rc = c->d_lists.reserve((size_t)nq * (splits + 1) * k * sizeof(u64_t))) return rc;  // + the carried-over top-k
-  if (int rc = c->d_cand.reserve(tavb::mfma_workspace_bytes(splits, r.nq_pad))) return rc;
+  const bool wide = !r.skinny;  // the 256-query tile leaves unsorted buffers + counts, one select kernel picks the best k over them
+  if (!wide)
+    if (int rc = c->d_lists.reserve((size_t)nq * (splits + 1) * k * sizeof(u64_t))) return rc;  // + the carried-over top-k
+  if (int rc = c->d_cand.reserve(tavb::mfma_workspace_bytes(splits, r.nq_pad, wide))) return rc;
+  if (wide)
+    if (int rc = c->d_counts.reserve((size_t)splits * r.nq_pad * sizeof(int))) return rc;
   tavb::MfmaParams p{};
   p.corpus = c->corpus;
   p.queries = r.queries;
   p.lists = reinterpret_cast<u64_t*>(c->d_lists.ptr);
   p.workspace = reinterpret_cast<u64_t*>(c->d_cand.ptr);
+  p.counts = reinterpret_cast<int*>(c->d_counts.ptr);
   p.rows = c->rows;
   p.dim = c->dim;
   p.nq = nq;
@@ -1083,7 +1081,6 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.index_base = r.index_base;
   p.min_score = r.kernel_min_score;
   p.n_splits = splits;
-  p.variant = c->mfma_variant == 0 ? 3 : (int)c->mfma_variant;  // auto: decided per phase below
   p.ablate = (int)c->mfma_ablate;
   p.sched = (int)c->mfma_sched;
   p.f32 = r.q32 ? 1 : 0;
@@ -1091,7 +1088,10 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.active = r.active;
   std::vector<int64_t> bounds;  // phase i scans rows [bounds[i], bounds[i+1])
   bounds.push_back(0);
-  const int64_t sample = (c->mfma_sample_rows + 255) / 256 * 256;
+  // first phase: `mfma_sample_rows`, or (0 = auto) two tiles per workgroup -- short enough that the 256-query tile's
+  // buffers (3+ tiles deep) never compact while everything is still being admitted
+  const int64_t auto_sample = (int64_t)splits * 2 * 320;
+  const int64_t sample = c->mfma_sample_rows > 0 ? (c->mfma_sample_rows + 255) / 256 * 256 : (c->mfma_sample_rows == 0 ? auto_sample : 0);
   if (r.ladder && sample > 0 && c->rows >= 8 * sample) {
     int64_t done = sample;
     bounds.push_back(done);
@@ -1105,7 +1105,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   const int n_phases = (int)bounds.size() - 1;
   if (n_phases > 1) {
     if (int rc = c->d_thr.reserve((size_t)r.nq_pad * sizeof(float))) return rc;
-    if (int rc = c->d_sample_keys.reserve((size_t)nq * k * sizeof(u64_t))) return rc;
+    if (int rc = c->d_sample_keys.reserve((size_t)2 * nq * k * sizeof(u64_t))) return rc;  // running top-k: two copies (ping-pong)
   }
   const size_t row_bytes = (size_t)c->dim * (r.q32 ? 4 : 2);  // of the corpus operand
   for (int ph = 0; ph < n_phases; ++ph) {
@@ -1115,14 +1115,15 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
     pp.rows = bounds[ph + 1] - bounds[ph];
     pp.index_base = r.index_base + (uint32_t)bounds[ph];
     pp.n_splits = pick_splits(pp.rows);
-    if (!r.skinny && c->mfma_variant == 0)  // the 4-wave whole-line tile needs enough tiles per workgroup to amortise its longer prologue
-      pp.variant = (pp.rows >= c->mfma_v6_min_rows) ? 6 : 3;
     if (c->mfma_splits > 0 || pp.n_splits > splits) pp.n_splits = splits;  // lists / candidate buffers are sized for `splits`
     const int carried = ph > 0 ? 1 : 0;  // the running top-k of the earlier phases occupies one more list slot
     pp.list_stride = pp.n_splits + carried;
     pp.thr_in = ph > 0 ? reinterpret_cast<const float*>(c->d_thr.ptr) : r.floor;
-    if (carried) {
-      TAVB_HIP(hipMemcpy2DAsync(pp.lists + (size_t)pp.n_splits * k, (size_t)pp.list_stride * k * sizeof(u64_t), c->d_sample_keys.ptr,
+    u64_t* const running = reinterpret_cast<u64_t*>(c->d_sample_keys.ptr);  // [2][nq][k]
+    const u64_t* const run_in = running + (size_t)((ph + 1) & 1) * nq * k;       // what phase ph - 1 left
+    u64_t* const run_out = running + (size_t)(ph & 1) * nq * k;
+    if (carried && !wide) {
+      TAVB_HIP(hipMemcpy2DAsync(pp.lists + (size_t)pp.n_splits * k, (size_t)pp.list_stride * k * sizeof(u64_t), run_in,
                                 (size_t)k * sizeof(u64_t), (size_t)k * sizeof(u64_t), (size_t)nq, hipMemcpyDeviceToDevice, c->stream));
     }
     {
@@ -1130,18 +1131,22 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
       hipError_t e = launch(pp);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "mfma scan launch failed (phase %d): %s", ph, hipGetErrorString(e));
     }
-    if (last) {
+    if (wide) {
+      Timed t(c, TAVB_KERNEL_MERGE);
+      if (!last) TAVB_HIP(hipMemsetAsync(c->d_thr.ptr, 0xFF, (size_t)r.nq_pad * sizeof(float), c->stream));  // padding queries: NaN bits, ignored by `>`
+      hipError_t e = tavb::launch_select_topk(pp.workspace, pp.counts, pp.n_splits, nq, r.nq_pad, k, carried ? run_in : nullptr, r.floor,
+                                              last ? d_out : run_out, last ? nullptr : reinterpret_cast<float*>(c->d_thr.ptr), c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "select launch failed: %s", hipGetErrorString(e));
+    } else if (last) {
       Timed t(c, r.active ? TAVB_KERNEL_RESCORE : TAVB_KERNEL_MERGE);
       hipError_t e = scatter ? tavb::launch_merge_scatter(pp.lists, pp.list_stride, nq, k, r.active, scatter, d_out, c->stream)
                              : tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true, d_out, c->stream);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
     } else {
-      hipError_t e = tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true,
-                                        reinterpret_cast<u64_t*>(c->d_sample_keys.ptr), c->stream);
+      hipError_t e = tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true, run_out, c->stream);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "phase merge launch failed: %s", hipGetErrorString(e));
       TAVB_HIP(hipMemsetAsync(c->d_thr.ptr, 0xFF, (size_t)r.nq_pad * sizeof(float), c->stream));  // NaN bits: ignored by `>`
-      e = tavb::launch_sample_thresholds(reinterpret_cast<const u64_t*>(c->d_sample_keys.ptr), nq, k, r.floor,
-                                         reinterpret_cast<float*>(c->d_thr.ptr), c->stream);
+      e = tavb::launch_sample_thresholds(run_out, nq, k, r.floor, reinterpret_cast<float*>(c->d_thr.ptr), c->stream);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "threshold launch failed: %s", hipGetErrorString(e));
     }
   }

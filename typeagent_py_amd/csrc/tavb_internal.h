@@ -72,6 +72,7 @@ struct MfmaParams {
   const void* queries;  // f16 [nq_padded, dim] device
   unsigned long long* lists;  // out [nq, n_splits, k]
   unsigned long long* workspace;  // candidate buffers, mfma_workspace_bytes() bytes
+  int* counts;                    // 256-query tile only: [n_splits * nq_padded] keys left per candidate buffer (the tile writes no lists)
   int64_t rows;
   int32_t dim;
   int32_t nq;
@@ -81,8 +82,6 @@ struct MfmaParams {
   float min_score;
   int32_t n_splits;  // row ranges the corpus is cut into (one list per (query, split))
   int32_t list_stride;  // lists per query in `lists`; 0 = n_splits (extra slots are the caller's, e.g. a carried-over top-k)
-  int32_t variant;   // K loop of the 256-query tile: 3 = 256-row tile on 8 waves, K steps of 32 halves;
-                     // 6 = 320-row tile on 4 waves, K steps of 64 halves (whole cache lines)
   int32_t sched;     // variant 6: staging schedule (measurement)
   int32_t ablate;    // measurement only (garbage results): see launch_mfma_scan
   const float* thr_in;  // optional per-query admission thresholds (device, [nq_padded]) from the earlier ladder phases
@@ -95,7 +94,11 @@ hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int 
 int mfma_query_tile();                    // queries per workgroup tile
 int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu);
 bool mfma_supported(int dim, int k);
-size_t mfma_workspace_bytes(int n_splits, int nq_padded);
+size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide);
+// best k keys per query over the 256-query tile's candidate buffers (+ an optional carried-over list [nq, k]) -> out [nq, k] sorted,
+// thr_out[q] = just below the k-th best score (or floor[q]); tavb_mfma.hip
+hipError_t launch_select_topk(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, const unsigned long long* carried,
+                              const float* floor, unsigned long long* out, float* thr_out, hipStream_t stream);
 // 32-query tiles at HBM speed, fp32 or fp16 corpora (same parameter block; `queries` in the corpus dtype)
 hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream);
 int skinny_query_tile(int nq);  // 32, or 64 for batches of 33 and more

@@ -8,39 +8,31 @@
 // Products of two fp16 values are exact in fp32, so against an oracle fed the same
 // fp16-rounded values only the accumulation order differs (fp32 noise ~5e-8).
 //
-// Decomposition
-//   * operand roles: A = corpus tile (M = 256 rows), B = query tile (N = 256 queries).
-//     With this orientation the MFMA result layout puts ONE query in each lane
-//     (col = lane & 31) and 16 corpus rows in its 16 accumulator registers, so the
-//     epilogue's "does this score beat the query's current k-th best" test needs one
-//     threshold register per lane and one v_cmp per score.
-//   * workgroup = 8 waves (2 along rows x 4 along queries), each wave a 128 x 64
-//     sub-tile = 4 x 2 MFMA tiles of 32 x 32 (128 accumulator registers).
-//   * K loop: both operand slabs are staged into LDS by LDS-DMA (16 B per lane) through rings that run ahead of the
-//     MFMAs across tile boundaries, with counted `s_waitcnt vmcnt(N)` and raw `s_barrier` (variant 3: K steps of 32
-//     halves, 6 + 3 slots of 16 KiB; variant 6: K steps of 64 halves, see its header).  The 16-byte slots of each LDS row
-//     are XOR-swizzled -- on the per-lane global SOURCE address, because LDS-DMA writes lane-linear, and on the
-//     fragment reads -- so that the 16 lanes of a ds_read_b128 group hit 16 different bank slots.
-//   * a workgroup owns one query tile and one contiguous range of corpus rows and walks
-//     that range tile by tile (persistent); the workgroups that share a row range (one
-//     per query tile) get block ids congruent mod 8 so they run on the same XCD at the
-//     same time and the corpus tile is fetched from HBM once and re-read from that
-//     XCD's L2.
-//   * selection: per (workgroup, query) a candidate buffer of CAP keys in global memory
-//     plus, in LDS, its fill count and the current admission threshold.  A score that
-//     beats the threshold is clipped, packed into a key and appended (LDS atomic for the
-//     slot).  When a buffer could overflow on the next tile it is compacted to its best k
-//     (wave-wide bitonic sort + merge) and the threshold rises to its k-th score; the
-//     expected number of compactions per query is O(log(rows / CAP)).  At the end every
-//     buffer is compacted and written as a sorted list; tavb_merge merges the lists of
-//     the row ranges.
-//   * the host scans the corpus in phases of growing size (threshold ladder, tavb_abi.hip): the
-//     k-th best score after a phase seeds the admission thresholds of the next (`thr_in`).
+// Decomposition (256-query tile, `mfma_scan_kernel`)
+//   * operand roles: A = corpus tile (M = 320 rows), B = query tile (N = 256 queries).  With this orientation the MFMA
+//     result layout puts ONE query in each lane (col = lane & 31) and 16 corpus rows in its 16 accumulator registers,
+//     so the epilogue's "does this score beat the query's current k-th best" test needs one threshold register per
+//     lane and one max3 chain + compare per 32 x 32 block.
+//   * workgroup = 4 waves (2 along rows x 2 along queries), one per SIMD with the whole 512-register budget: a
+//     160 x 128 sub-tile = 5 x 4 MFMA tiles each.  K advances in steps of 64 halves (whole 128-byte lines); both operand
+//     slabs are staged into a two-slot LDS ring by LDS-DMA (`buffer_load ... lds`, 16 B per lane) that runs ahead of the
+//     MFMAs across tile boundaries, with raw `s_barrier` and explicit `s_waitcnt`.  Details in the kernel's header.
+//   * a workgroup owns one query tile and one contiguous range of corpus rows and walks that range tile by tile
+//     (persistent); the workgroups that share a row range (one per query tile) get block ids congruent mod 8 so they
+//     run on the same XCD at the same time and the corpus tile is fetched from HBM once and re-read from that XCD's L2.
+//   * selection: per (workgroup, query) a candidate buffer of CAPW keys in global memory plus, in LDS, its fill count
+//     and the current admission threshold.  A score that beats the threshold is clipped, packed into a key and
+//     appended (one LDS atomic per lane per block).  A buffer that could overflow on the next tile is compacted to its
+//     best k (`compact_to_kth`: bisection on the score bits, no sort) and the threshold rises to its k-th score.  At the
+//     end of a launch the buffers are left as they are; `select_topk_kernel` (one workgroup per QUERY) picks the best k
+//     over all row ranges and derives the next admission threshold.
+//   * the host scans the corpus in phases of growing size (threshold ladder, tavb_abi.hip): the k-th best score after a
+//     phase seeds the admission thresholds of the next (`thr_in`).
 //
-// Two kernel families live here: the 256-query fp16 tile described above (variant 3 = this 8-wave form with K steps of
-// 32 halves, used for the small phases of the ladder; variant 6 = four waves, 320-row tile, K steps of whole cache lines,
-// used for the big ones) and, at the end of the file, a 32/64-query tile for fp32 and fp16 corpora that carries small
-// batches -- and every batch on the reference's fp32 layout -- at HBM speed.
+// Two kernel families live here: the 256-query fp16 tile described above and, at the end of the file, a 32/64-query tile
+// (`skinny_scan_kernel`) for fp32 and fp16 corpora that carries small batches -- and every batch on the reference's fp32
+// layout -- at HBM speed.  On fp16 corpora the 256-query tile multiplies fp16-ROUNDED queries: it is used as an exact
+// filter, its candidates are rescored with the fp32 queries (tavb_rescore.hip).
 
 #include <hip/hip_runtime.h>
 
@@ -53,11 +45,12 @@ namespace tavb {
 
 namespace {
 
-constexpr int BM = 256;   // corpus rows per tile
-constexpr int BN = 256;   // queries per tile
+constexpr int BM = 256;   // corpus rows per tile of the 32/64-query kernel
+constexpr int BN = 256;   // queries per tile of the 256-query kernel
 constexpr int BK = 64;    // dim must be a multiple of this
-constexpr int NTHREADS = 512;
-constexpr int CAP = 512;  // candidate keys per (workgroup, query); must be >= BM + max k
+constexpr int CAP = 512;    // candidate keys per (workgroup, query) of the 32/64-query tile; must be >= BM + max k
+constexpr int CAPW = 1024;  // ... of the 256-query tile: three 320-row tiles fit before the first compaction, so a short first
+                            // ladder phase (<= 2 tiles per workgroup) never compacts at all
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
@@ -66,7 +59,8 @@ typedef const __attribute__((address_space(1))) void global_void;
 struct MfmaDeviceParams {
   const _Float16* corpus;
   const _Float16* queries;  // [nq_padded, dim]
-  u64* cand;                // [blocks][BN][CAP]
+  u64* cand;                // [blocks][queries per tile][CAP or CAPW]
+  int* counts;              // 256-query tile: [blocks][BN] keys left in each candidate buffer when the launch ends
   u64* lists;               // [nq][n_splits][k]
   int64_t rows;
   int64_t rows_per_split;   // multiple of BM
@@ -124,6 +118,87 @@ __device__ __forceinline__ WaveTopK<1> best_of_buffer(const u64* buf, int n, int
   return best;
 }
 
+// Compaction of one query's candidate buffer (n <= CAPACITY unsorted keys) to the keys that can still make the top k:
+// everything at or above the k-th best key.  No sort: the k-th best SCORE is found by bisection on its bit pattern
+// (scores are in [0, 1]: the patterns order like the floats) -- one ballot per 64 keys per bit, on the bits below the
+// highest bit in which the buffer's scores differ (~20 of them) -- and the survivors are packed to the front with ballot
+// prefix sums.  When more than k + 32 keys tie at that score (duplicate rows), the same bisection on the ordinal half of
+// the key cuts the ties exactly (smaller ordinal wins), so a buffer always shrinks to about k and cannot overflow.
+// ~5x cheaper than sorting 64-key chunks and merging them (the cold start of a launch compacts every buffer of the
+// workgroup after its first tile).  One wave; wave-uniform arguments; returns the number of keys kept.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v, int lane) {
+  v = max(v, (uint32_t)xor_lane_i32<1>((int)v, lane));
+  v = max(v, (uint32_t)xor_lane_i32<2>((int)v, lane));
+  v = max(v, (uint32_t)xor_lane_i32<4>((int)v, lane));
+  v = max(v, (uint32_t)xor_lane_i32<8>((int)v, lane));
+  v = max(v, (uint32_t)xor_lane_i32<16>((int)v, lane));
+  v = max(v, (uint32_t)xor_lane_i32<32>((int)v, lane));
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+template <int CAPACITY>
+__device__ __forceinline__ int compact_to_kth(u64* buf, int n, int k, int lane, float* kth_score) {
+  constexpr int PER = CAPACITY / 64;
+  u64 key[PER];
+  uint32_t sc[PER];
+  uint32_t mx = 0u, mn_inv = 0u;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int idx = j * 64 + lane;
+    key[j] = (idx < n) ? buf[idx] : 0ull;
+    sc[j] = (uint32_t)(key[j] >> 32);
+    mx = max(mx, sc[j]);
+    if (key[j] != 0ull) mn_inv = max(mn_inv, ~sc[j]);
+  }
+  if (n <= k) {
+    *kth_score = -1.0f;
+    return n;
+  }
+  mx = wave_max_u32(mx, lane);
+  const uint32_t mn = ~wave_max_u32(mn_inv, lane);
+  auto count_ge = [&](uint32_t t) {
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) c += __popcll(__builtin_amdgcn_ballot_w64(key[j] != 0ull && sc[j] >= t));
+    return c;
+  };
+  uint32_t t = mn;  // every key is >= mn: count = n > k
+  if (mx != mn) {
+    const int top = 31 - __builtin_clz(mx ^ mn);
+    t = (top == 31) ? 0u : (mx & ~((2u << top) - 1u));  // the common leading bits
+    for (int b = top; b >= 0; --b) {
+      const uint32_t trial = t | (1u << b);
+      if (count_ge(trial) >= k) t = trial;
+    }
+  }
+  // t = the k-th best score.  Ties at t beyond the slack are cut by ordinal (the low word: bigger = smaller ordinal).
+  int above = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) above += __popcll(__builtin_amdgcn_ballot_w64(key[j] != 0ull && sc[j] > t));
+  uint32_t t_lo = 0u;
+  if (count_ge(t) > k + 32) {
+    const int need = k - above;  // >= 1 of the tied keys are still needed
+    for (int b = 31; b >= 0; --b) {
+      const uint32_t trial = t_lo | (1u << b);
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) c += __popcll(__builtin_amdgcn_ballot_w64(sc[j] == t && key[j] != 0ull && (uint32_t)key[j] >= trial));
+      if (c >= need) t_lo = trial;
+    }
+  }
+  int base = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const bool keep = key[j] != 0ull && (sc[j] > t || (sc[j] == t && (uint32_t)key[j] >= t_lo));
+    const u64 m = __builtin_amdgcn_ballot_w64(keep);
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep) buf[pos] = key[j];
+    base += __popcll(m);
+  }
+  *kth_score = __uint_as_float(t);
+  return base;
+}
+
 #define TAVB_SB() __builtin_amdgcn_sched_barrier(0)
 #define TAVB_BARRIER()            \
   do {                            \
@@ -132,306 +207,17 @@ __device__ __forceinline__ WaveTopK<1> best_of_buffer(const u64* buf, int n, int
     TAVB_SB();                    \
   } while (0)
 
-// ---------------------------------------------------------------------------------------------
-// VARIANT 3: same tile shape and ping-pong wave groups as variant 2, but the operand stream is
-// decoupled from the tile loop:
-//   * K advances in steps of 32 halves (64 bytes per row, 16 KiB per operand per step);
-//   * the corpus operand (A) and the query operand (B) have separate LDS rings -- NA slots for A
-//     (long latency: HBM / Infinity Cache), NB slots for B (short latency: the query tile stays in
-//     L2) -- and separate stagers: the four waves of group 0 issue A's LDS-DMA, the four waves of
-//     group 1 issue B's, so each wave's vmcnt queue holds one operand's loads only and a counted
-//     `s_waitcnt vmcnt(4 * (depth - 1))` retires exactly the step that is needed next while
-//     depth - 1 steps stay in flight;
-//   * the step stream runs straight across tile boundaries (the loads for the next tile's first
-//     steps are already in flight while the current tile's epilogue runs);
-//   * 16-byte slots of the 64-byte LDS rows are XOR-swizzled with (row >> 2) & 3.
-// Everything else (admission / append / compaction, result lists) is as in variants 1 and 2.
-// ---------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int NA, int NB, int ABL>
-__global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDeviceParams p) {
-  constexpr int KS = 32;                 // halves per step
-  constexpr int SLOT = 256 * KS * 2;     // 16 KiB: one operand, one step
-  constexpr int DA = NA - 1, DB = NB - 1;  // steps in flight
-  constexpr int B_RING = NA * SLOT;
-  constexpr int CTRL = (NA + NB) * SLOT;
-  extern __shared__ __align__(16) unsigned char smem[];
-  float* thr_lds = reinterpret_cast<float*>(smem + CTRL);
-  int* cnt_lds = reinterpret_cast<int*>(smem + CTRL + BN * 4);
-  volatile int* need_compact = reinterpret_cast<volatile int*>(smem + CTRL + BN * 8);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2;
-  const int wn = wave & 3;
-  const int group = wm;  // group 0 = waves 0-3 (tile rows 0-127, stages A); group 1 = waves 4-7 (stages B)
-  const int lw = wave & 3;
-
-  const int b = blockIdx.x;
-  const int xcd = b & 7;
-  const int t = b >> 3;
-  const int qtile = t % p.n_qtiles;
-  const int split = (t / p.n_qtiles) * 8 + xcd;
-  if (split >= p.n_splits) return;
-  const int64_t r_begin = (int64_t)split * p.rows_per_split;
-  const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
-  const int logical_block = split * p.n_qtiles + qtile;
-  u64* my_cand = p.cand + (size_t)logical_block * BN * CAP;
-
-  const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
-  for (int i = tid; i < BN; i += NTHREADS) {
-    float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
-    const int qg0 = qtile * BN + i;
-    if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
-    else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best of the sample pass: a valid lower bound
-    thr_lds[i] = t0;
-    cnt_lds[i] = 0;
-  }
-  if (tid == 0) *need_compact = 0;
-
-  const int D = p.dim;
-  const int steps_per_tile = D / KS;
-  const size_t row_bytes = (size_t)D * 2;
-  const char* corpus = reinterpret_cast<const char*>(p.corpus);
-  const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * BN * row_bytes;
-  const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BM - 1) / BM) : 0;
-  if (n_tiles == 0) {
-    // empty row range: emit empty lists
-    for (int q = wave; q < BN; q += NTHREADS / 64) {
-      const int qg = qtile * BN + q;
-      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.list_stride + split) * (size_t)p.k + lane] = 0ull;
-    }
-    return;
-  }
-
-  // ---- stager state: instruction j of this wave covers operand rows (lw*4 + j)*16 .. +15, four
-  //      lanes (16-byte slots) per 64-byte row
-  const int st_row_in_inst = lane >> 2;
-  const int st_slot = lane & 3;
-  uint32_t st_off[4];
-  auto set_offsets = [&](int64_t row0, bool clamp) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = (lw * 4 + j) * 16 + st_row_in_inst;
-      int64_t r = row;
-      if (clamp && row0 + r >= p.rows) r = p.rows - 1 - row0;  // stay in bounds; masked in the epilogue
-      st_off[j] = (uint32_t)r * (uint32_t)row_bytes + (uint32_t)((st_slot ^ ((row >> 2) & 3)) * 16);
-    }
-  };
-  int st_tile = 0;   // tile of the next step this wave stages (group 0 only; group 1's operand has no tiles)
-  int st_kt = 0;     // K step within the tile
-  int st_slot_idx = 0;  // ring slot it goes to
-  set_offsets(r_begin, group == 0);
-
-  auto stage_next = [&]() {
-    if (group == 0) {
-      const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
-      const int64_t src_row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM;  // ablation: every block re-reads tile 0 (L2 resident)
-      const char* g = sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * (KS * 2));
-      unsigned char* l = smem + st_slot_idx * SLOT + lw * 4096;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_global_load_lds((global_void*)(g + (size_t)st_off[j]), (lds_void*)(l + j * 1024), 16, 0, 0);
-      if (++st_slot_idx == NA) st_slot_idx = 0;
-      if (++st_kt == steps_per_tile) {
-        st_kt = 0;
-        ++st_tile;
-        if (st_tile < n_tiles) set_offsets(r_begin + (int64_t)st_tile * BM, true);
-      }
-    } else {
-      const char* g = sgpr_ptr(qbase + (size_t)st_kt * (KS * 2));
-      unsigned char* l = smem + B_RING + st_slot_idx * SLOT + lw * 4096;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_global_load_lds((global_void*)(g + (size_t)st_off[j]), (lds_void*)(l + j * 1024), 16, 0, 0);
-      if (++st_slot_idx == NB) st_slot_idx = 0;
-      if (++st_kt == steps_per_tile) st_kt = 0;
-    }
-  };
-
-  // ---- fragment read addresses: row (lane & 31) of a 32-row block, logical slot 2*k16 + (lane >> 5),
-  //      physical slot = logical ^ ((row >> 2) & 3)  ->  byte (k16 << 5) ^ frag_x within the 64-byte row
-  const int frag_row = lane & 31;
-  const uint32_t frag_x = (uint32_t)(((lane >> 5) ^ ((frag_row >> 2) & 3)) << 4);
-  const uint32_t a_lane = (uint32_t)((wm * 128 + frag_row) * 64);           // + mi * 2048
-  const uint32_t b_lane = (uint32_t)(B_RING + (wn * 64 + frag_row) * 64);   // + ni * 2048
-
-  // ---- prologue: fill the pipelines, wait for step 0
-  if (group == 0) {
-#pragma unroll 1
-    for (int i = 0; i < DA; ++i) stage_next();
-    wait_vmcnt<4 * (DA - 1)>();
-  } else {
-#pragma unroll 1
-    for (int i = 0; i < DB; ++i) stage_next();
-    wait_vmcnt<4 * (DB - 1)>();
-  }
-  __syncthreads();  // ring step 0 landed, thresholds initialised (no LDS-DMA is drained: the waits above are counted)
-  if (group == 1) TAVB_BARRIER();  // group 1 runs one barrier interval behind group 0
-
-  int rd_a = 0, rd_b = 0;  // ring slots of the step being consumed
-  for (int tile = 0; tile < n_tiles; ++tile) {
-    const int64_t row0 = r_begin + (int64_t)tile * BM;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-#pragma unroll 1
-    for (int kt = 0; kt < steps_per_tile; ++kt) {
-      // ---- LOAD phase
-      const unsigned char* abase = smem + rd_a * SLOT;
-      const unsigned char* bbase = smem + rd_b * SLOT;
-      f16x8 af[2][4], bf[2][2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const uint32_t kx = (uint32_t)(kk << 5) ^ frag_x;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) af[kk][mi] = *reinterpret_cast<const f16x8*>(abase + (a_lane + kx) + mi * 2048);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) bf[kk][ni] = *reinterpret_cast<const f16x8*>(bbase + (b_lane + kx) + ni * 2048);
-      }
-      if constexpr ((ABL & 2) == 0) {
-        stage_next();  // the slot being refilled was last read one step ago (two barriers back)
-        if (group == 1) wait_vmcnt<4 * (DB - 1)>();  // B of the next step has landed
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      TAVB_BARRIER();
-      // ---- MFMA phase
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            if constexpr ((ABL & 1) == 0)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
-            else
-              asm volatile("" ::"v"(af[kk][mi]), "v"(bf[kk][ni]));
-          }
-      __builtin_amdgcn_s_setprio(0);
-      if constexpr ((ABL & 2) == 0) {
-        if (group == 0) wait_vmcnt<4 * (DA - 1)>();  // A of the next step has landed
-      }
-      TAVB_BARRIER();
-      if (++rd_a == NA) rd_a = 0;
-      if (++rd_b == NB) rd_b = 0;
-    }
-    if (group == 0) TAVB_BARRIER();  // re-align the groups for the epilogue
-
-    // ---- epilogue: score, admission test, append
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int ql = wn * 64 + ni * 32 + (lane & 31);
-      const float thr = thr_lds[ql];
-      // Fast test on the raw dot products: score = fma(dot, 0.5, 0.5) is monotone in dot, so `score > thr` implies
-      // `dot > 2 thr - 1 - 2^-21` (the margin covers the roundings of both fmas with room to spare).  One max3
-      // chain + one compare per 32x32 block instead of 16 fmas + 16 compares; the exact test is in the slow path.
-      const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        float top = acc[mi][ni][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, acc[mi][ni][r]);
-        const bool any = (ABL == 0) && (top > thr_pre);
-        if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi][ni]));  // keep the MFMAs alive when admissions are ablated
-        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-          float sc[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
-          // slow path, taken by the whole wave when any lane admits something: every lane builds the
-          // bit mask of its admitted rows, reserves that many buffer slots with ONE LDS atomic (the
-          // latency of the returning atomic is paid once per 32x32 block, not once per key), then
-          // stores its keys with predicated stores.
-          const int64_t row_base = row0 + wm * 128 + mi * 32 + 4 * (lane >> 5);
-          unsigned admit = 0;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float s = sc[r];
-            s = (s > 0.0f) ? s : 0.0f;
-            s = (s > 1.0f) ? 1.0f : s;
-            const bool ok = (sc[r] > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s >= p.min_score);
-            admit |= ok ? (1u << r) : 0u;
-          }
-          const int n_adm = __popc(admit);
-          int pos = 0;
-          if (n_adm > 0) {
-            pos = lds_add_rtn(&cnt_lds[ql], n_adm);
-            if (pos + n_adm > CAP - BM) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if ((admit >> r) & 1u) {
-              float s = sc[r];
-              s = (s > 0.0f) ? s : 0.0f;
-              s = (s > 1.0f) ? 1.0f : s;
-              if (pos < CAP)
-                my_cand[(size_t)ql * CAP + pos] = make_key(s, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
-              ++pos;
-            }
-          }
-        }
-      }
-    }
-    // Compaction is rare (O(log rows) times per query).  Only then do the appended keys have to be in
-    // memory for another wave to read, so only then does the workgroup pay a drain of its (otherwise
-    // still flying) LDS-DMA queues; normally the epilogue ends at this barrier.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    if (*need_compact != 0) {  // workgroup-uniform: read after the barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    for (int q = wave; q < BN; q += NTHREADS / 64) {
-      const int n = cnt_lds[q];
-      if (n > CAP - BM) {
-        u64* buf = my_cand + (size_t)q * CAP;
-        const WaveTopK<1> best = best_of_buffer(buf, n < CAP ? n : CAP, lane);
-        if (lane < p.k) buf[lane] = best.key[0];
-        const int kept = __popcll(__ballot(best.key[0] != 0ull && lane < p.k));
-        const u64 kth = best.at(p.k - 1);
-        if (lane == 0) {
-          cnt_lds[q] = kept;
-          const float kth_score = __uint_as_float((uint32_t)(kth >> 32));
-          if (kth != 0ull && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    if (tid == 0) *need_compact = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TAVB_BARRIER();
-    }
-    if (group == 1) TAVB_BARRIER();  // stagger again
-  }
-  if (group == 0) TAVB_BARRIER();  // pairs with group 1's last stagger barrier
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead loads before the block retires
-  __syncthreads();
-
-  for (int q = wave; q < BN; q += NTHREADS / 64) {
-    const int qg = qtile * BN + q;
-    if (qg >= p.nq) continue;
-    const int n = cnt_lds[q];
-    const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane);
-    u64* out = p.lists + ((size_t)qg * p.list_stride + split) * (size_t)p.k;
-    if (lane < p.k) out[lane] = best.key[0];
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// VARIANT 6: four waves with the whole register file each, K steps of whole cache lines.
+// The 256-query tile: four waves with the whole register file each, K steps of whole cache lines.
+// (Round 1 shipped an 8-wave 256 x 256 tile with K steps of 32 halves -- "variant 3" -- and a 4-wave 384 x 256 one --
+// "variant 5"; this kernel, "variant 6" in the profiles, replaced both: profiles/r02_cfg3_ablation.md.)
 //
-// Why four waves: the 8-wave tile of variant 3 sits on the machine balance between the L2 -> CU operand path and the
+// Why four waves: an 8-wave 256 x 256 tile sits on the machine balance between the L2 -> CU operand path and the
 // matrix pipe (32 KiB of operands per 256 x 256 x 32 step).  Fewer operand bytes per flop needs a bigger tile per CU,
 // and the biggest one the register file allows is held by FOUR waves (2 x 2), one per SIMD, each with the full
 // 512-register budget.  hipcc picks the AGPR or the VGPR form of an MFMA builtin per FUNCTION, so > 256 accumulators
@@ -440,7 +226,7 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
 // -- MFMA, LDS read, MFMA, ..., MFMA, LDS-DMA -- IS the schedule (no sched_group_barrier).  The asm MFMAs are invisible
 // to the compiler's hazard recognizer: the epilogue opens with the wait states an MFMA result needs.
 //
-// Why whole lines: a staging piece of variant 3 (K steps of 32 halves) is sixteen 64-byte HALF lines; the CU's
+// Why whole lines: with K steps of 32 halves a staging piece is sixteen 64-byte HALF lines; the CU's
 // texture-address path serves a 1 KiB piece of that shape in ~14 ns from L2 against ~7.7 ns for eight whole 128-byte
 // lines (tools/microbench/load_paths.hip, all CUs pulling; profiles/r02_operand_path.md).  A round-1 four-wave kernel
 // with 32-half steps kept that path ~90 % busy and its waves stalled at the ISSUE of their staging loads.  Here a K
@@ -467,7 +253,6 @@ __global__ void __launch_bounds__(NTHREADS) mfma_scan_kernel_v3(const MfmaDevice
 //     Slot P is then free: the pieces of step S+2 are issued behind the MFMAs of q3 (N3 of them), of the next q0 (N0)
 //     and q1 (N1) -- corpus pieces first, they have the longest way -- and have until the next barrier to land.
 //   * the first quarter of a tile multiplies into a ZERO C operand instead of clearing 320 registers.
-//   * epilogue / candidate buffers / compaction / lists as in variant 3.
 // Measured and rejected (profiles/r02_cfg3_ablation.md): touching the corpus lines of the step 1 / 2 / 4 steps ahead
 // into L2 with one 4-byte load per line (-3 .. -6 %); other piece-per-quarter schedules (no difference).
 // ---------------------------------------------------------------------------------------------
@@ -493,7 +278,7 @@ constexpr int v6_piece_at(int q, int i) {
 }
 
 template <int ABL, int N3, int N0, int N1>
-__global__ void __launch_bounds__(NT6) mfma_scan_kernel_v6(const MfmaDeviceParams p) {
+__global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p) {
   static_assert(N3 + N0 + N1 == PIECES6, "every piece of a step is issued exactly once");
   extern __shared__ __align__(16) unsigned char smem[];
   float* thr_lds = reinterpret_cast<float*>(smem + CTRL6);
@@ -516,7 +301,8 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel_v6(const MfmaDeviceParam
   const int64_t r_begin = (int64_t)split * p.rows_per_split;
   const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
   const int logical_block = split * p.n_qtiles + qtile;
-  u64* my_cand = p.cand + (size_t)logical_block * BN * CAP;
+  u64* my_cand = p.cand + (size_t)logical_block * BN * CAPW;
+  int* my_counts = p.counts + (size_t)logical_block * BN;
 
   const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
   for (int i = tid; i < BN; i += NT6) {
@@ -536,10 +322,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel_v6(const MfmaDeviceParam
   const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * BN * row_bytes;
   const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BM6 - 1) / BM6) : 0;
   if (n_tiles == 0) {
-    for (int q = wave; q < BN; q += NT6 / 64) {
-      const int qg = qtile * BN + q;
-      if (qg < p.nq && lane < p.k) p.lists[((size_t)qg * p.list_stride + split) * (size_t)p.k + lane] = 0ull;
-    }
+    for (int i = tid; i < BN; i += NT6) my_counts[i] = 0;  // empty row range: empty buffers
     return;
   }
 
@@ -693,7 +476,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel_v6(const MfmaDeviceParam
 #pragma unroll 1
     for (int kt = 1; kt < steps_per_tile; ++kt) step(std::false_type{});
 
-    // ---- epilogue: admission test on the raw dot products, append (see variant 3).  The asm MFMAs are invisible
+    // ---- epilogue: admission test on the raw dot products, append .  The asm MFMAs are invisible
     //      to the compiler's hazard recognizer: a 32x32x16 MFMA needs 18 wait states before its result may be read.
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     int zero_e = 0;
@@ -705,7 +488,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel_v6(const MfmaDeviceParam
       for (int ni = 0; ni < 4; ++ni) {
         const int ql = wn * 128 + ni * 32 + (lane_e & 31);
         const float thr = thr_lds[ql];
-        const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;  // score > thr implies dot > thr_pre (see variant 3)
+        const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;  // score > thr implies dot > thr_pre: fma(dot, 0.5, 0.5) is monotone, the margin covers both roundings
 #pragma unroll
         for (int mi = 0; mi < 5; ++mi) {
           if ((mi * 4 + ni >= NA_TILES) != (pass == 0)) continue;  // pass 0: VGPR tiles, pass 1: AGPR tiles
@@ -732,7 +515,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel_v6(const MfmaDeviceParam
             int pos = 0;
             if (n_adm > 0) {
               pos = lds_add_rtn(&cnt_lds[ql], n_adm);
-              if (pos + n_adm > CAP - BM6) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
+              if (pos + n_adm > CAPW - BM6) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -741,8 +524,8 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel_v6(const MfmaDeviceParam
                 const float sc = fmaf(dots[r], 0.5f, 0.5f);
                 float s1 = (sc > 0.0f) ? sc : 0.0f;
                 s1 = (s1 > 1.0f) ? 1.0f : s1;
-                if (pos < CAP)
-                  my_cand[(size_t)ql * CAP + pos] = make_key(s1, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
+                if (pos < CAPW)
+                  my_cand[(size_t)ql * CAPW + pos] = make_key(s1, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
                 ++pos;
               }
             }
@@ -756,16 +539,13 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel_v6(const MfmaDeviceParam
       TAVB_BARRIER();
       for (int q = wave; q < BN; q += NT6 / 64) {
         const int n = cnt_lds[q];
-        if (n > CAP - BM6) {
-          u64* buf = my_cand + (size_t)q * CAP;
-          const WaveTopK<1> best = best_of_buffer(buf, n < CAP ? n : CAP, lane_e);
-          if (lane_e < p.k) buf[lane_e] = best.key[0];
-          const int kept = __popcll(__ballot(best.key[0] != 0ull && lane_e < p.k));
-          const u64 kth = best.at(p.k - 1);
+        if (n > CAPW - BM6) {
+          u64* buf = my_cand + (size_t)q * CAPW;
+          float kth_score;
+          const int kept = compact_to_kth<CAPW>(buf, n < CAPW ? n : CAPW, p.k, lane_e, &kth_score);
           if (lane_e == 0) {
             cnt_lds[q] = kept;
-            const float kth_score = __uint_as_float((uint32_t)(kth >> 32));
-            if (kth != 0ull && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
+            if (kept >= p.k && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -780,16 +560,8 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel_v6(const MfmaDeviceParam
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead LDS-DMA before the block retires
   __syncthreads();
 
-  for (int q = wave; q < BN; q += NT6 / 64) {
-    const int qg = qtile * BN + q;
-    if (qg >= p.nq) continue;
-    const int n = cnt_lds[q];
-    int lane_f = lane;
-    asm volatile("" : "+v"(lane_f));
-    const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane_f);
-    u64* out = p.lists + ((size_t)qg * p.list_stride + split) * (size_t)p.k;
-    if (lane_f < p.k) out[lane_f] = best.key[0];
-  }
+  // the buffers stay unsorted: tavb::select_topk_kernel picks the best k over all workgroups' buffers of a query
+  for (int i = tid; i < BN; i += NT6) my_counts[i] = cnt_lds[i] < CAPW ? cnt_lds[i] : CAPW;
 }
 
 
@@ -1065,14 +837,11 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
         const int n = cnt_lds[q];
         if (n > CAP - BM) {
           u64* buf = my_cand + (size_t)q * CAP;
-          const WaveTopK<1> best = best_of_buffer(buf, n < CAP ? n : CAP, lane);
-          if (lane < p.k) buf[lane] = best.key[0];
-          const int kept = __popcll(__ballot(best.key[0] != 0ull && lane < p.k));
-          const u64 kth = best.at(p.k - 1);
+          float kth_score;
+          const int kept = compact_to_kth<CAP>(buf, n < CAP ? n : CAP, p.k, lane, &kth_score);
           if (lane == 0) {
             cnt_lds[q] = kept;
-            const float kth_score = __uint_as_float((uint32_t)(kth >> 32));
-            if (kth != 0ull && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
+            if (kept >= p.k && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1094,6 +863,203 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
     const WaveTopK<1> best = best_of_buffer(my_cand + (size_t)q * CAP, n < CAP ? n : CAP, lane);
     u64* out = p.lists + ((size_t)qg * p.list_stride + split) * (size_t)p.k;
     if (lane < p.k) out[lane] = best.key[0];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Best k keys of ONE query over the (unsorted) candidate buffers that the workgroups of all row ranges left behind,
+// plus the running top-k of the earlier ladder phases -- and, from them, the admission threshold of the next phase.
+// One workgroup per query, so the selection work of a launch is spread over 1024 workgroups x 256 threads instead of
+// being the serial tail of 256 workgroups (each of which used to sort 256 buffers, 64 per wave, before it could retire).
+//   * the keys of the query (a few hundred after a selective phase; every row of the phase after the cold first one)
+//     stream ONCE through an LDS cache of SEL_CACHE keys.  Whenever the cache is nearly full it is cut down to its exact
+//     best k, and that k-th best -- a valid lower bound on the final one -- filters the keys that follow (expected
+//     survivors on data in random order: k * remaining / seen), so the exact selection always runs on a few thousand
+//     keys held in registers, whatever the total.
+//   * exact selection = bisection on the bit pattern of the score (scores are in [0, 1]: the patterns order like the
+//     floats), block-wide counts per bit, only on the bits in which the keys differ; ties at the k-th best score beyond
+//     what is needed are cut the same way on the ordinal half (smaller ordinal wins): exactly min(k, total) keys.
+//   * the picked keys (<= 64) are sorted by one wave and written best first; thr = just below the k-th best score (or
+//     the caller's floor), the same contract as sample_threshold_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int SEL_CACHE = 8192;  // keys of a query held in LDS (64 KiB)
+constexpr int SEL_PER = SEL_CACHE / 256;
+
+__global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict__ cand, const int* __restrict__ counts, int n_splits, int n_qtiles, int k,
+                                                          const u64* __restrict__ carried, const float* __restrict__ floor, u64* __restrict__ out,
+                                                          float* __restrict__ thr_out) {
+  extern __shared__ __align__(16) unsigned char sel_smem[];
+  u64* cache = reinterpret_cast<u64*>(sel_smem);  // [SEL_CACHE]
+  __shared__ int off[260];  // exclusive prefix of the per-split counts (+ the carried list as one more "split")
+  __shared__ float red[4];
+  __shared__ u64 picked[64];
+  __shared__ int n_picked, n_cached;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = blockIdx.x;
+  const int qtile = q / BN, ql = q - qtile * BN;
+  const int n_src = n_splits + (carried != nullptr ? 1 : 0);  // <= 257
+
+  auto block_sum = [&](int v) -> int {  // exact: counts stay far below 2^24
+    const float w = wave_sum((float)v);
+    if (lane == 0) red[wave] = w;
+    __syncthreads();
+    const int total = (int)(red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+    return total;
+  };
+  // ---- flat order of the query's keys: source s holds count(s) keys at flat positions off[s] .. off[s+1)
+  __shared__ int cnt_of[260];
+  for (int sp = tid; sp < n_src; sp += 256)  // (n_splits <= 256: one load per thread, all in flight at once)
+    cnt_of[sp] = (sp < n_splits) ? counts[((size_t)sp * n_qtiles + qtile) * BN + ql] : k;
+  if (tid == 0) n_picked = 0;
+  __syncthreads();
+  for (int sp = tid; sp <= n_src; sp += 256) {
+    int run = 0;
+    for (int j = 0; j < sp; ++j) run += cnt_of[j];
+    off[sp] = run;
+  }
+  __syncthreads();
+  const int total = off[n_src];
+  auto key_at = [&](int flat) -> u64 {
+    int lo = 0, hi = n_src - 1;  // last source with off[s] <= flat
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (off[mid] <= flat) lo = mid; else hi = mid - 1;
+    }
+    const int i = flat - off[lo];
+    if (lo == n_splits) return carried[(size_t)q * k + i];  // (empty slots of the carried list are 0: never picked)
+    return cand[(((size_t)lo * n_qtiles + qtile) * BN + ql) * (size_t)CAPW + i];
+  };
+
+  u64 key[SEL_PER];
+  int n_keys = 0;  // keys in the cache (block-uniform)
+  // exact (t_hi, t_lo): the need-th best key among cache[0 .. n) is the smallest key with score > t_hi or (score == t_hi and low >= t_lo);
+  // returns false when n < need (everything is wanted)
+  auto kth_of_cache = [&](int n, int need, uint32_t* t_hi_out, uint32_t* t_lo_out) -> bool {
+    if (n < need) return false;
+    uint32_t mx = 0u, mn_inv = 0u;
+#pragma unroll
+    for (int j = 0; j < SEL_PER; ++j) {
+      const int i = tid + 256 * j;
+      key[j] = (i < n) ? cache[i] : 0ull;
+      const uint32_t sc = (uint32_t)(key[j] >> 32);
+      mx = max(mx, sc);
+      if (key[j] != 0ull) mn_inv = max(mn_inv, ~sc);
+    }
+    mx = wave_max_u32(mx, lane);
+    mn_inv = wave_max_u32(mn_inv, lane);
+    if (lane == 0) red[wave] = __uint_as_float(mx);
+    __syncthreads();
+    mx = max(max(__float_as_uint(red[0]), __float_as_uint(red[1])), max(__float_as_uint(red[2]), __float_as_uint(red[3])));
+    __syncthreads();
+    if (lane == 0) red[wave] = __uint_as_float(mn_inv);
+    __syncthreads();
+    const uint32_t mn = ~max(max(__float_as_uint(red[0]), __float_as_uint(red[1])), max(__float_as_uint(red[2]), __float_as_uint(red[3])));
+    __syncthreads();
+    auto count = [&](auto&& pred) {
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < SEL_PER; ++j) c += (key[j] != 0ull && pred(key[j])) ? 1 : 0;
+      return block_sum(c);
+    };
+    uint32_t t = mn;
+    if (mx != mn) {
+      const int top = 31 - __builtin_clz(mx ^ mn);
+      t = (top == 31) ? 0u : (mx & ~((2u << top) - 1u));
+      for (int b = top; b >= 0; --b) {
+        const uint32_t trial = t | (1u << b);
+        if (count([&](u64 kk) { return (uint32_t)(kk >> 32) >= trial; }) >= need) t = trial;
+      }
+    }
+    const int above = count([&](u64 kk) { return (uint32_t)(kk >> 32) > t; });
+    const int ties = count([&](u64 kk) { return (uint32_t)(kk >> 32) == t; });
+    uint32_t t_lo = 0u;
+    if (above + ties > need) {  // cut the ties by ordinal (low word: bigger = smaller ordinal)
+      const int need_ties = need - above;
+      for (int b = 31; b >= 0; --b) {
+        const uint32_t trial = t_lo | (1u << b);
+        if (count([&](u64 kk) { return (uint32_t)(kk >> 32) == t && (uint32_t)kk >= trial; }) >= need_ties) t_lo = trial;
+      }
+    }
+    *t_hi_out = t;
+    *t_lo_out = t_lo;
+    return true;
+  };
+
+  // ---- stream the keys through the cache: whenever it is nearly full, it is cut down to its exact best k, and that k-th
+  //      best -- a valid lower bound on the final one -- filters what comes next.  On data in random order the first cut
+  //      is the only one (the filter then passes k * remaining / seen keys); adversarial orders just cut more often.
+  uint32_t f_hi = 0u, f_lo = 0u;
+  bool have_filter = false;
+  if (tid == 0) n_cached = 0;
+  __syncthreads();
+  constexpr int UNR = 8;  // keys per thread per round: their loads are all in flight together (the loop is latency-bound otherwise)
+  for (int base = 0; base < total; base += 256 * UNR) {
+    if (n_cached > SEL_CACHE - 256 * UNR) {  // block-uniform (read after a barrier)
+      const int n = n_cached;
+      __syncthreads();
+      have_filter = kth_of_cache(n, k, &f_hi, &f_lo);  // n >= k here
+      if (tid == 0) n_cached = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < SEL_PER; ++j) {  // keep exactly the best k (they sit in this thread's registers)
+        const u64 kk = key[j];
+        const uint32_t hi = (uint32_t)(kk >> 32);
+        if (kk != 0ull && (hi > f_hi || (hi == f_hi && (uint32_t)kk >= f_lo))) cache[atomicAdd(&n_cached, 1)] = kk;
+      }
+      __syncthreads();
+    }
+    u64 kk[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int i = base + u * 256 + tid;
+      kk[u] = (i < total) ? key_at(i) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const uint32_t hi = (uint32_t)(kk[u] >> 32);
+      const bool keep = kk[u] != 0ull && (!have_filter || hi > f_hi || (hi == f_hi && (uint32_t)kk[u] >= f_lo));
+      const u64 m = __builtin_amdgcn_ballot_w64(keep);
+      int wbase = 0;
+      if (lane == 0 && m != 0ull) wbase = atomicAdd(&n_cached, __popcll(m));
+      wbase = __builtin_amdgcn_readfirstlane(wbase);
+      if (keep) cache[wbase + __popcll(m & ((1ull << lane) - 1ull))] = kk[u];
+    }
+    __syncthreads();
+  }
+  n_keys = n_cached;
+  uint32_t t_hi = 0u, t_lo = 0u;
+  const bool enough = kth_of_cache(n_keys, k, &t_hi, &t_lo);
+  // ---- pick (exactly min(k, n_keys) keys), sort, write
+#pragma unroll
+  for (int j = 0; j < SEL_PER; ++j) {
+    const u64 kk = key[j];  // kth_of_cache left cache[tid + 256 j] here (when it ran); reload otherwise
+    const int i = tid + 256 * j;
+    const u64 kv = enough ? kk : ((i < n_keys) ? cache[i] : 0ull);
+    const uint32_t hi = (uint32_t)(kv >> 32);
+    const bool take = kv != 0ull && (!enough || hi > t_hi || (hi == t_hi && (uint32_t)kv >= t_lo));
+    if (take) {
+      const int idx = atomicAdd(&n_picked, 1);
+      if (idx < 64) picked[idx] = kv;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int n = n_picked < 64 ? n_picked : 64;
+    const u64 mine = sort64_ascending(tid < n ? picked[tid] : 0ull, tid);
+    const u64 best_first = shfl_u64(mine, 63 - tid);
+    if (tid < k) out[(size_t)q * k + tid] = best_first;
+    if (thr_out != nullptr) {
+      const u64 kth = shfl_u64(best_first, k - 1);
+      float t = -__builtin_inff();
+      if (kth != 0ull) {
+        const uint32_t bits = (uint32_t)(kth >> 32);
+        t = bits ? __uint_as_float(bits - 1u) : -__builtin_inff();
+      }
+      if (floor != nullptr && floor[q] > t) t = floor[q];
+      if (tid == 0) thr_out[q] = t;
+    }
   }
 }
 
@@ -1136,11 +1102,20 @@ int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu) {
   return splits;
 }
 
-static size_t mfma_cand_bytes(int n_splits, int nq_padded) {
-  return (size_t)n_splits * (size_t)nq_padded * CAP * sizeof(u64);  // nq_padded = tiles x queries per tile (256 or 32)
+// candidate buffers of a launch: nq_padded = tiles x queries per tile; the 256-query tile has the deeper buffers
+size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide) {
+  return (size_t)n_splits * (size_t)nq_padded * (wide ? CAPW : CAP) * sizeof(u64);
 }
 
-size_t mfma_workspace_bytes(int n_splits, int nq_padded) { return mfma_cand_bytes(n_splits, nq_padded); }
+hipError_t launch_select_topk(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, const unsigned long long* carried,
+                              const float* floor, unsigned long long* out, float* thr_out, hipStream_t stream) {
+  if (nq < 1 || k < 1 || k > 64 || n_splits < 1 || nq_padded % BN != 0) return hipErrorInvalidValue;
+  constexpr int lds = SEL_CACHE * (int)sizeof(u64);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(select_topk_kernel, dim3(nq), dim3(256), lds, stream, cand, counts, n_splits, nq_padded / BN, k, carried, floor, out, thr_out);
+  return hipGetLastError();
+}
 
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   if (!mfma_supported(p.dim, p.k) || p.nq_padded % BN != 0 || p.n_splits < 1) return hipErrorInvalidValue;
@@ -1159,10 +1134,11 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.min_score = p.min_score;
   d.thr_in = p.thr_in;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
-  const int bm = (p.variant == 6) ? BM6 : BM;
+  const int bm = BM6;
   d.rows_per_split = ((per + bm - 1) / bm) * bm;
-  if (!p.workspace) return hipErrorInvalidValue;
+  if (!p.workspace || !p.counts) return hipErrorInvalidValue;
   d.cand = p.workspace;
+  d.counts = p.counts;
   // grid: groups of 8 consecutive block ids = 8 different row ranges (one per XCD)
   const int groups = (p.n_splits + 7) / 8;
   const int grid = groups * d.n_qtiles * 8;
@@ -1173,28 +1149,23 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
     return hipGetLastError();
   };
   // `ablate` modes exist to time parts of a kernel (results are garbage): see profiles/r02_cfg3_ablation.md
-  if (p.variant == 6) {
+  {
     if (p.dim % 64 != 0) return hipErrorInvalidValue;
     switch (p.ablate) {
-      case 256: return go(mfma_scan_kernel_v6<256, 8, 6, 4>, NT6, LDS6);  // everything except admissions
-      case 260: return go(mfma_scan_kernel_v6<260, 8, 6, 4>, NT6, LDS6);  // same, corpus tile 0 re-read by every block (L2 resident)
-      case 264: return go(mfma_scan_kernel_v6<264, 8, 6, 4>, NT6, LDS6);  // same as 256, query operand K step 0 re-read (cache resident)
-      case 268: return go(mfma_scan_kernel_v6<268, 8, 6, 4>, NT6, LDS6);  // both operands cache resident
-      case 258: return go(mfma_scan_kernel_v6<258, 8, 6, 4>, NT6, LDS6);  // no LDS-DMA, no admissions
+      case 256: return go(mfma_scan_kernel<256, 8, 6, 4>, NT6, LDS6);  // everything except admissions
+      case 260: return go(mfma_scan_kernel<260, 8, 6, 4>, NT6, LDS6);  // same, corpus tile 0 re-read by every block (L2 resident)
+      case 264: return go(mfma_scan_kernel<264, 8, 6, 4>, NT6, LDS6);  // same as 256, query operand K step 0 re-read (cache resident)
+      case 268: return go(mfma_scan_kernel<268, 8, 6, 4>, NT6, LDS6);  // both operands cache resident
+      case 258: return go(mfma_scan_kernel<258, 8, 6, 4>, NT6, LDS6);  // no LDS-DMA, no admissions
       default: break;
     }
     switch (p.sched) {  // staging pieces per quarter (q3, q0, q1): measurement
-      case 1: return go(mfma_scan_kernel_v6<0, 10, 8, 0>, NT6, LDS6);
-      case 2: return go(mfma_scan_kernel_v6<0, 6, 6, 6>, NT6, LDS6);
-      default: return go(mfma_scan_kernel_v6<0, 8, 6, 4>, NT6, LDS6);
+      case 1: return go(mfma_scan_kernel<0, 10, 8, 0>, NT6, LDS6);
+      case 2: return go(mfma_scan_kernel<0, 6, 6, 6>, NT6, LDS6);
+      default: return go(mfma_scan_kernel<0, 8, 6, 4>, NT6, LDS6);
     }
   }
-  constexpr int NA3 = 6, NB3 = 3;
-  constexpr int LDS3 = (NA3 + NB3) * 16384 + BN * 8 + 16;
-  switch (p.ablate) {
-    case 256: return go(mfma_scan_kernel_v3<NA3, NB3, 256>, NTHREADS, LDS3);  // everything except admissions
-    default: return go(mfma_scan_kernel_v3<NA3, NB3, 0>, NTHREADS, LDS3);
-  }
+  return hipErrorInvalidValue;
 }
 
 int skinny_query_tile(int nq) { return nq > SQ32 ? 2 * SQ32 : SQ32; }  // 64-query tiles for batches of 33 and more
