@@ -406,7 +406,7 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < -1) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= -1");
     c->mfma_sample_rows = v;
   } else if (n == "mfma_sched") {
-    if (v < 0 || v > 3) return fail(TAVB_E_INVALID, "mfma_sched must be 0..3");
+    if (v < 0 || v > 9) return fail(TAVB_E_INVALID, "mfma_sched must be 0..9");
     c->mfma_sched = v;
   } else if (n == "skinny_min_batch_f32") {
     if (v < 1) return fail(TAVB_E_INVALID, "skinny_min_batch_f32 must be >= 1");
@@ -1056,7 +1056,7 @@ struct TileRun {
 // scatter[slot] of it for the slots below *active).
 int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scatter) {
   auto pick_splits = [&](int64_t rows) {
-    return r.skinny ? tavb::skinny_pick_splits(rows, r.nq_pad, r.qt, c->n_cu) : tavb::mfma_pick_splits(rows, r.nq_pad, c->n_cu);
+    return r.skinny ? tavb::skinny_pick_splits(rows, r.nq_pad, r.qt, c->n_cu, c->dim, r.q32) : tavb::mfma_pick_splits(rows, r.nq_pad, c->n_cu);
   };
   auto launch = [&](const tavb::MfmaParams& q) { return r.skinny ? tavb::launch_skinny_scan(q, c->stream) : tavb::launch_mfma_scan(q, c->stream); };
   const int nq = r.nq, k = r.k;

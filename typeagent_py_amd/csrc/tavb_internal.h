@@ -82,7 +82,7 @@ struct MfmaParams {
   float min_score;
   int32_t n_splits;  // row ranges the corpus is cut into (one list per (query, split))
   int32_t list_stride;  // lists per query in `lists`; 0 = n_splits (extra slots are the caller's, e.g. a carried-over top-k)
-  int32_t sched;     // variant 6: staging schedule (measurement)
+  int32_t sched;     // measurement: staging schedule of the 256-query tile (1, 2); 9 = 64-byte K steps in the 32/64-query tile
   int32_t ablate;    // measurement only (garbage results): see launch_mfma_scan
   const float* thr_in;  // optional per-query admission thresholds (device, [nq_padded]) from the earlier ladder phases
   const int* active;    // skinny kernel only, optional: device-side count of live queries (query tiles past it return at once)
@@ -102,7 +102,7 @@ hipError_t launch_select_topk(const unsigned long long* cand, const int* counts,
 // 32-query tiles at HBM speed, fp32 or fp16 corpora (same parameter block; `queries` in the corpus dtype)
 hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream);
 int skinny_query_tile(int nq);  // 32, or 64 for batches of 33 and more
-int skinny_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu);
+int skinny_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu, int dim, bool f32);
 bool skinny_supported(int dim, int k, bool f32);
 
 }  // namespace tavb

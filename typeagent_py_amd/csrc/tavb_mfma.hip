@@ -574,47 +574,59 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
 // only exists for fp16.  This kernel is the piece in between -- and the only matrix-core path for the
 // reference's own dtype, fp32: `v_mfma_f32_32x32x2_f32` multiplies fp32 exactly and accumulates in fp32
 // (157 TFLOP/s peak, enough to keep up with HBM at 32 queries: 1M x 1536 x 32 x 2 = 98 GFLOP per 6.1 GB pass).
-//   * tile = 256 corpus rows x 32 (or 64) queries, 4 waves, each wave owns 64 rows (two, or four, 32 x 32 MFMA tiles);
-//     two workgroups per CU (72 KiB of LDS, < 128 VGPRs each) overlap each other's waits.
-//   * K advances 64 bytes per row per step for either dtype (16 floats / 32 halves).  A wave stages the four
-//     1 KiB pieces of ITS OWN 64 rows by LDS-DMA, so the corpus operand needs no cross-wave synchronisation;
-//     waves 0 and 1 (all four for 64 queries) also stage one piece each of the query operand (16 queries x 64 bytes per
-//     piece), which all waves read: one barrier per step.  Ring of 3 or 4 slots, counted vmcnt.
-//   * LDS image, source-side XOR swizzle and fragment reads are those of variant 3 (64-byte rows).  For fp32
-//     a lane's 16-byte fragment is four consecutive k of its row -- lanes 0-31 take k = 8g .. 8g+3, lanes 32-63
-//     k = 8g+4 .. 8g+7 -- and feeds four MFMAs: MFMA e multiplies k = 8g+e (lower half-wave) and 8g+4+e
-//     (upper), the same pairing on both operands, which is all a dot product needs.
-//   * epilogue / candidate buffers / compaction / lists exactly as in the wide kernel (32 or 64 queries per block).
+//   * tile = 256 corpus rows x 32 (or 64) queries, 4 waves, each wave owns 64 rows (two, or four, 32 x 32 MFMA tiles).
+//   * K advances STEP bytes per row per step for either dtype: 128 (a whole cache line per row and staging lane group:
+//     the texture-address path serves eight 128-byte lines twice as fast as sixteen 64-byte half lines,
+//     profiles/r02_operand_path.md) whenever a row is a multiple of 128 bytes, else 64.  A wave stages the 1 KiB pieces of
+//     ITS OWN 64 rows by LDS-DMA, so the corpus operand needs no cross-wave synchronisation; the waves also share out
+//     the pieces of the query operand, which all of them read: one barrier per step.  Ring of 2 .. 4 slots, counted vmcnt;
+//     72 KiB configurations run two workgroups per CU, the others one.
+//   * LDS rows are STEP bytes; 16-byte slot j of row r sits at physical slot j ^ ((r >> 1) & 7) (128-byte rows) or
+//     j ^ ((r >> 2) & 3) (64-byte rows) -- on the global SOURCE address of the staging loads and on the fragment reads --
+//     so the 16 lanes of a ds_read_b128 group hit 16 different bank slots.  For fp32 a lane's 16-byte fragment is four
+//     consecutive k of its row -- lanes 0-31 take k = 8g .. 8g+3, lanes 32-63 k = 8g+4 .. 8g+7 -- and feeds four
+//     MFMAs: MFMA e multiplies k = 8g+e (lower half-wave) and 8g+4+e (upper), the same pairing on both operands, which
+//     is all a dot product needs.
+//   * fp16 corpora: the fp32 queries are split into an fp16 high and an fp16 low plane (q = hi + lo to 2^-22; both are
+//     multiplied -- the kernel is load-bound, the second MFMA is free), so a lookup on an fp16 corpus means the same
+//     thing here as in the streaming tiers (fp32 query x fp16 rows).
+//   * NI = 2 (64 queries per tile): twice the MFMAs per operand byte -- for batches of 33+ queries, which would
+//     otherwise stream the corpus once per 32 queries (fp32) or pay for a 256-query tile (fp16, 33 .. 64 queries).
+//   * epilogue / candidate buffers / compaction as in the 256-query tile (32 or 64 queries per block); at the end every
+//     buffer is sorted into a list, tavb::merge_kernel merges the lists of the row ranges.
 // ---------------------------------------------------------------------------------------------
 constexpr int SQ32 = 32;            // queries per 32 x 32 MFMA block; a tile is NI of them (32 or 64 queries)
 constexpr int S_THREADS = 256;
-constexpr int S_SLOT_A = BM * 64;   // 16 KiB
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// fp32: one query operand plane, ring of 4 (72 KiB).  fp16: the fp32 queries are split into an fp16 high and an fp16
-// low plane (q = hi + lo to 2^-22; both are multiplied -- the kernel is load-bound, the second MFMA is free), so a
-// lookup on an fp16 corpus means the same thing here as in the streaming tiers (fp32 query x fp16 rows); ring of 3 (60 KiB).
-// NI = 2 (64 queries per tile): twice the MFMAs per operand byte -- for batches of 33+ queries, which would otherwise
-// stream the corpus once per 32 queries (fp32) or pay for a 256-query tile (fp16, 33 .. 64 queries).  Ring of 3.
-template <typename T, int NI>
+template <typename T, int NI, int STEP>
 struct SkinnyGeom {
   static constexpr bool F32 = sizeof(T) == 4;
   static constexpr int SQ = NI * SQ32;
   static constexpr int PLANES = F32 ? 1 : 2;
-  static constexpr int RING = (F32 && NI == 1) ? 4 : 3;
-  static constexpr int PLANE_B = SQ * 64;          // one query operand plane, one step
+  static constexpr int LPR = STEP / 16;            // lanes (16-byte slots) per row of a staging piece
+  static constexpr int RPP = 64 / LPR;             // rows per 1 KiB piece: 16 or 8
+  static constexpr int NPA = 64 / RPP;             // corpus pieces per wave per step: 4 or 8
+  static constexpr int SH = STEP == 64 ? 2 : 1;    // swizzle term = (row >> SH) & (LPR - 1)
+  static constexpr int NG = STEP / 32;             // 32-byte k slices per step: 2 or 4
+  static constexpr int SLOT_A = BM * STEP;         // 16 or 32 KiB
+  static constexpr int PLANE_B = SQ * STEP;        // one query operand plane, one step
   static constexpr int SLOT_B = PLANES * PLANE_B;
-  static constexpr int B_RING = RING * S_SLOT_A;
-  static constexpr int CTRL = RING * (S_SLOT_A + SLOT_B);
+  static constexpr int RING = STEP == 64 ? ((F32 && NI == 1) ? 4 : 3) : ((F32 && NI == 1) ? 2 : 3);
+  static constexpr int B_RING = RING * SLOT_A;
+  static constexpr int CTRL = RING * (SLOT_A + SLOT_B);
   static constexpr int LDS = CTRL + SQ * 8 + 16;
-  static constexpr int B_WAVES = SQ / 16;          // waves that stage a query piece (per plane): 2 or 4
+  static constexpr int WG_PER_CU = LDS <= 76 * 1024 ? 2 : 1;
+  static constexpr int B_PIECES = SQ / RPP;        // query pieces per plane per step: 2 .. 8
+  static constexpr int NPB = (B_PIECES + 3) / 4;   // ... per wave (waves >= B_PIECES stage none when there are fewer than 4)
 };
 
-template <typename T, int NI, int ABL>
+template <typename T, int NI, int STEP, int ABL>
 __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDeviceParams p) {
-  using G = SkinnyGeom<T, NI>;
+  using G = SkinnyGeom<T, NI, STEP>;
   constexpr int SQ = G::SQ;
   constexpr bool F32 = G::F32;
-  constexpr int S_RING = G::RING, S_SLOT_B = G::SLOT_B, S_B_RING = G::B_RING, S_CTRL = G::CTRL;
+  constexpr int S_RING = G::RING, S_SLOT_A = G::SLOT_A, S_SLOT_B = G::SLOT_B, S_B_RING = G::B_RING, S_CTRL = G::CTRL;
+  constexpr int NPA = G::NPA, NPB = G::NPB, RPP = G::RPP, LPR = G::LPR, NG = G::NG;
   extern __shared__ __align__(16) unsigned char smem[];
   float* thr_lds = reinterpret_cast<float*>(smem + S_CTRL);
   int* cnt_lds = reinterpret_cast<int*>(smem + S_CTRL + SQ * 4);
@@ -630,9 +642,9 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
   const int qtile = t % p.n_qtiles;
   const int split = (t / p.n_qtiles) * 8 + xcd;
   if (split >= p.n_splits) return;
+  if (p.active != nullptr && qtile * SQ >= *p.active) return;  // fixed-shape launch over a device-side work list (tavb_rescore.hip)
   const int64_t r_begin = (int64_t)split * p.rows_per_split;
   const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
-  if (p.active != nullptr && qtile * SQ >= *p.active) return;  // fixed-shape launch over a device-side work list (tavb_rescore.hip)
   const int logical_block = split * p.n_qtiles + qtile;
   u64* my_cand = p.cand + (size_t)logical_block * SQ * CAP;
 
@@ -648,7 +660,7 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
   if (tid == 0) *need_compact = 0;
 
   const size_t row_bytes = (size_t)p.dim * sizeof(T);
-  const int steps_per_tile = (int)(row_bytes / 64);
+  const int steps_per_tile = (int)(row_bytes / STEP);
   const char* corpus = reinterpret_cast<const char*>(p.corpus);
   const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * SQ * row_bytes;
   const size_t plane_bytes = (size_t)p.n_qtiles * SQ * row_bytes;  // fp16: the low plane follows the high plane
@@ -661,39 +673,46 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
     return;
   }
 
-  // ---- stager: piece j of this wave = corpus rows wave * 64 + j * 16 .. + 15 of the tile (its own rows); lane l = row
-  //      l >> 2, 16-byte slot l & 3, fetched from the XOR-swizzled source slot.  Waves 0 / 1 add query rows 0-15 / 16-31.
-  const int st_row_in_piece = lane >> 2;
-  const uint32_t st_slot16 = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
-  uint32_t st_off[4];
+  // ---- stager: piece j of this wave = corpus rows wave * 64 + j * RPP .. of the tile (its own rows); lane l = row
+  //      l / LPR, PHYSICAL 16-byte slot l % LPR, which holds the logical slot (l % LPR) ^ ((row >> SH) & (LPR - 1)).
+  //      Query piece pb = wave + 4 i covers query rows pb * RPP ..
+  const int st_row_in_piece = lane / LPR;
+  uint32_t st_off[NPA];
   auto set_offsets = [&](int64_t row0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int64_t r = wave * 64 + j * 16 + st_row_in_piece;
+    for (int j = 0; j < NPA; ++j) {
+      const int row = wave * 64 + j * RPP + st_row_in_piece;  // row of the tile: fixes the swizzle term
+      int64_t r = row;
       if (row0 + r >= p.rows) r = p.rows - 1 - row0;  // stay in bounds; masked in the epilogue
-      st_off[j] = (uint32_t)r * (uint32_t)row_bytes + st_slot16;
+      st_off[j] = (uint32_t)r * (uint32_t)row_bytes + (uint32_t)((((lane % LPR) ^ ((row >> G::SH) & (LPR - 1)))) * 16);
     }
   };
-  const uint32_t st_off_b = (uint32_t)(wave * 16 + st_row_in_piece) * (uint32_t)row_bytes + st_slot16;
-  const bool stages_b = wave < G::B_WAVES;
+  uint32_t st_off_b[NPB];
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int row = (wave + 4 * i) * RPP + st_row_in_piece;
+    st_off_b[i] = (uint32_t)row * (uint32_t)row_bytes + (uint32_t)((((lane % LPR) ^ ((row >> G::SH) & (LPR - 1)))) * 16);
+  }
+  const bool stages_b = wave < G::B_PIECES;  // (with fewer than four query pieces the last waves stage none)
   int st_tile = 0, st_kt = 0, st_slot = 0;
   set_offsets(r_begin);
 
   auto stage_next = [&]() {
     const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
     const int64_t src_row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM;
-    const char* ga = sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * 64);
-    unsigned char* la = smem + st_slot * S_SLOT_A + wave * 4096;
+    const char* ga = sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * STEP);
+    unsigned char* la = smem + st_slot * S_SLOT_A + wave * (64 * STEP);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NPA; ++j)
       __builtin_amdgcn_global_load_lds((global_void*)(ga + (size_t)st_off[j]), (lds_void*)(la + j * 1024), 16, 0, 0);  // (a non-temporal policy here measured 30 % slower)
     if (stages_b) {
-      const char* gb = sgpr_ptr(qbase + (size_t)st_kt * 64);
-      unsigned char* lb = smem + S_B_RING + st_slot * S_SLOT_B + wave * 1024;
-      __builtin_amdgcn_global_load_lds((global_void*)(gb + (size_t)st_off_b), (lds_void*)lb, 16, 0, 0);
-      if constexpr (!F32) {  // the low plane of the split queries
-        const char* gl = sgpr_ptr(qbase + plane_bytes + (size_t)st_kt * 64);
-        __builtin_amdgcn_global_load_lds((global_void*)(gl + (size_t)st_off_b), (lds_void*)(lb + G::PLANE_B), 16, 0, 0);
+      const char* gb = sgpr_ptr(qbase + (size_t)st_kt * STEP);
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
+        unsigned char* lb = smem + S_B_RING + st_slot * S_SLOT_B + (wave + 4 * i) * 1024;
+        __builtin_amdgcn_global_load_lds((global_void*)(gb + (size_t)st_off_b[i]), (lds_void*)lb, 16, 0, 0);
+        if constexpr (!F32)  // the low plane of the split queries
+          __builtin_amdgcn_global_load_lds((global_void*)(gb + plane_bytes + (size_t)st_off_b[i]), (lds_void*)(lb + G::PLANE_B), 16, 0, 0);
       }
     }
     if (++st_slot == S_RING) st_slot = 0;
@@ -705,16 +724,16 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
   };
   auto wait_landed = [&]() {  // all but the newest S_RING - 2 steps of this wave's loads have landed
     if (stages_b)
-      wait_vmcnt<(4 + G::PLANES) * (S_RING - 2)>();
+      wait_vmcnt<(NPA + G::PLANES * NPB) * (S_RING - 2)>();
     else
-      wait_vmcnt<4 * (S_RING - 2)>();
+      wait_vmcnt<NPA * (S_RING - 2)>();
   };
 
   // ---- fragment addresses: row (lane & 31) of a 32-row block, logical 16-byte slot 2 * g + (lane >> 5)
   const int frag_row = lane & 31;
-  const uint32_t frag_x = (uint32_t)(((lane >> 5) ^ ((frag_row >> 2) & 3)) << 4);
-  const uint32_t a_lane = (uint32_t)((wave * 64 + frag_row) * 64);  // + mi * 2048
-  const uint32_t b_lane = (uint32_t)(S_B_RING + frag_row * 64);
+  const uint32_t frag_x = (uint32_t)(((lane >> 5) ^ ((frag_row >> G::SH) & (LPR - 1))) << 4);
+  const uint32_t a_lane = (uint32_t)((wave * 64 + frag_row) * STEP);  // + mi * 32 * STEP
+  const uint32_t b_lane = (uint32_t)(S_B_RING + frag_row * STEP);    // + ni * 32 * STEP
 
   // ---- prologue: S_RING - 1 steps in flight
 #pragma unroll 1
@@ -735,53 +754,56 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
     for (int kt = 0; kt < steps_per_tile; ++kt) {
       if constexpr ((ABL & 2) == 0) wait_landed();  // this wave's share of step S is in LDS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      TAVB_BARRIER();  // the query piece of step S is visible; everybody is done with the slot of step S - 1
+      TAVB_BARRIER();  // the query pieces of step S are visible; everybody is done with the slot of step S - 1
       if constexpr ((ABL & 2) == 0) stage_next();  // step S + S_RING - 1 -> the slot of step S - 1
       const unsigned char* abase = smem + rd * S_SLOT_A;
       const unsigned char* bbase = smem + rd * S_SLOT_B;
-      f32x4 af[2][2], bf[2][NI], bl[2][NI];
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const uint32_t kx = (uint32_t)(g << 5) ^ frag_x;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          bf[g][ni] = *reinterpret_cast<const f32x4*>(bbase + (b_lane + kx) + ni * 2048);
-          if constexpr (!F32) bl[g][ni] = *reinterpret_cast<const f32x4*>(bbase + (b_lane + kx) + ni * 2048 + G::PLANE_B);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) af[g][mi] = *reinterpret_cast<const f32x4*>(abase + (a_lane + kx) + mi * 2048);
-      }
-      if constexpr ((ABL & 1) == 0) {
+      for (int gh = 0; gh < NG / 2; ++gh) {  // two 32-byte k slices at a time
+        f32x4 af[2][2], bf[2][NI], bl[2][NI];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          if constexpr (F32) {
+          const uint32_t kx = (uint32_t)((gh * 2 + g) << 5) ^ frag_x;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+          for (int ni = 0; ni < NI; ++ni) {
+            bf[g][ni] = *reinterpret_cast<const f32x4*>(bbase + (b_lane + kx) + ni * 32 * STEP);
+            if constexpr (!F32) bl[g][ni] = *reinterpret_cast<const f32x4*>(bbase + (b_lane + kx) + ni * 32 * STEP + G::PLANE_B);
+          }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) af[g][mi] = *reinterpret_cast<const f32x4*>(abase + (a_lane + kx) + mi * 32 * STEP);
+        }
+        if constexpr ((ABL & 1) == 0) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            if constexpr (F32) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                  for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mi][e], bf[g][ni][e], acc[mi][ni], 0, 0, 0);
+            } else {
 #pragma unroll
               for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mi][e], bf[g][ni][e], acc[mi][ni], 0, 0, 0);
-          } else {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni) {
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[g][mi]), __builtin_bit_cast(f16x8, bl[g][ni]),
-                                                                     acc[mi][ni], 0, 0, 0);
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[g][mi]), __builtin_bit_cast(f16x8, bf[g][ni]),
-                                                                     acc[mi][ni], 0, 0, 0);
-              }
+                for (int ni = 0; ni < NI; ++ni) {
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[g][mi]), __builtin_bit_cast(f16x8, bl[g][ni]),
+                                                                       acc[mi][ni], 0, 0, 0);
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[g][mi]), __builtin_bit_cast(f16x8, bf[g][ni]),
+                                                                       acc[mi][ni], 0, 0, 0);
+                }
+            }
           }
+        } else {
+          asm volatile("" ::"v"(af[0][0]), "v"(af[1][1]), "v"(bf[0][0]), "v"(bf[1][NI - 1]));
+          if constexpr (!F32) asm volatile("" ::"v"(bl[0][0]), "v"(bl[1][NI - 1]));
         }
-      } else {
-        asm volatile("" ::"v"(af[0][0]), "v"(af[1][1]), "v"(bf[0][0]), "v"(bf[1][NI - 1]));
-        if constexpr (!F32) asm volatile("" ::"v"(bl[0][0]), "v"(bl[1][NI - 1]));
       }
       if (++rd == S_RING) rd = 0;
     }
 
-    // ---- epilogue: admission test on the raw dot products, append (see variant 3)
+    // ---- epilogue: admission test on the raw dot products, append (as in the 256-query tile)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int ql = ni * 32 + (lane & 31);
@@ -1174,19 +1196,32 @@ bool skinny_supported(int dim, int k, bool f32) {
   return (dim * (f32 ? 4 : 2)) % 64 == 0 && dim > 0 && k >= 1 && k <= 64;
 }
 
-int skinny_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu) {
+// K step of the tile: whole 128-byte lines whenever a row is a multiple of that
+static bool skinny_line_steps(int dim, bool f32) { return (dim * (f32 ? 4 : 2)) % 128 == 0; }
+
+static int skinny_wg_per_cu(int dim, bool f32, int tile) {
+  const bool line = skinny_line_steps(dim, f32);
+  if (f32) {
+    if (tile == 64) return line ? SkinnyGeom<float, 2, 128>::WG_PER_CU : SkinnyGeom<float, 2, 64>::WG_PER_CU;
+    return line ? SkinnyGeom<float, 1, 128>::WG_PER_CU : SkinnyGeom<float, 1, 64>::WG_PER_CU;
+  }
+  if (tile == 64) return line ? SkinnyGeom<_Float16, 2, 128>::WG_PER_CU : SkinnyGeom<_Float16, 2, 64>::WG_PER_CU;
+  return line ? SkinnyGeom<_Float16, 1, 128>::WG_PER_CU : SkinnyGeom<_Float16, 1, 64>::WG_PER_CU;
+}
+
+int skinny_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu, int dim, bool f32) {
   const int n_qtiles = nq_padded / tile;
-  int splits = (2 * n_cu) / (n_qtiles > 0 ? n_qtiles : 1);  // two workgroups per CU
-  splits = (splits / 8) * 8;                                 // whole groups of 8 (one row range per XCD)
+  int splits = (skinny_wg_per_cu(dim, f32, tile) * n_cu) / (n_qtiles > 0 ? n_qtiles : 1);  // every workgroup resident at once
+  splits = (splits / 8) * 8;                                                               // whole groups of 8 (one row range per XCD)
   if (splits < 8) splits = 8;
   const int64_t tiles = (rows + BM - 1) / BM;
   if (splits > tiles) splits = (int)tiles;
   return splits;
 }
 
-// Same contract as launch_mfma_scan.  p.queries: fp32 corpus -> [nq_padded, dim] fp32; fp16 corpus -> [2, nq_padded, dim]
-// fp16, the high and the low plane of the split fp32 queries (launch_f32_split_f16).  nq_padded is a multiple of the
-// tile (p.skinny_tile = 32 or 64 queries).
+// Same contract as launch_mfma_scan, except that the tile writes sorted lists (p.lists) itself.  p.queries: fp32 corpus ->
+// [nq_padded, dim] fp32; fp16 corpus -> [2, nq_padded, dim] fp16, the high and the low plane of the split fp32 queries
+// (launch_f32_split_f16).  nq_padded is a multiple of the tile (p.skinny_tile = 32 or 64 queries).
 hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
   const bool f32 = p.f32 != 0;
   const int tile = p.skinny_tile == 64 ? 64 : 32;
@@ -1217,12 +1252,14 @@ hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(S_THREADS), lds, stream, d);
     return hipGetLastError();
   };
+  const bool line = skinny_line_steps(p.dim, f32) && p.sched != 9;  // (sched 9: force the 64-byte steps, measurement)
   if (f32) {
-    if (tile == 64) return go(skinny_scan_kernel<float, 2, 0>, SkinnyGeom<float, 2>::LDS);
-    return go(skinny_scan_kernel<float, 1, 0>, SkinnyGeom<float, 1>::LDS);
+    if (tile == 64) return line ? go(skinny_scan_kernel<float, 2, 128, 0>, SkinnyGeom<float, 2, 128>::LDS) : go(skinny_scan_kernel<float, 2, 64, 0>, SkinnyGeom<float, 2, 64>::LDS);
+    return line ? go(skinny_scan_kernel<float, 1, 128, 0>, SkinnyGeom<float, 1, 128>::LDS) : go(skinny_scan_kernel<float, 1, 64, 0>, SkinnyGeom<float, 1, 64>::LDS);
   }
-  if (tile == 64) return go(skinny_scan_kernel<_Float16, 2, 0>, SkinnyGeom<_Float16, 2>::LDS);
-  return go(skinny_scan_kernel<_Float16, 1, 0>, SkinnyGeom<_Float16, 1>::LDS);
+  if (tile == 64)
+    return line ? go(skinny_scan_kernel<_Float16, 2, 128, 0>, SkinnyGeom<_Float16, 2, 128>::LDS) : go(skinny_scan_kernel<_Float16, 2, 64, 0>, SkinnyGeom<_Float16, 2, 64>::LDS);
+  return line ? go(skinny_scan_kernel<_Float16, 1, 128, 0>, SkinnyGeom<_Float16, 1, 128>::LDS) : go(skinny_scan_kernel<_Float16, 1, 64, 0>, SkinnyGeom<_Float16, 1, 64>::LDS);
 }
 
 }  // namespace tavb
