@@ -541,7 +541,29 @@ def run_cfg5(args, wl) -> None:
         ms, n = eng.profile_read(_native.KERNEL_SCAN)
         out["roofline"]["scan_kernel_ms_per_user_query"] = ms / steps
         out["roofline"]["scan_launches_per_user_query"] = n / steps
-    print(json.dumps(out))
+    emit_result(out)
+
+
+_RESULT_FD = None
+
+
+def quiet_stdout() -> None:
+    """Point fd 1 at stderr for the whole run (RCCL / HIP runtime banners, stray prints of imported code) and keep the real
+    stdout aside: the one JSON line is the only thing the driver finds on stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_result(line: dict) -> None:
+    data = (json.dumps(line) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
 
 
 def respawn_under_torchrun(args) -> int:
@@ -581,6 +603,7 @@ def main() -> None:
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
 
+    quiet_stdout()
     if args.workload == "cfg5":
         wl = dict(WORKLOADS["cfg5"])
         if args.rows:
@@ -630,7 +653,7 @@ def main() -> None:
     ok = True
     if ctx.rank == 0:
         line = headline_line(ctx, rec, name, wl, scaling, sub)
-        print(json.dumps(line), flush=True)
+        emit_result(line)
         checks = [rec.get("parity")] + [r.get("parity") for r in (sub or {}).values()]
         ok = all(c is None or c.get("ok") for c in checks)
     if ctx.dist is not None:

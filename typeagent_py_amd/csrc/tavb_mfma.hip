@@ -611,6 +611,8 @@ struct SkinnyGeom {
   static constexpr int SLOT_A = BM * STEP;         // 16 or 32 KiB
   static constexpr int PLANE_B = SQ * STEP;        // one query operand plane, one step
   static constexpr int SLOT_B = PLANES * PLANE_B;
+  // ring depth: measured (profiles/r02_mid_batch.md) -- for 32 fp32 queries two workgroups per CU with two slots each beat one
+  // workgroup with three or four slots (the depth in flight is not what limits this tile)
   static constexpr int RING = STEP == 64 ? ((F32 && NI == 1) ? 4 : 3) : ((F32 && NI == 1) ? 2 : 3);
   static constexpr int B_RING = RING * SLOT_A;
   static constexpr int CTRL = RING * (SLOT_A + SLOT_B);
