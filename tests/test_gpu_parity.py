@@ -676,10 +676,11 @@ def test_mfma_tile_against_the_exact_tile_on_a_large_corpus():
     eng.close()
 
 
-@pytest.mark.parametrize("nq", [64, 65, 256, 1024])
+@pytest.mark.parametrize("nq", [64, 65, 100, 128, 129, 256, 1024])
 def test_batch_equals_sequential_for_arbitrary_fp32_queries_on_fp16_corpus(nq):
     """`fuzzy_lookup_embeddings(E) == [fuzzy_lookup_embedding(e) for e in E]` at every batch size, for queries that are NOT
-    fp16-representable: 64 rides the 64-query tile (split hi/lo planes), 65+ the 256-query tile + fp32 rescoring.  The
+    fp16-representable: 64 rides the 64-query tile (split hi/lo planes), 65 .. 128 the 128-query tile and 129+ the 256-query
+    tile, both + fp32 rescoring.  The
     sequential answers come from the streaming kernel (fp32 query x fp16 row), both are checked against the oracle."""
     v, _ = make_corpus(30_011, 1536, 7200)
     qs = make_queries(nq, 1536, 7201)
@@ -703,6 +704,36 @@ def test_batch_equals_sequential_for_arbitrary_fp32_queries_on_fp16_corpus(nq):
         seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=32, min_score=thr)
         assert [r.item for r in batch_t[qi]] == [r.item for r in seq]
     assert len(batch_t[0]) == 21
+
+@pytest.mark.parametrize("n,nq,k,ms,sample", [(200_003, 100, 32, 0.0, 0), (120_000, 300, 10, 0.5, 4096), (641, 128, 48, 0.0, -1), (90_000, 65, 32, 0.0, 2048)])
+def test_128_and_256_query_tiles_agree(n, nq, k, ms, sample):
+    """The wide fp16 kernel comes in two widths (4 or 2 MFMA blocks per wave along the queries).  Same products, same
+    candidates, same rescoring: the answers must be identical key for key, whatever the width, the number of query tiles
+    (300 queries = 3 tiles of 128 or 2 of 256) and the ladder phases -- and equal to the oracle's."""
+    v, _ = make_corpus(n, 1536, 8800 + nq)
+    qs = make_queries(nq, 1536, 8801 + nq)
+    qs[1] = v[n - 1]
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    eng.set_option("mfma_sample_rows", sample)
+    eng.profile_enable(True)
+    res = {}
+    for tile in (128, 256):
+        eng.set_option("mfma_tile", tile)
+        eng.profile_reset()
+        res[tile] = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
+        assert eng.get_option("last_tier") == 4 and eng.profile_read(_native.KERNEL_MFMA)[1] == 1
+    for qi in range(nq):
+        assert [(r.item, r.score) for r in res[128][qi]] == [(r.item, r.score) for r in res[256][qi]]
+    eng.set_option("mfma_tile", 0)
+    auto = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
+    assert [(r.item, r.score) for r in auto[1]] == [(r.item, r.score) for r in res[128][1]] and auto[1][0].item == n - 1
+    v16 = _f16(v)
+    for qi in sorted(set(np.linspace(0, nq - 1, 16).astype(int).tolist())):
+        rep = vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(res[128][qi]), k, ms)
+        assert rep.tie_permuted_positions <= 2
+    with pytest.raises(ValueError):
+        eng.set_option("mfma_tile", 64)
 
 
 def test_wide_tile_falls_back_to_the_exact_tile_when_candidates_cannot_be_proven_complete():

@@ -105,6 +105,7 @@ struct tavb_ctx {
   int64_t mfma_splits = 0;  // 0 = auto
   int64_t mfma_ablate = 0;
   int64_t mfma_sched = 0;
+  int64_t mfma_tile = 0;  // 0 = auto (128 queries per tile up to 128 queries, else 256)
   int64_t mfma_sample_rows = 0;  // rows of the first (threshold-seeding) phase: 0 = auto (two tiles per workgroup), -1 = one phase, no seeding
   int64_t skinny_min_batch_f32 = 5;   // fp32 corpus: batches from this size up use the 32-query MFMA tile
   int64_t skinny_min_batch_f16 = 3;   // fp16 corpus: batches from this size up to mfma_min_batch - 1 use it
@@ -405,6 +406,9 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_sample_rows") {
     if (v < -1) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= -1");
     c->mfma_sample_rows = v;
+  } else if (n == "mfma_tile") {
+    if (v != 0 && v != 128 && v != 256) return fail(TAVB_E_INVALID, "mfma_tile must be 0 (auto), 128 or 256");
+    c->mfma_tile = v;
   } else if (n == "mfma_sched") {
     if (v < 0 || v > 9) return fail(TAVB_E_INVALID, "mfma_sched must be 0..9");
     c->mfma_sched = v;
@@ -441,6 +445,7 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "force_tier") *out = c->geom.tier;
   else if (n == "mfma_min_batch") *out = c->mfma_min_batch;
   else if (n == "mfma_splits") *out = c->mfma_splits;
+  else if (n == "mfma_tile") *out = c->mfma_tile;
   else if (n == "mfma_ladder") *out = c->mfma_ladder;
   else if (n == "skinny_min_batch_f32") *out = c->skinny_min_batch_f32;
   else if (n == "skinny_min_batch_f16") *out = c->skinny_min_batch_f16;
@@ -1056,7 +1061,7 @@ struct TileRun {
 // scatter[slot] of it for the slots below *active).
 int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scatter) {
   auto pick_splits = [&](int64_t rows) {
-    return r.skinny ? tavb::skinny_pick_splits(rows, r.nq_pad, r.qt, c->n_cu, c->dim, r.q32) : tavb::mfma_pick_splits(rows, r.nq_pad, c->n_cu);
+    return r.skinny ? tavb::skinny_pick_splits(rows, r.nq_pad, r.qt, c->n_cu, c->dim, r.q32) : tavb::mfma_pick_splits(rows, r.nq_pad, r.qt, c->n_cu);
   };
   auto launch = [&](const tavb::MfmaParams& q) { return r.skinny ? tavb::launch_skinny_scan(q, c->stream) : tavb::launch_mfma_scan(q, c->stream); };
   const int nq = r.nq, k = r.k;
@@ -1085,6 +1090,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.sched = (int)c->mfma_sched;
   p.f32 = r.q32 ? 1 : 0;
   p.skinny_tile = r.skinny ? r.qt : 0;
+  p.wide_tile = r.skinny ? 0 : r.qt;
   p.active = r.active;
   std::vector<int64_t> bounds;  // phase i scans rows [bounds[i], bounds[i+1])
   bounds.push_back(0);
@@ -1156,7 +1162,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
 // The 256-query fp16 tile as an exact filter + fp32-query rescoring of its candidates (tavb_rescore.hip).
 int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_score, uint32_t index_base, u64_t* d_out) {
   constexpr int KC = 64;  // candidates per query
-  const int qt = tavb::mfma_query_tile();
+  const int qt = c->mfma_tile > 0 ? (int)c->mfma_tile : tavb::mfma_query_tile(nq);
   const int nq_pad = ((nq + qt - 1) / qt) * qt;
   const int cap = ((nq + 63) / 64) * 64;  // slots of the work list of queries that need the exact tile
   const size_t q16_bytes = (size_t)nq_pad * c->dim * 2;

@@ -88,11 +88,12 @@ struct MfmaParams {
   const int* active;    // skinny kernel only, optional: device-side count of live queries (query tiles past it return at once)
   int32_t f32;          // skinny kernel only: corpus and queries are fp32 (else fp16)
   int32_t skinny_tile;  // skinny kernel only: queries per tile, 32 or 64
+  int32_t wide_tile;    // 128/256-query kernel only: queries per tile, 128 or 256 (0 = 256)
 };
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
 hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, const float* floor, float* thr, hipStream_t stream);
-int mfma_query_tile();                    // queries per workgroup tile
-int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu);
+int mfma_query_tile(int nq);              // queries per workgroup tile: 128 for batches of up to 128 queries, else 256
+int mfma_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu);
 bool mfma_supported(int dim, int k);
 size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide);
 // best k keys per query over the 256-query tile's candidate buffers (+ an optional carried-over list [nq, k]) -> out [nq, k] sorted,

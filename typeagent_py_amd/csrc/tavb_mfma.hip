@@ -259,27 +259,43 @@ __device__ __forceinline__ void wait_vmcnt() {
 constexpr int BM6 = 320;
 constexpr int NT6 = 256;
 constexpr int SLOT_A6 = BM6 * 128;  // 40 KiB
-constexpr int SLOT_B6 = BN * 128;   // 32 KiB
-constexpr int B_RING6 = 2 * SLOT_A6;
-constexpr int CTRL6 = 2 * SLOT_A6 + 2 * SLOT_B6;
-constexpr int LDS6 = CTRL6 + BN * 8 + 16;
 constexpr int PIECES_A6 = BM6 / 8 / 4;  // per wave per step: 10
-constexpr int PIECES_B6 = BN / 8 / 4;   // 8
-constexpr int PIECES6 = PIECES_A6 + PIECES_B6;
 
-// index of the staging piece issued behind MFMA `i` of quarter `q` (-1: none): n pieces spread evenly over the 20 MFMAs
-template <int N3, int N0, int N1>
+// NI = 32-query MFMA blocks per wave along the query axis: 4 (256-query workgroup tile) or 2 (128-query tile, for batches of
+// 65 .. 128 queries: half the MFMAs and half the query-operand traffic per corpus byte -- HBM-bound instead of padding-bound)
+template <int NI>
+struct WideGeom {
+  static constexpr int QT = 64 * NI;           // queries per workgroup tile
+  static constexpr int WQ = 32 * NI;           // ... per wave
+  static constexpr int NT = 5 * NI;            // 32 x 32 accumulator blocks per wave: 20 or 10
+  static constexpr int NA = NI == 4 ? 15 : NT; // blocks 0 .. NA-1 accumulate in AGPRs, the rest in VGPRs (the spare AGPRs are where the allocator parks VGPR values in the epilogue: no scratch)
+  static constexpr int SLOT_B = QT * 128;      // 32 or 16 KiB
+  // corpus ring: the 128-query tile is HBM-bound and has the LDS for a third slot (3 x 40 + 2 x 16 KiB): the corpus slab of
+  // step S + 2 is in flight while step S is multiplied (one slab in flight left the tile latency-bound at 5.2 TB/s)
+  static constexpr int RA = NI == 2 ? 3 : 2;
+  static constexpr int B_RING = RA * SLOT_A6;  // the query ring (always two slots) sits behind the corpus ring
+  static constexpr int CTRL = B_RING + 2 * SLOT_B;
+  static constexpr int LDS = CTRL + QT * 8 + 16;
+  static constexpr int PIECES_B = QT / 8 / 4;  // per wave per step: 8 or 4
+  static constexpr int PIECES = PIECES_A6 + PIECES_B;
+};
+
+// index of the staging piece issued behind MFMA `i` of quarter `q` (-1: none): n pieces spread evenly over the NT MFMAs
+template <int NT, int N3, int N0, int N1>
 constexpr int v6_piece_at(int q, int i) {
   const int n = q == 3 ? N3 : q == 0 ? N0 : q == 1 ? N1 : 0;
   const int base = q == 3 ? 0 : q == 0 ? N3 : N3 + N0;
   for (int j = 0; j < n; ++j)
-    if ((j * 20 + 10) / n == i) return base + j;
+    if ((j * NT + NT / 2) / n == i) return base + j;
   return -1;
 }
 
-template <int ABL, int N3, int N0, int N1>
+template <int ABL, int NI, int N3, int N0, int N1>
 __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p) {
+  using G = WideGeom<NI>;
+  constexpr int BN = G::QT, NT = G::NT, SLOT_B6 = G::SLOT_B, CTRL6 = G::CTRL, PIECES_B6 = G::PIECES_B, PIECES6 = G::PIECES, RA = G::RA, B_RING6 = G::B_RING;
   static_assert(N3 + N0 + N1 == PIECES6, "every piece of a step is issued exactly once");
+  static_assert(N3 <= NT && N0 <= NT && N1 <= NT && NI + 5 <= NT, "one piece / one fragment read behind an MFMA at most");
   extern __shared__ __align__(16) unsigned char smem[];
   float* thr_lds = reinterpret_cast<float*>(smem + CTRL6);
   int* cnt_lds = reinterpret_cast<int*>(smem + CTRL6 + BN * 4);
@@ -290,7 +306,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1;  // rows wm * 160 ..
-  const int wn = wave & 1;   // queries wn * 128 ..
+  const int wn = wave & 1;   // queries wn * 32 * NI ..
 
   const int b = blockIdx.x;
   const int xcd = b & 7;
@@ -341,51 +357,77 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
     const int frag_row = ln & 31;
     frag_x = (uint32_t)(((ln >> 5) ^ ((frag_row >> 1) & 7)) << 4);  // byte (k16 << 5) ^ frag_x within the 128-byte row
     a_lane = (uint32_t)((wm * 160 + frag_row) * 128);              // + mi * 4096
-    b_lane = (uint32_t)(B_RING6 + (wn * 128 + frag_row) * 128);    // + ni * 4096
+    b_lane = (uint32_t)(B_RING6 + (wn * G::WQ + frag_row) * 128);    // + ni * 4096
   }
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sgpr_ptr(qbase)), 0, (int)(BN * row_bytes), 0x00020000);
 
-  // ---- stager: piece IDX of the step being staged (0 .. 9 corpus pieces, 10 .. 17 query pieces of this wave)
-  int st_kt = 0, st_tile = 0, st_slot = 0;
+  // ---- stager.  A "round" is what one K step issues: two slots deep (256-query tile) round S = corpus slab S + 1 then query
+  //      slab S + 1; three corpus slots deep (128-query tile) round S = query slab S + 1 FIRST, then corpus slab S + 2, so that
+  //      the counted wait of step S ("everything but the newest PIECES_A6 loads has landed") covers query slab S + 1 and corpus
+  //      slab S + 1 while corpus slab S + 2 stays in flight.  Piece IDX of a round: its position in that order.
+  int sa_kt = 0, sa_tile = 0, sa_slot = 0;  // corpus slab being staged
+  int sb_kt = 0, sb_slot = 0;               // query slab being staged
+  auto stage_a = [&](auto j_tag) {
+    constexpr int J = decltype(j_tag)::value;
+    const int tile = sa_tile < n_tiles ? sa_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
+    const int64_t row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM6;
+    const int64_t left = p.rows - row0;
+    const int valid = (int)(left < BM6 ? left : BM6);  // rows past the end of the corpus read as zero (masked in the epilogue)
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(sgpr_ptr(corpus + (size_t)row0 * row_bytes)), 0, __builtin_amdgcn_readfirstlane(valid * (int)row_bytes), 0x00020000);
+    const int pc = wave * PIECES_A6 + J;
+    unsigned char* la = smem + sa_slot * SLOT_A6 + pc * 1024;
+    const int soff = __builtin_amdgcn_readfirstlane(sa_kt * 128 + pc * 8 * (int)row_bytes);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)la, 16, (J & 1) ? st_odd : st_even, soff, 0, 0);
+    if constexpr (J == PIECES_A6 - 1) {
+      sa_slot = (sa_slot + 1 == RA) ? 0 : sa_slot + 1;
+      const bool wrap = (sa_kt + 1 == steps_per_tile);
+      sa_kt = wrap ? 0 : sa_kt + 1;
+      sa_tile += wrap ? 1 : 0;
+    }
+  };
+  auto stage_b = [&](auto j_tag) {
+    constexpr int BJ = decltype(j_tag)::value;
+    const int pc = wave * PIECES_B6 + BJ;
+    unsigned char* lb = smem + B_RING6 + sb_slot * SLOT_B6 + pc * 1024;
+    const int soff = __builtin_amdgcn_readfirstlane(((ABL & 8) ? 0 : sb_kt * 128) + pc * 8 * (int)row_bytes);  // ablation 8: the query operand's K step 0 every time (cache resident)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void*)lb, 16, (BJ & 1) ? st_odd : st_even, soff, 0, 0);
+    if constexpr (BJ == PIECES_B6 - 1) {
+      sb_slot ^= 1;
+      sb_kt = (sb_kt + 1 == steps_per_tile) ? 0 : sb_kt + 1;
+    }
+  };
   auto stage_piece = [&](auto idx_tag) {
     constexpr int IDX = decltype(idx_tag)::value;
-    if constexpr (IDX < PIECES_A6) {
-      const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
-      const int64_t row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM6;
-      const int64_t left = p.rows - row0;
-      const int valid = (int)(left < BM6 ? left : BM6);  // rows past the end of the corpus read as zero (masked in the epilogue)
-      const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(sgpr_ptr(corpus + (size_t)row0 * row_bytes)), 0, __builtin_amdgcn_readfirstlane(valid * (int)row_bytes), 0x00020000);
-      const int pc = wave * PIECES_A6 + IDX;
-      unsigned char* la = smem + st_slot * SLOT_A6 + pc * 1024;
-      const int soff = __builtin_amdgcn_readfirstlane(st_kt * 128 + pc * 8 * (int)row_bytes);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)la, 16, (IDX & 1) ? st_odd : st_even, soff, 0, 0);
+    if constexpr (RA == 2) {
+      if constexpr (IDX < PIECES_A6) stage_a(std::integral_constant<int, IDX>{});
+      else stage_b(std::integral_constant<int, IDX - PIECES_A6>{});
     } else {
-      constexpr int BJ = IDX - PIECES_A6;
-      const int pc = wave * PIECES_B6 + BJ;
-      unsigned char* lb = smem + B_RING6 + st_slot * SLOT_B6 + pc * 1024;
-      const int soff = __builtin_amdgcn_readfirstlane(((ABL & 8) ? 0 : st_kt * 128) + pc * 8 * (int)row_bytes);  // ablation 8: the query operand's K step 0 every time (cache resident)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void*)lb, 16, (BJ & 1) ? st_odd : st_even, soff, 0, 0);
-    }
-    if constexpr (IDX == PIECES6 - 1) {
-      st_slot ^= 1;
-      const bool wrap = (st_kt + 1 == steps_per_tile);
-      st_kt = wrap ? 0 : st_kt + 1;
-      st_tile += wrap ? 1 : 0;
+      if constexpr (IDX < PIECES_B6) stage_b(std::integral_constant<int, IDX>{});
+      else stage_a(std::integral_constant<int, IDX - PIECES_B6>{});
     }
   };
   auto stage_range = [&]<int... I>(std::integer_sequence<int, I...>) { (stage_piece(std::integral_constant<int, I>{}), ...); };
+  auto stage_a_all = [&]<int... I>(std::integer_sequence<int, I...>) { (stage_a(std::integral_constant<int, I>{}), ...); };
 
-  // ---- prologue: step 0 whole, the first N3 pieces of step 1 (what quarter 3 of a step "-1" would have issued)
-  stage_range(std::make_integer_sequence<int, PIECES6>{});
-  stage_range(std::make_integer_sequence<int, N3>{});
-  wait_vmcnt<N3>();
-  __syncthreads();  // step 0 landed everywhere, thresholds initialised (the wait above is counted: nothing is drained)
+  // ---- prologue: step 0 whole (three slots: and corpus slab 1), then the first N3 pieces of round 0 (what quarter 3 of a
+  //      step "-1" would have issued)
+  if constexpr (RA == 2) {
+    stage_range(std::make_integer_sequence<int, PIECES6>{});
+    stage_range(std::make_integer_sequence<int, N3>{});
+    wait_vmcnt<N3>();
+  } else {
+    stage_a_all(std::make_integer_sequence<int, PIECES_A6>{});  // corpus slab 0
+    stage_range(std::make_integer_sequence<int, PIECES6>{});    // "round -1": query slab 0, corpus slab 1
+    stage_range(std::make_integer_sequence<int, N3>{});
+    wait_vmcnt<PIECES_A6 + N3>();
+  }
+  __syncthreads();  // step 0 landed everywhere, thresholds initialised (the waits above are counted: nothing is drained)
 
   typedef int i32x4 __attribute__((ext_vector_type(4)));
-  constexpr int NA_TILES = 15;  // tiles 0 .. 14 accumulate in AGPRs, 15 .. 19 in VGPRs (the spare AGPRs are where the allocator parks VGPR values in the epilogue: no scratch)
+  constexpr int NA_TILES = G::NA;
   f32x16 acc_a[NA_TILES];
-  f32x16 acc_v[20 - NA_TILES];
+  f32x16 acc_v[NT - NA_TILES > 0 ? NT - NA_TILES : 1];
 #define TAVB_MFMA6_A(ACC, A, B) \
   asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(__builtin_bit_cast(i32x4, A)), "v"(__builtin_bit_cast(i32x4, B)))
 #define TAVB_MFMA6_V(ACC, A, B) \
@@ -395,29 +437,29 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
 #define TAVB_MFMA6_V0(ACC, A, B) \
   asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(__builtin_bit_cast(i32x4, A)), "v"(__builtin_bit_cast(i32x4, B)))
 
-  f16x8 a0[5], b0[4], a1[5], b1[4];
+  f16x8 a0[5], b0[NI], a1[5], b1[NI];
   {
     const unsigned char* abase = smem + (a_lane + frag_x);
     const unsigned char* bbase = smem + (b_lane + frag_x);
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) b0[ni] = *reinterpret_cast<const f16x8*>(bbase + ni * 4096);
+    for (int ni = 0; ni < NI; ++ni) b0[ni] = *reinterpret_cast<const f16x8*>(bbase + ni * 4096);
 #pragma unroll
     for (int mi = 0; mi < 5; ++mi) a0[mi] = *reinterpret_cast<const f16x8*>(abase + mi * 4096);
   }
-  int rd = 0;  // ring slot of the step being multiplied
+  int rd = 0, rd_a = 0;  // ring slots (query, corpus) of the step being multiplied
 
-  // One quarter: the 20 MFMAs of one k16 slice on (fa, fb); behind them, in program order, the 9 fragment reads of the
+  // One quarter: the NT MFMAs of one k16 slice on (fa, fb); behind them, in program order, the NI + 5 fragment reads of the
   // next quarter (slot `nslot`, slice NKK) into (na, nb) and the staging pieces the schedule puts into quarter Q.
-  auto quarter = [&](auto q_tag, auto first_tag, f16x8(&fa)[5], f16x8(&fb)[4], f16x8(&na)[5], f16x8(&nb)[4], int nslot, auto nkk_tag) {
+  auto quarter = [&](auto q_tag, auto first_tag, f16x8(&fa)[5], f16x8(&fb)[NI], f16x8(&na)[5], f16x8(&nb)[NI], int nslot_a, int nslot, auto nkk_tag) {
     constexpr int Q = decltype(q_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;  // first quarter of a tile: C = 0
     constexpr int NKK = decltype(nkk_tag)::value;
     const uint32_t kx = (uint32_t)(NKK << 5) ^ frag_x;
-    const unsigned char* abase = smem + nslot * SLOT_A6 + (a_lane + kx);
+    const unsigned char* abase = smem + nslot_a * SLOT_A6 + (a_lane + kx);
     const unsigned char* bbase = smem + nslot * SLOT_B6 + (b_lane + kx);
     auto mfma_at = [&](auto i_tag) {
       constexpr int I = decltype(i_tag)::value;
-      constexpr int mi = I >> 2, ni = I & 3;
+      constexpr int mi = I / NI, ni = I % NI;
       if constexpr ((ABL & 1) == 0) {
         if constexpr (FIRST) {
           if constexpr (I < NA_TILES)
@@ -432,32 +474,35 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
         }
       }
       if constexpr ((ABL & 32) == 0) {
-        if constexpr (I < 4) nb[I] = *reinterpret_cast<const f16x8*>(bbase + I * 4096);
-        if constexpr (I >= 4 && I < 9) na[I - 4] = *reinterpret_cast<const f16x8*>(abase + (I - 4) * 4096);
+        if constexpr (I < NI) nb[I] = *reinterpret_cast<const f16x8*>(bbase + I * 4096);
+        if constexpr (I >= NI && I < NI + 5) na[I - NI] = *reinterpret_cast<const f16x8*>(abase + (I - NI) * 4096);
       }
       if constexpr ((ABL & 2) == 0) {
-        constexpr int PC = v6_piece_at<N3, N0, N1>(Q, I);
+        constexpr int PC = v6_piece_at<NT, N3, N0, N1>(Q, I);
         if constexpr (PC >= 0) stage_piece(std::integral_constant<int, PC>{});
       }
     };
     [&]<int... I>(std::integer_sequence<int, I...>) { (mfma_at(std::integral_constant<int, I>{}), ...); }
-    (std::make_integer_sequence<int, 20>{});
-    if constexpr ((ABL & 1) != 0) asm volatile("" ::"v"(fa[0]), "v"(fa[4]), "v"(fb[0]), "v"(fb[3]));
+    (std::make_integer_sequence<int, NT>{});
+    if constexpr ((ABL & 1) != 0) asm volatile("" ::"v"(fa[0]), "v"(fa[4]), "v"(fb[0]), "v"(fb[NI - 1]));
   };
   using Q0 = std::integral_constant<int, 0>;
   using Q1 = std::integral_constant<int, 1>;
   using Q2 = std::integral_constant<int, 2>;
   using Q3 = std::integral_constant<int, 3>;
   auto step = [&](auto first_tag) {
-    quarter(Q0{}, first_tag, a0, b0, a1, b1, rd, Q1{});
-    quarter(Q1{}, std::false_type{}, a1, b1, a0, b0, rd, Q2{});
-    quarter(Q2{}, std::false_type{}, a0, b0, a1, b1, rd, Q3{});
-    // ---- step S+1 has landed in this wave (nothing newer is in flight); slot rd is read out; meet
-    if constexpr ((ABL & 2) == 0) wait_vmcnt<0>();
+    quarter(Q0{}, first_tag, a0, b0, a1, b1, rd_a, rd, Q1{});
+    quarter(Q1{}, std::false_type{}, a1, b1, a0, b0, rd_a, rd, Q2{});
+    quarter(Q2{}, std::false_type{}, a0, b0, a1, b1, rd_a, rd, Q3{});
+    // ---- step S+1 has landed in this wave (two slots: nothing newer is in flight; three: only corpus slab S+2 is); the
+    //      slots of step S are read out; meet
+    if constexpr ((ABL & 2) == 0) wait_vmcnt<(RA == 2 ? 0 : PIECES_A6)>();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) through the builtin: visible to the compiler's wait-count pass
     TAVB_BARRIER();
-    quarter(Q3{}, std::false_type{}, a1, b1, a0, b0, rd ^ 1, Q0{});
+    const int nxt_a = (RA == 2) ? (rd_a ^ 1) : (rd_a + 1 == RA ? 0 : rd_a + 1);
+    quarter(Q3{}, std::false_type{}, a1, b1, a0, b0, nxt_a, rd ^ 1, Q0{});
     rd ^= 1;
+    rd_a = nxt_a;
   };
 
   for (int tile = 0; tile < n_tiles; ++tile) {
@@ -468,7 +513,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_a[i][r] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 20 - NA_TILES; ++i)
+      for (int i = 0; i < NT - NA_TILES; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_v[i][r] = 0.f;
     }
@@ -485,14 +530,15 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int ql = wn * 128 + ni * 32 + (lane_e & 31);
+      for (int ni = 0; ni < NI; ++ni) {
+        const int ql = wn * G::WQ + ni * 32 + (lane_e & 31);
         const float thr = thr_lds[ql];
         const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;  // score > thr implies dot > thr_pre: fma(dot, 0.5, 0.5) is monotone, the margin covers both roundings
 #pragma unroll
         for (int mi = 0; mi < 5; ++mi) {
-          if ((mi * 4 + ni >= NA_TILES) != (pass == 0)) continue;  // pass 0: VGPR tiles, pass 1: AGPR tiles
-          const f32x16 dots = (mi * 4 + ni < NA_TILES) ? acc_a[mi * 4 + ni] : acc_v[mi * 4 + ni - NA_TILES];
+          constexpr int VT = NT - NA_TILES > 0 ? NT - NA_TILES : 1;
+          if ((mi * NI + ni >= NA_TILES) != (pass == 0)) continue;  // pass 0: VGPR tiles, pass 1: AGPR tiles
+          const f32x16 dots = (mi * NI + ni < NA_TILES) ? acc_a[mi * NI + ni] : acc_v[(mi * NI + ni - NA_TILES + VT) % VT];
           float top = dots[0];
 #pragma unroll
           for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, dots[r]);
@@ -909,7 +955,7 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
 constexpr int SEL_CACHE = 8192;  // keys of a query held in LDS (64 KiB)
 constexpr int SEL_PER = SEL_CACHE / 256;
 
-__global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict__ cand, const int* __restrict__ counts, int n_splits, int n_qtiles, int k,
+__global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict__ cand, const int* __restrict__ counts, int n_splits, int nq_padded, int k,
                                                           const u64* __restrict__ carried, const float* __restrict__ floor, u64* __restrict__ out,
                                                           float* __restrict__ thr_out) {
   extern __shared__ __align__(16) unsigned char sel_smem[];
@@ -921,7 +967,6 @@ __global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict_
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x;
-  const int qtile = q / BN, ql = q - qtile * BN;
   const int n_src = n_splits + (carried != nullptr ? 1 : 0);  // <= 257
 
   auto block_sum = [&](int v) -> int {  // exact: counts stay far below 2^24
@@ -935,7 +980,7 @@ __global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict_
   // ---- flat order of the query's keys: source s holds count(s) keys at flat positions off[s] .. off[s+1)
   __shared__ int cnt_of[260];
   for (int sp = tid; sp < n_src; sp += 256)  // (n_splits <= 256: one load per thread, all in flight at once)
-    cnt_of[sp] = (sp < n_splits) ? counts[((size_t)sp * n_qtiles + qtile) * BN + ql] : k;
+    cnt_of[sp] = (sp < n_splits) ? counts[(size_t)sp * nq_padded + q] : k;  // buffers are laid out [row range][padded query] whatever the tile width
   if (tid == 0) n_picked = 0;
   __syncthreads();
   for (int sp = tid; sp <= n_src; sp += 256) {
@@ -953,7 +998,7 @@ __global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict_
     }
     const int i = flat - off[lo];
     if (lo == n_splits) return carried[(size_t)q * k + i];  // (empty slots of the carried list are 0: never picked)
-    return cand[(((size_t)lo * n_qtiles + qtile) * BN + ql) * (size_t)CAPW + i];
+    return cand[((size_t)lo * nq_padded + q) * (size_t)CAPW + i];
   };
 
   u64 key[SEL_PER];
@@ -1110,15 +1155,15 @@ hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int 
   return hipGetLastError();
 }
 
-int mfma_query_tile() { return BN; }
+int mfma_query_tile(int nq) { return nq <= 128 ? 128 : BN; }  // 128-query tiles for batches of up to 128 queries
 
 bool mfma_supported(int dim, int k) { return dim % BK == 0 && dim >= BK && dim <= 16384 && k >= 1 && k <= 64; }
 
-int mfma_pick_splits(int64_t rows, int nq_padded, int n_cu) {
+int mfma_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu) {
   // One workgroup per CU and all of them resident at once: the grid is (groups of 8 row ranges) x query tiles x 8, so the
   // number of row ranges is a multiple of 8 with groups * n_qtiles * 8 <= n_cu.  (85 ranges for 3 query tiles made 264
   // workgroups on 256 CUs: a second scheduling round for the last 8, and a 768-query batch slower than a 1024-query one.)
-  const int n_qtiles = nq_padded / BN > 0 ? nq_padded / BN : 1;
+  const int n_qtiles = nq_padded / tile > 0 ? nq_padded / tile : 1;
   int splits = (n_cu / (8 * n_qtiles)) * 8;
   if (splits < 8) splits = 8;
   const int64_t tiles = (rows + BM - 1) / BM;
@@ -1133,16 +1178,17 @@ size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide) {
 
 hipError_t launch_select_topk(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, const unsigned long long* carried,
                               const float* floor, unsigned long long* out, float* thr_out, hipStream_t stream) {
-  if (nq < 1 || k < 1 || k > 64 || n_splits < 1 || nq_padded % BN != 0) return hipErrorInvalidValue;
+  if (nq < 1 || k < 1 || k > 64 || n_splits < 1 || nq_padded < nq) return hipErrorInvalidValue;
   constexpr int lds = SEL_CACHE * (int)sizeof(u64);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(select_topk_kernel, dim3(nq), dim3(256), lds, stream, cand, counts, n_splits, nq_padded / BN, k, carried, floor, out, thr_out);
+  hipLaunchKernelGGL(select_topk_kernel, dim3(nq), dim3(256), lds, stream, cand, counts, n_splits, nq_padded, k, carried, floor, out, thr_out);
   return hipGetLastError();
 }
 
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
-  if (!mfma_supported(p.dim, p.k) || p.nq_padded % BN != 0 || p.n_splits < 1) return hipErrorInvalidValue;
+  const int tile = p.wide_tile == 128 ? 128 : BN;
+  if (!mfma_supported(p.dim, p.k) || p.nq_padded % tile != 0 || p.n_splits < 1) return hipErrorInvalidValue;
   MfmaDeviceParams d{};
   d.corpus = reinterpret_cast<const _Float16*>(p.corpus);
   d.queries = reinterpret_cast<const _Float16*>(p.queries);
@@ -1150,7 +1196,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.rows = p.rows;
   d.dim = p.dim;
   d.nq = p.nq;
-  d.n_qtiles = p.nq_padded / BN;
+  d.n_qtiles = p.nq_padded / tile;
   d.n_splits = p.n_splits;
   d.list_stride = p.list_stride > p.n_splits ? p.list_stride : p.n_splits;
   d.k = p.k;
@@ -1175,18 +1221,20 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   // `ablate` modes exist to time parts of a kernel (results are garbage): see profiles/r02_cfg3_ablation.md
   {
     if (p.dim % 64 != 0) return hipErrorInvalidValue;
+    constexpr int LDS256 = WideGeom<4>::LDS, LDS128 = WideGeom<2>::LDS;
+    if (tile == 128) return go(mfma_scan_kernel<0, 2, 6, 4, 4>, NT6, LDS128);
     switch (p.ablate) {
-      case 256: return go(mfma_scan_kernel<256, 8, 6, 4>, NT6, LDS6);  // everything except admissions
-      case 260: return go(mfma_scan_kernel<260, 8, 6, 4>, NT6, LDS6);  // same, corpus tile 0 re-read by every block (L2 resident)
-      case 264: return go(mfma_scan_kernel<264, 8, 6, 4>, NT6, LDS6);  // same as 256, query operand K step 0 re-read (cache resident)
-      case 268: return go(mfma_scan_kernel<268, 8, 6, 4>, NT6, LDS6);  // both operands cache resident
-      case 258: return go(mfma_scan_kernel<258, 8, 6, 4>, NT6, LDS6);  // no LDS-DMA, no admissions
+      case 256: return go(mfma_scan_kernel<256, 4, 8, 6, 4>, NT6, LDS256);  // everything except admissions
+      case 260: return go(mfma_scan_kernel<260, 4, 8, 6, 4>, NT6, LDS256);  // same, corpus tile 0 re-read by every block (L2 resident)
+      case 264: return go(mfma_scan_kernel<264, 4, 8, 6, 4>, NT6, LDS256);  // same as 256, query operand K step 0 re-read (cache resident)
+      case 268: return go(mfma_scan_kernel<268, 4, 8, 6, 4>, NT6, LDS256);  // both operands cache resident
+      case 258: return go(mfma_scan_kernel<258, 4, 8, 6, 4>, NT6, LDS256);  // no LDS-DMA, no admissions
       default: break;
     }
     switch (p.sched) {  // staging pieces per quarter (q3, q0, q1): measurement
-      case 1: return go(mfma_scan_kernel<0, 10, 8, 0>, NT6, LDS6);
-      case 2: return go(mfma_scan_kernel<0, 6, 6, 6>, NT6, LDS6);
-      default: return go(mfma_scan_kernel<0, 8, 6, 4>, NT6, LDS6);
+      case 1: return go(mfma_scan_kernel<0, 4, 10, 8, 0>, NT6, LDS256);
+      case 2: return go(mfma_scan_kernel<0, 4, 6, 6, 6>, NT6, LDS256);
+      default: return go(mfma_scan_kernel<0, 4, 8, 6, 4>, NT6, LDS256);
     }
   }
   return hipErrorInvalidValue;
