@@ -587,6 +587,7 @@ def main() -> None:
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="one workload only (default: the north-star suite, headline cfg3)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="--gpus N > 1: split the same corpus (strong) or 12.5M rows per GPU (weak, cfg4)")
     ap.add_argument("--rows", type=int, default=None, help="override the row count (debugging)")
+    ap.add_argument("--queries", type=int, default=None, help="override the queries per step (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="north-star suite: headline only")
@@ -617,6 +618,8 @@ def main() -> None:
     wl = dict(WORKLOADS[name])
     if args.rows:
         wl["rows"] = args.rows
+    if args.queries:
+        wl["nq"] = args.queries
     weak = (name == "cfg4") or (ctx.world > 1 and args.scaling == "weak")
     scaling = "weak" if weak else "strong"
     if ctx.world == 1:

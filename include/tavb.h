@@ -80,7 +80,7 @@ int tavb_synchronize(tavb_ctx* ctx);
  *                   mfma_min_batch - 1); smaller batches use the streaming tiers
  *   "mfma_sample_rows", "mfma_ladder"  phases of the MFMA paths' threshold ladder: rows of the first phase (0 = auto: two
  *                   tiles per workgroup; -1 = a single phase, no seeding) and the growth factor of the following ones
- *   "mfma_tile"             queries per workgroup tile of the wide fp16 kernel: 0 = auto (128 up to 128 queries, else 256), 128, 256
+ *   "mfma_tile"             queries per workgroup tile of the wide fp16 kernel: 0 = auto (128 where that pads less: up to 128, 257..384, 513..640 queries; else 256), 128, 256
  *   "mfma_splits", "mfma_sched", "mfma_ablate"  measurement knobs, see DESIGN.md
  *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile (exact
  *                   filter + fp32-query rescoring of its candidates), 5 = 32/64-query MFMA tile
