@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Summarise a `rocprofv3 --pmc ... --kernel-trace --output-format csv` pass: per kernel the dispatch count, the mean duration
+and the per-dispatch mean of every counter; with --steps N also the FETCH_SIZE / WRITE_SIZE totals per bench step over the
+lookup kernels (corpus generation -- torch RNG, normalize_rows, f32_to_f16 -- excluded).
+
+    python tools/pmc_summary.py gpurun_out/x/*/*_counter_collection.csv --steps 3 [--json out.json --name cfg3]
+
+FETCH_SIZE counts KiB; on gfx950 a wide coalesced 16 B/lane stream is counted at half its bytes
+(/opt/skills/guides/MI355X_MICROARCH.md, HBM section), so HBM bytes read = FETCH_SIZE x 1024 x 2 for these kernels.
+"""
+import argparse
+import collections
+import csv
+import json
+import re
+import sys
+
+SETUP = ("at::native", "normalize_rows_kernel", "f32_to_f16_kernel", "corpus_max_norm_kernel", "__amd_rocclr_copyBuffer")
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\(tavb::\w+(?: const)?[&*]?(?:, [^)]*)?\)$", "", name)
+    name = name.replace("void ", "").replace("tavb::", "")
+    return name if len(name) <= 100 else name[:97] + "..."
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("csv", nargs="+")
+    ap.add_argument("--steps", type=int, default=0, help="bench steps + warm-up steps in the profiled run")
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--name", default=None)
+    args = ap.parse_args()
+    csv.field_size_limit(1 << 30)
+    per = collections.defaultdict(lambda: collections.defaultdict(float))  # kernel -> counter -> sum
+    disp = collections.defaultdict(set)
+    dur = collections.defaultdict(float)
+    seen = set()
+    for path in args.csv:
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                k = short(row["Kernel_Name"])
+                d = (path, row["Dispatch_Id"])
+                per[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                disp[k].add(d)
+                if d not in seen:
+                    seen.add(d)
+                    dur[k] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    counters = sorted({c for k in per for c in per[k]})
+    print("| kernel | dispatches | mean us | " + " | ".join(counters) + " |")
+    print("|---|---|---|" + "---|" * len(counters))
+    for k in sorted(per, key=lambda k: -dur[k]):
+        n = len(disp[k])
+        print(f"| `{k}` | {n} | {dur[k] / n / 1e3:.1f} | " + " | ".join(f"{per[k].get(c, 0.0) / n:.6g}" for c in counters) + " |")
+    if args.steps:
+        out = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            if c in counters:
+                tot = sum(per[k][c] for k in per if not any(s in k for s in SETUP))
+                out[c] = tot / args.steps
+        if "FETCH_SIZE" in out:
+            b = out["FETCH_SIZE"] * 1024 * 2
+            print(f"\nlookup kernels, per step ({args.steps} steps): FETCH_SIZE {out['FETCH_SIZE']:.6g} KiB -> {b:.6g} B read (x1024 x2)"
+                  + (f", WRITE_SIZE {out['WRITE_SIZE']:.6g} KiB" if "WRITE_SIZE" in out else ""))
+            if args.json and args.name:
+                try:
+                    blob = json.load(open(args.json))
+                except Exception:
+                    blob = {}
+                blob[args.name] = {
+                    "traffic_bytes_per_step": b,
+                    "counter": "FETCH_SIZE (KiB) x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM section), summed over every lookup kernel of a step",
+                    "source": f"rocprofv3 --pmc FETCH_SIZE WRITE_SIZE pass, {args.steps} steps (tools/gpu_r2_profiles.sh, tools/pmc_summary.py)",
+                }
+                json.dump(blob, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
