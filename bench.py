@@ -348,9 +348,9 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     if wl["bound"] == "hbm" and kt["scan"][1]:
         kern_name, parts = "tavb::scan_*_kernel (streaming dot + score + select)", ["scan"]
     elif kt["mfma_last_phase"][1]:
-        kern_name, parts = "tavb::mfma_scan_kernel_* (256-query fp16 MFMA tile; all threshold-ladder phases of a batch)", ["mfma_last_phase", "mfma_earlier_phases"]
+        kern_name, parts = "tavb::mfma_scan_kernel<0, NI, ...> (fp16 MFMA tile, NI = 4: 256 queries, NI = 2: 128 queries; all threshold-ladder phases of a batch)", ["mfma_last_phase", "mfma_earlier_phases"]
     elif kt["skinny_last_phase"][1]:
-        kern_name, parts = "tavb::skinny_scan_kernel (32/64/128-query MFMA tile; all threshold-ladder phases)", ["skinny_last_phase", "mfma_earlier_phases"]
+        kern_name, parts = "tavb::skinny_scan_kernel (32/64-query MFMA tile; all threshold-ladder phases)", ["skinny_last_phase", "mfma_earlier_phases"]
     else:
         kern_name, parts = "tavb::scan_*_kernel", ["scan"]
     kern_ms_per_step = sum(kt[p][0] for p in parts) / steps
