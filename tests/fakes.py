@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from typeagent_py_amd.embeddings import CachingEmbeddingModel
+from typeagent_py_amd.embeddings import IEmbedder, NormalizedEmbedding, NormalizedEmbeddings
 
 
 def _hashish(s: str) -> int:
@@ -48,6 +48,45 @@ class FakeTextEmbedder:
         norms = np.linalg.norm(e, axis=1, keepdims=True).astype(np.float32)
         norms = np.where(norms > 0, norms, np.float32(1.0))
         return (e / norms).astype(np.float32)
+
+
+class CachingEmbeddingModel:
+    """In-memory key -> embedding cache in front of an IEmbedder."""
+
+    def __init__(self, embedder: IEmbedder) -> None:
+        self._embedder = embedder
+        self._cache: dict[str, NormalizedEmbedding] = {}
+
+    @property
+    def model_name(self) -> str:
+        return self._embedder.model_name
+
+    def add_embedding(self, key: str, embedding: NormalizedEmbedding) -> None:
+        self._cache[key] = embedding
+
+    async def get_embedding_nocache(self, input: str) -> NormalizedEmbedding:
+        return await self._embedder.get_embedding_nocache(input)
+
+    async def get_embeddings_nocache(self, input: list[str]) -> NormalizedEmbeddings:
+        return await self._embedder.get_embeddings_nocache(input)
+
+    async def get_embedding(self, key: str) -> NormalizedEmbedding:
+        hit = self._cache.get(key)
+        if hit is not None:
+            return hit
+        fresh = await self._embedder.get_embedding_nocache(key)
+        self._cache[key] = fresh
+        return fresh
+
+    async def get_embeddings(self, keys: list[str]) -> NormalizedEmbeddings:
+        if not keys:
+            raise ValueError("Cannot embed an empty list")
+        todo = [k for k in keys if k not in self._cache]
+        if todo:
+            fresh = await self._embedder.get_embeddings_nocache(todo)
+            for row, k in zip(fresh, todo):
+                self._cache[k] = row
+        return np.array([self._cache[k] for k in keys], dtype=np.float32)
 
 
 def create_test_embedding_model(embedding_size: int = 3) -> CachingEmbeddingModel:

@@ -9,10 +9,9 @@ import asyncio
 import numpy as np
 import pytest
 
-from tests.fakes import NamedModel, NullModel, create_test_embedding_model
+from tests.fakes import CachingEmbeddingModel, NamedModel, NullModel, create_test_embedding_model
 from typeagent_py_amd import (
     DEFAULT_MIN_SCORE,
-    CachingEmbeddingModel,
     ScoredInt,
     TextEmbeddingIndexSettings,
     VectorBase,
