@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Drive the C ABI without torch (torch's CUDA init does not survive the ASan runtime): device buffers come from hipMalloc through
+ctypes.  Meant for `libtavb_debug.so` (host side under AddressSanitizer + UBSan, `make -C typeagent_py_amd/csrc debug`), see
+tools/gpu_asan.sh.  Checks answers against numpy on the way (test infrastructure, not product)."""
+import ctypes
+import os
+import sys
+from ctypes import POINTER, byref, c_float, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from typeagent_py_amd import _native  # noqa: E402
+
+lib = _native.load_library(preload_torch=False)
+hip = ctypes.CDLL("libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
+hip.hipMalloc.argtypes = [POINTER(c_void_p), ctypes.c_size_t]
+hip.hipFree.argtypes = [c_void_p]
+hip.hipMemcpy.argtypes = [c_void_p, c_void_p, ctypes.c_size_t, c_int]
+
+
+def ok(rc):
+    if rc:
+        raise RuntimeError(lib.tavb_last_error().decode())
+
+
+def dmalloc(n):
+    p = c_void_p()
+    assert hip.hipMalloc(byref(p), n) == 0
+    return p
+
+
+def ptr(a):
+    return a.ctypes.data_as(c_void_p)
+
+
+def scores(v, q):
+    return np.clip((v @ q + np.float32(1)) * np.float32(0.5), 0, 1).astype(np.float32)
+
+
+def main():
+    rng = np.random.default_rng(7)
+    n, d, k = 70_003, 1536, 32
+    v = rng.standard_normal((n, d)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    h = c_void_p()
+    bad = []
+    ok(lib.tavb_create(0, None, byref(h)))
+    for dtype, esz in ((_native.TAVB_F32, 4), (_native.TAVB_F16, 2)):
+        vv = v if dtype == _native.TAVB_F32 else v.astype(np.float16).astype(np.float32)
+        dev = dmalloc(n * d * esz)
+        ok(lib.tavb_upload_rows(h, ptr(v), n, d, dev, dtype))  # pinned ring + staging threads + on-device conversion
+        ok(lib.tavb_set_corpus(h, dev, n, d, dtype, 0))
+        ok(lib.tavb_corpus_modified(h, 0))
+        # one query, every tier of batch (streaming, 32/64-query tile, 128/256-query tile + rescoring)
+        for nq in (1, 3, 20, 64, 100, 300):
+            q = rng.standard_normal((nq, d)).astype(np.float32)
+            q /= np.linalg.norm(q, axis=1, keepdims=True)
+            o = np.empty((nq, k), np.int64); s = np.empty((nq, k), np.float32); c = np.empty(nq, np.int32)
+            thr = np.zeros(nq, np.float32)
+            ok(lib.tavb_search_batch(h, ptr(q), nq, k, ptr(thr), ptr(o), ptr(s), ptr(c)))
+            for qi in (0, nq - 1):
+                ref = np.argsort(-scores(vv, q[qi]), kind="stable")[:k]
+                if not (c[qi] == k and (o[qi] == ref).mean() > 0.9):
+                    tier = c_int64(); lib.tavb_get_option(h, b"last_tier", byref(tier))
+                    print("MISMATCH", dtype, nq, qi, "count", c[qi], "tier", tier.value, "\n got", o[qi][:8], s[qi][:8], "\n ref", ref[:8], scores(vv, q[qi])[ref[:8]], flush=True)
+                    bad.append((dtype, nq, qi))
+            keys = np.empty((nq, k), np.uint64)
+            ok(lib.tavb_search_begin(h, ptr(q), nq, k, ptr(thr), None))
+            ok(lib.tavb_search_end(h, nq, k, ptr(keys)))
+            two = np.stack([keys, keys])
+            merged = np.empty((nq, k), np.uint64)
+            ok(lib.tavb_merge_keys_host(ptr(two), 2, nq, k, ptr(merged)))
+            o2 = np.empty((nq, k), np.int64); s2 = np.empty((nq, k), np.float32); c2 = np.empty(nq, np.int32)
+            ok(lib.tavb_decode_keys(ptr(keys), nq, k, ptr(o2), ptr(s2), ptr(c2)))
+            if not (o2 == o).all(): print("begin/end differs from search_batch at nq", nq, "counts", c2[:4], flush=True)
+        q = v[5].copy()
+        o = np.empty(k, np.int64); s = np.empty(k, np.float32); cnt = c_int32()
+        ok(lib.tavb_search(h, ptr(q), k, c_float(0.0), ptr(o), ptr(s), byref(cnt)))
+        print("single search: count", cnt.value, "first", o[0], flush=True)
+        rows = rng.integers(0, n, 5000).astype(np.int64)
+        ok(lib.tavb_search_subset(h, ptr(q), ptr(rows), rows.size, k, c_float(0.0), ptr(o), ptr(s), byref(cnt)))
+        print("subset search: count", cnt.value, flush=True)
+        cap = 4096
+        oa = np.empty(cap, np.int64); sa = np.empty(cap, np.float32); got = c_int64(); tot = c_int64()
+        ok(lib.tavb_search_all(h, ptr(q), c_float(0.52), cap, ptr(oa), ptr(sa), byref(got), byref(tot)))
+        print("search_all: got", got.value, "expected", int((scores(vv, q) >= np.float32(0.52)).sum()), flush=True)
+        ok(lib.tavb_search_subset_all(h, ptr(q), ptr(rows), rows.size, c_float(0.5), cap, ptr(oa), ptr(sa), byref(got), byref(tot)))
+        # message re-rank
+        r2m = (np.arange(n) // 3).astype(np.int32)
+        dmap = dmalloc(n * 4)
+        assert hip.hipMemcpy(dmap, ptr(r2m), n * 4, 1) == 0
+        ok(lib.tavb_set_row_messages(h, dmap, n, int(r2m.max()) + 1))
+        om = np.empty(k, np.int64); sm = np.empty(k, np.float32)
+        acc = np.arange(0, int(r2m.max()) + 1, 2).astype(np.int32)
+        ok(lib.tavb_search_messages(h, ptr(q), k, c_float(0.0), ptr(acc), acc.size, 10, ptr(om), ptr(sm), byref(cnt)))
+        print("messages: count", cnt.value, flush=True)
+        ok(lib.tavb_search_messages_subset(h, ptr(q), ptr(rows), rows.size, k, c_float(0.0), 10, ptr(om), ptr(sm), byref(cnt)))
+        # bad arguments must come back as error codes, not as crashes
+        assert lib.tavb_search(h, ptr(q), 100000, c_float(0.0), ptr(o), ptr(s), byref(cnt)) != 0
+        assert lib.tavb_set_option(h, b"no_such_option", 1) != 0
+        ok(lib.tavb_set_corpus(h, dev, 0, d, dtype, 0))
+        hip.hipFree(dev); hip.hipFree(dmap)
+        print("dtype", dtype, "ok", flush=True)
+    ok(lib.tavb_destroy(h))
+    print("asan exercise:", "all good" if not bad else f"MISMATCHES {bad}")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1125,9 +1125,9 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
     const int carried = ph > 0 ? 1 : 0;  // the running top-k of the earlier phases occupies one more list slot
     pp.list_stride = pp.n_splits + carried;
     pp.thr_in = ph > 0 ? reinterpret_cast<const float*>(c->d_thr.ptr) : r.floor;
-    u64_t* const running = reinterpret_cast<u64_t*>(c->d_sample_keys.ptr);  // [2][nq][k]
-    const u64_t* const run_in = running + (size_t)((ph + 1) & 1) * nq * k;       // what phase ph - 1 left
-    u64_t* const run_out = running + (size_t)(ph & 1) * nq * k;
+    u64_t* const running = reinterpret_cast<u64_t*>(c->d_sample_keys.ptr);  // [2][nq][k]; not allocated for a single phase
+    const u64_t* const run_in = running ? running + (size_t)((ph + 1) & 1) * nq * k : nullptr;  // what phase ph - 1 left
+    u64_t* const run_out = running ? running + (size_t)(ph & 1) * nq * k : nullptr;
     if (carried && !wide) {
       TAVB_HIP(hipMemcpy2DAsync(pp.lists + (size_t)pp.n_splits * k, (size_t)pp.list_stride * k * sizeof(u64_t), run_in,
                                 (size_t)k * sizeof(u64_t), (size_t)k * sizeof(u64_t), (size_t)nq, hipMemcpyDeviceToDevice, c->stream));
