@@ -541,7 +541,64 @@ def run_cfg5(args, wl) -> None:
         ms, n = eng.profile_read(_native.KERNEL_SCAN)
         out["roofline"]["scan_kernel_ms_per_user_query"] = ms / steps
         out["roofline"]["scan_launches_per_user_query"] = n / steps
+        eng.profile_enable(False)
+    if not args.no_parity:
+        out["parity"] = cfg5_parity(eng, one, user_queries[:2], {"terms": (terms, 50_043), "messages": (msgs, 50_044), "threads": (threads, 50_045)},
+                                    dim, wl["dtype"], subset)
     emit_result(out)
+    if out.get("parity") and not out["parity"]["ok"]:
+        sys.stderr.write("bench.py: PARITY CHECK FAILED (see the `parity` object in the line above)\n")
+        raise SystemExit(3)
+
+
+def cfg5_parity(eng, one, user_queries, corpora: dict, dim: int, dtype: str, subset) -> dict:
+    """Two user queries (12 lookups) of the cfg5 submission against the oracle over the WHOLE corpora (10M-row passes in
+    ORACLE_CHUNK-row chunks): term lookups k=50 @0.85, message re-rank k=25 @0.7 (full scan or subset), thread lookup k=10 @0.7."""
+    from oracle import vectorbase_oracle as vo
+
+    t0 = time.perf_counter()
+    checked = exact = permuted = near = hits = 0
+    worst = 0.0
+    try:
+        results = []
+        for ui in range(len(user_queries)):
+            res = one(ui)
+            results.append((res.terms, res.messages, res.threads) if hasattr(res, "terms") else (res[:4], res[4], res[5]))
+        # one oracle pass per corpus for all the user queries' lookups on it
+        legs = [("terms", np.concatenate([u[0] for u in user_queries]), [h for r in results for h in r[0]], 50, 0.85),
+                ("messages", np.stack([u[1] for u in user_queries]), [r[1] for r in results], 25, 0.7),
+                ("threads", np.stack([u[2] for u in user_queries]), [r[2] for r in results], 10, 0.7)]
+        for cname, qs, got_lists, k, ms in legs:
+            tensor, seed = corpora[cname]
+            thr = float(_f32_threshold(ms))
+            ref = vo.scores_full_chunked(oracle_chunks(eng, tensor, 0, int(tensor.shape[0]), dim, seed, dtype), np.asarray(qs, dtype=np.float32))
+            for j, got in enumerate(got_lists):
+                items, scs = [r.item for r in got], [r.score for r in got]
+                if cname == "messages" and subset is not None:
+                    sub = np.asarray(subset, dtype=np.int64)
+                    pos = {int(o): i for i, o in enumerate(subset)}
+                    rep, n_near = vo.check_topk_parity_large(ref[j][sub], [pos[i] for i in items], scs, k, thr)
+                else:
+                    rep, n_near = vo.check_topk_parity_large(ref[j], items, scs, k, thr)
+                    if items:
+                        worst = max(worst, float(np.max(np.abs(ref[j][np.asarray(items)] - np.asarray(scs, dtype=np.float32)))))
+                checked += 1
+                hits += len(items)
+                exact += rep.exact_positions
+                permuted += rep.tie_permuted_positions
+                near += n_near
+    except AssertionError as exc:
+        return {"ok": False, "error": str(exc)[:300], "lookups_checked": checked}
+    return {"ok": True, "lookups_checked": checked, "hits_returned": hits, "positions_exact": exact, "positions_permuted_inside_near_ties": permuted,
+            "near_tie_pairs_in_reference_topk": near, "max_abs_score_error": worst, "score_tolerance": vo.SCORE_TOL,
+            "oracle": "numpy restatement of vectorbase.py:163-230 over the whole corpora in %d-row chunks" % ORACLE_CHUNK,
+            "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def _f32_threshold(x: float):
+    from typeagent_py_amd import _native
+
+    return _native.f32_threshold(x)
 
 
 _RESULT_FD = None
