@@ -64,7 +64,7 @@ WORKLOADS = {
     "cfg1": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="hbm", seed=43),
     # batches on the reference's own dtype (fp32): 32 queries ride one HBM pass; 1024 are bound by the fp32 matrix rate
     "cfg2_b32": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=32, k=32, bound="hbm", seed=1043),
-    "cfg2_b1024": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1024, k=32, bound="mfma", seed=1043),
+    "cfg2_b1024": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1024, k=32, bound="mfma", seed=1043),  # fp16 shadow + exact fp32 rescoring (--opt f32_shadow=0: fp32 MFMAs)
     # middle batch sizes on the fp16 corpus (the 64/128-query tiles)
     "cfg3_b32": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=32, k=32, bound="hbm", seed=10043),
     "cfg3_b128": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=128, k=32, bound="hbm", seed=10043),  # 128-query tile: one HBM pass (3.9 PFLOP would take 3.2 ms at 0.49 of the matrix peak)
@@ -363,8 +363,12 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     else:
         alg = 2.0 * nq * rows_local * dim
         achieved = alg / (kern_ms_per_step * 1e-3) / 1e12 if kern_ms_per_step > 0 else 0.0
-        peak = MFMA_F16_PEAK_TFLOPS if wl["dtype"] == "fp16" else MFMA_F32_PEAK_TFLOPS
-        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}
+        # the pipe that did the work: fp16 MFMAs for the 128/256-query tile (fp16 corpora, and fp32 corpora through their fp16 shadow + exact
+        # rescoring), fp32 MFMAs for the 64-query tile on fp32 corpora
+        fp16_pipe = wl["dtype"] == "fp16" or parts[0] == "mfma_last_phase"
+        peak = MFMA_F16_PEAK_TFLOPS if fp16_pipe else MFMA_F32_PEAK_TFLOPS
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "pipe": "v_mfma_f32_32x32x16_f16" if fp16_pipe else "v_mfma_f32_32x32x2_f32"}
     try:  # HBM traffic comes from a separate rocprofv3 --pmc pass (bench.py cannot count it itself)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f).get(name)

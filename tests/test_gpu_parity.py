@@ -783,6 +783,85 @@ def test_wide_tile_row_norm_cache_follows_appends_and_rewrites():
     assert second[0][0].item == 9_000 and second[0][0].score == 1.0
     assert [r.item for r in first[60]] == [r.item for r in second[60]][: len(first[60])] or True
 
+# --------------------------------------------------------------------------------------
+# fp32 corpora, 65+ queries: the 128/256-query fp16 tile filters on an fp16 SHADOW of the corpus, the candidates are
+# rescored with the fp32 rows and fp32 queries (tavb_rescore.hip) -- same answers as the single-query fp32 kernels
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nq", [65, 128, 300, 1024])
+def test_f32_corpus_large_batches_ride_the_fp16_shadow(nq):
+    v, _ = make_corpus(60_007, 1536, 7600)
+    qs = make_queries(nq, 1536, 7601 + nq)
+    qs[1] = v[60_006]
+    vb = new_vb(v)
+    eng = vb.engine
+    eng.profile_enable(True)
+    eng.profile_reset()
+    batch = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert eng.get_option("last_tier") == 4 and eng.profile_read(_native.KERNEL_MFMA)[1] == 1 and eng.get_option("last_flagged") == 0
+    assert batch[1][0].item == 60_006 and abs(batch[1][0].score - 1.0) < 1e-6
+    sample = sorted(set(np.linspace(0, nq - 1, 20).astype(int).tolist()))
+    for qi in sample:
+        seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=32, min_score=0.0)
+        assert eng.get_option("last_tier") in (1, 2, 3)
+        assert [r.item for r in batch[qi]] == [r.item for r in seq]
+        np.testing.assert_allclose([r.score for r in batch[qi]], [r.score for r in seq], atol=3e-7, rtol=0)
+        assert vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(batch[qi]), 32, 0.0).ordinals_bit_exact
+    # the 64-query fp32 tile (no shadow) gives the same answers
+    eng.set_option("f32_shadow", 0)
+    plain = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert eng.get_option("last_tier") == 5
+    for qi in sample:
+        assert [r.item for r in plain[qi]] == [r.item for r in batch[qi]]
+    # a threshold near the scores: relaxed filter threshold, exact re-test
+    eng.set_option("f32_shadow", 1)
+    thr = float(np.float32(batch[0][20].score))
+    batch_t = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=thr)
+    assert eng.get_option("last_tier") == 4 and len(batch_t[0]) == 21
+    for qi in sample[:6]:
+        seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=32, min_score=thr)
+        assert [r.item for r in batch_t[qi]] == [r.item for r in seq]
+
+
+def test_f32_shadow_follows_appends_rewrites_and_falls_back_on_near_duplicates():
+    v, _ = make_corpus(20_000, 1536, 7700)
+    qs = make_queries(80, 1536, 7701)
+    vb = new_vb(v)
+    eng = vb.engine
+    first = vb.fuzzy_lookup_embeddings(qs, max_hits=10, min_score=0.0)
+    assert eng.get_option("last_tier") == 4
+    # appended rows (the shadow is extended, or rebuilt when the device buffer moved)
+    extra = make_queries(3000, 1536, 7702)
+    extra[7] = qs[5]
+    vb.add_embeddings(None, extra)
+    second = vb.fuzzy_lookup_embeddings(qs, max_hits=10, min_score=0.0)
+    assert eng.get_option("last_tier") == 4 and second[5][0].item == 20_007 and abs(second[5][0].score - 1.0) < 1e-6
+    allv = np.concatenate([v, extra])
+    for qi in range(0, 80, 9):
+        assert vo.check_topk_parity(vo.scores_full(allv, qs[qi]), *items_scores(second[qi]), 10, 0.0).ordinals_bit_exact
+    # a row rewritten in place in the serialized matrix (noticed by the fingerprint or mark_dirty): the shadow must follow
+    m = vb.serialize()
+    m[123] = qs[9]
+    vb.mark_dirty()
+    third = vb.fuzzy_lookup_embeddings(qs, max_hits=10, min_score=0.0)
+    assert third[9][0].item == 123 and abs(third[9][0].score - 1.0) < 1e-6
+    # near-duplicate rows around rank k: the fp16 shadow cannot separate them, the candidate set cannot be proven complete,
+    # the exact fp32 tile answers those queries
+    rng = np.random.default_rng(7703)
+    base = qs[3].copy()
+    dups = np.stack([base + 3e-4 * rng.standard_normal(1536).astype(np.float32) for _ in range(100)])
+    dups /= np.linalg.norm(dups, axis=1, keepdims=True)
+    vb2 = new_vb(np.concatenate([v, dups.astype(np.float32)]))
+    out = vb2.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert vb2.engine.get_option("last_tier") == 4 and vb2.engine.get_option("last_flagged") >= 1
+    allv2 = np.concatenate([v, dups.astype(np.float32)])
+    for qi in [0, 4, 40, 79]:
+        vo.check_topk_parity(vo.scores_full(allv2, qs[qi]), *items_scores(out[qi]), 32, 0.0)
+    # query 3 sits in the middle of 100 rows whose scores differ by less than fp32 summation noise: the ORDER among them is
+    # not defined (not even by the reference), the set of scores is
+    assert all(r.item >= 20_000 for r in out[3]) and len(set(r.item for r in out[3])) == 32
+    ref3 = np.sort(vo.scores_full(allv2, qs[3]))[::-1][:32]
+    np.testing.assert_allclose([r.score for r in out[3]], ref3, atol=1e-6, rtol=0)
+
 
 # --------------------------------------------------------------------------------------
 # 32-query MFMA tile ("skinny" kernel): batches of 3..32 on fp16 corpora, every batch >= 5 on fp32 corpora
@@ -819,6 +898,7 @@ def test_skinny_kernel_serves_large_batches_on_fp32_corpora(nq):
     v, _ = make_corpus(n, 1536, 9600)
     qs = make_queries(nq, 1536, 9601 + nq)
     vb = new_vb(v)
+    vb.engine.set_option("f32_shadow", 0)  # without the fp16 shadow (its default-on form: test_f32_corpus_large_batches_*)
     got = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     assert vb.engine.get_option("last_tier") == 5
     for qi in range(0, nq, 7):

@@ -114,6 +114,8 @@ struct tavb_ctx {
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand, d_thr, d_sample_keys;
   Buffer d_counts;  // 256-query tile: keys left per candidate buffer
   Buffer d_delta, d_approx, d_flag, d_fb_queries, d_norm;  // exact rescoring of the 256-query tile (tavb_rescore.hip)
+  Buffer d_shadow;         // fp32 corpora: fp16 shadow copy of rows [0, norm_rows), the filter operand of the 128/256-query tile
+  int64_t f32_shadow = 1;  // option: large batches on fp32 corpora go through that shadow (+50 % HBM); 0 = 64-query fp32 tile only
   Buffer d_accept, d_bits;  // message re-rank: accepted message ordinals, their bitmap
   Buffer d_emit;            // survivors of tavb_search_all: a counter, then the keys
   // load path (tavb_upload_rows): two pinned staging slots + two device scratch slots, recycled through events
@@ -122,7 +124,7 @@ struct tavb_ctx {
   hipEvent_t ring_done[2] = {nullptr, nullptr};
   const int32_t* row_to_msg = nullptr;  // borrowed device map chunk row -> message ordinal
   int64_t row_to_msg_rows = 0, n_messages = 0;
-  int64_t norm_rows = 0;  // rows of the corpus covered by the cached maximum row norm (d_norm)
+  int64_t norm_rows = 0;  // rows of the corpus covered by the cached row-norm maxima (d_norm) -- and, for fp32 corpora, by the fp16 shadow
   Buffer h_stage{nullptr, 0, true};
   Buffer h_out{nullptr, 0, true};  // pinned + device-visible: the last kernel of a synchronous lookup writes its keys straight here
 
@@ -406,6 +408,12 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_sample_rows") {
     if (v < -1) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= -1");
     c->mfma_sample_rows = v;
+  } else if (n == "f32_shadow") {
+    c->f32_shadow = v ? 1 : 0;
+    if (!v) {
+      c->d_shadow.release();
+      if (c->dtype == TAVB_F32) c->norm_rows = 0;
+    }
   } else if (n == "mfma_tile") {
     if (v != 0 && v != 128 && v != 256) return fail(TAVB_E_INVALID, "mfma_tile must be 0 (auto), 128 or 256");
     c->mfma_tile = v;
@@ -446,6 +454,7 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "mfma_min_batch") *out = c->mfma_min_batch;
   else if (n == "mfma_splits") *out = c->mfma_splits;
   else if (n == "mfma_tile") *out = c->mfma_tile;
+  else if (n == "f32_shadow") *out = c->f32_shadow;
   else if (n == "mfma_ladder") *out = c->mfma_ladder;
   else if (n == "skinny_min_batch_f32") *out = c->skinny_min_batch_f32;
   else if (n == "skinny_min_batch_f16") *out = c->skinny_min_batch_f16;
@@ -475,6 +484,7 @@ int tavb_set_corpus(tavb_ctx* c, const void* dev_rows, int64_t rows, int32_t dim
   if (rows >= 0x7FFFFFFFll) return fail(TAVB_E_UNSUPPORTED, "at most 2^31-2 rows per device shard (got %lld)", (long long)rows);
   if (ordinal_base < 0) return fail(TAVB_E_INVALID, "ordinal_base must be >= 0");
   if (dev_rows != c->corpus || dim != c->dim || dtype != c->dtype || rows < c->norm_rows) c->norm_rows = 0;  // cached row-norm maximum: keep it across appends only
+  if (dtype != TAVB_F32 || rows == 0) c->d_shadow.release();  // the fp16 shadow belongs to an fp32 corpus
   c->corpus = dev_rows;
   c->rows = rows;
   c->dim = dim;
@@ -1047,6 +1057,7 @@ struct TileRun {
   float kernel_min_score; // uniform threshold applied inside the kernel
   const float* floor;     // optional device [nq_pad]: per-query exclusive admission thresholds valid from the first row on
   const void* queries;    // operand in the kernel's layout
+  const void* corpus;     // corpus operand (nullptr: the context's corpus; the fp16 shadow of an fp32 corpus for the filter pass)
   const int* active;      // optional device-side live-query count (fixed-shape launch over a work list)
   bool ladder;            // scan in phases of growing size (else one phase)
 };
@@ -1073,7 +1084,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   if (wide)
     if (int rc = c->d_counts.reserve((size_t)splits * r.nq_pad * sizeof(int))) return rc;
   tavb::MfmaParams p{};
-  p.corpus = c->corpus;
+  p.corpus = r.corpus ? r.corpus : c->corpus;
   p.queries = r.queries;
   p.lists = reinterpret_cast<u64_t*>(c->d_lists.ptr);
   p.workspace = reinterpret_cast<u64_t*>(c->d_cand.ptr);
@@ -1159,9 +1170,11 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   return TAVB_OK;
 }
 
-// The 256-query fp16 tile as an exact filter + fp32-query rescoring of its candidates (tavb_rescore.hip).
+// The 128/256-query fp16 tile as an exact filter + fp32-query rescoring of its candidates (tavb_rescore.hip).  fp32 corpora:
+// the filter reads the fp16 shadow (d_shadow, reserved by the caller), the rescoring and the fallback tile the fp32 rows.
 int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_score, uint32_t index_base, u64_t* d_out) {
   constexpr int KC = 64;  // candidates per query
+  const bool f32c = (c->dtype == TAVB_F32);
   const int qt = c->mfma_tile > 0 ? (int)c->mfma_tile : tavb::mfma_query_tile(nq);
   const int nq_pad = ((nq + qt - 1) / qt) * qt;
   const int cap = ((nq + 63) / 64) * 64;  // slots of the work list of queries that need the exact tile
@@ -1179,14 +1192,19 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   int* d_flagged = d_nflag + 64;
   {
     Timed t(c, TAVB_KERNEL_RESCORE);
-    if (c->norm_rows > c->rows || c->norm_rows == 0) {  // first use on this corpus (or it shrank: the old maximum is still an upper bound, but start over)
-      TAVB_HIP(hipMemsetAsync(d_norm, 0, sizeof(float), c->stream));
+    if (c->norm_rows > c->rows || c->norm_rows == 0) {  // first use on this corpus (or it shrank: the old maxima are still upper bounds, but start over)
+      TAVB_HIP(hipMemsetAsync(d_norm, 0, 2 * sizeof(float), c->stream));
       c->norm_rows = 0;
     }
-    if (c->norm_rows < c->rows) {  // rows appended since: extend the maximum
-      hipError_t e = tavb::launch_corpus_max_norm(reinterpret_cast<const char*>(c->corpus) + (size_t)c->norm_rows * c->dim * 2,
-                                                  c->rows - c->norm_rows, c->dim, d_norm, c->stream);
-      if (e != hipSuccess) return fail(TAVB_E_HIP, "corpus norm launch failed: %s", hipGetErrorString(e));
+    if (c->norm_rows < c->rows) {  // rows appended since: extend the maxima (and the shadow)
+      hipError_t e;
+      if (f32c)
+        e = tavb::launch_shadow_convert(reinterpret_cast<const float*>(c->corpus) + (size_t)c->norm_rows * c->dim, c->rows - c->norm_rows, c->dim,
+                                        reinterpret_cast<char*>(c->d_shadow.ptr) + (size_t)c->norm_rows * c->dim * 2, d_norm, c->stream);
+      else
+        e = tavb::launch_corpus_max_norm(reinterpret_cast<const char*>(c->corpus) + (size_t)c->norm_rows * c->dim * 2, c->rows - c->norm_rows, c->dim,
+                                         d_norm, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "corpus norm / shadow launch failed: %s", hipGetErrorString(e));
       c->norm_rows = c->rows;
     }
     TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16_bytes, c->stream));  // padding queries
@@ -1203,21 +1221,23 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   filt.kernel_min_score = (min_score > 0.0f) ? 0.0f : min_score;  // the per-query relaxed thresholds (floor) do the filtering; NaN stays NaN
   filt.floor = d_floor;
   filt.queries = c->d_queries_f16.ptr;
+  filt.corpus = f32c ? c->d_shadow.ptr : nullptr;
   filt.ladder = true;
   if (int rc = run_tile_ladder(c, filt, reinterpret_cast<u64_t*>(c->d_approx.ptr), nullptr)) return rc;
   {
     Timed t(c, TAVB_KERNEL_RESCORE);
-    hipError_t e = tavb::launch_rescore(c->corpus, c->dim, index_base, d_q, reinterpret_cast<const u64_t*>(c->d_approx.ptr), d_delta, min_score, nq, k,
-                                        d_out, d_nflag, d_flagged, c->stream);
+    hipError_t e = tavb::launch_rescore(c->corpus, f32c, c->dim, index_base, d_q, reinterpret_cast<const u64_t*>(c->d_approx.ptr), d_delta, min_score,
+                                        nq, k, d_out, d_nflag, d_flagged, c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "rescore launch failed: %s", hipGetErrorString(e));
     char* fb = reinterpret_cast<char*>(c->d_fb_queries.ptr);
     float* fb_thr = reinterpret_cast<float*>(fb + (size_t)2 * cap * c->dim * 2);
-    e = tavb::launch_gather_flagged(d_q, c->dim, min_score, d_nflag, d_flagged, cap, fb, fb + (size_t)cap * c->dim * 2, fb_thr, c->stream);
+    e = f32c ? tavb::launch_gather_flagged_f32(d_q, c->dim, min_score, d_nflag, d_flagged, cap, reinterpret_cast<float*>(fb), fb_thr, c->stream)
+             : tavb::launch_gather_flagged(d_q, c->dim, min_score, d_nflag, d_flagged, cap, fb, fb + (size_t)cap * c->dim * 2, fb_thr, c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "gather launch failed: %s", hipGetErrorString(e));
     // the exact tile over the work list: returns at once when the list is empty (the normal case)
     TileRun ex{};
     ex.skinny = true;
-    ex.q32 = false;
+    ex.q32 = f32c;
     ex.qt = 64;
     ex.nq = cap;
     ex.nq_pad = cap;
@@ -1243,8 +1263,15 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (min_scores[i] == min_scores[0]);
   const bool f16c = (c->dtype == TAVB_F16);
   // the filter keeps 64 candidates per query: k up to 48 leaves the slack the completeness proof needs
-  const bool wide = f16c && c->corpus && nq >= c->mfma_min_batch && uniform_thr && tavb::mfma_supported(c->dim, 64) && k <= 48 && c->rows > 0 &&
-                    tavb::skinny_supported(c->dim, k, false);
+  bool wide = (f16c || c->f32_shadow) && c->corpus && nq >= c->mfma_min_batch && uniform_thr && tavb::mfma_supported(c->dim, 64) && k <= 48 &&
+              c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c);
+  if (wide && !f16c) {  // fp32 corpus: the filter needs the fp16 shadow; without the memory for it the 64-query fp32 tile serves the batch
+    const size_t need = (size_t)c->rows * c->dim * 2;
+    if (c->d_shadow.cap < need) {
+      c->norm_rows = 0;  // reserve() does not keep the old contents
+      if (c->d_shadow.reserve(need) != TAVB_OK) wide = false;
+    }
+  }
   // 32/64-query tiles at HBM speed: small batches on fp16 corpora, every batch from `skinny_min_batch_f32` up on fp32 ones
   const bool skinny = !wide && c->corpus && uniform_thr && c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c) &&
                       nq >= (f16c ? c->skinny_min_batch_f16 : c->skinny_min_batch_f32);

@@ -57,8 +57,11 @@ hipError_t launch_message_rerank(const unsigned long long* hits, int nq, int k, 
 hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, float* out_sq, hipStream_t stream);
 hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, const float* max_norm_sq, void* q16, float* delta, float* thr,
                                 hipStream_t stream);
-hipError_t launch_rescore(const void* corpus_f16, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx, const float* delta,
-                          float min_score, int nq, int k, unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream);
+hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
+                          const float* delta, float min_score, int nq, int k, unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream);
+hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, float* stats /*[2]*/, hipStream_t stream);
+hipError_t launch_gather_flagged_f32(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, float* out,
+                                     float* thr, hipStream_t stream);
 hipError_t launch_gather_flagged(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, void* hi, void* lo,
                                  float* thr, hipStream_t stream);
 

@@ -303,7 +303,6 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   lds_flag* need_compact = (lds_flag*)(smem + CTRL6 + BN * 8);
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1;  // rows wm * 160 ..
   const int wn = wave & 1;   // queries wn * 32 * NI ..

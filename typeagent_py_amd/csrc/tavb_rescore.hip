@@ -21,6 +21,14 @@
 //      64-query tile with split hi/lo query planes (exact by construction, tavb_mfma.hip) serves the list and returns
 //      at once when it is empty.  No host round trip anywhere: the asynchronous device-resident form stays asynchronous.
 
+//
+// fp32 corpora (the reference's own layout) ride the same filter through an fp16 SHADOW copy of the corpus
+// (shadow_convert_kernel: built once, extended on append, +50 % HBM; `f32_shadow` option): the bound gains the corpus
+// rounding term,  |x.q - x16.q16| <= ||x - x16|| ||q|| + ||x16|| ||q - q16||  with E = max ||x - x16|| and R = max ||x16||
+// over the rows, the candidates are rescored with the fp32 rows and fp32 queries, and flagged queries fall back to the
+// exact fp32 64-query tile.  1024 queries over 1M x 1536 fp32 rows: one fp16 MFMA pass instead of 16 passes at the fp32
+// matrix rate.
+
 #include <hip/hip_runtime.h>
 
 #include "tavb_device.h"
@@ -58,10 +66,50 @@ __global__ void __launch_bounds__(256) corpus_max_norm_kernel(const _Float16* __
   if (lane == 0) atomic_max_nonneg(out_sq, best);
 }
 
+// fp32 rows -> fp16 shadow rows, and the two maxima the bound needs: stats[0] = max sum(x16^2), stats[1] = max sum((x - x16)^2).
+// A non-finite row makes the maxima +inf (every query then takes the exact path).  One wave per row.
+__global__ void __launch_bounds__(256) shadow_convert_kernel(const float* __restrict__ rows, int64_t n, int dim, _Float16* __restrict__ out,
+                                                             float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int n4 = dim / 4;  // dim % 64 == 0 on this path
+  float best16 = 0.f, best_err = 0.f;
+  for (int64_t r = wave; r < n; r += n_waves) {
+    const f32x4* x = reinterpret_cast<const f32x4*>(rows + r * (int64_t)dim);
+    _Float16* y = out + r * (int64_t)dim;
+    float ss = 0.f, se = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+      const f32x4 v = __builtin_nontemporal_load(x + i);
+      const float e[4] = {v.x, v.y, v.z, v.w};
+      _Float16 h[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = (_Float16)e[j];
+        const float hf = (float)h[j];
+        const float d = e[j] - hf;
+        ss = fmaf(hf, hf, ss);
+        se = fmaf(d, d, se);
+      }
+      *reinterpret_cast<uint2*>(y + i * 4) = *reinterpret_cast<const uint2*>(h);
+    }
+    ss = wave_sum(ss);
+    se = wave_sum(se);
+    if (!(ss < __builtin_inff())) ss = __builtin_inff();
+    if (!(se < __builtin_inff())) se = __builtin_inff();
+    best16 = fmaxf(best16, ss);
+    best_err = fmaxf(best_err, se);
+  }
+  if (lane == 0) {
+    atomic_max_nonneg(stats, best16);
+    atomic_max_nonneg(stats + 1, best_err);
+  }
+}
+
 // One wave per query.  q16 <- fp16(q); delta <- score-units bound described above; thr <- the exclusive admission
 // threshold of the approximate pass (just below min_score - 2 delta; -inf when every row qualifies; +inf for NaN).
 __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restrict__ q, int nq, int dim, float min_score,
-                                                            const float* __restrict__ max_norm_sq, _Float16* __restrict__ q16,
+                                                            const float* __restrict__ max_norm_sq /*[2]: max |x16|^2, max |x - x16|^2*/, _Float16* __restrict__ q16,
                                                             float* __restrict__ delta, float* __restrict__ thr) {
   const int lane = threadIdx.x & 63;
   const int qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -80,9 +128,10 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
   err = wave_sum(err);
   qq = wave_sum(qq);
   if (lane == 0) {
-    const float R = sqrtf(*max_norm_sq);
-    // rounding of the query + summation slack of two fp32 dot products (blocked accumulation: dim / 8 effective terms)
-    float d = 0.5f * (sqrtf(err) * R * 1.0001f + 2.0f * (float)(dim / 8 + 8) * 5.9604645e-8f * R * sqrtf(qq)) + 1.2e-7f;
+    const float R = sqrtf(max_norm_sq[0]);
+    const float E = sqrtf(max_norm_sq[1]);  // 0 for fp16 corpora (the rows ARE the fp16 values); the shadow's rounding for fp32 ones
+    // rounding of the query (+ of the rows) + summation slack of two fp32 dot products (blocked accumulation: dim / 8 effective terms)
+    float d = 0.5f * (sqrtf(err) * R * 1.0001f + E * sqrtf(qq) * 1.0001f + 2.0f * (float)(dim / 8 + 8) * 5.9604645e-8f * (R + E) * sqrtf(qq)) + 1.2e-7f;
     if (!(d < __builtin_inff())) d = __builtin_inff();  // inf / NaN query or corpus: nothing can be proven
     delta[qi] = d;
     float t;
@@ -97,7 +146,8 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
 }
 
 // One workgroup (4 waves) per query: exact scores of its K' = 64 candidates, exact threshold, sort, completeness test.
-__global__ void __launch_bounds__(256) rescore_kernel(const _Float16* __restrict__ corpus, int dim, uint32_t index_base,
+template <typename T>
+__global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corpus, int dim, uint32_t index_base,
                                                       const float* __restrict__ queries, const u64* __restrict__ approx /*[nq, 64]*/,
                                                       const float* __restrict__ delta, float min_score, int k,
                                                       u64* __restrict__ out /*[nq, k]*/, int* __restrict__ n_flagged,
@@ -114,20 +164,32 @@ __global__ void __launch_bounds__(256) rescore_kernel(const _Float16* __restrict
     u64 out_key = 0ull;
     if (key != 0ull) {
       const uint32_t ord = 0xFFFFFFFFu - (uint32_t)key;
-      const f16x8* x = reinterpret_cast<const f16x8*>(corpus + (size_t)(ord - index_base) * dim);
       float dot = 0.f;
-      for (int i = lane; i < n8; i += 64) {
-        const f16x8 v = x[i];
-        const f32x4 qa = *reinterpret_cast<const f32x4*>(q + i * 8);
-        const f32x4 qb = *reinterpret_cast<const f32x4*>(q + i * 8 + 4);
-        dot = fmaf((float)v[0], qa.x, dot);
-        dot = fmaf((float)v[1], qa.y, dot);
-        dot = fmaf((float)v[2], qa.z, dot);
-        dot = fmaf((float)v[3], qa.w, dot);
-        dot = fmaf((float)v[4], qb.x, dot);
-        dot = fmaf((float)v[5], qb.y, dot);
-        dot = fmaf((float)v[6], qb.z, dot);
-        dot = fmaf((float)v[7], qb.w, dot);
+      if constexpr (sizeof(T) == 2) {
+        const f16x8* x = reinterpret_cast<const f16x8*>(corpus + (size_t)(ord - index_base) * dim);
+        for (int i = lane; i < n8; i += 64) {
+          const f16x8 v = x[i];
+          const f32x4 qa = *reinterpret_cast<const f32x4*>(q + i * 8);
+          const f32x4 qb = *reinterpret_cast<const f32x4*>(q + i * 8 + 4);
+          dot = fmaf((float)v[0], qa.x, dot);
+          dot = fmaf((float)v[1], qa.y, dot);
+          dot = fmaf((float)v[2], qa.z, dot);
+          dot = fmaf((float)v[3], qa.w, dot);
+          dot = fmaf((float)v[4], qb.x, dot);
+          dot = fmaf((float)v[5], qb.y, dot);
+          dot = fmaf((float)v[6], qb.z, dot);
+          dot = fmaf((float)v[7], qb.w, dot);
+        }
+      } else {
+        const f32x4* x = reinterpret_cast<const f32x4*>(corpus + (size_t)(ord - index_base) * dim);
+        for (int i = lane; i < 2 * n8; i += 64) {
+          const f32x4 v = x[i];
+          const f32x4 qa = *reinterpret_cast<const f32x4*>(q + i * 4);
+          dot = fmaf(v.x, qa.x, dot);
+          dot = fmaf(v.y, qa.y, dot);
+          dot = fmaf(v.z, qa.z, dot);
+          dot = fmaf(v.w, qa.w, dot);
+        }
       }
       dot = wave_sum(dot);
       const float s = cosine_to_score(dot);
@@ -181,6 +243,21 @@ __global__ void __launch_bounds__(256) gather_flagged_kernel(const float* __rest
   }
 }
 
+// the same for the exact fp32 tile: plain fp32 queries [cap, dim]
+__global__ void __launch_bounds__(256) gather_flagged_f32_kernel(const float* __restrict__ queries, int dim, float min_score,
+                                                                 const int* __restrict__ n_flagged, const int* __restrict__ flagged, int cap,
+                                                                 float* __restrict__ out, float* __restrict__ thr) {
+  const int n = *n_flagged;
+  if (n == 0) return;
+  const int slot = blockIdx.x;
+  if (slot >= cap) return;
+  const bool used = slot < n;
+  const float thr0 = (min_score > 0.0f) ? __uint_as_float(__float_as_uint(min_score) - 1u) : -__builtin_inff();
+  if (threadIdx.x == 0) thr[slot] = used ? ((min_score != min_score) ? __builtin_inff() : thr0) : __builtin_inff();
+  const float* src = used ? queries + (size_t)flagged[slot] * dim : nullptr;
+  for (int i = threadIdx.x; i < dim; i += blockDim.x) out[(size_t)slot * dim + i] = used ? src[i] : 0.0f;
+}
+
 __global__ void zero_int_kernel(int* p) { *p = 0; }
 
 }  // namespace
@@ -193,6 +270,14 @@ hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, floa
   return hipGetLastError();
 }
 
+hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, float* stats, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int64_t blocks = (n + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(shadow_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rows_f32, n, dim, reinterpret_cast<_Float16*>(out_f16), stats);
+  return hipGetLastError();
+}
+
 hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, const float* max_norm_sq, void* q16, float* delta, float* thr,
                                 hipStream_t stream) {
   hipLaunchKernelGGL(query_prepare_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, q, nq, dim, min_score, max_norm_sq,
@@ -200,11 +285,21 @@ hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score
   return hipGetLastError();
 }
 
-hipError_t launch_rescore(const void* corpus_f16, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx, const float* delta,
-                          float min_score, int nq, int k, unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream) {
+hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
+                          const float* delta, float min_score, int nq, int k, unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream) {
   hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, stream, n_flagged);
-  hipLaunchKernelGGL(rescore_kernel, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(corpus_f16), dim, index_base, queries, approx,
-                     delta, min_score, k, out, n_flagged, flagged);
+  if (f32_rows)
+    hipLaunchKernelGGL(rescore_kernel<float>, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const float*>(corpus), dim, index_base, queries, approx,
+                       delta, min_score, k, out, n_flagged, flagged);
+  else
+    hipLaunchKernelGGL(rescore_kernel<_Float16>, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(corpus), dim, index_base, queries,
+                       approx, delta, min_score, k, out, n_flagged, flagged);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_flagged_f32(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, float* out,
+                                     float* thr, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_flagged_f32_kernel, dim3(cap), dim3(256), 0, stream, queries, dim, min_score, n_flagged, flagged, cap, out, thr);
   return hipGetLastError();
 }
 
