@@ -281,6 +281,8 @@ class VectorBase:
                 self._engine = DeviceGroup(self._devices)
             else:
                 self._engine = _native.Engine(self._device_index)
+            if os.environ.get("TYPEAGENT_VB_F32_SHADOW", "1") in ("0", "false", "no"):
+                self._engine.set_option("f32_shadow", 0)  # no fp16 shadow of fp32 corpora (+50 % device memory) for large batches
         return self._engine
 
     def _sync_device(self) -> _native.Engine:
