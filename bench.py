@@ -345,6 +345,13 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
 
     qps = steps * nq / elapsed
     esize = 2 if wl["dtype"] == "fp16" else 4
+    shadow = False
+    try:
+        shadow = wl["dtype"] == "fp32" and bool(eng.get_option("last_shadow"))
+    except Exception:
+        pass
+    if shadow:
+        esize = 2  # the pass that streams the corpus read its fp16 shadow (exact fp32 answers: candidates rescored with the fp32 rows)
     if wl["bound"] == "hbm" and kt["scan"][1]:
         kern_name, parts = "tavb::scan_*_kernel (streaming dot + score + select)", ["scan"]
     elif kt["mfma_last_phase"][1]:
@@ -378,6 +385,8 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
             roof["traffic_source"] = pmc["source"]
     except Exception:
         pass
+    if shadow:
+        roof["scanned"] = "fp16 shadow of the fp32 corpus (rows x dim x 2 B per pass) as an exact filter; 64 candidates per query rescored with the fp32 rows"
     roof.update({
         "kernel": kern_name,
         "kernel_ms_per_step": kern_ms_per_step,

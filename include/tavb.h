@@ -82,7 +82,10 @@ int tavb_synchronize(tavb_ctx* ctx);
  *                   tiles per workgroup; -1 = a single phase, no seeding) and the growth factor of the following ones
  *   "f32_shadow"            1 (default): batches of mfma_min_batch+ queries on FP32 corpora run the fp16 tile over an fp16 shadow copy of the corpus
  *                           (built on first use, +50 % device memory, extended on append) and rescore the candidates with the fp32 rows: same
- *                           answers, ~10x the throughput of the fp32 matrix path; 0: 64-query fp32 tile only (the shadow is freed)
+ *                           answers, ~6x the throughput of the fp32 matrix path; 0: fp32 kernels only (the shadow is freed); 2: EVERY lookup
+ *                           (single queries included) on fp32 corpora of "f32_shadow_min_bytes" (default 2 GiB) and more filters on the
+ *                           shadow with the 32/64-query tile: half the bytes per pass (1M x 1536: 0.93 -> 0.70 ms per query, 32 queries 1.46 -> 0.94 ms)
+ *   "last_shadow"           (get) 1 when the last lookup's corpus pass read the shadow
  *   "mfma_tile"             queries per workgroup tile of the wide fp16 kernel: 0 = auto (128 where that pads less: up to 128, 257..384, 513..640 queries; else 256), 128, 256
  *   "mfma_splits", "mfma_sched", "mfma_ablate"  measurement knobs, see DESIGN.md
  *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile (exact

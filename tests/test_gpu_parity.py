@@ -822,6 +822,53 @@ def test_f32_corpus_large_batches_ride_the_fp16_shadow(nq):
         assert [r.item for r in batch_t[qi]] == [r.item for r in seq]
 
 
+@pytest.mark.parametrize("n,nq,k,ms", [(257, 70, 32, 0.0), (5, 65, 10, 0.0), (3_001, 200, 48, 0.5), (40_000, 129, 1, 0.0)])
+def test_f32_shadow_small_and_odd_shapes(n, nq, k, ms):
+    v, _ = make_corpus(n, 1536, 7650 + n % 7)
+    v[n // 2] = 0.0  # a zero row scores exactly 0.5
+    qs = make_queries(nq, 1536, 7651 + nq)
+    qs[0] = v[n - 1]
+    vb = new_vb(v)
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
+    assert vb.engine.get_option("last_tier") == 4
+    for qi in sorted(set(np.linspace(0, nq - 1, 24).astype(int).tolist())):
+        assert vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(out[qi]), k, ms).tie_permuted_positions <= 1
+    assert out[0][0].item == n - 1
+
+
+@pytest.mark.parametrize("nq", [1, 2, 7, 32, 33, 64])
+def test_f32_shadow_level_2_serves_small_batches_and_single_queries(nq):
+    """`f32_shadow = 2`: lookups of ANY size on a big enough fp32 corpus filter on the fp16 shadow (32/64-query tile, exact
+    queries as split fp16 planes) and rescore 64 candidates with the fp32 rows: same answers as the fp32 kernels."""
+    v, _ = make_corpus(12_345, 1536, 7800)
+    qs = make_queries(nq, 1536, 7801 + nq)
+    qs[0] = v[12_344]
+    vb = new_vb(v)
+    eng = vb.engine
+    plain = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert eng.get_option("last_shadow") == 0
+    eng.set_option("f32_shadow", 2)
+    eng.set_option("f32_shadow_min_bytes", 1 << 20)  # (default: 2 GB of fp32 rows)
+    got = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert eng.get_option("last_shadow") == 1 and eng.get_option("last_flagged") == 0
+    swapped = 0
+    for qi in range(nq):  # two fp32 summation orders: positions may swap inside fp32 near-ties only (the oracle check below is tie-aware)
+        np.testing.assert_allclose([r.score for r in got[qi]], [r.score for r in plain[qi]], atol=3e-7, rtol=0)
+        swapped += sum(a.item != b.item for a, b in zip(got[qi], plain[qi]))
+        assert len({r.item for r in got[qi]} ^ {r.item for r in plain[qi]}) <= 2
+    assert swapped <= 4
+    for qi in range(0, nq, 5):
+        vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(got[qi]), 32, 0.0)
+    one = vb.fuzzy_lookup_embedding(qs[0], max_hits=10, min_score=0.6)  # the single-query API takes the same route
+    assert eng.get_option("last_shadow") == 1 and [r.item for r in one] == [12_344]
+    k50 = vb.fuzzy_lookup_embeddings(qs, max_hits=50, min_score=0.0)  # 64 candidates cannot prove a top-50: the fp32 kernels answer
+    assert eng.get_option("last_shadow") == 0 and len(k50[0]) == 50
+    small = new_vb(v[:1000])  # below the size where halving the pass pays for the rescoring launches
+    small.engine.set_option("f32_shadow", 2)
+    small.fuzzy_lookup_embeddings(qs, max_hits=5, min_score=0.0)
+    assert small.engine.get_option("last_shadow") == 0
+
+
 def test_f32_shadow_follows_appends_rewrites_and_falls_back_on_near_duplicates():
     v, _ = make_corpus(20_000, 1536, 7700)
     qs = make_queries(80, 1536, 7701)

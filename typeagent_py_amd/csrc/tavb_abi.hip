@@ -115,7 +115,10 @@ struct tavb_ctx {
   Buffer d_counts;  // 256-query tile: keys left per candidate buffer
   Buffer d_delta, d_approx, d_flag, d_fb_queries, d_norm;  // exact rescoring of the 256-query tile (tavb_rescore.hip)
   Buffer d_shadow;         // fp32 corpora: fp16 shadow copy of rows [0, norm_rows), the filter operand of the 128/256-query tile
-  int64_t f32_shadow = 1;  // option: large batches on fp32 corpora go through that shadow (+50 % HBM); 0 = 64-query fp32 tile only
+  int64_t f32_shadow = 1;  // option: 1 = batches of mfma_min_batch+ queries on fp32 corpora go through that shadow (+50 % HBM); 2 = every lookup on
+                           // fp32 corpora of f32_shadow_min_bytes and more (half the bytes per pass); 0 = never
+  int64_t f32_shadow_min_bytes = (int64_t)2 << 30;  // level 2 only: fp32 corpora from this size up (below it the extra launches cost more than half a pass saves)
+  int last_shadow = 0;     // the last lookup's filter pass read the shadow
   Buffer d_accept, d_bits;  // message re-rank: accepted message ordinals, their bitmap
   Buffer d_emit;            // survivors of tavb_search_all: a counter, then the keys
   // load path (tavb_upload_rows): two pinned staging slots + two device scratch slots, recycled through events
@@ -409,11 +412,15 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     if (v < -1) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= -1");
     c->mfma_sample_rows = v;
   } else if (n == "f32_shadow") {
-    c->f32_shadow = v ? 1 : 0;
+    if (v < 0 || v > 2) return fail(TAVB_E_INVALID, "f32_shadow must be 0, 1 or 2");
+    c->f32_shadow = v;
     if (!v) {
       c->d_shadow.release();
       if (c->dtype == TAVB_F32) c->norm_rows = 0;
     }
+  } else if (n == "f32_shadow_min_bytes") {
+    if (v < 0) return fail(TAVB_E_INVALID, "f32_shadow_min_bytes must be >= 0");
+    c->f32_shadow_min_bytes = v;
   } else if (n == "mfma_tile") {
     if (v != 0 && v != 128 && v != 256) return fail(TAVB_E_INVALID, "mfma_tile must be 0 (auto), 128 or 256");
     c->mfma_tile = v;
@@ -455,6 +462,8 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "mfma_splits") *out = c->mfma_splits;
   else if (n == "mfma_tile") *out = c->mfma_tile;
   else if (n == "f32_shadow") *out = c->f32_shadow;
+  else if (n == "last_shadow") *out = c->last_shadow;
+  else if (n == "f32_shadow_min_bytes") *out = c->f32_shadow_min_bytes;
   else if (n == "mfma_ladder") *out = c->mfma_ladder;
   else if (n == "skinny_min_batch_f32") *out = c->skinny_min_batch_f32;
   else if (n == "skinny_min_batch_f16") *out = c->skinny_min_batch_f16;
@@ -1172,13 +1181,15 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
 
 // The 128/256-query fp16 tile as an exact filter + fp32-query rescoring of its candidates (tavb_rescore.hip).  fp32 corpora:
 // the filter reads the fp16 shadow (d_shadow, reserved by the caller), the rescoring and the fallback tile the fp32 rows.
-int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_score, uint32_t index_base, u64_t* d_out) {
+// `small` (fp32 corpora only): the filter is the 32/64-query tile over the shadow with the EXACT queries (split fp16 planes), for batches
+// below the wide tile's range -- half the bytes of an fp32 pass.
+int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_score, uint32_t index_base, u64_t* d_out, bool small = false) {
   constexpr int KC = 64;  // candidates per query
   const bool f32c = (c->dtype == TAVB_F32);
-  const int qt = c->mfma_tile > 0 ? (int)c->mfma_tile : tavb::mfma_query_tile(nq);
+  const int qt = small ? tavb::skinny_query_tile(nq) : (c->mfma_tile > 0 ? (int)c->mfma_tile : tavb::mfma_query_tile(nq));
   const int nq_pad = ((nq + qt - 1) / qt) * qt;
   const int cap = ((nq + 63) / 64) * 64;  // slots of the work list of queries that need the exact tile
-  const size_t q16_bytes = (size_t)nq_pad * c->dim * 2;
+  const size_t q16_bytes = (size_t)nq_pad * c->dim * 2 * (small ? 2 : 1);  // small: high and low plane
   if (int rc = c->d_queries_f16.reserve(q16_bytes)) return rc;
   if (int rc = c->d_delta.reserve((size_t)nq_pad * 2 * sizeof(float))) return rc;  // delta, then the relaxed thresholds
   if (int rc = c->d_approx.reserve((size_t)nq * KC * sizeof(u64_t))) return rc;
@@ -1208,11 +1219,16 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
       c->norm_rows = c->rows;
     }
     TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16_bytes, c->stream));  // padding queries
-    hipError_t e = tavb::launch_query_prepare(d_q, nq, c->dim, min_score, d_norm, c->d_queries_f16.ptr, d_delta, d_floor, c->stream);
+    hipError_t e = tavb::launch_query_prepare(d_q, nq, c->dim, min_score, small, d_norm, small ? nullptr : c->d_queries_f16.ptr, d_delta, d_floor, c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "query prepare launch failed: %s", hipGetErrorString(e));
+    if (small) {
+      e = tavb::launch_f32_split_f16(d_q, c->d_queries_f16.ptr, reinterpret_cast<char*>(c->d_queries_f16.ptr) + q16_bytes / 2, (int64_t)nq * c->dim, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "query split launch failed: %s", hipGetErrorString(e));
+    }
   }
   TileRun filt{};
-  filt.skinny = false;
+  filt.skinny = small;
+  filt.q32 = false;
   filt.qt = qt;
   filt.nq = nq;
   filt.nq_pad = nq_pad;
@@ -1223,6 +1239,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   filt.queries = c->d_queries_f16.ptr;
   filt.corpus = f32c ? c->d_shadow.ptr : nullptr;
   filt.ladder = true;
+  c->last_shadow = f32c ? 1 : 0;
   if (int rc = run_tile_ladder(c, filt, reinterpret_cast<u64_t*>(c->d_approx.ptr), nullptr)) return rc;
   {
     Timed t(c, TAVB_KERNEL_RESCORE);
@@ -1265,12 +1282,20 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   // the filter keeps 64 candidates per query: k up to 48 leaves the slack the completeness proof needs
   bool wide = (f16c || c->f32_shadow) && c->corpus && nq >= c->mfma_min_batch && uniform_thr && tavb::mfma_supported(c->dim, 64) && k <= 48 &&
               c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c);
-  if (wide && !f16c) {  // fp32 corpus: the filter needs the fp16 shadow; without the memory for it the 64-query fp32 tile serves the batch
+  // f32_shadow = 2: smaller batches (and single queries) on big fp32 corpora filter on the shadow too, with the 32/64-query tile
+  bool shadow_small = !wide && !f16c && c->f32_shadow >= 2 && c->corpus && nq <= 64 && uniform_thr && tavb::mfma_supported(c->dim, 64) && k <= 48 &&
+                      tavb::skinny_supported(c->dim, k, false) && (int64_t)c->rows * c->dim * 4 >= c->f32_shadow_min_bytes;
+  if ((wide || shadow_small) && !f16c) {  // fp32 corpus: the filter needs the fp16 shadow; without the memory for it the fp32 kernels serve the batch
     const size_t need = (size_t)c->rows * c->dim * 2;
     if (c->d_shadow.cap < need) {
       c->norm_rows = 0;  // reserve() does not keep the old contents
-      if (c->d_shadow.reserve(need) != TAVB_OK) wide = false;
+      if (c->d_shadow.reserve(need) != TAVB_OK) wide = shadow_small = false;
     }
+  }
+  c->last_shadow = 0;
+  if (shadow_small) {
+    c->last_tier = 5;
+    return search_wide_exact(c, d_q, nq, k, min_scores[0], index_base, d_out, /*small=*/true);
   }
   // 32/64-query tiles at HBM speed: small batches on fp16 corpora, every batch from `skinny_min_batch_f32` up on fp32 ones
   const bool skinny = !wide && c->corpus && uniform_thr && c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c) &&

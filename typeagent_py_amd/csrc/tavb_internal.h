@@ -55,8 +55,9 @@ hipError_t launch_message_rerank(const unsigned long long* hits, int nq, int k, 
 
 // exact fp32-query semantics for the 256-query tile (tavb_rescore.hip)
 hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, float* out_sq, hipStream_t stream);
-hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, const float* max_norm_sq, void* q16, float* delta, float* thr,
-                                hipStream_t stream);
+// q16 may be null (rows_only: the filter uses the exact queries, only the rows' rounding enters the bound)
+hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
+                                float* thr, hipStream_t stream);
 hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
                           const float* delta, float min_score, int nq, int k, unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream);
 hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, float* stats /*[2]*/, hipStream_t stream);

@@ -108,19 +108,20 @@ __global__ void __launch_bounds__(256) shadow_convert_kernel(const float* __rest
 
 // One wave per query.  q16 <- fp16(q); delta <- score-units bound described above; thr <- the exclusive admission
 // threshold of the approximate pass (just below min_score - 2 delta; -inf when every row qualifies; +inf for NaN).
-__global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restrict__ q, int nq, int dim, float min_score,
+// rows_only: the filter multiplies the EXACT queries (split fp16 high + low planes) with the shadow rows: only the rows' rounding counts.
+__global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restrict__ q, int nq, int dim, float min_score, int rows_only,
                                                             const float* __restrict__ max_norm_sq /*[2]: max |x16|^2, max |x - x16|^2*/, _Float16* __restrict__ q16,
                                                             float* __restrict__ delta, float* __restrict__ thr) {
   const int lane = threadIdx.x & 63;
   const int qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (qi >= nq) return;
   const float* src = q + (size_t)qi * dim;
-  _Float16* dst = q16 + (size_t)qi * dim;
+  _Float16* dst = q16 ? q16 + (size_t)qi * dim : nullptr;
   float err = 0.f, qq = 0.f;
   for (int i = lane; i < dim; i += 64) {
     const float v = src[i];
     const _Float16 h = (_Float16)v;
-    dst[i] = h;
+    if (dst) dst[i] = h;
     const float d = v - (float)h;
     err = fmaf(d, d, err);
     qq = fmaf(v, v, qq);
@@ -131,7 +132,8 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
     const float R = sqrtf(max_norm_sq[0]);
     const float E = sqrtf(max_norm_sq[1]);  // 0 for fp16 corpora (the rows ARE the fp16 values); the shadow's rounding for fp32 ones
     // rounding of the query (+ of the rows) + summation slack of two fp32 dot products (blocked accumulation: dim / 8 effective terms)
-    float d = 0.5f * (sqrtf(err) * R * 1.0001f + E * sqrtf(qq) * 1.0001f + 2.0f * (float)(dim / 8 + 8) * 5.9604645e-8f * (R + E) * sqrtf(qq)) + 1.2e-7f;
+    float d = 0.5f * ((rows_only ? 0.0f : sqrtf(err) * R * 1.0001f) + E * sqrtf(qq) * 1.0001f + 2.0f * (float)(dim / 8 + 8) * 5.9604645e-8f * (R + E) * sqrtf(qq)) +
+              1.2e-7f;
     if (!(d < __builtin_inff())) d = __builtin_inff();  // inf / NaN query or corpus: nothing can be proven
     delta[qi] = d;
     float t;
@@ -278,9 +280,9 @@ hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void
   return hipGetLastError();
 }
 
-hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, const float* max_norm_sq, void* q16, float* delta, float* thr,
-                                hipStream_t stream) {
-  hipLaunchKernelGGL(query_prepare_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, q, nq, dim, min_score, max_norm_sq,
+hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
+                                float* thr, hipStream_t stream) {
+  hipLaunchKernelGGL(query_prepare_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, q, nq, dim, min_score, rows_only ? 1 : 0, max_norm_sq,
                      reinterpret_cast<_Float16*>(q16), delta, thr);
   return hipGetLastError();
 }

@@ -281,8 +281,11 @@ class VectorBase:
                 self._engine = DeviceGroup(self._devices)
             else:
                 self._engine = _native.Engine(self._device_index)
-            if os.environ.get("TYPEAGENT_VB_F32_SHADOW", "1") in ("0", "false", "no"):
+            level = os.environ.get("TYPEAGENT_VB_F32_SHADOW", "1").lower()
+            if level in ("0", "false", "no"):
                 self._engine.set_option("f32_shadow", 0)  # no fp16 shadow of fp32 corpora (+50 % device memory) for large batches
+            elif level == "2":
+                self._engine.set_option("f32_shadow", 2)  # every lookup on big fp32 corpora filters on the shadow (tavb.h)
         return self._engine
 
     def _sync_device(self) -> _native.Engine:
