@@ -253,6 +253,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 //     Slot P is then free: the pieces of step S+2 are issued behind the MFMAs of q3 (N3 of them), of the next q0 (N0)
 //     and q1 (N1) -- corpus pieces first, they have the longest way -- and have until the next barrier to land.
 //   * the first quarter of a tile multiplies into a ZERO C operand instead of clearing 320 registers.
+//   * NI = 2 (the 128-query width, WideGeom<2>): a wave owns 160 x 64 = 10 accumulator blocks, all in AGPRs; half the MFMAs per
+//     step no longer cover the loaded HBM latency with one corpus slab in flight, and this width has the LDS for a THIRD
+//     corpus slot (3 x 40 + 2 x 16 KiB): a round then stages query slab S + 1 first and corpus slab S + 2 behind it, and the
+//     wait in front of quarter 3 is counted (`vmcnt(10)`: everything but the ten corpus pieces of slab S + 2 has landed).
+//     HBM-bound: 5.8 TB/s at 128 queries (profiles/r02_mid_batch.md).
 // Measured and rejected (profiles/r02_cfg3_ablation.md): touching the corpus lines of the step 1 / 2 / 4 steps ahead
 // into L2 with one 4-byte load per line (-3 .. -6 %); other piece-per-quarter schedules (no difference).
 // ---------------------------------------------------------------------------------------------
@@ -282,7 +287,7 @@ struct WideGeom {
 
 // index of the staging piece issued behind MFMA `i` of quarter `q` (-1: none): n pieces spread evenly over the NT MFMAs
 template <int NT, int N3, int N0, int N1>
-constexpr int v6_piece_at(int q, int i) {
+constexpr int staging_piece_at(int q, int i) {
   const int n = q == 3 ? N3 : q == 0 ? N0 : q == 1 ? N1 : 0;
   const int base = q == 3 ? 0 : q == 0 ? N3 : N3 + N0;
   for (int j = 0; j < n; ++j)
@@ -477,7 +482,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
         if constexpr (I >= NI && I < NI + 5) na[I - NI] = *reinterpret_cast<const f16x8*>(abase + (I - NI) * 4096);
       }
       if constexpr ((ABL & 2) == 0) {
-        constexpr int PC = v6_piece_at<NT, N3, N0, N1>(Q, I);
+        constexpr int PC = staging_piece_at<NT, N3, N0, N1>(Q, I);
         if constexpr (PC >= 0) stage_piece(std::integral_constant<int, PC>{});
       }
     };
