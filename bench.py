@@ -325,10 +325,12 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         r = searcher.search(dq_all[:nq], k, min_score)
         return r.ordinals, r.scores, r.counts
 
-    for i in range(warmup):
-        one_step(i)
-    eng.profile_enable(True)
-    eng.profile_reset()
+    w0, n_w = time.perf_counter(), 0
+    while n_w < warmup or (args.warmup is None and time.perf_counter() - w0 < 0.3):  # default: at least 0.3 s, the clocks ramp for that long
+        one_step(n_w)
+        n_w += 1
+    warmup = n_w
+    # ---- the timed region: exactly `steps` steps, nothing instrumented
     ctx.barrier()
     lat = []
     t0 = time.perf_counter()
@@ -336,12 +338,27 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         s0 = time.perf_counter_ns()
         one_step(warmup + i)
         lat.append((time.perf_counter_ns() - s0) / 1e3)
+    t_loop = time.perf_counter() - t0
     ctx.barrier()
     elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    if os.environ.get("TAVB_BENCH_DEBUG"):
+        sys.stderr.write(f"[bench debug] {name}: loop {t_loop * 1e3:.2f} ms, sum of steps {sum(lat) / 1e3:.2f} ms, max step {max(lat) / 1e3:.3f} ms, "
+                         f"closing barrier {(elapsed - t_loop) * 1e3:.2f} ms\n")
+    # ---- the same `steps` steps again with a HIP event pair around every kernel launch (on the library's stream): the kernel times of the
+    #      roofline.  Kept out of the timed region: an event pair costs the stream ~0.03-0.07 ms of bubbles per launch (10 % of a 1.4 ms step).
+    eng.profile_enable(True)
+    eng.profile_reset()
+    ctx.barrier()
+    e0 = time.perf_counter()
+    for i in range(steps):
+        one_step(warmup + i)
+    ctx.barrier()
+    elapsed_with_events = ctx.max_over_ranks(time.perf_counter() - e0)
     kt = kernel_times(ctx)
+    eng.profile_enable(False)
     host_form = None
     if searcher is None and nq > 1:  # the same batch handed over as a host buffer (what VectorBase.fuzzy_lookup_embeddings does): PCIe-inclusive
-        one_step(0, True)  # (kernel timing events stay on, as in the timed region: they cost ~0.04 ms per kernel)
+        one_step(0, True)
         n_host = max(3, min(steps, 20))
         h0 = time.perf_counter()
         for i in range(n_host):
@@ -349,7 +366,6 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         h_ms = (time.perf_counter() - h0) / n_host * 1e3
         host_form = {"ms_per_step": h_ms, "queries_per_sec": nq / (h_ms * 1e-3), "steps": n_host,
                      "what": "tavb_search_batch: host queries in (H2D inside the call), host results out"}
-    eng.profile_enable(False)
 
     # answers for the parity sample (outside the timed region)
     if nq == 1:
@@ -413,6 +429,7 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         "kernel_launches_per_step": launches_per_step,
         "algorithmic_per_step": alg,
         "algorithmic_unit": "B" if wl["bound"] == "hbm" else "flop",
+        "kernel_timing": "HIP event pairs around every launch on the library's stream, over a second run of the same %d steps (%.3f ms per step with the events in)" % (steps, elapsed_with_events / steps * 1e3),
         "kernel_parts_ms_per_step": {p: kt[p][0] / steps for p in parts},
         "other_kernels_ms_per_step": {p: kt[p][0] / steps for p in kt if p not in parts and kt[p][1]},
     })
@@ -546,18 +563,21 @@ def run_cfg5(args, wl) -> None:
 
     for i in range(warmup):
         one(i)
-    if not args.cfg5_separate:
-        eng.profile_enable(True)
-        eng.profile_reset()
     torch.cuda.synchronize()
     lat = []
     t0 = time.perf_counter()
-    for i in range(steps):
+    for i in range(steps):  # the timed region: un-instrumented
         s0 = time.perf_counter_ns()
         one(warmup + i)
         lat.append((time.perf_counter_ns() - s0) / 1e3)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if not args.cfg5_separate:  # the same steps again with HIP event pairs around the launches (kernel times)
+        eng.profile_enable(True)
+        eng.profile_reset()
+        for i in range(steps):
+            one(warmup + i)
+        torch.cuda.synchronize()
     esize = 2 if wl["dtype"] == "fp16" else 4
     alg = rows * dim * esize + (len(subset) if subset else rows) * dim * esize + 1000 * dim * esize
     out = {
