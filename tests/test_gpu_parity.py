@@ -787,6 +787,26 @@ def test_wide_tile_row_norm_cache_follows_appends_and_rewrites():
 # fp32 corpora, 65+ queries: the 128/256-query fp16 tile filters on an fp16 SHADOW of the corpus, the candidates are
 # rescored with the fp32 rows and fp32 queries (tavb_rescore.hip) -- same answers as the single-query fp32 kernels
 # --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+@pytest.mark.parametrize("d,tier", [(64, 4), (768, 4), (3072, 4), (4096, 4), (1000, None), (96, None)])
+def test_wide_tile_other_dimensions(dtype, d, tier):
+    """The 128/256-query tile takes any D that is a multiple of 64 (K steps of whole 128-byte lines); other widths fall back to
+    the 32/64-query tile (D % 32 == 0 on fp16, % 16 on fp32) or the streaming tiers.  130 queries: one 256-query tile."""
+    n, nq, k = 20_011, 130, 32
+    v, _ = make_corpus(n, d, 9900 + d)
+    qs = make_queries(nq, d, 9901 + d)
+    qs[3] = v[n - 1]
+    vb = new_vb(v, dtype=dtype)
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    t = vb.engine.get_option("last_tier")
+    assert t == tier if tier else t in (1, 2, 3, 5)
+    ref_v = v if dtype == "fp32" else _f16(v)
+    for qi in range(0, nq, 9):
+        rep = vo.check_topk_parity(vo.scores_full(ref_v, qs[qi]), *items_scores(out[qi]), k, 0.0)
+        assert rep.tie_permuted_positions <= 2
+    assert out[3][0].item == n - 1
+
+
 @pytest.mark.parametrize("nq", [65, 128, 300, 1024])
 def test_f32_corpus_large_batches_ride_the_fp16_shadow(nq):
     v, _ = make_corpus(60_007, 1536, 7600)
