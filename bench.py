@@ -308,7 +308,10 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
             keys_np = keys_buf.numpy()
             torch.cuda.synchronize()
 
+    n_lookups = [0]
+
     def one_step(i: int, host_queries_form: bool = False):
+        n_lookups[0] += 1
         if nq == 1:
             qi = i % len(queries)
             if searcher is None:
@@ -378,6 +381,7 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     if ctx.rank != 0:
         # rank 0 regenerates what it needs for the oracle; the others only keep the collective calls aligned
         return {}
+    sys.stderr.write(f"bench.py: {name}: {n_lookups[0]} lookups in this process (warm-up, timed steps, event pass, host-buffer form, answers)\n")
 
     qps = steps * nq / elapsed
     esize = 2 if wl["dtype"] == "fp16" else 4

@@ -8,11 +8,12 @@ O=$R/gpurun_out/r02pmc
 rm -rf $O; mkdir -p $O
 cd /tmp
 Q="--no-cpu-baseline --no-parity"
-pmc() { # name steps+warmup workload-args counters...
+pmc() { # name (unused) workload-args counters...
   local name=$1 total=$2 wl="$3"; shift 3
   timeout -k 5 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/raw_$name -- python $R/bench.py $Q $wl > $O/pmc_$name.log 2>&1
   echo "$name rc=$? $(date -u +%T)" >> $O/round.log
-  python $R/tools/pmc_summary.py $O/raw_$name/*/*_counter_collection.csv --steps $total ${PMC_NAME:+--json $O/pmc_traffic.json --name $PMC_NAME} > $O/pmc_$name.md 2>> $O/round.log
+  total=$(grep -o "[0-9]* lookups in this process" $O/pmc_$name.log | head -1 | cut -d" " -f1)  # bench.py says how many lookups the run made
+  python $R/tools/pmc_summary.py $O/raw_$name/*/*_counter_collection.csv --steps ${total:-1} --cmd "bench.py $Q $wl" ${PMC_NAME:+--json $O/pmc_traffic.json --name $PMC_NAME} > $O/pmc_$name.md 2>> $O/round.log
   rm -rf $O/raw_$name
 }
 PMC_NAME=cfg3 pmc cfg3_fetch 3 "--workload cfg3 --steps 2 --warmup 1" FETCH_SIZE

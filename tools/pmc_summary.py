@@ -15,7 +15,7 @@ import json
 import re
 import sys
 
-SETUP = ("at::native", "normalize_rows_kernel", "f32_to_f16_kernel", "corpus_max_norm_kernel", "__amd_rocclr_copyBuffer")
+SETUP = ("at::native", "normalize_rows_kernel", "f32_to_f16_kernel", "corpus_max_norm_kernel", "shadow_convert_kernel", "__amd_rocclr_copyBuffer")
 
 
 def short(name: str) -> str:
@@ -28,7 +28,8 @@ def short(name: str) -> str:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("csv", nargs="+")
-    ap.add_argument("--steps", type=int, default=0, help="bench steps + warm-up steps in the profiled run")
+    ap.add_argument("--steps", type=int, default=0, help="lookups the profiled run made (bench.py prints the number on stderr)")
+    ap.add_argument("--cmd", default=None, help="the profiled command (for the header)")
     ap.add_argument("--json", default=None)
     ap.add_argument("--name", default=None)
     args = ap.parse_args()
@@ -48,6 +49,10 @@ def main() -> None:
                     seen.add(d)
                     dur[k] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
     counters = sorted({c for k in per for c in per[k]})
+    if args.cmd:
+        print(f"# rocprofv3 --pmc pass (MI355X): `cd /tmp && rocprofv3 --pmc {' '.join(counters)} --kernel-trace --output-format csv -- python {args.cmd}`\n")
+        print("Per-dispatch means (tools/pmc_summary.py).  SQ_* wave counters count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles (32 per 32x32x16 MFMA, "
+              "summed over all SIMDs), GRBM_GUI_ACTIVE is summed over the 8 XCDs; FETCH_SIZE / WRITE_SIZE are KiB.\n")
     print("| kernel | dispatches | mean us | " + " | ".join(counters) + " |")
     print("|---|---|---|" + "---|" * len(counters))
     for k in sorted(per, key=lambda k: -dur[k]):
@@ -61,7 +66,8 @@ def main() -> None:
                 out[c] = tot / args.steps
         if "FETCH_SIZE" in out:
             b = out["FETCH_SIZE"] * 1024 * 2
-            print(f"\nlookup kernels, per step ({args.steps} steps): FETCH_SIZE {out['FETCH_SIZE']:.6g} KiB -> {b:.6g} B read (x1024 x2)"
+            print(f"\nThe run made {args.steps} lookups.  Lookup kernels (corpus generation and the one-time per-corpus kernels excluded), per lookup: "
+                  f"FETCH_SIZE {out['FETCH_SIZE']:.6g} KiB x 1024 x 2 = **{b / 1e9:.3f} GB read**"
                   + (f", WRITE_SIZE {out['WRITE_SIZE']:.6g} KiB" if "WRITE_SIZE" in out else ""))
             if args.json and args.name:
                 try:
@@ -71,7 +77,7 @@ def main() -> None:
                 blob[args.name] = {
                     "traffic_bytes_per_step": b,
                     "counter": "FETCH_SIZE (KiB) x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM section), summed over every lookup kernel of a step",
-                    "source": f"rocprofv3 --pmc FETCH_SIZE WRITE_SIZE pass, {args.steps} steps (tools/gpu_r2_profiles.sh, tools/pmc_summary.py)",
+                    "source": f"rocprofv3 --pmc FETCH_SIZE --kernel-trace pass of `{args.cmd or 'bench.py'}` ({args.steps} lookups in the run), tools/gpu_r2_pmc.sh + tools/pmc_summary.py, profiles/r02_pmc_{args.name}_fetch.md",
                 }
                 json.dump(blob, open(args.json, "w"), indent=1)
 
