@@ -324,6 +324,21 @@ def test_batch_equals_sequential(nq, d, k):
         np.testing.assert_allclose(bs, ss, atol=2e-7, rtol=0)
 
 
+def test_batch_lookup_as_arrays():
+    v, _ = make_corpus(3_000, 384, 4100)
+    qs = make_queries(70, 384, 4101)
+    vb = new_vb(v)
+    lists = vb.fuzzy_lookup_embeddings(qs, max_hits=7, min_score=0.55)
+    o, s, c = vb.fuzzy_lookup_embeddings(qs, max_hits=7, min_score=0.55, as_arrays=True)
+    assert o.shape == (70, 7) and s.dtype == np.float32 and c.dtype == np.int32
+    for qi in range(70):
+        assert [(r.item, r.score) for r in lists[qi]] == list(zip(o[qi, : c[qi]].tolist(), s[qi, : c[qi]].tolist()))
+    e = new_vb().fuzzy_lookup_embeddings(qs, max_hits=7, as_arrays=True)
+    assert e[0].shape == (70, 7) and not e[2].any()
+    with pytest.raises(ValueError):
+        vb.fuzzy_lookup_embeddings(qs, max_hits=1000, as_arrays=True)
+
+
 @pytest.mark.parametrize("d", [8, 384, 1536, 2048])
 def test_f16_corpus_differential(d):
     v, q = make_corpus(6000, d, 500 + d)

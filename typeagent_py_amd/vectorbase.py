@@ -61,7 +61,7 @@ def cosine_to_score(cosine_similarity: np.ndarray) -> np.ndarray:
     return np.clip((cosine_similarity + 1.0) / 2.0, 0.0, 1.0)
 
 
-@dataclass
+@dataclass(slots=True)  # same fields / equality / repr as the reference's (vectorbase.py:50-55); slots halve the cost of building 32k hits per 1024-query batch
 class ScoredInt:
     item: int
     score: float
@@ -419,24 +419,32 @@ class VectorBase:
         embeddings: NormalizedEmbeddings,
         max_hits: int | None = None,
         min_score: float | None = None,
-    ) -> list[list[ScoredInt]]:
+        as_arrays: bool = False,
+    ):
         """Batch form: equals [fuzzy_lookup_embedding(e, max_hits, min_score) for e in embeddings],
-        served by one device submission (the reference loops, storage/memory/reltermsindex.py:320-332)."""
+        served by one device submission (the reference loops, storage/memory/reltermsindex.py:320-332).
+        `as_arrays=True` (1 <= max_hits <= 256) returns (ordinals int64 [Q, max_hits], scores float32 [Q, max_hits], counts
+        int32 [Q]) instead of Q lists of ScoredInt: building 32k Python objects takes as long as a third of the 1024-query
+        lookup over 10M rows itself."""
         queries = np.asarray(embeddings, dtype=np.float32)
         if queries.ndim != 2:
             raise ValueError(f"Expected 2D embeddings array, got {queries.ndim}D")
         max_hits, thr = self._limits(max_hits, min_score)
+        if as_arrays and not (1 <= max_hits <= _PAGE):
+            raise ValueError(f"as_arrays needs 1 <= max_hits <= {_PAGE}")
         if self._count == 0 or len(queries) == 0:
+            if as_arrays:
+                nq = len(queries)
+                return np.zeros((nq, max_hits), np.int64), np.zeros((nq, max_hits), np.float32), np.zeros(nq, np.int32)
             return [[] for _ in range(len(queries))]
         if not (1 <= max_hits <= _PAGE):
             return [self.fuzzy_lookup_embedding(q, max_hits, min_score) for q in queries]
         eng = self._sync_device()
         ords, scs, cnts = eng.search_batch(queries, max_hits, thr)
-        out: list[list[ScoredInt]] = []
-        for qi in range(len(queries)):
-            m = int(cnts[qi])
-            out.append([ScoredInt(int(i), float(s)) for i, s in zip(ords[qi, :m].tolist(), scs[qi, :m].tolist())])
-        return out
+        if as_arrays:
+            return ords, scs, cnts
+        rows_o, rows_s = ords.tolist(), scs.tolist()
+        return [list(map(ScoredInt, rows_o[qi][:m], rows_s[qi][:m])) for qi, m in enumerate(cnts.tolist())]
 
     # ------------------------------------------------------------------ message re-rank (additive)
     def set_row_messages(self, row_to_message) -> None:
