@@ -1116,7 +1116,9 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   bounds.push_back(0);
   // first phase: `mfma_sample_rows`, or (0 = auto) two tiles per workgroup -- short enough that the 256-query tile's
   // buffers (3+ tiles deep) never compact while everything is still being admitted
-  const int64_t auto_sample = (int64_t)splits * 2 * 320;
+  // (at most 40960 rows: with one query tile there are 256 row ranges, and select_topk_kernel -- one workgroup per QUERY -- would
+  // stream 163840 unfiltered keys per query: 0.88 of the 6.3 ms of a 128-query batch over 10M rows)
+  const int64_t auto_sample = (int64_t)std::min(splits, 64) * 2 * 320;
   const int64_t sample = c->mfma_sample_rows > 0 ? (c->mfma_sample_rows + 255) / 256 * 256 : (c->mfma_sample_rows == 0 ? auto_sample : 0);
   if (r.ladder && sample > 0 && c->rows >= 8 * sample) {
     int64_t done = sample;
