@@ -956,7 +956,8 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
 //   * the picked keys (<= 64) are sorted by one wave and written best first; thr = just below the k-th best score (or
 //     the caller's floor), the same contract as sample_threshold_kernel.
 // ---------------------------------------------------------------------------------------------
-constexpr int SEL_CACHE = 8192;  // keys of a query held in LDS (64 KiB)
+constexpr int SEL_CACHE = 4096;  // keys of a query held in LDS (32 KiB: four workgroups per CU, so the 1024 queries of a batch are all resident at
+                                 // once -- the streaming is latency-bound; 8192 keys / two workgroups per CU: 0.53 ms per cfg3 batch instead of 0.29)
 constexpr int SEL_PER = SEL_CACHE / 256;
 
 __global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict__ cand, const int* __restrict__ counts, int n_splits, int nq_padded, int k,
