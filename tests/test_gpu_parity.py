@@ -904,6 +904,29 @@ def test_f32_shadow_level_2_serves_small_batches_and_single_queries(nq):
     assert small.engine.get_option("last_shadow") == 0
 
 
+def test_per_corpus_caches_do_not_survive_a_new_tensor_at_the_same_address():
+    """The allocator hands a new tensor the address of a freed one of the same shape; the library keys its row-norm maxima
+    and the fp16 shadow on the address: adopting a DIFFERENT tensor object must drop them."""
+    import torch
+
+    qs = make_queries(70, 1536, 7900)
+    vb = new_vb()
+    addresses = []
+    for seed in (7901, 7902, 7903):
+        v, _ = make_corpus(20_000, 1536, seed)
+        v[17] = qs[4]
+        t = torch.from_numpy(v).cuda()
+        addresses.append(t.data_ptr())
+        vb.adopt_device_corpus(t)
+        out = vb.fuzzy_lookup_embeddings(qs, max_hits=10, min_score=0.0)
+        assert vb.engine.get_option("last_tier") == 4 and out[4][0].item == 17
+        for qi in (0, 33, 69):
+            assert vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(out[qi]), 10, 0.0).ordinals_bit_exact
+        del t
+        vb.clear()
+    # (whether the addresses repeated is the allocator's business; the answers must be right either way)
+
+
 def test_f32_shadow_follows_appends_rewrites_and_falls_back_on_near_duplicates():
     v, _ = make_corpus(20_000, 1536, 7700)
     qs = make_queries(80, 1536, 7701)

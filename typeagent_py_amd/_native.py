@@ -240,6 +240,10 @@ class Engine:
         if sync_torch:
             torch.cuda.current_stream(self.device).synchronize()
         _check(self.lib, self.lib.tavb_set_corpus(self._h, c_void_p(tensor.data_ptr()), n, tensor.shape[1], dt, int(ordinal_base)))
+        if not _owned and tensor is not self.corpus:
+            # a caller's tensor: the allocator may have put it where a freed one of the same shape lived, and the library keys its
+            # per-corpus caches (row-norm maxima, the fp16 shadow of an fp32 corpus) on the address
+            _check(self.lib, self.lib.tavb_corpus_modified(self._h, 0))
         self.corpus, self.rows, self.dim, self.dtype, self.ordinal_base = tensor, n, int(tensor.shape[1]), dt, int(ordinal_base)
         self._owns_corpus = _owned
 
