@@ -115,8 +115,10 @@ int tavb_upload_rows(tavb_ctx* ctx, const float* rows_host, int64_t n_rows, int3
 
 /* Tell the library that rows [first_row, rows) of the borrowed corpus buffer were rewritten in place (e.g. an append into
  * spare capacity followed by tavb_set_corpus with the new row count, or a re-upload after the host matrix was edited):
- * per-corpus quantities it caches (the largest row norm, used by the batched fp16 path's exactness proof) are refreshed
- * on the next lookup.  tavb_set_corpus with a different pointer / shape / dtype implies it. */
+ * per-corpus quantities it caches (the row-norm maxima of the batched path's exactness proof; the fp16 shadow copy of an
+ * fp32 corpus, see "f32_shadow") are refreshed on the next lookup.  tavb_set_corpus with a different pointer / shape /
+ * dtype implies it; the caches are keyed on the ADDRESS, so a new buffer that happens to sit where a freed one lived needs
+ * tavb_corpus_modified(ctx, 0) (the Python binding does that whenever it is handed a different tensor object). */
 int tavb_corpus_modified(tavb_ctx* ctx, int64_t first_row);
 
 /* K1: rows / ||row||_2 in float32, zero rows unchanged
