@@ -29,6 +29,7 @@ class FakeEngine:
         self._pending = None
         self.row_messages = None
         self.uploads: list = []  # (start, count) per upload_rows call
+        self.options: dict = {}
         FakeEngine.instances.append(self)
 
     def close(self):
@@ -38,10 +39,10 @@ class FakeEngine:
         self.rows = 0
 
     def set_option(self, name, value):
-        pass
+        self.options[name] = value
 
     def get_option(self, name):
-        return 0
+        return self.options.get(name, 0)
 
     def upload_rows(self, host_rows, start, dtype, capacity_hint=0):
         n_new = start + host_rows.shape[0]

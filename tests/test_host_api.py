@@ -255,5 +255,55 @@ def test_product_package_does_not_import_the_oracle():
 
 
 def test_scoredint_is_a_plain_dataclass():
+    import dataclasses
+
     a = ScoredInt(3, 0.5)
-    assert (a.item, a.score) == (3, 0.5) and a == ScoredInt(3, 0.5)
+    assert (a.item, a.score) == (3, 0.5) and a == ScoredInt(3, 0.5) and a != ScoredInt(3, 0.25)
+    assert [f.name for f in dataclasses.fields(ScoredInt)] == ["item", "score"] and dataclasses.asdict(a) == {"item": 3, "score": 0.5}
+    assert repr(a) == "ScoredInt(item=3, score=0.5)"
+    a.score = 0.75  # mutable, like the reference's
+    assert a.score == 0.75
+
+
+def test_scoredint_matches_the_reference_dataclass():
+    """Same fields, repr, equality and keyword construction as vectorbase.py:50-55 (needs /root/reference)."""
+    import dataclasses
+
+    from oracle import ref_loader
+
+    if not ref_loader.reference_available():
+        pytest.skip("reference checkout not present")
+    ref = ref_loader.load_reference_vectorbase().ScoredInt
+    ours, theirs = ScoredInt(item=7, score=0.25), ref(item=7, score=0.25)
+    assert [f.name for f in dataclasses.fields(ours)] == [f.name for f in dataclasses.fields(theirs)]
+    assert repr(ours) == repr(theirs) and dataclasses.astuple(ours) == dataclasses.astuple(theirs)
+    assert (ours == ScoredInt(7, 0.25)) and (theirs == ref(7, 0.25)) and (ours != ScoredInt(8, 0.25))
+
+
+def test_batch_lookup_as_arrays_and_shadow_env_knob_on_a_fake_engine(monkeypatch):
+    from tests.fake_engine import FakeEngine
+    from typeagent_py_amd import _native
+
+    FakeEngine.instances = []
+    monkeypatch.setattr(_native, "Engine", FakeEngine)
+    monkeypatch.setenv("TYPEAGENT_VB_F32_SHADOW", "2")
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal((300, 24)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    qs = v[[5, 9, 200]]
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()))
+    vb.add_embeddings(None, v)
+    lists = vb.fuzzy_lookup_embeddings(qs, max_hits=4, min_score=0.6)
+    o, s, c = vb.fuzzy_lookup_embeddings(qs, max_hits=4, min_score=0.6, as_arrays=True)
+    assert FakeEngine.instances[0].options.get("f32_shadow") == 2
+    assert o.shape == (3, 4) and [int(x) for x in o[:, 0]] == [5, 9, 200]
+    for qi in range(3):
+        assert [(r.item, r.score) for r in lists[qi]] == list(zip(o[qi, : c[qi]].tolist(), s[qi, : c[qi]].tolist()))
+        assert all(isinstance(r.item, int) and isinstance(r.score, float) for r in lists[qi])
+    with pytest.raises(ValueError):
+        vb.fuzzy_lookup_embeddings(qs, max_hits=0, as_arrays=True)
+    monkeypatch.setenv("TYPEAGENT_VB_F32_SHADOW", "0")
+    vb0 = VectorBase(TextEmbeddingIndexSettings(NullModel()))
+    vb0.add_embeddings(None, v)
+    vb0.fuzzy_lookup_embedding(qs[0])
+    assert FakeEngine.instances[-1].options.get("f32_shadow") == 0
