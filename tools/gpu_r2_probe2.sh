@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: kept as run (mid round 2).  The `mfma_variant` option no longer exists -- variant 6 is the only 256-query kernel --, so drop it to re-run;
+# variant 5 (round 1's 4-wave 384 x 256 tile) was deleted after this measurement.
 # round 2, probe 2: variant 6 (K = 64 whole-line staging) correctness + speed
 mkdir -p gpurun_out/r2p2
 true

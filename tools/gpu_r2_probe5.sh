@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: kept as run (mid round 2).  The `mfma_variant` option no longer exists -- variant 6 is the only 256-query kernel --, so drop it to re-run;
+# variant 5 (round 1's 4-wave 384 x 256 tile) was deleted after this measurement.
 mkdir -p gpurun_out/r2p5
 B="python bench.py --workload cfg3 --no-cpu-baseline --no-parity --steps 5 --warmup 2"
 for v in "mfma_variant=6 --opt mfma_ablate=256" "mfma_variant=6 --opt mfma_ablate=260" "mfma_variant=6 --opt mfma_ablate=264" "mfma_variant=6 --opt mfma_ablate=268" "mfma_variant=6 --opt mfma_ablate=258" "mfma_variant=6 --opt mfma_ablate=256"; do
