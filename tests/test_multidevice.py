@@ -168,3 +168,56 @@ def test_gpu_two_real_devices_when_present():
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
     for qi in range(0, 130, 13):
         assert vo.check_topk_parity(vo.scores_full(vv, qs[qi]), [r.item for r in out[qi]], [r.score for r in out[qi]], 32, 0.0).ordinals_bit_exact
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# seeded random histories on fake devices: appends of random sizes interleaved with every kind of lookup
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(40))
+def test_group_random_history_on_fake_devices(fake_group, seed):
+    rng = np.random.default_rng(5000 + seed)
+    n_dev = int(rng.integers(1, 6))
+    dim = int(rng.choice([3, 16, 48]))
+    vb = _vb(list(range(n_dev)))
+    rows = np.zeros((0, dim), dtype=np.float32)
+    for step in range(int(rng.integers(2, 7))):
+        add = int(rng.choice([1, 2, 7, 40, 300]))
+        fresh = rng.standard_normal((add, dim)).astype(np.float32)
+        fresh /= np.linalg.norm(fresh, axis=1, keepdims=True)
+        if rng.random() < 0.3 and len(rows):
+            fresh[0] = rows[int(rng.integers(len(rows)))]  # an exact duplicate: ties across shards resolve to the smaller ordinal
+        if add == 1:
+            vb.add_embedding(None, fresh[0])
+        else:
+            vb.add_embeddings(None, fresh)
+        rows = np.concatenate([rows, fresh])
+        n = len(rows)
+        assert len(vb) == n and vb.engine.bounds[-1] == n and sorted(vb.engine.bounds) == vb.engine.bounds
+        q = rows[int(rng.integers(n))] if rng.random() < 0.5 else fresh[-1]
+        k = int(rng.choice([1, 3, 10, 32]))
+        ms = float(rng.choice([0.0, 0.4, 0.55]))
+        # single
+        # (exact ties -- the duplicated rows -- have no defined order in the reference; ours is ascending ordinal, also across shards)
+        res = vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=ms)
+        vo.check_topk_parity(vo.scores_full(rows, q), [r.item for r in res], [r.score for r in res], k, ms)
+        assert all(a.score > b.score or (a.score == b.score and a.item < b.item) for a, b in zip(res, res[1:]))
+        # batch
+        qs = rows[rng.integers(0, n, size=int(rng.integers(2, 6)))]
+        out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
+        for qi in range(len(qs)):
+            vo.check_topk_parity(vo.scores_full(rows, qs[qi]), [r.item for r in out[qi]], [r.score for r in out[qi]], k, ms)
+            assert all(a.score > b.score or (a.score == b.score and a.item < b.item) for a, b in zip(out[qi], out[qi][1:]))
+        # subset (duplicates and negative ordinals allowed), also with more hits than one page
+        sub = rng.integers(-min(n, 3), n, size=int(rng.integers(1, min(n, 50) + 1))).tolist()
+        got = vb.fuzzy_lookup_embedding_in_subset(q, sub, max_hits=k, min_score=ms)
+        sub_a = np.asarray(sub, dtype=np.int64)
+        vo.check_topk_parity(vo.scores_full(rows, q)[sub_a], [r.item for r in got], [r.score for r in got], k, ms, candidate_ordinals=sub_a)
+        assert len(got) == len(vo.lookup_in_subset(rows, q, sub, k, ms))
+        # all survivors / predicate
+        everything = vb.fuzzy_lookup_embedding(q, max_hits=0, min_score=0.5)
+        assert sorted(r.item for r in everything) == sorted(i for i, _ in vo.lookup(rows, q, 0, 0.5))
+        assert [r.score for r in everything] == sorted((r.score for r in everything), reverse=True)
+        pred = vb.fuzzy_lookup_embedding(q, max_hits=5, min_score=0.0, predicate=lambda i: i % 2 == 0)
+        want = vo.lookup(rows, q, 5, 0.0, predicate=lambda i: i % 2 == 0)  # (the predicate branch IS stable: ties by ascending ordinal, vectorbase.py:200)
+        assert [r.item for r in pred] == [i for i, _ in want]
+    np.testing.assert_array_equal(vb.serialize(), rows)
