@@ -133,23 +133,22 @@ class DeviceGroup:
             raise ValueError(f"shapes ({self.rows},{self.dim}) and {tuple(np.shape(q))} not aligned: query must have {self.dim} elements")
         return a
 
-    def _gather(self, queries: np.ndarray, k: int, thrs: np.ndarray, cursor_key: int | None = None) -> np.ndarray:
+    def _gather(self, queries: np.ndarray, k: int, thrs: np.ndarray) -> np.ndarray:
         """-> merged uint64 [nq, k] keys over all shards"""
         act = self._active()
         nq = queries.shape[0]
         if not act:
             return np.zeros((nq, k), dtype=np.uint64)
         for e, lo, hi in act:  # enqueue everywhere first: the devices scan concurrently
-            e.search_begin(queries, k, thrs, cursor_key)
+            e.search_begin(queries, k, thrs)
         keys = np.empty((len(act), nq, k), dtype=np.uint64)
         for i, (e, lo, hi) in enumerate(act):
             e.search_end(nq, k, keys[i])
         return keys[0] if len(act) == 1 else _native.merge_keys(keys)
 
-    def search(self, q, k: int, thr: np.float32, after: tuple[float, int] | None = None):
+    def search(self, q, k: int, thr: np.float32):
         a = self._query(q)[None, :]
-        cursor = _native.make_key(after[0], after[1]) if after is not None else None
-        ords, scs, cnts = _native.decode_keys(self._gather(a, k, np.asarray([thr], dtype=np.float32), cursor))
+        ords, scs, cnts = _native.decode_keys(self._gather(a, k, np.asarray([thr], dtype=np.float32)))
         m = int(cnts[0])
         return ords[0, :m], scs[0, :m]
 
@@ -184,7 +183,7 @@ class DeviceGroup:
             order = order[:max_out]
         return ids[order], sc[order]
 
-    def search_subset(self, q, rows: np.ndarray, k: int, thr: np.float32, after: tuple[float, int] | None = None):
+    def search_subset(self, q, rows: np.ndarray, k: int, thr: np.float32):
         """rows: int64 global corpus row per subset position -> (positions int64[m], scores float32[m]); the order is
         (score desc, position asc) like one device's."""
         a = self._query(q)
@@ -194,14 +193,7 @@ class DeviceGroup:
             idx = np.flatnonzero((rows >= lo) & (rows < hi))
             if idx.size == 0:
                 continue
-            cur = None
-            if after is not None:
-                j = int(np.searchsorted(idx, after[1], side="right")) - 1  # last local position at or before the cursor's
-                if j >= 0:
-                    cur = (float(after[0]), j)
-                elif after[0] < 1.0:  # every local position lies behind the cursor's: all hits with score <= its score
-                    cur = (float(np.nextafter(np.float32(after[0]), np.float32(2.0))), int(idx.size) - 1)
-            p, s = e.search_subset(a, rows[idx] - lo, k, thr, after=cur)
+            p, s = e.search_subset(a, rows[idx] - lo, k, thr)
             pos_all.append(idx[p])
             sc_all.append(s)
         if not pos_all:
