@@ -324,6 +324,42 @@ def test_batch_equals_sequential(nq, d, k):
         np.testing.assert_allclose(bs, ss, atol=2e-7, rtol=0)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_cursor_forms_enumerate_what_the_one_pass_form_returns(dtype):
+    """`tavb_search_after` / `tavb_search_subset_after` (kept for callers that stop early): feeding the last hit of a page as the
+    cursor of the next enumerates every survivor, best first, duplicates (exact ties) included -- the same sequence
+    `tavb_search_all` / `tavb_search_subset_all` produce in one pass."""
+    v, q = make_corpus(6_001, 384, 4300)
+    v[100:140] = v[7]  # 41 rows with exactly equal scores: a page boundary falls inside the tie
+    vb = new_vb(v, dtype=dtype)
+    vb.fuzzy_lookup_embedding(q)  # sync the device mirror
+    eng = vb.engine
+    thr = np.float32(0.5)
+    want_o, want_s = eng.search_all(v[7], thr)
+    got_o, got_s, after = [], [], None
+    while True:
+        o, s = eng.search(v[7], 16, thr, after=after)
+        if len(o) == 0:
+            break
+        got_o += o.tolist()
+        got_s += s.tolist()
+        after = (float(s[-1]), int(o[-1]))
+        assert len(got_o) <= len(want_o)
+    assert got_o == want_o.tolist() and got_s == want_s.tolist() and len(got_o) > 41
+    rows = np.asarray(subset_choice(6_001, 900, 4301) + list(range(100, 140)) + [7, 7], dtype=np.int64)
+    want_p, want_ps = eng.search_all(v[7], thr, subset_rows=rows)
+    got_p, got_ps, after = [], [], None
+    while True:
+        p, s = eng.search_subset(v[7], rows, 10, thr, after=after)
+        if len(p) == 0:
+            break
+        got_p += p.tolist()
+        got_ps += s.tolist()
+        after = (float(s[-1]), int(p[-1]))
+        assert len(got_p) <= len(want_p)
+    assert got_p == want_p.tolist() and got_ps == want_ps.tolist() and len(got_p) >= 43
+
+
 def test_batch_lookup_as_arrays():
     v, _ = make_corpus(3_000, 384, 4100)
     qs = make_queries(70, 384, 4101)
