@@ -47,6 +47,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+BASELINE_METRIC = "queries/sec + p50 lookup latency, 1536-d top-32 kNN at 1/2/4/8 MI355X"  # BASELINE.json `metric`, verbatim
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32 matrix rate (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md peak table
 CHUNK_ROWS = 262_144           # generation granule of the synthetic corpus
@@ -470,7 +471,7 @@ def shard_bounds(total: int, world: int, rank: int) -> tuple[int, int]:
 
 def headline_line(ctx: Ctx, rec: dict, name: str, wl: dict, scaling: str, sub: dict | None) -> dict:
     out = {
-        "metric": "queries/sec + p50 lookup latency, 1536-d top-32 kNN",
+        "metric": BASELINE_METRIC,
         "value": rec["queries_per_sec"],
         "unit": "queries/s",
         "n_gpus": ctx.world,

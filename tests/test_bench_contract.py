@@ -1,0 +1,58 @@
+"""CPU suite: the shape of the one JSON line `bench.py` prints (the driver's contract), without a GPU: `headline_line` over a synthetic
+record, the workload table against BASELINE.json, the shard arithmetic of `--scaling strong`."""
+
+import json
+import os
+import types
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rec():
+    return {
+        "workload": "cfg3: 10000000x1536 fp16, 1024 queries/step, top-32, min_score 0.0", "queries_per_sec": 37000.0, "steps": 10, "warmup": 12,
+        "ms_per_step": 27.6, "p50_latency_us": 27500.0, "p99_latency_us": 27900.0, "min_latency_us": 27400.0, "dtype": "f16 storage, f32 accumulate",
+        "roofline": {"bound": "mfma", "achieved": 1180.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.472, "traffic": 5.19e10},
+        "cpu_baseline": {"value": 0.97, "unit": "queries/s", "cores": 256, "kind": "port", "sample": "..."},
+        "parity": {"ok": True}, "host_buffer_form": {"ms_per_step": 27.9},
+    }
+
+
+def test_headline_line_has_every_contract_field():
+    ctx = types.SimpleNamespace(world=1)
+    wl = dict(bench.WORKLOADS["cfg3"], rows_total=10_000_000)
+    line = bench.headline_line(ctx, _rec(), "cfg3", wl, "strong", {"cfg2": {"queries_per_sec": 1000.0}})
+    json.loads(json.dumps(line))  # serialisable
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "parity", "sub"):
+        assert key in line, key
+    assert line["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert line["value"] == 37000.0 and line["unit"] == "queries/s" and line["n_gpus"] == 1 and line["higher_is_better"] is True
+    assert line["vs_baseline"] is None and line["data"] == "synthetic" and line["scaling"] == "strong"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in line["roofline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in line["cpu_baseline"]
+    eight = bench.headline_line(types.SimpleNamespace(world=8), _rec(), "cfg3", wl, "strong", None)
+    assert eight["n_gpus"] == 8 and "row-sharded x8" in eight["config"]["parallelism"] and "sub" not in eight
+
+
+def test_workload_table_matches_the_baseline_configs():
+    w = bench.WORKLOADS
+    assert (w["cfg2"]["rows"], w["cfg2"]["dim"], w["cfg2"]["dtype"], w["cfg2"]["nq"], w["cfg2"]["k"]) == (1_000_000, 1536, "fp32", 1, 32)
+    assert (w["cfg3"]["rows"], w["cfg3"]["dim"], w["cfg3"]["dtype"], w["cfg3"]["nq"], w["cfg3"]["k"]) == (10_000_000, 1536, "fp16", 1024, 32)
+    assert (w["cfg4"]["rows"] * 8, w["cfg4"]["dtype"], w["cfg4"]["nq"]) == (100_000_000, "fp16", 1024)
+    assert (w["cfg1"]["rows"], w["cfg1"]["k"]) == (10_000, 10)
+    assert w["cfg3"]["bound"] == "mfma" and w["cfg2"]["bound"] == "hbm" and w["cfg3_q1"]["bound"] == "hbm"
+
+
+def test_strong_scaling_shards_cover_the_corpus_once():
+    for world in (1, 2, 3, 4, 8):
+        bounds = [bench.shard_bounds(10_000_000, world, r) for r in range(world)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == 10_000_000
+        assert all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+        sizes = [hi - lo for lo, hi in bounds]
+        assert max(sizes) - min(sizes) <= 1
