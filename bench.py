@@ -52,6 +52,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32 matrix rate (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md peak table
 CHUNK_ROWS = 262_144           # generation granule of the synthetic corpus
 ORACLE_CHUNK = 1_000_000       # rows handed to the CPU oracle at a time (a reference-sized VectorBase)
+BATCH_ROTATION = 4             # different query batches that take turns in the timed region of a batched workload
 PARITY_QUERIES = 16
 
 WORKLOADS = {
@@ -59,6 +60,9 @@ WORKLOADS = {
     "cfg2": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1, k=32, bound="hbm", seed=1043),
     "cfg2_f16": dict(rows=1_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm", seed=1043),
     "cfg3": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma", seed=10043),
+    # the same shape on a CLUSTERED corpus (100-row clusters of near-duplicates incl. exact duplicates; every query sits next to a cluster
+    # centre, so its top-64 spans < 2e-4 in score -- inside the fp16 filter's error bound): what real embedding corpora do to the wide tile
+    "cfg3_clustered": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma", seed=10143, kind="clustered"),
     # the north star's single-query target on the cfg3 corpus: HBM-bound, 30.72 GB per query
     "cfg3_q1": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm", seed=10043),
     "cfg4": dict(rows=12_500_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma", seed=100043),  # PER GPU (weak scaling)
@@ -77,21 +81,53 @@ WORKLOADS = {
 # ----------------------------------------------------------------------------------------------------------------
 # synthetic corpus: reproducible per chunk, generated where it is used
 # ----------------------------------------------------------------------------------------------------------------
-def gen_rows(eng, lo: int, hi: int, dim: int, seed: int, dtype: str):
+CLUSTER_ROWS = 100      # rows per cluster of the clustered corpus
+CLUSTER_SPREAD = 0.002  # |row - centre| before normalisation: scores inside a cluster spread over ~2e-4
+CLUSTER_MULT = 7_368_787  # row -> cluster hash (a prime): the rows of a cluster are scattered over the whole corpus
+
+
+def cluster_centres(eng, rows_total: int, dim: int, seed: int):
+    """[rows_total // CLUSTER_ROWS, dim] fp32 unit vectors on the device (same on every rank: one seeded torch generator)."""
+    import torch
+
+    dev = torch.device("cuda", eng.device)
+    n_c = max(1, rows_total // CLUSTER_ROWS)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed * 1_000_003 + 999_983)
+    c = torch.empty((n_c, dim), dtype=torch.float32, device=dev)
+    c.normal_(generator=gen)
+    eng.normalize_rows_(c)
+    return c
+
+
+def gen_rows(eng, lo: int, hi: int, dim: int, seed: int, dtype: str, kind: str = "gaussian", rows_total: int | None = None):
     """Rows [lo, hi) of the synthetic corpus `seed` as a device tensor (fp32 or fp16).  Chunk c (CHUNK_ROWS rows) is
     torch.randn with generator seed `seed * 1000003 + c`, L2-normalised by our K1 kernel and (fp16) rounded by our
-    convert kernel, so every rank / the parity checker reproduce the same bytes for any row range."""
+    convert kernel, so every rank / the parity checker reproduce the same bytes for any row range.
+    kind = "clustered": row i belongs to cluster (i * CLUSTER_MULT) % n_clusters and is centre + CLUSTER_SPREAD * noise / sqrt(dim),
+    normalised; every row with i % 8 == 5 takes the NEXT cluster's centre as its noise instead -- all such rows of a cluster are
+    exact duplicates of one another (about a dozen per cluster)."""
     import torch
 
     dev = torch.device("cuda", eng.device)
     out = torch.empty((hi - lo, dim), dtype=torch.float16 if dtype == "fp16" else torch.float32, device=dev)
     gen = torch.Generator(device=dev)
+    centres = cluster_centres(eng, rows_total if rows_total is not None else hi, dim, seed) if kind == "clustered" else None
     c = lo // CHUNK_ROWS
     while c * CHUNK_ROWS < hi:
         c_lo = c * CHUNK_ROWS
         gen.manual_seed(seed * 1_000_003 + c)
         tmp = torch.empty((CHUNK_ROWS, dim), dtype=torch.float32, device=dev)
         tmp.normal_(generator=gen)
+        if centres is not None:
+            n_c = centres.shape[0]
+            ids = torch.arange(c_lo, c_lo + CHUNK_ROWS, dtype=torch.int64, device=dev)
+            cl = (ids * CLUSTER_MULT) % n_c
+            tmp.mul_(CLUSTER_SPREAD / float(np.sqrt(dim)))
+            dup = (ids % 8) == 5
+            tmp[dup] = centres[(cl[dup] + 1) % n_c] * CLUSTER_SPREAD
+            tmp.add_(centres[cl])
+            del ids, cl, dup
         a, b = max(lo, c_lo), min(hi, c_lo + CHUNK_ROWS)
         part = tmp[a - c_lo : b - c_lo]
         eng.normalize_rows_(part)
@@ -100,6 +136,16 @@ def gen_rows(eng, lo: int, hi: int, dim: int, seed: int, dtype: str):
         c += 1
     torch.cuda.synchronize(dev)
     return out
+
+
+def clustered_queries(eng, count: int, rows_total: int, dim: int, seed: int) -> np.ndarray:
+    """`count` unit queries next to cluster centres of the clustered corpus `seed` (centre + 0.05 * noise: cosine ~0.9988 to the centre)."""
+    centres = cluster_centres(eng, rows_total, dim, seed)
+    rng = np.random.default_rng(seed + 17)
+    pick = rng.choice(centres.shape[0], size=count, replace=centres.shape[0] < count)
+    q = centres[np.sort(pick)].cpu().numpy() + 0.05 * rng.standard_normal((count, dim)).astype(np.float32) / np.sqrt(dim)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q.astype(np.float32)
 
 
 def make_device_corpus(eng, rows: int, dim: int, seed: int, dtype: str):
@@ -117,7 +163,7 @@ def host_queries(count: int, dim: int, seed: int) -> np.ndarray:
 # ----------------------------------------------------------------------------------------------------------------
 # CPU legs: parity oracle and the reported baseline
 # ----------------------------------------------------------------------------------------------------------------
-def oracle_chunks(eng, resident, resident_lo: int, total_rows: int, dim: int, seed: int, dtype: str):
+def oracle_chunks(eng, resident, resident_lo: int, total_rows: int, dim: int, seed: int, dtype: str, kind: str = "gaussian"):
     """The whole corpus as float32 host chunks of ORACLE_CHUNK rows (fp16 values widened, as the kernels see them):
     rows this rank holds come from the resident tensor, the rest are regenerated on the device."""
     for lo in range(0, total_rows, ORACLE_CHUNK):
@@ -125,7 +171,7 @@ def oracle_chunks(eng, resident, resident_lo: int, total_rows: int, dim: int, se
         if resident is not None and lo >= resident_lo and hi <= resident_lo + resident.shape[0]:
             t = resident[lo - resident_lo : hi - resident_lo]
         else:
-            t = gen_rows(eng, lo, hi, dim, seed, dtype)
+            t = gen_rows(eng, lo, hi, dim, seed, dtype, kind, total_rows)
         yield t.float().cpu().numpy()
 
 
@@ -135,7 +181,7 @@ def parity_check(eng, resident, resident_lo, wl, queries: np.ndarray, sample: li
     from oracle import vectorbase_oracle as vo
 
     t0 = time.perf_counter()
-    ref = vo.scores_full_chunked(oracle_chunks(eng, resident, resident_lo, wl["rows_total"], wl["dim"], wl["seed"], wl["dtype"]),
+    ref = vo.scores_full_chunked(oracle_chunks(eng, resident, resident_lo, wl["rows_total"], wl["dim"], wl["seed"], wl["dtype"], wl.get("kind", "gaussian")),
                                  queries[sample])
     exact = permuted = near = 0
     worst = 0.0
@@ -292,7 +338,13 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     rows_local, rows_total = int(corpus.shape[0]), wl["rows_total"]
     min_score = args.min_score
     thr = float(ctx.native.f32_threshold(min_score))
-    queries = host_queries(max(64, nq), dim, 4242)  # identical on every rank; arbitrary fp32 values (not fp16-representable)
+    # identical on every rank; arbitrary fp32 values (not fp16-representable).  BATCH_ROTATION different batches take turns in the timed region.
+    n_rot = BATCH_ROTATION if nq > 1 else 1
+    if wl.get("kind") == "clustered":
+        queries = clustered_queries(eng, max(64, nq * n_rot), rows_total, dim, wl["seed"])
+        queries = queries[np.random.default_rng(7).permutation(len(queries))]  # (neighbouring clusters do not share a query tile)
+    else:
+        queries = host_queries(max(64, nq * n_rot), dim, 4242)
 
     searcher = None
     if ctx.distributed:
@@ -304,7 +356,7 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     else:
         eng.set_corpus_tensor(corpus)
         if nq > 1:  # batches: the queries are resident too when the timed region starts (the host-buffer rate is reported beside it)
-            dq_all = torch.from_numpy(queries[:nq]).to(torch.device("cuda", ctx.dev))
+            dq_all = torch.from_numpy(queries[: nq * n_rot]).to(torch.device("cuda", ctx.dev))
             keys_buf = torch.empty((nq, k), dtype=torch.int64, pin_memory=True)  # the last kernel writes the result keys straight into pinned host memory
             keys_np = keys_buf.numpy()
             torch.cuda.synchronize()
@@ -320,13 +372,14 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
                 return eng.search(queries[qi], k, np.float32(thr))
             r = searcher.search(dq_all[qi : qi + 1], k, min_score)
             return r.ordinals[0, : r.counts[0]], r.scores[0, : r.counts[0]]
+        b0 = (i % n_rot) * nq  # the batch of this step
         if searcher is None:
             if host_queries_form:
-                return eng.search_batch(queries[:nq], k, np.float32(thr))
-            eng.search_device(dq_all, k, thr, out_keys=keys_buf)
+                return eng.search_batch(queries[b0 : b0 + nq], k, np.float32(thr))
+            eng.search_device(dq_all[b0 : b0 + nq], k, thr, out_keys=keys_buf)
             eng.synchronize()
             return ctx.native.decode_keys(keys_np)
-        r = searcher.search(dq_all[:nq], k, min_score)
+        r = searcher.search(dq_all[b0 : b0 + nq], k, min_score)
         return r.ordinals, r.scores, r.counts
 
     w0, n_w = time.perf_counter(), 0
@@ -377,8 +430,17 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         got = {qi: one_step(qi)[:2] for qi in sample}
     else:
         sample = sorted(set(np.linspace(0, nq - 1, PARITY_QUERIES).astype(int).tolist()))
-        o, s, c = one_step(0)
+        o, s, c = one_step(0)  # (batch 0 of the rotation)
         got = {qi: (o[qi, : c[qi]], s[qi, : c[qi]]) for qi in sample}
+        flagged = []
+        if searcher is None:
+            try:  # queries whose candidate band did not fit and were re-run on the exact tile (0 on ordinary data), per batch of the rotation
+                for b in range(n_rot):
+                    if b:
+                        one_step(b)
+                    flagged.append(int(eng.get_option("last_flagged")))
+            except Exception:
+                flagged = []
     if ctx.rank != 0:
         # rank 0 regenerates what it needs for the oracle; the others only keep the collective calls aligned
         return {}
@@ -452,6 +514,11 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         "dtype": "f32" if wl["dtype"] == "fp32" else "f16 storage, f32 accumulate",
         "roofline": roof,
     }
+    if nq > 1:
+        rec["query_batches_in_rotation"] = n_rot
+        if searcher is None and flagged:
+            rec["flagged_queries_per_batch"] = flagged
+            rec["flagged_fraction"] = float(sum(flagged)) / (len(flagged) * nq)
     if host_form:
         rec["host_buffer_form"] = host_form
     if not args.no_parity:
@@ -755,7 +822,7 @@ def main() -> None:
     torch = ctx.torch
     stream_ctx = torch.cuda.stream(ctx.backend.stream) if ctx.backend is not None else torch.cuda.stream(torch.cuda.current_stream(ctx.dev))
     with stream_ctx:
-        corpus = gen_rows(ctx.eng, lo, hi, wl["dim"], wl["seed"], wl["dtype"])
+        corpus = gen_rows(ctx.eng, lo, hi, wl["dim"], wl["seed"], wl["dtype"], wl.get("kind", "gaussian"), wl["rows_total"])
     rec = run_record(ctx, name, wl, corpus, lo, steps, warmup, with_cpu=(ctx.world == 1))
 
     sub = None

@@ -8,6 +8,7 @@ import pytest
 
 from oracle import vectorbase_oracle as vo
 from tests.fakes import NullModel
+from tests.synth import make_clustered_corpus
 from typeagent_py_amd import TextEmbeddingIndexSettings, VectorBase
 
 pytestmark = pytest.mark.gpu
@@ -83,3 +84,29 @@ def test_random_case_against_the_oracle(seed):
         except AssertionError as exc:
             raise AssertionError(f"{tag} query {qi} tier {vb.engine.get_option('last_tier')}: {exc}") from exc
         assert all(0.0 <= r.score <= 1.0 for r in got), tag
+
+
+@pytest.mark.parametrize("cluster_rows,nq,k,expect_flagged", [(40, 130, 32, False), (100, 300, 32, False), (100, 1024, 50, False), (300, 130, 10, False),
+                                                               (900, 130, 32, True)])
+def test_clustered_corpus_batches_against_the_oracle(cluster_rows, nq, k, expect_flagged):
+    """The mid-size twin of bench.py's cfg3_clustered: every query sits next to a cluster of near-duplicate rows (incl. exact duplicates),
+    so the scores around rank k are packed far inside the fp16 filter's error bound.  The wide tile keeps the whole BAND below the k-th
+    best (a cluster, not a fixed 64 candidates) and rescoring makes the answer exact: no query may need the exact-tile fallback until a
+    cluster outgrows the band capacity (900-row clusters: flagged, re-run exactly, same answers)."""
+    n = 60_000
+    v, q, cl, qc = make_clustered_corpus(n, 1536, 4100 + cluster_rows, cluster_rows=cluster_rows, n_queries=nq)
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), corpus_dtype="fp16")
+    vb.add_embeddings(None, v)
+    out = vb.fuzzy_lookup_embeddings(q, max_hits=k, min_score=0.0)
+    assert vb.engine.get_option("last_tier") == 4
+    flagged = vb.engine.get_option("last_flagged")
+    assert (flagged > 0) == expect_flagged, flagged
+    seen = v.astype(np.float16).astype(np.float32)
+    for qi in sorted(set(np.linspace(0, nq - 1, 20).astype(int).tolist())):
+        ref = vo.scores_full(seen, q[qi])
+        items = [r.item for r in out[qi]]
+        vo.check_topk_parity(ref, items, [r.score for r in out[qi]], k, 0.0)
+        members = np.flatnonzero(cl == qc[qi])
+        assert set(items[: min(k, len(members))]) <= set(members.tolist())  # the best hits are the query's own cluster
+        seq = vb.fuzzy_lookup_embedding(q[qi], max_hits=k, min_score=0.0)  # the single-query kernel: same rows, same order (exact ties by ordinal)
+        assert items == [r.item for r in seq]

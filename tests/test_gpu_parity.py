@@ -787,35 +787,94 @@ def test_128_and_256_query_tiles_agree(n, nq, k, ms, sample):
         eng.set_option("mfma_tile", 64)
 
 
-def test_wide_tile_falls_back_to_the_exact_tile_when_candidates_cannot_be_proven_complete():
-    """Near-duplicate rows around rank k: the 64 candidates by fp16-query score do not provably contain the fp32-query
-    top-k (scores closer than the rounding bound), so those queries are re-run on the exact 64-query tile, on the device,
-    through the work list.  Answers must still be the oracle's."""
+def _plant_near_duplicates(v, qs, qi, rows, rng, eps=2e-4):
+    """rows of v <- tiny perturbations of one vector near query qi: their scores to that query lie within ~1e-5 of one another"""
+    base = qs[qi] + 0.3 * rng.standard_normal(v.shape[1]).astype(np.float32) / np.sqrt(v.shape[1])
+    base /= np.linalg.norm(base)
+    for r in rows:
+        w = base + eps * rng.standard_normal(v.shape[1]).astype(np.float32) / np.sqrt(v.shape[1])
+        v[r] = w / np.linalg.norm(w)
+
+
+def test_wide_tile_band_holds_a_cluster_of_near_duplicates():
+    """300 near-duplicate rows around rank k: the fp16-query scores cannot order them, so the wide tile keeps the whole BAND (every row
+    within 2 delta of the approximate k-th best) and the fp32 rescoring of the band gives the exact answer -- no fallback pass."""
     n, nq, k = 20_000, 130, 32
     v, _ = make_corpus(n, 1536, 7300)
     qs = make_queries(nq, 1536, 7301)
     rng = np.random.default_rng(7302)
-    # 300 rows within ~1e-5 of one another in cosine to query 3 (tiny perturbations of one vector near that query)
-    base = qs[3] + 0.3 * rng.standard_normal(1536).astype(np.float32) / np.sqrt(1536)
-    base /= np.linalg.norm(base)
     dup_rows = rng.choice(n, size=300, replace=False)
-    for r in dup_rows:
-        w = base + 2e-4 * rng.standard_normal(1536).astype(np.float32) / np.sqrt(1536)
-        v[r] = w / np.linalg.norm(w)
+    _plant_near_duplicates(v, qs, 3, dup_rows, rng)
+    v[dup_rows[:40]] = v[dup_rows[0]]  # and 40 exact duplicates among them: ties resolve to ascending ordinal
     vb = new_vb(v, dtype="fp16")
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     assert vb.engine.get_option("last_tier") == 4
-    flagged = vb.engine.get_option("last_flagged")
-    assert 1 <= flagged <= 5, flagged
+    assert vb.engine.get_option("last_flagged") == 0
     v16 = _f16(v)
     for qi in [0, 1, 2, 3, 4, 64, 129]:
         vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0)
     assert set(r.item for r in out[3]) <= set(dup_rows.tolist())
-    # with a threshold, and again (the work list is rebuilt per call)
+    seq = vb.fuzzy_lookup_embedding(qs[3], max_hits=k, min_score=0.0)
+    assert [r.item for r in out[3]] == [r.item for r in seq]
+    # with a threshold, and again
     out2 = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.6)
     for qi in [2, 3, 4]:
         vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out2[qi]), k, 0.6)
     assert len(out2[3]) == k and len(out2[2]) == 0
+    # k = 50 (the reference's related-terms max_matches, convsettings.py:61-63) and k = 64 ride the wide tile too
+    for kk in (50, 64):
+        o = vb.fuzzy_lookup_embeddings(qs, max_hits=kk, min_score=0.0)
+        assert vb.engine.get_option("last_tier") == 4 and vb.engine.get_option("last_flagged") == 0
+        for qi in [3, 77]:
+            vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(o[qi]), kk, 0.0)
+
+
+def test_wide_tile_falls_back_to_the_exact_tile_when_the_band_overflows():
+    """A band bigger than the rescoring takes (512 candidates per query): 700 near-duplicates for one query, 600 exact duplicates of the
+    best row of another.  Those queries are flagged on the device and re-run on the exact 64-query tile through the work list; the
+    others are not.  Answers must still be the oracle's, ties by ascending ordinal."""
+    n, nq, k = 20_000, 130, 32
+    v, _ = make_corpus(n, 1536, 7310)
+    qs = make_queries(nq, 1536, 7311)
+    rng = np.random.default_rng(7312)
+    rows = rng.choice(n, size=1300, replace=False)
+    _plant_near_duplicates(v, qs, 3, rows[:700], rng)
+    best = qs[9] + 0.2 * rng.standard_normal(1536).astype(np.float32) / np.sqrt(1536)
+    v[rows[700:]] = best / np.linalg.norm(best)
+    vb = new_vb(v, dtype="fp16")
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert vb.engine.get_option("last_tier") == 4
+    flagged = vb.engine.get_option("last_flagged")
+    assert 2 <= flagged <= 4, flagged
+    v16 = _f16(v)
+    for qi in [0, 3, 4, 9, 64, 129]:
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0)
+    assert [r.item for r in out[9]] == sorted(rows[700:].tolist())[:k]
+    assert set(r.item for r in out[3]) <= set(rows[:700].tolist())
+    out2 = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.6)  # the work list is rebuilt per call
+    for qi in [2, 3, 9]:
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out2[qi]), k, 0.6)
+    assert len(out2[3]) == k and len(out2[2]) == 0
+
+
+@pytest.mark.parametrize("sample", [-1, 0])
+def test_wide_tile_band_overflow_inside_one_row_range(sample):
+    """900 near-duplicates in CONSECUTIVE rows: one workgroup's candidate buffer (1024 keys) cannot hold the band while it walks its
+    row range -- the in-kernel compaction falls back to the strict best k and flags the query; everything else stays on the band path."""
+    n, nq, k = 200_000, 130, 32
+    v, _ = make_corpus(n, 1536, 7320)
+    qs = make_queries(nq, 1536, 7321)
+    rng = np.random.default_rng(7322)
+    _plant_near_duplicates(v, qs, 5, range(150_000, 150_900), rng)
+    vb = new_vb(v, dtype="fp16")
+    vb.engine.set_option("mfma_sample_rows", sample)
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert vb.engine.get_option("last_tier") == 4
+    assert vb.engine.get_option("last_flagged") == 1
+    v16 = _f16(v)
+    for qi in [0, 4, 5, 6, 129]:
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0)
+    assert all(150_000 <= r.item < 150_900 for r in out[5])
 
 
 def test_wide_tile_row_norm_cache_follows_appends_and_rewrites():
@@ -963,7 +1022,7 @@ def test_per_corpus_caches_do_not_survive_a_new_tensor_at_the_same_address():
     # (whether the addresses repeated is the allocator's business; the answers must be right either way)
 
 
-def test_f32_shadow_follows_appends_rewrites_and_falls_back_on_near_duplicates():
+def test_f32_shadow_follows_appends_rewrites_and_near_duplicates():
     v, _ = make_corpus(20_000, 1536, 7700)
     qs = make_queries(80, 1536, 7701)
     vb = new_vb(v)
@@ -985,15 +1044,15 @@ def test_f32_shadow_follows_appends_rewrites_and_falls_back_on_near_duplicates()
     vb.mark_dirty()
     third = vb.fuzzy_lookup_embeddings(qs, max_hits=10, min_score=0.0)
     assert third[9][0].item == 123 and abs(third[9][0].score - 1.0) < 1e-6
-    # near-duplicate rows around rank k: the fp16 shadow cannot separate them, the candidate set cannot be proven complete,
-    # the exact fp32 tile answers those queries
+    # near-duplicate rows around rank k: the fp16 shadow cannot separate them; the band below the approximate k-th best holds all
+    # of them and the fp32 rescoring orders them (no fallback pass)
     rng = np.random.default_rng(7703)
     base = qs[3].copy()
     dups = np.stack([base + 3e-4 * rng.standard_normal(1536).astype(np.float32) for _ in range(100)])
     dups /= np.linalg.norm(dups, axis=1, keepdims=True)
     vb2 = new_vb(np.concatenate([v, dups.astype(np.float32)]))
     out = vb2.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
-    assert vb2.engine.get_option("last_tier") == 4 and vb2.engine.get_option("last_flagged") >= 1
+    assert vb2.engine.get_option("last_tier") == 4 and vb2.engine.get_option("last_flagged") == 0
     allv2 = np.concatenate([v, dups.astype(np.float32)])
     for qi in [0, 4, 40, 79]:
         vo.check_topk_parity(vo.scores_full(allv2, qs[qi]), *items_scores(out[qi]), 32, 0.0)

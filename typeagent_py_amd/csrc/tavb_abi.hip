@@ -1069,6 +1069,10 @@ struct TileRun {
   const void* corpus;     // corpus operand (nullptr: the context's corpus; the fp16 shadow of an fp32 corpus for the filter pass)
   const int* active;      // optional device-side live-query count (fixed-shape launch over a work list)
   bool ladder;            // scan in phases of growing size (else one phase)
+  // 128/256-query tile only: band selection (tavb_mfma.hip::select_band_kernel).  d_out then receives [nq, kBandMax] unsorted keys,
+  const float* band;      // device [nq_pad]: width of the band below the k-th best
+  int* band_cnt;          // device [nq]: out, keys per query in d_out
+  int* overflow;          // device [nq_pad]: out (zeroed by the caller), 1 where a band did not fit
 };
 
 // Threshold ladder.  The corpus is scanned in phases of growing size -- the first `mfma_sample_rows` rows, then
@@ -1131,10 +1135,13 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   }
   bounds.push_back(c->rows);
   const int n_phases = (int)bounds.size() - 1;
+  const int kc = wide ? tavb::kBandMax : k;  // keys per query of the running selection between phases
   if (n_phases > 1) {
     if (int rc = c->d_thr.reserve((size_t)r.nq_pad * sizeof(float))) return rc;
-    if (int rc = c->d_sample_keys.reserve((size_t)2 * nq * k * sizeof(u64_t))) return rc;  // running top-k: two copies (ping-pong)
+    if (int rc = c->d_sample_keys.reserve((size_t)2 * nq * kc * sizeof(u64_t) + (size_t)2 * nq * sizeof(int))) return rc;  // running selection: two copies (ping-pong) + counts
   }
+  p.band = r.band;
+  p.overflow = r.overflow;
   const size_t row_bytes = (size_t)c->dim * (r.q32 ? 4 : 2);  // of the corpus operand
   for (int ph = 0; ph < n_phases; ++ph) {
     const bool last = (ph == n_phases - 1);
@@ -1147,9 +1154,12 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
     const int carried = ph > 0 ? 1 : 0;  // the running top-k of the earlier phases occupies one more list slot
     pp.list_stride = pp.n_splits + carried;
     pp.thr_in = ph > 0 ? reinterpret_cast<const float*>(c->d_thr.ptr) : r.floor;
-    u64_t* const running = reinterpret_cast<u64_t*>(c->d_sample_keys.ptr);  // [2][nq][k]; not allocated for a single phase
-    const u64_t* const run_in = running ? running + (size_t)((ph + 1) & 1) * nq * k : nullptr;  // what phase ph - 1 left
-    u64_t* const run_out = running ? running + (size_t)(ph & 1) * nq * k : nullptr;
+    u64_t* const running = reinterpret_cast<u64_t*>(c->d_sample_keys.ptr);  // [2][nq][kc] (+ [2][nq] counts); not allocated for a single phase
+    const u64_t* const run_in = running ? running + (size_t)((ph + 1) & 1) * nq * kc : nullptr;  // what phase ph - 1 left
+    u64_t* const run_out = running ? running + (size_t)(ph & 1) * nq * kc : nullptr;
+    int* const run_cnt = running ? reinterpret_cast<int*>(running + (size_t)2 * nq * kc) : nullptr;
+    const int* const cnt_in = run_cnt ? run_cnt + (size_t)((ph + 1) & 1) * nq : nullptr;
+    int* const cnt_out = run_cnt ? run_cnt + (size_t)(ph & 1) * nq : nullptr;
     if (carried && !wide) {
       TAVB_HIP(hipMemcpy2DAsync(pp.lists + (size_t)pp.n_splits * k, (size_t)pp.list_stride * k * sizeof(u64_t), run_in,
                                 (size_t)k * sizeof(u64_t), (size_t)k * sizeof(u64_t), (size_t)nq, hipMemcpyDeviceToDevice, c->stream));
@@ -1162,8 +1172,9 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
     if (wide) {
       Timed t(c, TAVB_KERNEL_MERGE);
       if (!last) TAVB_HIP(hipMemsetAsync(c->d_thr.ptr, 0xFF, (size_t)r.nq_pad * sizeof(float), c->stream));  // padding queries: NaN bits, ignored by `>`
-      hipError_t e = tavb::launch_select_topk(pp.workspace, pp.counts, pp.n_splits, nq, r.nq_pad, k, carried ? run_in : nullptr, r.floor,
-                                              last ? d_out : run_out, last ? nullptr : reinterpret_cast<float*>(c->d_thr.ptr), c->stream);
+      hipError_t e = tavb::launch_select_band(pp.workspace, pp.counts, pp.n_splits, nq, r.nq_pad, k, kc, carried ? run_in : nullptr, carried ? cnt_in : nullptr,
+                                              r.floor, r.band, last ? d_out : run_out, last ? r.band_cnt : cnt_out,
+                                              last ? nullptr : reinterpret_cast<float*>(c->d_thr.ptr), r.overflow, c->stream);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "select launch failed: %s", hipGetErrorString(e));
     } else if (last) {
       Timed t(c, r.active ? TAVB_KERNEL_RESCORE : TAVB_KERNEL_MERGE);
@@ -1186,14 +1197,16 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
 // `small` (fp32 corpora only): the filter is the 32/64-query tile over the shadow with the EXACT queries (split fp16 planes), for batches
 // below the wide tile's range -- half the bytes of an fp32 pass.
 int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_score, uint32_t index_base, u64_t* d_out, bool small = false) {
-  constexpr int KC = 64;  // candidates per query
+  // candidates per query handed to the rescoring: the wide tile selects a BAND (every row within 2 delta of the approximate k-th best: as many
+  // as the data makes it, up to kBandMax), the 32/64-query tile (`small`) the best 64 by approximate score
+  const int KC = small ? 64 : tavb::kBandMax;
   const bool f32c = (c->dtype == TAVB_F32);
   const int qt = small ? tavb::skinny_query_tile(nq) : (c->mfma_tile > 0 ? (int)c->mfma_tile : tavb::mfma_query_tile(nq));
   const int nq_pad = ((nq + qt - 1) / qt) * qt;
   const int cap = ((nq + 63) / 64) * 64;  // slots of the work list of queries that need the exact tile
   const size_t q16_bytes = (size_t)nq_pad * c->dim * 2 * (small ? 2 : 1);  // small: high and low plane
   if (int rc = c->d_queries_f16.reserve(q16_bytes)) return rc;
-  if (int rc = c->d_delta.reserve((size_t)nq_pad * 2 * sizeof(float))) return rc;  // delta, then the relaxed thresholds
+  if (int rc = c->d_delta.reserve((size_t)nq_pad * 5 * sizeof(float))) return rc;  // delta, the relaxed thresholds, the band widths; band counts, overflow flags
   if (int rc = c->d_approx.reserve((size_t)nq * KC * sizeof(u64_t))) return rc;
   if (int rc = c->d_flag.reserve((size_t)(cap + 64) * sizeof(int))) return rc;
   if (int rc = c->d_fb_queries.reserve((size_t)2 * cap * c->dim * 2 + (size_t)cap * sizeof(float))) return rc;
@@ -1201,6 +1214,9 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   float* d_norm = reinterpret_cast<float*>(c->d_norm.ptr);
   float* d_delta = reinterpret_cast<float*>(c->d_delta.ptr);
   float* d_floor = d_delta + nq_pad;
+  float* d_band = d_floor + nq_pad;
+  int* d_band_cnt = reinterpret_cast<int*>(d_band + nq_pad);
+  int* d_overflow = d_band_cnt + nq_pad;
   int* d_nflag = reinterpret_cast<int*>(c->d_flag.ptr);
   int* d_flagged = d_nflag + 64;
   {
@@ -1221,7 +1237,9 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
       c->norm_rows = c->rows;
     }
     TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16_bytes, c->stream));  // padding queries
-    hipError_t e = tavb::launch_query_prepare(d_q, nq, c->dim, min_score, small, d_norm, small ? nullptr : c->d_queries_f16.ptr, d_delta, d_floor, c->stream);
+    TAVB_HIP(hipMemsetAsync(d_band, 0, (size_t)nq_pad * 3 * sizeof(float), c->stream));  // band widths of the padding queries, counts, overflow flags
+    hipError_t e = tavb::launch_query_prepare(d_q, nq, c->dim, min_score, small, d_norm, small ? nullptr : c->d_queries_f16.ptr, d_delta, d_floor,
+                                              small ? nullptr : d_band, c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "query prepare launch failed: %s", hipGetErrorString(e));
     if (small) {
       e = tavb::launch_f32_split_f16(d_q, c->d_queries_f16.ptr, reinterpret_cast<char*>(c->d_queries_f16.ptr) + q16_bytes / 2, (int64_t)nq * c->dim, c->stream);
@@ -1234,7 +1252,10 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   filt.qt = qt;
   filt.nq = nq;
   filt.nq_pad = nq_pad;
-  filt.k = KC;
+  filt.k = small ? KC : k;  // the wide tile ranks by the caller's k and keeps the band below it
+  filt.band = small ? nullptr : d_band;
+  filt.band_cnt = small ? nullptr : d_band_cnt;
+  filt.overflow = small ? nullptr : d_overflow;
   filt.index_base = index_base;
   filt.kernel_min_score = (min_score > 0.0f) ? 0.0f : min_score;  // the per-query relaxed thresholds (floor) do the filtering; NaN stays NaN
   filt.floor = d_floor;
@@ -1245,8 +1266,9 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   if (int rc = run_tile_ladder(c, filt, reinterpret_cast<u64_t*>(c->d_approx.ptr), nullptr)) return rc;
   {
     Timed t(c, TAVB_KERNEL_RESCORE);
-    hipError_t e = tavb::launch_rescore(c->corpus, f32c, c->dim, index_base, d_q, reinterpret_cast<const u64_t*>(c->d_approx.ptr), d_delta, min_score,
-                                        nq, k, d_out, d_nflag, d_flagged, c->stream);
+    hipError_t e = tavb::launch_rescore(c->corpus, f32c, c->dim, index_base, d_q, reinterpret_cast<const u64_t*>(c->d_approx.ptr), KC,
+                                        small ? nullptr : d_band_cnt, small ? nullptr : d_overflow, d_delta, min_score, nq, k, d_out, d_nflag, d_flagged,
+                                        c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "rescore launch failed: %s", hipGetErrorString(e));
     char* fb = reinterpret_cast<char*>(c->d_fb_queries.ptr);
     float* fb_thr = reinterpret_cast<float*>(fb + (size_t)2 * cap * c->dim * 2);
@@ -1281,10 +1303,11 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   bool uniform_thr = true;
   for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (min_scores[i] == min_scores[0]);
   const bool f16c = (c->dtype == TAVB_F16);
-  // the filter keeps 64 candidates per query: k up to 48 leaves the slack the completeness proof needs
-  bool wide = (f16c || c->f32_shadow) && c->corpus && nq >= c->mfma_min_batch && uniform_thr && tavb::mfma_supported(c->dim, 64) && k <= 48 &&
+  // the wide tile keeps a band below the k-th best (any k the tiles serve: the reference's max_matches = 50, convsettings.py:61-63, included)
+  bool wide = (f16c || c->f32_shadow) && c->corpus && nq >= c->mfma_min_batch && uniform_thr && tavb::mfma_supported(c->dim, k) &&
               c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c);
   // f32_shadow = 2: smaller batches (and single queries) on big fp32 corpora filter on the shadow too, with the 32/64-query tile
+  // (it keeps the best 64 candidates per query: k up to 48 leaves the slack the completeness test needs)
   bool shadow_small = !wide && !f16c && c->f32_shadow >= 2 && c->corpus && nq <= 64 && uniform_thr && tavb::mfma_supported(c->dim, 64) && k <= 48 &&
                       tavb::skinny_supported(c->dim, k, false) && (int64_t)c->rows * c->dim * 4 >= c->f32_shadow_min_bytes;
   if ((wide || shadow_small) && !f16c) {  // fp32 corpus: the filter needs the fp16 shadow; without the memory for it the fp32 kernels serve the batch

@@ -74,6 +74,8 @@ struct MfmaDeviceParams {
   float min_score;
   const float* thr_in;  // optional [nq_padded] admission thresholds from a sample pass (exclusive bound)
   const int* active;    // optional: number of live queries, read on the device; query tiles past it return at once
+  const float* band;    // 128/256-query tile, optional [nq_padded]: keep every key within band[q] below the k-th best (band selection)
+  int* overflow;        // ... [nq_padded]: set to 1 for a query whose band did not fit a candidate buffer (the caller re-runs it exactly)
 };
 
 // Pin a wave-uniform pointer into SGPRs.  Without this the compiler strength-reduces the eight
@@ -196,6 +198,93 @@ __device__ __forceinline__ int compact_to_kth(u64* buf, int n, int k, int lane, 
     base += __popcll(m);
   }
   *kth_score = __uint_as_float(t);
+  return base;
+}
+
+// Score bits of the BAND cut that goes with a k-th best score `t_bits`: a key is kept when its score bits are >= the result.
+// cut = t - band, rounded DOWN one more ulp (the subtraction rounds to nearest); 0 = keep everything (band wider than the score,
+// or infinite: nothing can be ruled out).
+__device__ __forceinline__ uint32_t band_cut_bits(uint32_t t_bits, float band) {
+  const float c = __uint_as_float(t_bits) - band;
+  if (!(c > 0.0f)) return 0u;
+  const uint32_t b = __float_as_uint(c);
+  return b > 0u ? b - 1u : 0u;
+}
+
+// Band compaction of one query's candidate buffer (the 128/256-query tile as an exact FILTER, tavb_rescore.hip): keep every key
+// whose score is within `band` (= 2 delta_q, the filter's rigorous error bound both ways) of the k-th best score of the buffer --
+// all of them, not a fixed number -- because exactly those rows can still be among the query's exact top k.  On ordinary data
+// that is k + a handful; on clustered data (near-duplicate rows around rank k) it is the cluster, whatever its size, as long as
+// it fits: when more than `limit` keys would stay, the buffer is cut to its strict best k (by key: smaller ordinal wins ties)
+// and *overflowed is set -- the query's result is then not provably complete and the caller re-runs it on the exact tile.
+// Returns the number of keys kept; *thr_excl = the exclusive admission bound that goes with the cut (score > *thr_excl), or
+// -inf when everything qualifies.  One wave; wave-uniform arguments.
+template <int CAPACITY>
+__device__ __forceinline__ int compact_to_band(u64* buf, int n, int k, int lane, float band, int limit, float* thr_excl, bool* overflowed) {
+  constexpr int PER = CAPACITY / 64;
+  u64 key[PER];
+  uint32_t sc[PER];
+  uint32_t mx = 0u, mn_inv = 0u;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int idx = j * 64 + lane;
+    key[j] = (idx < n) ? buf[idx] : 0ull;
+    sc[j] = (uint32_t)(key[j] >> 32);
+    mx = max(mx, sc[j]);
+    if (key[j] != 0ull) mn_inv = max(mn_inv, ~sc[j]);
+  }
+  *overflowed = false;
+  *thr_excl = -__builtin_inff();
+  if (n <= k) return n;
+  mx = wave_max_u32(mx, lane);
+  const uint32_t mn = ~wave_max_u32(mn_inv, lane);
+  auto count_ge = [&](uint32_t t) {
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) c += __popcll(__builtin_amdgcn_ballot_w64(key[j] != 0ull && sc[j] >= t));
+    return c;
+  };
+  uint32_t t = mn;  // every key is >= mn: count = n > k
+  if (mx != mn) {
+    const int top = 31 - __builtin_clz(mx ^ mn);
+    t = (top == 31) ? 0u : (mx & ~((2u << top) - 1u));  // the common leading bits
+    for (int b = top; b >= 0; --b) {
+      const uint32_t trial = t | (1u << b);
+      if (count_ge(trial) >= k) t = trial;
+    }
+  }
+  // t = the k-th best score
+  uint32_t cut = band_cut_bits(t, band);
+  uint32_t t_lo = 0u;
+  if (count_ge(cut) > limit) {  // the band does not fit: strict best k (ties at t cut by ordinal, the low word: bigger = smaller ordinal)
+    *overflowed = true;
+    cut = t;
+    int above = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) above += __popcll(__builtin_amdgcn_ballot_w64(key[j] != 0ull && sc[j] > t));
+    if (count_ge(t) > k + 32) {
+      const int need = k - above;  // >= 1 of the tied keys are still needed
+      for (int b = 31; b >= 0; --b) {
+        const uint32_t trial = t_lo | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) c += __popcll(__builtin_amdgcn_ballot_w64(sc[j] == t && key[j] != 0ull && (uint32_t)key[j] >= trial));
+        if (c >= need) t_lo = trial;
+      }
+    }
+  }
+  int base = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const bool keep = key[j] != 0ull && (sc[j] > cut || (sc[j] == cut && (uint32_t)key[j] >= t_lo));
+    const u64 m = __builtin_amdgcn_ballot_w64(keep);
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep) buf[pos] = key[j];
+    base += __popcll(m);
+  }
+  // rows that come later in this row range have bigger ordinals than everything kept: at a strict cut a tie at t loses (score > t);
+  // at a band cut every score >= cut stays welcome (score > the float just below cut)
+  *thr_excl = *overflowed ? __uint_as_float(t) : (cut > 0u ? __uint_as_float(cut - 1u) : -__builtin_inff());
   return base;
 }
 
@@ -591,11 +680,15 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
         const int n = cnt_lds[q];
         if (n > CAPW - BM6) {
           u64* buf = my_cand + (size_t)q * CAPW;
-          float kth_score;
-          const int kept = compact_to_kth<CAPW>(buf, n < CAPW ? n : CAPW, p.k, lane_e, &kth_score);
+          const int qg = qtile * BN + q;  // (a padding query admits nothing: never here)
+          const float band = p.band ? p.band[qg] : 0.0f;
+          float thr_excl;
+          bool over;
+          const int kept = compact_to_band<CAPW>(buf, n < CAPW ? n : CAPW, p.k, lane_e, band, CAPW - BM6 - 64, &thr_excl, &over);
           if (lane_e == 0) {
             cnt_lds[q] = kept;
-            if (kept >= p.k && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
+            if (thr_excl > thr_lds[q]) thr_lds[q] = thr_excl;
+            if ((over || n > CAPW) && p.overflow) p.overflow[qg] = 1;  // (n > CAPW cannot happen: a tile appends at most BM6 keys)
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -941,38 +1034,41 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
 }
 
 // ---------------------------------------------------------------------------------------------
-// Best k keys of ONE query over the (unsorted) candidate buffers that the workgroups of all row ranges left behind,
-// plus the running top-k of the earlier ladder phases -- and, from them, the admission threshold of the next phase.
+// BAND of ONE query over the (unsorted) candidate buffers that the workgroups of all row ranges left behind, plus the band
+// carried over from the earlier ladder phases -- and, from it, the admission threshold of the next phase.
+// The band = every key whose score is within band[q] (= 2 delta_q, tavb_rescore.hip) of the query's k-th best score: exactly
+// the rows that can still be in the exact top k once the candidates are rescored with the fp32 query.  Its size is whatever the
+// data makes it (k + a few on isotropic data, a whole cluster of near-duplicates on clustered data), up to kc_max; a bigger
+// band is cut to the strict best k and overflow[q] is set (the caller re-runs that query on the exact tile).
 // One workgroup per query, so the selection work of a launch is spread over 1024 workgroups x 256 threads instead of
-// being the serial tail of 256 workgroups (each of which used to sort 256 buffers, 64 per wave, before it could retire).
+// being the serial tail of 256 workgroups.
 //   * the keys of the query (a few hundred after a selective phase; every row of the phase after the cold first one)
-//     stream ONCE through an LDS cache of SEL_CACHE keys.  Whenever the cache is nearly full it is cut down to its exact
-//     best k, and that k-th best -- a valid lower bound on the final one -- filters the keys that follow (expected
-//     survivors on data in random order: k * remaining / seen), so the exact selection always runs on a few thousand
-//     keys held in registers, whatever the total.
-//   * exact selection = bisection on the bit pattern of the score (scores are in [0, 1]: the patterns order like the
-//     floats), block-wide counts per bit, only on the bits in which the keys differ; ties at the k-th best score beyond
-//     what is needed are cut the same way on the ordinal half (smaller ordinal wins): exactly min(k, total) keys.
-//   * the picked keys (<= 64) are sorted by one wave and written best first; thr = just below the k-th best score (or
-//     the caller's floor), the same contract as sample_threshold_kernel.
+//     stream ONCE through an LDS cache of SEL_CACHE keys.  Whenever the cache is nearly full it is cut down to its band,
+//     and that cut -- a valid lower bound on the final one -- filters the keys that follow (expected survivors on data in
+//     random order: k * remaining / seen), so the exact selection always runs on a few thousand keys held in registers.
+//   * exact selection of the k-th best = bisection on the bit pattern of the score (scores are in [0, 1]: the patterns order
+//     like the floats), block-wide counts per bit, only on the bits in which the keys differ; in the strict (overflow) form
+//     ties at the k-th best score are cut the same way on the ordinal half (smaller ordinal wins): exactly min(k, total) keys.
+//   * output: the band's keys, UNSORTED, + their count; thr = just below the band cut (or the caller's floor).
 // ---------------------------------------------------------------------------------------------
 constexpr int SEL_CACHE = 4096;  // keys of a query held in LDS (32 KiB: four workgroups per CU, so the 1024 queries of a batch are all resident at
                                  // once -- the streaming is latency-bound; 8192 keys / two workgroups per CU: 0.53 ms per cfg3 batch instead of 0.29)
 constexpr int SEL_PER = SEL_CACHE / 256;
 
-__global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict__ cand, const int* __restrict__ counts, int n_splits, int nq_padded, int k,
-                                                          const u64* __restrict__ carried, const float* __restrict__ floor, u64* __restrict__ out,
-                                                          float* __restrict__ thr_out) {
+__global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict__ cand, const int* __restrict__ counts, int n_splits, int nq_padded, int k,
+                                                          int kc_max, const u64* __restrict__ carried, const int* __restrict__ carried_cnt,
+                                                          const float* __restrict__ floor, const float* __restrict__ band, u64* __restrict__ out,
+                                                          int* __restrict__ out_cnt, float* __restrict__ thr_out, int* __restrict__ overflow) {
   extern __shared__ __align__(16) unsigned char sel_smem[];
   u64* cache = reinterpret_cast<u64*>(sel_smem);  // [SEL_CACHE]
-  __shared__ int off[260];  // exclusive prefix of the per-split counts (+ the carried list as one more "split")
+  __shared__ int off[260];  // exclusive prefix of the per-split counts (+ the carried band as one more "split")
   __shared__ float red[4];
-  __shared__ u64 picked[64];
   __shared__ int n_picked, n_cached;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x;
   const int n_src = n_splits + (carried != nullptr ? 1 : 0);  // <= 257
+  const float band_q = band ? band[q] : 0.0f;
 
   auto block_sum = [&](int v) -> int {  // exact: counts stay far below 2^24
     const float w = wave_sum((float)v);
@@ -985,7 +1081,7 @@ __global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict_
   // ---- flat order of the query's keys: source s holds count(s) keys at flat positions off[s] .. off[s+1)
   __shared__ int cnt_of[260];
   for (int sp = tid; sp < n_src; sp += 256)  // (n_splits <= 256: one load per thread, all in flight at once)
-    cnt_of[sp] = (sp < n_splits) ? counts[(size_t)sp * nq_padded + q] : k;  // buffers are laid out [row range][padded query] whatever the tile width
+    cnt_of[sp] = (sp < n_splits) ? counts[(size_t)sp * nq_padded + q] : carried_cnt[q];  // buffers are laid out [row range][padded query] whatever the tile width
   if (tid == 0) n_picked = 0;
   __syncthreads();
   for (int sp = tid; sp <= n_src; sp += 256) {
@@ -1002,21 +1098,30 @@ __global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict_
       if (off[mid] <= flat) lo = mid; else hi = mid - 1;
     }
     const int i = flat - off[lo];
-    if (lo == n_splits) return carried[(size_t)q * k + i];  // (empty slots of the carried list are 0: never picked)
+    if (lo == n_splits) return carried[(size_t)q * kc_max + i];
     return cand[((size_t)lo * nq_padded + q) * (size_t)CAPW + i];
   };
 
   u64 key[SEL_PER];
   int n_keys = 0;  // keys in the cache (block-uniform)
-  // exact (t_hi, t_lo): the need-th best key among cache[0 .. n) is the smallest key with score > t_hi or (score == t_hi and low >= t_lo);
-  // returns false when n < need (everything is wanted)
-  auto kth_of_cache = [&](int n, int need, uint32_t* t_hi_out, uint32_t* t_lo_out) -> bool {
-    if (n < need) return false;
-    uint32_t mx = 0u, mn_inv = 0u;
+  auto count = [&](auto&& pred) {
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < SEL_PER; ++j) c += (key[j] != 0ull && pred(key[j])) ? 1 : 0;
+    return block_sum(c);
+  };
+  // loads cache[0 .. n) into key[] and finds the exact (t_hi, t_lo): the need-th best key among them is the smallest key with score > t_hi or
+  // (score == t_hi and low >= t_lo) [t_lo only when `strict`]; returns false when n < need (everything is wanted)
+  auto kth_of_cache = [&](int n, int need, bool strict, uint32_t* t_hi_out, uint32_t* t_lo_out) -> bool {
 #pragma unroll
     for (int j = 0; j < SEL_PER; ++j) {
       const int i = tid + 256 * j;
       key[j] = (i < n) ? cache[i] : 0ull;
+    }
+    if (n < need) return false;
+    uint32_t mx = 0u, mn_inv = 0u;
+#pragma unroll
+    for (int j = 0; j < SEL_PER; ++j) {
       const uint32_t sc = (uint32_t)(key[j] >> 32);
       mx = max(mx, sc);
       if (key[j] != 0ull) mn_inv = max(mn_inv, ~sc);
@@ -1031,12 +1136,6 @@ __global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict_
     __syncthreads();
     const uint32_t mn = ~max(max(__float_as_uint(red[0]), __float_as_uint(red[1])), max(__float_as_uint(red[2]), __float_as_uint(red[3])));
     __syncthreads();
-    auto count = [&](auto&& pred) {
-      int c = 0;
-#pragma unroll
-      for (int j = 0; j < SEL_PER; ++j) c += (key[j] != 0ull && pred(key[j])) ? 1 : 0;
-      return block_sum(c);
-    };
     uint32_t t = mn;
     if (mx != mn) {
       const int top = 31 - __builtin_clz(mx ^ mn);
@@ -1046,24 +1145,46 @@ __global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict_
         if (count([&](u64 kk) { return (uint32_t)(kk >> 32) >= trial; }) >= need) t = trial;
       }
     }
-    const int above = count([&](u64 kk) { return (uint32_t)(kk >> 32) > t; });
-    const int ties = count([&](u64 kk) { return (uint32_t)(kk >> 32) == t; });
     uint32_t t_lo = 0u;
-    if (above + ties > need) {  // cut the ties by ordinal (low word: bigger = smaller ordinal)
-      const int need_ties = need - above;
-      for (int b = 31; b >= 0; --b) {
-        const uint32_t trial = t_lo | (1u << b);
-        if (count([&](u64 kk) { return (uint32_t)(kk >> 32) == t && (uint32_t)kk >= trial; }) >= need_ties) t_lo = trial;
+    if (strict) {
+      const int above = count([&](u64 kk) { return (uint32_t)(kk >> 32) > t; });
+      const int ties = count([&](u64 kk) { return (uint32_t)(kk >> 32) == t; });
+      if (above + ties > need) {  // cut the ties by ordinal (low word: bigger = smaller ordinal)
+        const int need_ties = need - above;
+        for (int b = 31; b >= 0; --b) {
+          const uint32_t trial = t_lo | (1u << b);
+          if (count([&](u64 kk) { return (uint32_t)(kk >> 32) == t && (uint32_t)kk >= trial; }) >= need_ties) t_lo = trial;
+        }
       }
     }
     *t_hi_out = t;
     *t_lo_out = t_lo;
     return true;
   };
+  // the cut that goes with the k-th best of the n cached keys (which kth_of_cache leaves in key[]): the band below it, or -- when the
+  // band holds more than `room` keys -- the strict best k; (f_hi, f_lo): keep a key iff score > f_hi or (score == f_hi and low >= f_lo)
+  bool strict = false;  // sticky: once a band did not fit, the query is cut strictly (and flagged)
+  auto cut_of_cache = [&](int n, int room, uint32_t* f_hi, uint32_t* f_lo) -> bool {
+    uint32_t t_hi = 0u, t_lo = 0u;
+    if (!kth_of_cache(n, k, strict, &t_hi, &t_lo)) return false;
+    if (!strict) {
+      const uint32_t cut = band_cut_bits(t_hi, band_q);
+      if (count([&](u64 kk) { return (uint32_t)(kk >> 32) >= cut; }) <= room) {
+        *f_hi = cut;
+        *f_lo = 0u;
+        return true;
+      }
+      strict = true;
+      kth_of_cache(n, k, true, &t_hi, &t_lo);
+    }
+    *f_hi = t_hi;
+    *f_lo = t_lo;
+    return true;
+  };
 
-  // ---- stream the keys through the cache: whenever it is nearly full, it is cut down to its exact best k, and that k-th
-  //      best -- a valid lower bound on the final one -- filters what comes next.  On data in random order the first cut
-  //      is the only one (the filter then passes k * remaining / seen keys); adversarial orders just cut more often.
+  // ---- stream the keys through the cache: whenever it is nearly full, it is cut down to its band, and that cut -- a valid
+  //      lower bound on the final one -- filters what comes next.  On data in random order the first cut is the only one
+  //      (the filter then passes k * remaining / seen keys); adversarial orders just cut more often.
   uint32_t f_hi = 0u, f_lo = 0u;
   bool have_filter = false;
   if (tid == 0) n_cached = 0;
@@ -1073,11 +1194,11 @@ __global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict_
     if (n_cached > SEL_CACHE - 256 * UNR) {  // block-uniform (read after a barrier)
       const int n = n_cached;
       __syncthreads();
-      have_filter = kth_of_cache(n, k, &f_hi, &f_lo);  // n >= k here
+      have_filter = cut_of_cache(n, SEL_CACHE / 4, &f_hi, &f_lo);  // n >= k here
       if (tid == 0) n_cached = 0;
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < SEL_PER; ++j) {  // keep exactly the best k (they sit in this thread's registers)
+      for (int j = 0; j < SEL_PER; ++j) {  // keep the band (the keys sit in this thread's registers)
         const u64 kk = key[j];
         const uint32_t hi = (uint32_t)(kk >> 32);
         if (kk != 0ull && (hi > f_hi || (hi == f_hi && (uint32_t)kk >= f_lo))) cache[atomicAdd(&n_cached, 1)] = kk;
@@ -1103,36 +1224,30 @@ __global__ void __launch_bounds__(256) select_topk_kernel(const u64* __restrict_
     __syncthreads();
   }
   n_keys = n_cached;
+  __syncthreads();
   uint32_t t_hi = 0u, t_lo = 0u;
-  const bool enough = kth_of_cache(n_keys, k, &t_hi, &t_lo);
-  // ---- pick (exactly min(k, n_keys) keys), sort, write
+  const bool enough = cut_of_cache(n_keys, kc_max, &t_hi, &t_lo);  // (fewer than k keys: all of them are the band; key[] is loaded either way)
+  // ---- write the band (unsorted) and its size
 #pragma unroll
   for (int j = 0; j < SEL_PER; ++j) {
-    const u64 kk = key[j];  // kth_of_cache left cache[tid + 256 j] here (when it ran); reload otherwise
-    const int i = tid + 256 * j;
-    const u64 kv = enough ? kk : ((i < n_keys) ? cache[i] : 0ull);
+    const u64 kv = key[j];
     const uint32_t hi = (uint32_t)(kv >> 32);
     const bool take = kv != 0ull && (!enough || hi > t_hi || (hi == t_hi && (uint32_t)kv >= t_lo));
     if (take) {
       const int idx = atomicAdd(&n_picked, 1);
-      if (idx < 64) picked[idx] = kv;
+      if (idx < kc_max) out[(size_t)q * kc_max + idx] = kv;
     }
   }
   __syncthreads();
-  if (tid < 64) {
-    const int n = n_picked < 64 ? n_picked : 64;
-    const u64 mine = sort64_ascending(tid < n ? picked[tid] : 0ull, tid);
-    const u64 best_first = shfl_u64(mine, 63 - tid);
-    if (tid < k) out[(size_t)q * k + tid] = best_first;
+  if (tid == 0) {
+    out_cnt[q] = n_picked < kc_max ? n_picked : kc_max;
+    if (strict && overflow != nullptr) overflow[q] = 1;
     if (thr_out != nullptr) {
-      const u64 kth = shfl_u64(best_first, k - 1);
       float t = -__builtin_inff();
-      if (kth != 0ull) {
-        const uint32_t bits = (uint32_t)(kth >> 32);
-        t = bits ? __uint_as_float(bits - 1u) : -__builtin_inff();
-      }
+      if (enough && t_hi > 0u) t = __uint_as_float(t_hi - (strict ? 0u : 1u));  // strict: later rows tie-lose (score > t); band: score >= cut
+      if (enough && strict && t_hi == 0u) t = -__builtin_inff();
       if (floor != nullptr && floor[q] > t) t = floor[q];
-      if (tid == 0) thr_out[q] = t;
+      thr_out[q] = t;
     }
   }
 }
@@ -1186,13 +1301,15 @@ size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide) {
   return (size_t)n_splits * (size_t)nq_padded * (wide ? CAPW : CAP) * sizeof(u64);
 }
 
-hipError_t launch_select_topk(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, const unsigned long long* carried,
-                              const float* floor, unsigned long long* out, float* thr_out, hipStream_t stream) {
-  if (nq < 1 || k < 1 || k > 64 || n_splits < 1 || nq_padded < nq) return hipErrorInvalidValue;
+hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
+                              const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
+                              int* out_cnt, float* thr_out, int* overflow, hipStream_t stream) {
+  if (nq < 1 || k < 1 || k > 64 || n_splits < 1 || n_splits > 256 || nq_padded < nq || kc_max < k || kc_max > SEL_CACHE / 4) return hipErrorInvalidValue;
   constexpr int lds = SEL_CACHE * (int)sizeof(u64);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(select_topk_kernel, dim3(nq), dim3(256), lds, stream, cand, counts, n_splits, nq_padded, k, carried, floor, out, thr_out);
+  hipLaunchKernelGGL(select_band_kernel, dim3(nq), dim3(256), lds, stream, cand, counts, n_splits, nq_padded, k, kc_max, carried, carried_cnt, floor, band,
+                     out, out_cnt, thr_out, overflow);
   return hipGetLastError();
 }
 
@@ -1213,6 +1330,8 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.index_base = p.index_base;
   d.min_score = p.min_score;
   d.thr_in = p.thr_in;
+  d.band = p.band;
+  d.overflow = p.overflow;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
   const int bm = BM6;
   d.rows_per_split = ((per + bm - 1) / bm) * bm;

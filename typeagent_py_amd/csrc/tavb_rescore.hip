@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) shadow_convert_kernel(const float* __rest
 // rows_only: the filter multiplies the EXACT queries (split fp16 high + low planes) with the shadow rows: only the rows' rounding counts.
 __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restrict__ q, int nq, int dim, float min_score, int rows_only,
                                                             const float* __restrict__ max_norm_sq /*[2]: max |x16|^2, max |x - x16|^2*/, _Float16* __restrict__ q16,
-                                                            float* __restrict__ delta, float* __restrict__ thr) {
+                                                            float* __restrict__ delta, float* __restrict__ thr, float* __restrict__ band) {
   const int lane = threadIdx.x & 63;
   const int qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (qi >= nq) return;
@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
               1.2e-7f;
     if (!(d < __builtin_inff())) d = __builtin_inff();  // inf / NaN query or corpus: nothing can be proven
     delta[qi] = d;
+    if (band) band[qi] = 2.0f * d;
     float t;
     if (min_score != min_score) {
       t = __builtin_inff();
@@ -147,21 +148,31 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
   }
 }
 
-// One workgroup (4 waves) per query: exact scores of its K' = 64 candidates, exact threshold, sort, completeness test.
+// One workgroup (4 waves) per query: exact scores of its candidates, exact threshold, best k sorted, completeness.
+//   * band mode (cand_cnt != nullptr; the 128/256-query tile): cand_cnt[q] <= kBandMax unsorted candidates = every row whose
+//     approximate score is within 2 delta of the approximate k-th best.  A row outside has approx < a_k - 2 delta, so its exact
+//     score is < a_k - delta <= the exact score of each of the k rows that lead the approximate ranking: it cannot be in the
+//     exact top k.  Complete by construction -- unless overflow[q] says that a band did not fit somewhere on the way.
+//   * cut mode (cand_cnt == nullptr; the 32/64-query tile over an fp16 shadow): the best `stride` = 64 rows by approximate
+//     score, sorted.  Fewer than 64: nothing was cut.  Else a row outside has approx <= a_63, exact <= a_63 + delta, and is
+//     out when that is below the exact k-th best of the candidates (one delta: the exact k-th is known by now).
 template <typename T>
 __global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corpus, int dim, uint32_t index_base,
-                                                      const float* __restrict__ queries, const u64* __restrict__ approx /*[nq, 64]*/,
+                                                      const float* __restrict__ queries, const u64* __restrict__ approx /*[nq, stride]*/, int stride,
+                                                      const int* __restrict__ cand_cnt, const int* __restrict__ overflow,
                                                       const float* __restrict__ delta, float min_score, int k,
                                                       u64* __restrict__ out /*[nq, k]*/, int* __restrict__ n_flagged,
                                                       int* __restrict__ flagged) {
-  __shared__ u64 exact[64];
+  __shared__ u64 exact[kBandMax];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int qi = blockIdx.x;
-  const u64* cand = approx + (size_t)qi * 64;
+  const u64* cand = approx + (size_t)qi * stride;
   const float* q = queries + (size_t)qi * dim;
   const int n8 = dim / 8;
-  for (int c = wave; c < 64; c += 4) {
+  int n_cand = cand_cnt ? cand_cnt[qi] : stride;
+  if (n_cand > kBandMax) n_cand = kBandMax;
+  for (int c = wave; c < n_cand; c += 4) {
     const u64 key = cand[c];  // wave-uniform
     u64 out_key = 0ull;
     if (key != 0ull) {
@@ -195,23 +206,35 @@ __global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corp
       }
       dot = wave_sum(dot);
       const float s = cosine_to_score(dot);
-      if (s >= min_score) out_key = make_key(s, ord);  // NaN fails, like numpy's >=
+      if (s == s) out_key = make_key(s, ord);  // a NaN score ranks nowhere (numpy's >= drops it)
     }
     if (lane == 0) exact[c] = out_key;
   }
   __syncthreads();
   if (wave != 0) return;
-  u64 mine = sort64_ascending(exact[lane], lane);  // lane 63 = best
-  const u64 best_first = shfl_u64(mine, 63 - lane);
-  if (lane < k) out[(size_t)qi * k + lane] = best_first;
+  // best 64 of the exact keys, sorted best first (rank r in lane r)
+  WaveTopK<1> best;
+  best.clear();
+  for (int off = 0; off < n_cand; off += 64) {
+    WaveTopK<1> chunk;
+    chunk.key[0] = sort64_ascending((off + lane < n_cand) ? exact[off + lane] : 0ull, lane);  // ascending == "reversed best-first"
+    best.merge_reversed(chunk, lane);
+  }
+  const u64 mine = best.key[0];
+  const float my_score = __uint_as_float((uint32_t)(mine >> 32));
+  if (lane < k) out[(size_t)qi * k + lane] = (mine != 0ull && my_score >= min_score) ? mine : 0ull;  // sorted by score: the rows that fail are a tail
   // completeness of the candidate set
-  const u64 a_last = cand[63];
   bool ok = true;
-  if (a_last != 0ull) {  // 64 candidates: the set was cut
-    const float a63 = __uint_as_float((uint32_t)(a_last >> 32));
-    const float ak = __uint_as_float((uint32_t)(cand[k - 1] >> 32));
-    const float d = delta[qi];
-    ok = (a63 < ak - 2.0f * d);  // false for d = inf / NaN
+  if (cand_cnt != nullptr) {
+    ok = (overflow[qi] == 0);
+  } else {
+    const u64 a_last = cand[stride - 1];
+    if (a_last != 0ull) {  // the set was cut
+      const float a_cut = __uint_as_float((uint32_t)(a_last >> 32));
+      const u64 kth = readlane_u64(mine, k - 1);
+      const float e_k = __uint_as_float((uint32_t)(kth >> 32));
+      ok = (kth != 0ull) && (a_cut + delta[qi] < e_k);  // false for delta = inf
+    }
   }
   if (!ok && lane == 0) {
     const int slot = atomicAdd(n_flagged, 1);
@@ -281,21 +304,23 @@ hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void
 }
 
 hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
-                                float* thr, hipStream_t stream) {
+                                float* thr, float* band, hipStream_t stream) {
   hipLaunchKernelGGL(query_prepare_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, q, nq, dim, min_score, rows_only ? 1 : 0, max_norm_sq,
-                     reinterpret_cast<_Float16*>(q16), delta, thr);
+                     reinterpret_cast<_Float16*>(q16), delta, thr, band);
   return hipGetLastError();
 }
 
 hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
-                          const float* delta, float min_score, int nq, int k, unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream) {
+                          int stride, const int* cand_cnt, const int* overflow, const float* delta, float min_score, int nq, int k,
+                          unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream) {
+  if (stride < 1 || stride > kBandMax || k < 1 || k > 64 || (cand_cnt != nullptr && overflow == nullptr)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, stream, n_flagged);
   if (f32_rows)
     hipLaunchKernelGGL(rescore_kernel<float>, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const float*>(corpus), dim, index_base, queries, approx,
-                       delta, min_score, k, out, n_flagged, flagged);
+                       stride, cand_cnt, overflow, delta, min_score, k, out, n_flagged, flagged);
   else
     hipLaunchKernelGGL(rescore_kernel<_Float16>, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(corpus), dim, index_base, queries,
-                       approx, delta, min_score, k, out, n_flagged, flagged);
+                       approx, stride, cand_cnt, overflow, delta, min_score, k, out, n_flagged, flagged);
   return hipGetLastError();
 }
 
