@@ -570,6 +570,9 @@ def headline_line(ctx: Ctx, rec: dict, name: str, wl: dict, scaling: str, sub: d
         out["parity"] = rec["parity"]
     if "host_buffer_form" in rec:
         out["host_buffer_form"] = rec["host_buffer_form"]  # PCIe-inclusive rate of the same batch (never `value`)
+    for key in ("query_batches_in_rotation", "flagged_queries_per_batch", "flagged_fraction"):
+        if key in rec:
+            out[key] = rec[key]
     if scaling == "weak" and ctx.world >= 1:
         out["row_queries_per_sec"] = rec["queries_per_sec"] * wl["rows_total"]
     if sub:

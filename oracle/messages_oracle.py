@@ -60,3 +60,13 @@ def memory_messages_from_hits(hits: Sequence[tuple[int, float]], position_to_msg
         else:
             best[msg] = max(score, best[msg])
     return sorted(best.items(), key=lambda t: t[1], reverse=True)
+
+
+def memory_lookup_in_subset_by_embedding(lookup_in_subset, embedding, position_to_msg, ordinals_to_search, max_matches=None, threshold_score=None):
+    """storage/memory/messageindex.py:173-183 `lookup_in_subset_by_embedding`: the caller's MESSAGE ordinals are handed to
+    `TextToTextLocationIndex.lookup_in_subset_by_embedding` (knowpro/textlocindex.py:164-177), which passes them on as ROW ordinals of
+    the VectorBase (`fuzzy_lookup_embedding_in_subset`, vectorbase.py:203-230) and maps each hit row to its text location -- so with
+    several chunks per message the rows searched are rows[ordinal], not the chunks of message `ordinal` -- then
+    `to_scored_message_ordinals` (:185-207).  `lookup_in_subset(embedding, rows, max_hits, min_score)` -> [(row, score)]."""
+    hits = lookup_in_subset(embedding, list(ordinals_to_search), max_matches, threshold_score)
+    return memory_messages_from_hits(hits, position_to_msg)

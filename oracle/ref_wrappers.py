@@ -11,6 +11,15 @@ dependencies), but these consumer files are valid 3.10 and only need a handful o
     storage/sqlite/messageindex.py   SqliteMessageTextIndex         (top-k THEN filter THEN per-message max, :182-257, 296-326)
     storage/sqlite/reltermsindex.py  SqliteRelatedTermsFuzzy        (sequential `lookup_terms`, :259-271)
 
+and the two memory-provider consumers, which are valid 3.10 except for PEP 695 type-parameter lists on a few `def`s
+(`async def build_message_index[TMessage: IMessage, ...](...)`, messageindex.py:22-25, 73, 96, 116; reltermsindex.py:98-101):
+
+    storage/memory/messageindex.py   MessageTextIndex               (MESSAGE ordinals handed to the subset search as row ordinals, :173-183)
+    storage/memory/reltermsindex.py  TermEmbeddingIndex             (sequential `lookup_terms`, :320-332), RelatedTermsIndex
+
+Those two are executed through `pep695_to_310()`: the type-parameter lists are deleted and `from __future__ import annotations`
+is prepended (so the annotations that name the deleted parameters are never evaluated); every other byte is the reference's.
+
 `load_consumers(vectorbase_module)` executes those files unmodified inside a throw-away `typeagent` package whose
 `typeagent.aitools.vectorbase` IS the given module (the verbatim reference's, or `typeagent_py_amd.vectorbase`) and whose
 other siblings are the minimal stand-ins below.  It is the in-container proof of "drop-in": the same consumer bytes run over
@@ -21,8 +30,10 @@ from __future__ import annotations
 
 import importlib.util
 import os
+import re
 import sys
 import types
+import typing
 from dataclasses import dataclass
 
 import numpy as np
@@ -40,8 +51,23 @@ CONSUMER_FILES = {
 }
 
 
+# executed after pep695_to_310(); loaded in this order, memory/messageindex BEFORE sqlite/messageindex (which imports its base class from it)
+TRANSFORMED_FILES = {
+    "typeagent.storage.memory.messageindex": "storage/memory/messageindex.py",
+    "typeagent.storage.memory.reltermsindex": "storage/memory/reltermsindex.py",
+}
+
+_TYPE_PARAMS = re.compile(r"((?:def|class)\s+\w+)\s*\[[^\]]*\](?=\s*[\(:])")
+
+
+def pep695_to_310(source: str) -> str:
+    """The whole source transform: drop PEP 695 type-parameter lists (`def f[T: X](...)` -> `def f(...)`) and make every
+    annotation lazy.  Nothing else changes -- asserted by the caller (the number of edited lines is checked)."""
+    return "from __future__ import annotations\n" + _TYPE_PARAMS.sub(r"\1", source)
+
+
 def consumers_available() -> bool:
-    return all(os.path.isfile(os.path.join(_SRC, rel)) for rel in CONSUMER_FILES.values())
+    return all(os.path.isfile(os.path.join(_SRC, rel)) for rel in list(CONSUMER_FILES.values()) + list(TRANSFORMED_FILES.values()))
 
 
 # ---- stand-ins for `typeagent.knowpro.interfaces` (only what the five files touch) ---------------------------------
@@ -80,6 +106,9 @@ class Term:
     text: str
     weight: float | None = None
 
+    def serialize(self) -> dict:  # knowpro/interfaces_core.py:399-402 (pydantic, by_alias, exclude_none)
+        return {"text": self.text} if self.weight is None else {"text": self.text, "weight": self.weight}
+
 
 @dataclass
 class Thread:
@@ -103,10 +132,18 @@ def _interfaces_module() -> types.ModuleType:
         ConversationThreadData=_Subscriptable, ThreadDataItem=_Subscriptable, MessageOrdinal=int,
     ).items():
         setattr(m, name, obj)
+    # (typing.Protocol bases: memory/reltermsindex.py:253 declares `class ITermEmbeddingIndex(ITermToRelatedTermsFuzzy, Protocol)`)
     for proto in ("IMessage", "IMessageCollection", "IConversationThreads", "ITermToRelatedTerms", "ITermToRelatedTermsFuzzy", "ITermToRelatedTermsIndex",
-                  "IKnowledgeExtractor", "IStorageProvider"):
-        setattr(m, proto, type(proto, (), {}))
+                  "IKnowledgeExtractor", "IStorageProvider", "IConversation", "IMessageTextIndex", "ITermToSemanticRefIndex"):
+        setattr(m, proto, types.new_class(proto, (typing.Protocol,)))
+    m.SearchTerm = SearchTerm
     return m
+
+
+@dataclass
+class SearchTerm:  # knowpro/interfaces_search.py (only named by memory/reltermsindex.py's resolve_related_terms, off the lookup path)
+    term: Term
+    related_terms: list | None = None
 
 
 def _pkg(name: str) -> types.ModuleType:
@@ -148,23 +185,51 @@ def load_consumers(vectorbase_module: types.ModuleType, keep: bool = False) -> t
         conv.MessageTextIndexSettings = MessageTextIndexSettings
         conv.RelatedTermIndexSettings = RelatedTermIndexSettings
         mods["typeagent.knowpro.convsettings"] = conv
-        memidx = types.ModuleType("typeagent.storage.memory.messageindex")  # PEP 695 syntax at :22 -- only the base class name is needed
-        memidx.IMessageTextEmbeddingIndex = type("IMessageTextEmbeddingIndex", (), {})
-        mods["typeagent.storage.memory.messageindex"] = memidx
+        # siblings memory/reltermsindex.py imports at module level but only uses in resolve_related_terms / dedupe_related_terms
+        # (the query compiler's side of the file: out of scope, never called here)
+        coll = types.ModuleType("typeagent.knowpro.collections")
+        coll.TermSet = type("TermSet", (), {})
+        mods["typeagent.knowpro.collections"] = coll
+        common = types.ModuleType("typeagent.knowpro.common")
+        common.is_search_term_wildcard = lambda search_term: search_term.term.text == "*"  # knowpro/common.py
+        mods["typeagent.knowpro.common"] = common
         schema = types.ModuleType("typeagent.storage.sqlite.schema")  # storage/sqlite/schema.py:193-212 (PEP 695 elsewhere in the file)
         schema.serialize_embedding = lambda e: None if e is None else e.tobytes()
         schema.deserialize_embedding = lambda b: None if b is None else np.frombuffer(b, dtype=np.float32)
         mods["typeagent.storage.sqlite.schema"] = schema
         sys.modules.update(mods)
         ns = types.SimpleNamespace(interfaces=mods["typeagent.knowpro.interfaces"], convsettings=conv)
-        for modname, rel in CONSUMER_FILES.items():
-            spec = importlib.util.spec_from_file_location(modname, os.path.join(_SRC, rel))
-            assert spec is not None and spec.loader is not None
-            mod = importlib.util.module_from_spec(spec)
+        def _exec(modname: str, rel: str, transform) -> types.ModuleType:
+            path = os.path.join(_SRC, rel)
+            mod = types.ModuleType(modname)
+            mod.__file__ = path
+            mod.__package__ = modname.rsplit(".", 1)[0]
             sys.modules[modname] = mod
-            spec.loader.exec_module(mod)  # the reference's bytes, unmodified
-            setattr(ns, modname.rsplit(".", 1)[1] if not modname.endswith("sqlite.messageindex") and not modname.endswith("sqlite.reltermsindex")
-                    else "sqlite_" + modname.rsplit(".", 1)[1], mod)
+            with open(path, encoding="utf-8") as f:
+                source = f.read()
+            if transform is not None:
+                edited = transform(source)
+                # the transform may only shorten `def name[...](` headers: every other line of the reference survives byte for byte
+                kept_lines = set(edited.splitlines())
+                lost = [ln for ln in source.splitlines() if ln not in kept_lines]
+                assert 0 < len(lost) <= 12 and all("[" in ln or ln.strip().endswith(",") or ln.strip() in ("](", "]") for ln in lost), lost
+                source = edited
+            exec(compile(source, path, "exec"), mod.__dict__)  # the reference's bytes
+            return mod
+
+        def _attr(modname: str) -> str:
+            leaf = modname.rsplit(".", 1)[1]
+            if ".sqlite." in modname:
+                return "sqlite_" + leaf
+            if modname in TRANSFORMED_FILES:
+                return "memory_" + leaf
+            return leaf
+
+        order = list(CONSUMER_FILES.items())
+        first_sqlite = next(i for i, (name, _) in enumerate(order) if ".sqlite." in name)
+        order[first_sqlite:first_sqlite] = list(TRANSFORMED_FILES.items())
+        for modname, rel in order:
+            setattr(ns, _attr(modname), _exec(modname, rel, pep695_to_310 if modname in TRANSFORMED_FILES else None))
         done = True
         return ns
     finally:

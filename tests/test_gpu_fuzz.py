@@ -108,5 +108,7 @@ def test_clustered_corpus_batches_against_the_oracle(cluster_rows, nq, k, expect
         vo.check_topk_parity(ref, items, [r.score for r in out[qi]], k, 0.0)
         members = np.flatnonzero(cl == qc[qi])
         assert set(items[: min(k, len(members))]) <= set(members.tolist())  # the best hits are the query's own cluster
-        seq = vb.fuzzy_lookup_embedding(q[qi], max_hits=k, min_score=0.0)  # the single-query kernel: same rows, same order (exact ties by ordinal)
-        assert items == [r.item for r in seq]
+        # the single-query kernel: the same answer up to fp32 near-ties (its summation order differs; rows ~1e-7 apart may swap)
+        seq = vb.fuzzy_lookup_embedding(q[qi], max_hits=k, min_score=0.0)
+        vo.check_topk_parity(ref, [r.item for r in seq], [r.score for r in seq], k, 0.0)
+        np.testing.assert_allclose([r.score for r in out[qi]], [r.score for r in seq], atol=1e-6, rtol=0)

@@ -195,8 +195,8 @@ def test_sqlite_related_terms_and_the_batched_lookup_terms_patch(both, monkeypat
     kept = ref_wrappers.load_consumers(ours, keep=True)
     try:
         report = adapters.install_batched_lookup_terms()
-        assert report["patched"] == ["typeagent.storage.sqlite.reltermsindex.SqliteRelatedTermsFuzzy"]
-        assert "typeagent.storage.memory.reltermsindex" in report["skipped"]  # reported, not swallowed
+        assert report["patched"] == ["typeagent.storage.memory.reltermsindex.TermEmbeddingIndex", "typeagent.storage.sqlite.reltermsindex.SqliteRelatedTermsFuzzy"]
+        assert report["skipped"] == {}
         db = sqlite3.connect(":memory:")
         db.execute(RELATED_TERMS_DDL)
         idx = kept.sqlite_reltermsindex.SqliteRelatedTermsFuzzy(db, settings(kept, dim=12, min_score=0.0, max_matches=4))
@@ -205,6 +205,115 @@ def test_sqlite_related_terms_and_the_batched_lookup_terms_patch(both, monkeypat
         adapters.uninstall_batched_lookup_terms()
         sequential = run(idx.lookup_terms(["apple crumble", "banana loaf", "fig jam"], 3, 0.0))
         assert [[(t.text, t.weight) for t in ts] for ts in batched] == [[(t.text, t.weight) for t in ts] for ts in sequential]
+    finally:
+        adapters.uninstall_batched_lookup_terms()
+        kept.cleanup()
+
+
+def test_memory_message_index_behaves_the_same_and_pins_the_messages_oracle(both):
+    """storage/memory/messageindex.py (the default in-memory provider's MessageTextIndex), executed through the PEP 695 source
+    transform of oracle/ref_wrappers.py: add / lookup by embedding / lookup in subset / serialize -> deserialize, over both
+    classes.  Note :173-183 hands MESSAGE ordinals to `TextToTextLocationIndex.lookup_in_subset_by_embedding`, which uses them as
+    ROW ordinals of the VectorBase (textlocindex.py:164-177): with several chunks per message the subset form searches the wrong
+    rows -- reproduced by both classes, restated by messages_oracle.memory_lookup_in_subset_by_embedding."""
+    v, _ = make_corpus(300, 24, 87)
+    qs = make_queries(5, 24, 88)
+    chunks_per_msg = [1 + (i % 3) for i in range(200)]
+    msgs, pos = [], 0
+    for c in chunks_per_msg:
+        if pos + c > len(v):
+            break
+        msgs.append((_Msg([f"m{len(msgs)}c{j}" for j in range(c)]), list(v[pos : pos + c])))
+        pos += c
+    row_to_msg = [mi for mi, (m, _) in enumerate(msgs) for _ in m.text_chunks]
+    outs = []
+    for ns in both:
+        idx = ns.memory_messageindex.MessageTextIndex(ns.convsettings.MessageTextIndexSettings(settings(ns, dim=24, min_score=0.0)))
+        assert run(idx.is_empty())
+        run(idx.add_messages_starting_at_with_embeddings(0, [m for m, _ in msgs[:90]], [e for _, es in msgs[:90] for e in es]))
+        run(idx.add_messages_starting_at_with_embeddings(90, [m for m, _ in msgs[90:]], [e for _, es in msgs[90:] for e in es]))
+        assert run(idx.size()) == pos
+        with pytest.raises(ValueError):
+            run(idx.add_messages_starting_at_with_embeddings(len(msgs), [msgs[0][0]], []))
+        data = run(idx.serialize())
+        idx2 = ns.memory_messageindex.MessageTextIndex(ns.convsettings.MessageTextIndexSettings(settings(ns, dim=24, min_score=0.0)))
+        run(idx2.deserialize(data))
+        subset = list(range(0, len(msgs), 2))
+        res = []
+        for q in qs:
+            res.append(run(idx.lookup_in_subset_by_embedding(q, subset, 9, 0.0)))
+            res.append(run(idx2.lookup_in_subset_by_embedding(q, [3, 4, 5, 3], 40, 0.0)))
+            res.append(run(idx.lookup_in_subset_by_embedding(q, subset, None, 0.5)))
+            res.append(idx.to_scored_message_ordinals(idx.text_location_index.lookup_by_embedding(q, 12, 0.0)))
+        outs.append(res)
+        if ns is both[0]:
+            vb = idx.text_location_index._embedding_index._vector_base  # (the verbatim class)
+            look_sub = lambda e, rows, k, t: [(s.item, s.score) for s in vb.fuzzy_lookup_embedding_in_subset(e, rows, max_hits=k, min_score=t)]
+            for q in qs:
+                for k, t, sub in ((9, 0.0, subset), (40, 0.0, [3, 4, 5, 3]), (None, 0.5, subset)):
+                    want = run(idx.lookup_in_subset_by_embedding(q, sub, k, t))
+                    got = mo.memory_lookup_in_subset_by_embedding(look_sub, q, row_to_msg, sub, k, t)
+                    assert [(m.message_ordinal, m.score) for m in want] == got
+    for a, b in zip(*outs):
+        same_scored(a, b, lambda x: x.message_ordinal)
+
+
+def test_memory_term_embedding_index_and_the_batched_lookup_terms_patch(both):
+    """storage/memory/reltermsindex.py: TermEmbeddingIndex (add / lookup_term / lookup_terms / serialize -> deserialize) and
+    RelatedTermsIndex over both classes; then `install_batched_lookup_terms()` on the memory class -- the one the default
+    in-memory provider uses (reltermsindex.py:320-332, called from :183-192): same answers as the sequential loop."""
+    terms = ["apple pie", "banana bread", "cherry tart", "apple tart", "banana split", "date square", "elderflower cordial"]
+    probes = ["apple crumble", "banana loaf", "fig jam"]
+    outs = []
+    for ns in both:
+        M = ns.memory_reltermsindex
+        idx = M.TermEmbeddingIndex(settings(ns, dim=12, min_score=0.0, max_matches=4))
+        run(idx.add_terms(terms))
+        run(idx.add_terms([]))
+        with pytest.raises(ValueError):
+            run(idx.add_terms_with_embeddings(["x"], []))
+        seq = run(idx.lookup_terms(probes, 3, 0.0))
+        one = run(idx.lookup_term("cherry cake"))  # defaults from the settings (max_matches=4, min_score=0.0)
+        idx2 = M.TermEmbeddingIndex(settings(ns, dim=12, min_score=0.0, max_matches=4), idx.serialize())
+        seq2 = run(idx2.lookup_terms(probes[:1]))
+        rti = M.RelatedTermsIndex(ns.convsettings.RelatedTermIndexSettings(settings(ns, dim=12, min_score=0.0, max_matches=4)))
+        run(rti.fuzzy_index.add_terms(terms))
+        run(rti.aliases.add_related_term("pie", ns.interfaces.Term("tart", 0.9)))
+        data = run(rti.serialize())
+        rti2 = M.RelatedTermsIndex(ns.convsettings.RelatedTermIndexSettings(settings(ns, dim=12, min_score=0.0, max_matches=4)))
+        run(rti2.deserialize(data))
+        seq3 = run(rti2.fuzzy_index.lookup_terms(probes, 2, 0.0))
+        outs.append((seq + [one] + seq2 + seq3, run(idx.size()), [t.text for t in run(rti2.aliases.lookup_term("pie"))]))
+    (r, rn, ra), (n, nn, na) = outs
+    as_scored = lambda ts: [type("T", (), {"score": t.weight, "text": t.text}) for t in ts]
+    for a, b in zip(r, n):
+        same_scored(as_scored(a), as_scored(b), lambda x: x.text)
+    assert rn == nn == 7 and ra == na == ["tart"]
+
+    import typeagent_py_amd.vectorbase as ours
+    from typeagent_py_amd import adapters
+
+    kept = ref_wrappers.load_consumers(ours, keep=True)
+    try:
+        report = adapters.install_batched_lookup_terms()
+        assert "typeagent.storage.memory.reltermsindex.TermEmbeddingIndex" in report["patched"]
+        idx = kept.memory_reltermsindex.TermEmbeddingIndex(settings(kept, dim=12, min_score=0.0, max_matches=4))
+        run(idx.add_terms(terms))
+        calls = []
+        orig = ours.VectorBase.fuzzy_lookup_embeddings
+        ours.VectorBase.fuzzy_lookup_embeddings = lambda self, *a, **kw: (calls.append(1), orig(self, *a, **kw))[1]
+        try:
+            batched = run(idx.lookup_terms(probes, 3, 0.0))
+            batched_defaults = run(idx.lookup_terms(probes))
+        finally:
+            ours.VectorBase.fuzzy_lookup_embeddings = orig
+        assert len(calls) == 2  # ONE device submission per lookup_terms call
+        adapters.uninstall_batched_lookup_terms()
+        sequential = run(idx.lookup_terms(probes, 3, 0.0))
+        sequential_defaults = run(idx.lookup_terms(probes))
+        flat = lambda res: [[(t.text, t.weight) for t in ts] for ts in res]
+        assert flat(batched) == flat(sequential) and flat(batched_defaults) == flat(sequential_defaults)
+        assert run(idx.lookup_terms([])) == []
     finally:
         adapters.uninstall_batched_lookup_terms()
         kept.cleanup()
