@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define TAVB_ABI_VERSION 1
+/* bumped whenever an entry point, a signature, an option or a kernel id changes incompatibly; the binding refuses a library of another version */
+#define TAVB_ABI_VERSION 3
 
 #define TAVB_OK 0
 #define TAVB_E_INVALID (-1)     /* bad argument */

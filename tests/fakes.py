@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from typeagent_py_amd.embeddings import IEmbedder, NormalizedEmbedding, NormalizedEmbeddings
+from typeagent_py_amd.embeddings import CachingEmbeddingModel, IEmbedder, NormalizedEmbedding, NormalizedEmbeddings  # noqa: F401
 
 
 def _hashish(s: str) -> int:
@@ -48,47 +48,6 @@ class FakeTextEmbedder:
         norms = np.linalg.norm(e, axis=1, keepdims=True).astype(np.float32)
         norms = np.where(norms > 0, norms, np.float32(1.0))
         return (e / norms).astype(np.float32)
-
-
-class CachingEmbeddingModel:
-    """Test double for the provider-side cache that sits between VectorBase and an embedder (the reference keeps one in
-    aitools/embeddings.py:73-114; typeagent's tests look into `_cache` to see what `add_key(..., cache=...)` did).
-    One dict, filled by whatever had to be computed; everything else is a pass-through to the embedder."""
-
-    def __init__(self, embedder: IEmbedder) -> None:
-        self._embedder = embedder
-        self._cache: dict[str, NormalizedEmbedding] = {}
-
-    model_name = property(lambda self: self._embedder.model_name)
-
-    def add_embedding(self, key: str, embedding: NormalizedEmbedding) -> None:
-        self._cache[key] = embedding
-
-    # uncached forms: straight to the embedder
-    async def get_embedding_nocache(self, input: str) -> NormalizedEmbedding:
-        return await self._embedder.get_embedding_nocache(input)
-
-    async def get_embeddings_nocache(self, input: list[str]) -> NormalizedEmbeddings:
-        return await self._embedder.get_embeddings_nocache(input)
-
-    # cached forms: compute what is missing (in one embedder call), remember it, answer from the dict
-    async def _fill(self, keys: list[str]) -> None:
-        missing = list(dict.fromkeys(k for k in keys if k not in self._cache))
-        if len(missing) == 1:
-            self._cache[missing[0]] = await self._embedder.get_embedding_nocache(missing[0])
-        elif missing:
-            rows = await self._embedder.get_embeddings_nocache(missing)
-            self._cache.update(zip(missing, rows))
-
-    async def get_embedding(self, key: str) -> NormalizedEmbedding:
-        await self._fill([key])
-        return self._cache[key]
-
-    async def get_embeddings(self, keys: list[str]) -> NormalizedEmbeddings:
-        if not keys:
-            raise ValueError("Cannot embed an empty list")
-        await self._fill(keys)
-        return np.stack([self._cache[k] for k in keys]).astype(np.float32, copy=False)
 
 
 def create_test_embedding_model(embedding_size: int = 3) -> CachingEmbeddingModel:

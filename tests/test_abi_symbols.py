@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_string_and_host_helpers():
     lib = _native.load_library()
-    assert lib.tavb_version() == 1
+    header = open(os.path.join(ROOT, "include", "tavb.h")).read()
+    assert lib.tavb_version() == _native.ABI_VERSION == int(re.search(r"#define TAVB_ABI_VERSION (\d+)", header).group(1))
     # a failing call sets a readable message and never aborts
     rc = lib.tavb_destroy(None)
     assert rc == 0
@@ -57,3 +58,18 @@ def test_engine_refuses_to_start_without_gpu():
         pytest.skip("a GPU is present")
     with pytest.raises(RuntimeError, match="no HIP device"):
         _native.Engine()
+
+
+def test_a_library_of_another_abi_version_is_refused(tmp_path, monkeypatch):
+    """Round-2 advice: a stale libtavb.so (or one picked through TAVB_LIBRARY) used to fail with an AttributeError at bind time or
+    mis-index the profile slots; now the version is compared first, with a message that says what to do."""
+    import subprocess
+
+    src = tmp_path / "stale.c"
+    src.write_text("int tavb_version(void) { return 1; }\n")
+    so = tmp_path / "libtavb_stale.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "library_path", lambda: str(so))
+    with pytest.raises(RuntimeError, match="C ABI version 1, this binding needs"):
+        _native.load_library()

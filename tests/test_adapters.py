@@ -63,3 +63,42 @@ def test_load_sqlite_embeddings_mirrors_the_reference_reload(tmp_path):
         tv.add_embeddings(None, np.zeros((1, 5), np.float32))
     with pytest.raises(ValueError):
         load_sqlite_embeddings(db, mv, table="x; DROP TABLE y")
+
+
+def test_row_to_message_map_that_grows_with_the_index_is_resnapshotted(monkeypatch):
+    """A caller that keeps ONE list and appends to it as chunks are added (round-2 advice): the adapters used to key the device map on the
+    object's identity alone and then raise 'the row -> message map covers L rows, the index has L+n'; an int64 array edited in place
+    was aliased by the index.  Now: a snapshot (copy), retaken whenever the length changed or the index outgrew it."""
+    from oracle import messages_oracle as mo
+    from tests.fake_engine import FakeEngine
+    from typeagent_py_amd import _native
+    from typeagent_py_amd.adapters import lookup_messages_by_embedding, lookup_messages_in_subset
+
+    FakeEngine.instances = []
+    monkeypatch.setattr(_native, "Engine", FakeEngine)
+    rng = np.random.default_rng(3)
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()))
+    rows = rng.standard_normal((40, 8)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    row_to_msg: list[int] = []
+
+    def check(q):
+        got = lookup_messages_by_embedding(vb, q, row_to_msg, 6, 0.0)
+        hits = [(h.item, h.score) for h in vb.fuzzy_lookup_embedding(q, max_hits=6, min_score=0.0)]
+        assert [(g.item, g.score) for g in got] == mo.sqlite_messages_from_hits(hits, row_to_msg, None, 6)
+        sub = list(range(0, len(vb), 3))
+        got = lookup_messages_in_subset(vb, q, sub, row_to_msg, 4, 0.0)
+        hits = [(h.item, h.score) for h in vb.fuzzy_lookup_embedding_in_subset(q, sub, max_hits=4, min_score=0.0)]
+        assert [(g.item, g.score) for g in got] == mo.memory_messages_from_hits(hits, row_to_msg)[:4]
+
+    vb.add_embeddings(None, rows[:25])
+    row_to_msg.extend(i // 2 for i in range(25))
+    check(rows[3])
+    vb.add_embeddings(None, rows[25:])  # the index grows, the SAME list grows with it
+    row_to_msg.extend(100 + i for i in range(15))
+    check(rows[30])
+    assert FakeEngine.instances[-1].row_messages.tolist() == row_to_msg
+    arr = np.asarray(row_to_msg, dtype=np.int64)
+    vb.set_row_messages(arr)
+    arr[:] = -5  # the caller's array is not the index's
+    assert vb._row_messages.tolist() == row_to_msg

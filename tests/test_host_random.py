@@ -83,3 +83,116 @@ def test_random_history_on_a_fake_engine(monkeypatch, seed):
         elif op == "lookup_only":
             assert len(eng.uploads) == uploads_before  # nothing changed: nothing uploaded
         uploads_before, synced_rows = len(eng.uploads), n
+
+
+def _fresh(monkeypatch, n=50, d=8, seed=1, **kw):
+    FakeEngine.instances = []
+    monkeypatch.setattr(_native, "Engine", FakeEngine)
+    rng = np.random.default_rng(seed)
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), **kw)
+    rows = _unit(rng, n, d)
+    vb.add_embeddings(None, rows)
+    return vb, rows, rng
+
+
+def _answers_for_current_rows(vb, q):
+    live = np.asarray(vb.serialize()).copy()
+    res = vb.fuzzy_lookup_embedding(q, max_hits=5, min_score=0.0)
+    vo.check_topk_parity(vo.scores_full(live, q), [r.item for r in res], [r.score for r in res], 5, 0.0)
+    return res
+
+
+@pytest.mark.parametrize("write", ["row", "element", "slice_of_view", "row_view", "imul", "ufunc_out", "copyto", "fill", "put", "putmask", "sort"])
+def test_writes_through_the_serialized_matrix_reach_the_device_mirror(monkeypatch, write):
+    """serialize() hands out the live matrix like the reference (vectorbase.py:268-271), which always scores the live matrix (:176).
+    Every write numpy can see -- on the array or on views derived from it -- must be answered for on the next lookup, whichever row
+    it touches (the 32-row sampled fingerprint of round 2 missed single rows)."""
+    vb, rows, rng = _fresh(monkeypatch)
+    q = rows[17]
+    first = _answers_for_current_rows(vb, q)
+    assert first[0].item == 17
+    m = vb.serialize()
+    assert isinstance(m, np.ndarray) and m.dtype == np.float32 and m.shape == (50, 8)
+    uploads = len(FakeEngine.instances[-1].uploads)
+    new = _unit(rng, 1, 8)[0]
+    if write == "row":
+        m[17] = new
+    elif write == "element":
+        m[17, 3] = -m[17, 3] - 0.5
+    elif write == "slice_of_view":
+        m[10:20][7] = new
+    elif write == "row_view":
+        row = vb.get_embedding_at(17)
+        row[:] = new
+    elif write == "imul":
+        m *= np.float32(-1.0)
+    elif write == "ufunc_out":
+        np.negative(m, out=m)
+    elif write == "copyto":
+        np.copyto(m, -np.asarray(m))
+    elif write == "fill":
+        m[17:18].fill(0.25)
+    elif write == "put":
+        m.put(np.arange(17 * 8, 18 * 8), new)
+    elif write == "putmask":
+        np.putmask(m, np.broadcast_to(np.arange(50)[:, None] == 17, m.shape), new)
+    elif write == "sort":
+        m.sort(axis=0)
+    after = _answers_for_current_rows(vb, q)
+    assert len(FakeEngine.instances[-1].uploads) > uploads  # the mirror was refreshed
+    assert [(r.item, r.score) for r in after] != [(r.item, r.score) for r in first]
+    # reads do not dirty anything
+    uploads = len(FakeEngine.instances[-1].uploads)
+    _ = vb.serialize().sum(), vb.serialize()[3].copy(), np.linalg.norm(vb.serialize(), axis=1), vb.serialize() @ q, vb.serialize() * 2
+    _answers_for_current_rows(vb, q)
+    assert len(FakeEngine.instances[-1].uploads) == uploads
+    assert type(vb.serialize() * 2) is np.ndarray  # arithmetic gives plain copies
+
+
+def test_raw_writers_use_mark_dirty_and_adopted_matrices_follow_their_watch_mode(monkeypatch):
+    vb, rows, rng = _fresh(monkeypatch)
+    q = rows[5]
+    _answers_for_current_rows(vb, q)
+    raw = np.asarray(vb.serialize())  # a base-class view: numpy no longer tells us about writes (documented residual)
+    raw[5] = -raw[5]
+    stale = vb.fuzzy_lookup_embedding(q, max_hits=1, min_score=0.0)
+    assert stale[0].item == 5  # the mirror is stale ...
+    vb.mark_dirty()  # ... until the writer says so
+    assert _answers_for_current_rows(vb, q)[0].item != 5
+
+    # a matrix the CALLER owns (deserialize keeps it by reference, :287): the same object comes back, edits are watched by fingerprint
+    for mode, single_row_seen in (("sampled", False), ("full", True)):
+        FakeEngine.instances = []
+        other = VectorBase(TextEmbeddingIndexSettings(NullModel()), verify_host=mode)
+        data = _unit(rng, 200, 8)
+        other.deserialize(data)
+        assert other.serialize() is data
+        q2 = data[101].copy()
+        assert other.fuzzy_lookup_embedding(q2, max_hits=1)[0].item == 101
+        data[101] = -data[101]  # one row, not among the 32 sampled ones (rows 0, 6, 12, ... of 200)
+        got = other.fuzzy_lookup_embedding(q2, max_hits=1)[0].item
+        assert (got != 101) == single_row_seen, mode
+        data *= np.float32(-1.0)  # a bulk edit is seen by both
+        res = other.fuzzy_lookup_embedding(q2, max_hits=3)
+        vo.check_topk_parity(vo.scores_full(data, q2), [r.item for r in res], [r.score for r in res], 3, 0.0)
+        # an append moves the index onto its own buffer (the reference's np.append copies too): edits made to `data` BEFORE the append are in
+        data[7] = q2
+        other.mark_dirty() if mode == "sampled" else None
+        other.add_embedding(None, _unit(rng, 1, 8)[0])
+        assert other.serialize() is not data and len(other) == 201
+        assert other.fuzzy_lookup_embedding(q2, max_hits=1)[0].item == 7
+    with pytest.raises(ValueError):
+        VectorBase(TextEmbeddingIndexSettings(NullModel()), verify_host="sometimes")
+
+
+def test_a_serialized_matrix_adopted_by_another_index_is_watched_by_both(monkeypatch):
+    vb, rows, rng = _fresh(monkeypatch)
+    m = vb.serialize()
+    other = VectorBase(TextEmbeddingIndexSettings(NullModel()))
+    other.deserialize(m)  # e.g. a copy of an index built from its serialized form, by reference (:287)
+    assert other.serialize() is m
+    q = rows[30].copy()
+    assert vb.fuzzy_lookup_embedding(q, max_hits=1)[0].item == 30 and other.fuzzy_lookup_embedding(q, max_hits=1)[0].item == 30
+    m[30] = -m[30]
+    m[2] = q
+    assert vb.fuzzy_lookup_embedding(q, max_hits=1)[0].item == 2 and other.fuzzy_lookup_embedding(q, max_hits=1)[0].item == 2

@@ -221,3 +221,59 @@ def test_group_random_history_on_fake_devices(fake_group, seed):
         want = vo.lookup(rows, q, 5, 0.0, predicate=lambda i: i % 2 == 0)  # (the predicate branch IS stable: ties by ascending ordinal, vectorbase.py:200)
         assert [r.item for r in pred] == [i for i, _ in want]
     np.testing.assert_array_equal(vb.serialize(), rows)
+
+
+def test_group_growing_from_a_small_seed_reshards_a_logarithmic_number_of_times(fake_group):
+    """Round-2 advice: a group first populated with a few rows fixed block = ceil(n / g); every re-shard then picked a block only
+    (1 + 1/g) times bigger -- ~g ln(N) full re-uploads.  A replacement layout now at least doubles the block."""
+    d, g = 8, 8
+    v, q = make_corpus(6000, d, 41)
+    vb = _vb(list(range(g)))
+    vb.add_embeddings(None, v[:16])
+    vb.fuzzy_lookup_embedding(q, max_hits=1)
+    full_uploads = moved = 0
+    e0 = vb.engine.engines[0]
+    seen = len(e0.uploads)
+    n = 16
+    while n < 6000:
+        step = min(37, 6000 - n)
+        vb.add_embeddings(None, v[n : n + step])
+        n += step
+        vb.fuzzy_lookup_embedding(q, max_hits=1)
+        if len(e0.uploads) > seen:  # shard 0 is only ever written by a (re-)shard from row 0
+            full_uploads += len(e0.uploads) - seen
+            moved += n
+            seen = len(e0.uploads)
+    assert full_uploads <= 10, full_uploads  # log2(6000 / 16) ~ 8.6 (the old rule: ~40)
+    assert moved <= 3 * 6000, moved
+    _check(vb, v, q, 10, 0.0)
+
+
+def test_group_lookups_from_several_threads_do_not_mix_their_results(fake_group):
+    import threading
+
+    v, _ = make_corpus(2000, 16, 51)
+    qs = make_queries(40, 16, 52)
+    vb = _vb([0, 1, 2])
+    vb.add_embeddings(None, v)
+    want = [[i for i, _ in vo.lookup(v, q, 5, 0.0)] for q in qs]
+    errors = []
+
+    def worker(lo):
+        try:
+            for rep in range(20):
+                for qi in range(lo, 40, 4):
+                    if rep % 2:
+                        got = vb.fuzzy_lookup_embedding(qs[qi], max_hits=5, min_score=0.0)
+                    else:
+                        got = vb.fuzzy_lookup_embeddings(qs[qi : qi + 1], max_hits=5, min_score=0.0)[0]
+                    assert [r.item for r in got] == want[qi], qi
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:1]

@@ -13,7 +13,7 @@ over the GPUs of a node.  Host code is Python over a ctypes C ABI
 contract uses; Python cannot import a hyphenated name, hence the alias.)
 """
 
-from .embeddings import IEmbedder, IEmbeddingModel, NormalizedEmbedding, NormalizedEmbeddings
+from .embeddings import CachingEmbeddingModel, IEmbedder, IEmbeddingModel, NormalizedEmbedding, NormalizedEmbeddings
 from .vectorbase import (
     DEFAULT_MIN_SCORE,
     MODEL_DEFAULT_MIN_SCORES,
@@ -26,6 +26,7 @@ from .vectorbase import (
 from .install import install, uninstall
 
 __all__ = [
+    "CachingEmbeddingModel",
     "DEFAULT_MIN_SCORE",
     "IEmbedder",
     "IEmbeddingModel",

@@ -16,6 +16,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 
 import numpy as np
 
+ABI_VERSION = 3  # include/tavb.h TAVB_ABI_VERSION this binding was written against
 TAVB_F32 = 0
 TAVB_F16 = 1
 MAX_FUSED_K = 256
@@ -100,6 +101,15 @@ def load_library(preload_torch: bool = True):
             except Exception:  # pragma: no cover - torch is part of the image
                 pass
         lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        try:
+            lib.tavb_version.restype = c_int
+            lib.tavb_version.argtypes = []
+            found = int(lib.tavb_version())
+        except AttributeError as exc:
+            raise RuntimeError(f"{path} is not a libtavb build (no tavb_version): rebuild it with `make -C typeagent_py_amd/csrc`") from exc
+        if found != ABI_VERSION:
+            raise RuntimeError(f"{path} implements C ABI version {found}, this binding needs {ABI_VERSION} (include/tavb.h): "
+                               "a stale build -- run `make -C typeagent_py_amd/csrc` (or check TAVB_LIBRARY)")
         for name, restype, argtypes in _SIGNATURES:
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = restype

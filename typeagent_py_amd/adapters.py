@@ -111,6 +111,17 @@ def best_score_per_message(
     return out if max_matches is None else out[:max_matches]
 
 
+def _ensure_row_messages(vector_base: VectorBase, row_to_message) -> None:
+    """Hand `row_to_message` to the index unless it already holds a snapshot of this very object that still covers it: the index
+    keeps a COPY (a list the caller keeps appending to, or an array edited in place, must not alias the device map), so the
+    snapshot is retaken when the object is another one, when its length changed, or when the index has outgrown it.  A caller that
+    rewrites entries of a same-length map in place calls `vector_base.set_row_messages(map)` itself afterwards."""
+    same = getattr(vector_base, "_row_messages_src", None) is row_to_message
+    held = getattr(vector_base, "_row_messages", None)
+    if not same or held is None or len(held) != len(row_to_message) or len(held) < len(vector_base):
+        vector_base.set_row_messages(row_to_message)
+
+
 def lookup_messages_by_embedding(
     vector_base: VectorBase,
     embedding,
@@ -128,8 +139,7 @@ def lookup_messages_by_embedding(
     arbitrary callable -> lookup on the device, aggregation on the host."""
     if accept is None or not callable(accept):
         if not callable(row_to_message):
-            if getattr(vector_base, "_row_messages_src", None) is not row_to_message:
-                vector_base.set_row_messages(row_to_message)
+            _ensure_row_messages(vector_base, row_to_message)
             return vector_base.lookup_messages_by_embedding(embedding, max_matches, threshold_score, accept_ordinals=accept)
         if accept is not None:
             members = set(int(x) for x in accept)
@@ -150,8 +160,7 @@ def lookup_messages_in_subset(
     a true subset gather on the device, then best score per message and the cut (one device submission when
     `row_to_message` is an array)."""
     if not callable(row_to_message):
-        if getattr(vector_base, "_row_messages_src", None) is not row_to_message:
-            vector_base.set_row_messages(row_to_message)
+        _ensure_row_messages(vector_base, row_to_message)
         out = vector_base.lookup_messages_in_subset_by_embedding(embedding, list(rows_of_subset), max_matches, threshold_score)
         return out if max_matches is None else out[:max_matches]
     hits = vector_base.fuzzy_lookup_embedding_in_subset(embedding, list(rows_of_subset), max_hits=max_matches, min_score=threshold_score)

@@ -1072,7 +1072,8 @@ struct TileRun {
   // 128/256-query tile only: band selection (tavb_mfma.hip::select_band_kernel).  d_out then receives [nq, kBandMax] unsorted keys,
   const float* band;      // device [nq_pad]: width of the band below the k-th best
   int* band_cnt;          // device [nq]: out, keys per query in d_out
-  int* overflow;          // device [nq_pad]: out (zeroed by the caller), 1 where a band did not fit
+  unsigned* lost;         // device [nq_pad]: scratch (zeroed by the caller), score level below which a query lost band rows
+  int* verdict;           // device [nq]: out, 1 where the band handed over is not provably complete
 };
 
 // Threshold ladder.  The corpus is scanned in phases of growing size -- the first `mfma_sample_rows` rows, then
@@ -1141,7 +1142,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
     if (int rc = c->d_sample_keys.reserve((size_t)2 * nq * kc * sizeof(u64_t) + (size_t)2 * nq * sizeof(int))) return rc;  // running selection: two copies (ping-pong) + counts
   }
   p.band = r.band;
-  p.overflow = r.overflow;
+  p.lost = r.lost;
   const size_t row_bytes = (size_t)c->dim * (r.q32 ? 4 : 2);  // of the corpus operand
   for (int ph = 0; ph < n_phases; ++ph) {
     const bool last = (ph == n_phases - 1);
@@ -1174,7 +1175,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
       if (!last) TAVB_HIP(hipMemsetAsync(c->d_thr.ptr, 0xFF, (size_t)r.nq_pad * sizeof(float), c->stream));  // padding queries: NaN bits, ignored by `>`
       hipError_t e = tavb::launch_select_band(pp.workspace, pp.counts, pp.n_splits, nq, r.nq_pad, k, kc, carried ? run_in : nullptr, carried ? cnt_in : nullptr,
                                               r.floor, r.band, last ? d_out : run_out, last ? r.band_cnt : cnt_out,
-                                              last ? nullptr : reinterpret_cast<float*>(c->d_thr.ptr), r.overflow, c->stream);
+                                              last ? nullptr : reinterpret_cast<float*>(c->d_thr.ptr), r.lost, last ? r.verdict : nullptr, c->stream);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "select launch failed: %s", hipGetErrorString(e));
     } else if (last) {
       Timed t(c, r.active ? TAVB_KERNEL_RESCORE : TAVB_KERNEL_MERGE);
@@ -1206,7 +1207,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   const int cap = ((nq + 63) / 64) * 64;  // slots of the work list of queries that need the exact tile
   const size_t q16_bytes = (size_t)nq_pad * c->dim * 2 * (small ? 2 : 1);  // small: high and low plane
   if (int rc = c->d_queries_f16.reserve(q16_bytes)) return rc;
-  if (int rc = c->d_delta.reserve((size_t)nq_pad * 5 * sizeof(float))) return rc;  // delta, the relaxed thresholds, the band widths; band counts, overflow flags
+  if (int rc = c->d_delta.reserve((size_t)nq_pad * 6 * sizeof(float))) return rc;  // delta, the relaxed thresholds, the band widths; band counts, lost levels, verdicts
   if (int rc = c->d_approx.reserve((size_t)nq * KC * sizeof(u64_t))) return rc;
   if (int rc = c->d_flag.reserve((size_t)(cap + 64) * sizeof(int))) return rc;
   if (int rc = c->d_fb_queries.reserve((size_t)2 * cap * c->dim * 2 + (size_t)cap * sizeof(float))) return rc;
@@ -1216,7 +1217,8 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   float* d_floor = d_delta + nq_pad;
   float* d_band = d_floor + nq_pad;
   int* d_band_cnt = reinterpret_cast<int*>(d_band + nq_pad);
-  int* d_overflow = d_band_cnt + nq_pad;
+  unsigned* d_lost = reinterpret_cast<unsigned*>(d_band_cnt + nq_pad);
+  int* d_verdict = d_band_cnt + 2 * nq_pad;
   int* d_nflag = reinterpret_cast<int*>(c->d_flag.ptr);
   int* d_flagged = d_nflag + 64;
   {
@@ -1237,7 +1239,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
       c->norm_rows = c->rows;
     }
     TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16_bytes, c->stream));  // padding queries
-    TAVB_HIP(hipMemsetAsync(d_band, 0, (size_t)nq_pad * 3 * sizeof(float), c->stream));  // band widths of the padding queries, counts, overflow flags
+    TAVB_HIP(hipMemsetAsync(d_band, 0, (size_t)nq_pad * 4 * sizeof(float), c->stream));  // band widths of the padding queries, counts, lost levels, verdicts
     hipError_t e = tavb::launch_query_prepare(d_q, nq, c->dim, min_score, small, d_norm, small ? nullptr : c->d_queries_f16.ptr, d_delta, d_floor,
                                               small ? nullptr : d_band, c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "query prepare launch failed: %s", hipGetErrorString(e));
@@ -1255,7 +1257,8 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   filt.k = small ? KC : k;  // the wide tile ranks by the caller's k and keeps the band below it
   filt.band = small ? nullptr : d_band;
   filt.band_cnt = small ? nullptr : d_band_cnt;
-  filt.overflow = small ? nullptr : d_overflow;
+  filt.lost = small ? nullptr : d_lost;
+  filt.verdict = small ? nullptr : d_verdict;
   filt.index_base = index_base;
   filt.kernel_min_score = (min_score > 0.0f) ? 0.0f : min_score;  // the per-query relaxed thresholds (floor) do the filtering; NaN stays NaN
   filt.floor = d_floor;
@@ -1267,7 +1270,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   {
     Timed t(c, TAVB_KERNEL_RESCORE);
     hipError_t e = tavb::launch_rescore(c->corpus, f32c, c->dim, index_base, d_q, reinterpret_cast<const u64_t*>(c->d_approx.ptr), KC,
-                                        small ? nullptr : d_band_cnt, small ? nullptr : d_overflow, d_delta, min_score, nq, k, d_out, d_nflag, d_flagged,
+                                        small ? nullptr : d_band_cnt, small ? nullptr : d_verdict, d_delta, min_score, nq, k, d_out, d_nflag, d_flagged,
                                         c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "rescore launch failed: %s", hipGetErrorString(e));
     char* fb = reinterpret_cast<char*>(c->d_fb_queries.ptr);

@@ -59,10 +59,10 @@ hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, floa
 // band (optional, [nq]): 2 * delta, the width of the band selection
 hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
                                 float* thr, float* band, hipStream_t stream);
-// candidates [nq, stride] (+ cand_cnt [nq]: band mode, the set is complete by construction unless overflow[q]; cand_cnt == nullptr: the
+// candidates [nq, stride] (+ cand_cnt [nq]: band mode, the set is complete by construction unless incomplete[q]; cand_cnt == nullptr: the
 // sorted best `stride` = 64 by approximate score, complete when rank 63 + delta < the exact k-th best) -> exact top k [nq, k]
 hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
-                          int stride, const int* cand_cnt, const int* overflow, const float* delta, float min_score, int nq, int k,
+                          int stride, const int* cand_cnt, const int* incomplete, const float* delta, float min_score, int nq, int k,
                           unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream);
 hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, float* stats /*[2]*/, hipStream_t stream);
 hipError_t launch_gather_flagged_f32(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, float* out,
@@ -98,7 +98,7 @@ struct MfmaParams {
   int32_t skinny_tile;  // skinny kernel only: queries per tile, 32 or 64
   int32_t wide_tile;    // 128/256-query kernel only: queries per tile, 128 or 256 (0 = 256)
   const float* band;    // 128/256-query kernel only, optional [nq_padded]: band selection (keep every key within band[q] of the k-th best)
-  int* overflow;        // ... [nq_padded]: set to 1 where a band did not fit a candidate buffer
+  unsigned* lost;       // ... [nq_padded]: atomicMax of the score level (bits) below which a query lost band rows to a buffer that could not hold its band
 };
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
 hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, const float* floor, float* thr, hipStream_t stream);
@@ -106,13 +106,14 @@ int mfma_query_tile(int nq);              // queries per workgroup tile: 128 whe
 int mfma_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu);
 bool mfma_supported(int dim, int k);
 size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide);
-// the BAND of every query (all keys within band[q] of its k-th best; at most kc_max, else the strict best k + overflow[q] = 1) over the
-// 128/256-query tile's candidate buffers (+ an optional carried-over band [nq, kc_max] / carried_cnt [nq]) -> out [nq, kc_max] unsorted,
-// out_cnt [nq]; thr_out[q] = just below the band's cut (or floor[q]); tavb_mfma.hip
+// the BAND of every query (all keys within band[q] of its k-th best; at most kc_max, else the strict best k) over the 128/256-query tile's
+// candidate buffers (+ an optional carried-over band [nq, kc_max] / carried_cnt [nq]) -> out [nq, kc_max] unsorted, out_cnt [nq];
+// thr_out[q] = just below the band's cut (or floor[q]); lost [nq]: highest score level (bits) at which band rows were dropped so far
+// (in/out); verdict (optional, last phase) [nq]: 1 = the band handed over is not provably complete; tavb_mfma.hip
 constexpr int kBandMax = 512;  // candidates per query the rescoring accepts (kc_max)
 hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
-                              int* out_cnt, float* thr_out, int* overflow, hipStream_t stream);
+                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream);
 // 32-query tiles at HBM speed, fp32 or fp16 corpora (same parameter block; `queries` in the corpus dtype)
 hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream);
 int skinny_query_tile(int nq);  // 32, or 64 for batches of 33 and more

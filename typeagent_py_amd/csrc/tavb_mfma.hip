@@ -75,7 +75,7 @@ struct MfmaDeviceParams {
   const float* thr_in;  // optional [nq_padded] admission thresholds from a sample pass (exclusive bound)
   const int* active;    // optional: number of live queries, read on the device; query tiles past it return at once
   const float* band;    // 128/256-query tile, optional [nq_padded]: keep every key within band[q] below the k-th best (band selection)
-  int* overflow;        // ... [nq_padded]: set to 1 for a query whose band did not fit a candidate buffer (the caller re-runs it exactly)
+  unsigned* lost;       // ... [nq_padded]: atomicMax of the score bits below which a query LOST band rows (a band that did not fit a buffer)
 };
 
 // Pin a wave-uniform pointer into SGPRs.  Without this the compiler strength-reduces the eight
@@ -216,11 +216,14 @@ __device__ __forceinline__ uint32_t band_cut_bits(uint32_t t_bits, float band) {
 // all of them, not a fixed number -- because exactly those rows can still be among the query's exact top k.  On ordinary data
 // that is k + a handful; on clustered data (near-duplicate rows around rank k) it is the cluster, whatever its size, as long as
 // it fits: when more than `limit` keys would stay, the buffer is cut to its strict best k (by key: smaller ordinal wins ties)
-// and *overflowed is set -- the query's result is then not provably complete and the caller re-runs it on the exact tile.
+// and *lost_bits = the score bits of that k-th best: rows scoring <= it were (and, through the raised threshold, will be) dropped
+// although they may lie inside the band.  That only matters if the query's FINAL band reaches down to that level -- the select
+// kernel compares (a big cluster of near-duplicates inside one row range overflows the buffers of every query whose local k-th
+// best is below the cluster's score, but it is irrelevant to all those whose final k-th best is far above it).
 // Returns the number of keys kept; *thr_excl = the exclusive admission bound that goes with the cut (score > *thr_excl), or
-// -inf when everything qualifies.  One wave; wave-uniform arguments.
+// -inf when everything qualifies; *lost_bits = 0 when nothing was lost.  One wave; wave-uniform arguments.
 template <int CAPACITY>
-__device__ __forceinline__ int compact_to_band(u64* buf, int n, int k, int lane, float band, int limit, float* thr_excl, bool* overflowed) {
+__device__ __forceinline__ int compact_to_band(u64* buf, int n, int k, int lane, float band, int limit, float* thr_excl, uint32_t* lost_bits) {
   constexpr int PER = CAPACITY / 64;
   u64 key[PER];
   uint32_t sc[PER];
@@ -233,7 +236,7 @@ __device__ __forceinline__ int compact_to_band(u64* buf, int n, int k, int lane,
     mx = max(mx, sc[j]);
     if (key[j] != 0ull) mn_inv = max(mn_inv, ~sc[j]);
   }
-  *overflowed = false;
+  *lost_bits = 0u;
   *thr_excl = -__builtin_inff();
   if (n <= k) return n;
   mx = wave_max_u32(mx, lane);
@@ -256,8 +259,10 @@ __device__ __forceinline__ int compact_to_band(u64* buf, int n, int k, int lane,
   // t = the k-th best score
   uint32_t cut = band_cut_bits(t, band);
   uint32_t t_lo = 0u;
+  bool strict = false;
   if (count_ge(cut) > limit) {  // the band does not fit: strict best k (ties at t cut by ordinal, the low word: bigger = smaller ordinal)
-    *overflowed = true;
+    strict = true;
+    *lost_bits = t > 0u ? t : 1u;
     cut = t;
     int above = 0;
 #pragma unroll
@@ -284,7 +289,7 @@ __device__ __forceinline__ int compact_to_band(u64* buf, int n, int k, int lane,
   }
   // rows that come later in this row range have bigger ordinals than everything kept: at a strict cut a tie at t loses (score > t);
   // at a band cut every score >= cut stays welcome (score > the float just below cut)
-  *thr_excl = *overflowed ? __uint_as_float(t) : (cut > 0u ? __uint_as_float(cut - 1u) : -__builtin_inff());
+  *thr_excl = strict ? __uint_as_float(t) : (cut > 0u ? __uint_as_float(cut - 1u) : -__builtin_inff());
   return base;
 }
 
@@ -683,12 +688,12 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
           const int qg = qtile * BN + q;  // (a padding query admits nothing: never here)
           const float band = p.band ? p.band[qg] : 0.0f;
           float thr_excl;
-          bool over;
-          const int kept = compact_to_band<CAPW>(buf, n < CAPW ? n : CAPW, p.k, lane_e, band, CAPW - BM6 - 64, &thr_excl, &over);
+          uint32_t lost;
+          const int kept = compact_to_band<CAPW>(buf, n < CAPW ? n : CAPW, p.k, lane_e, band, CAPW - BM6 - 64, &thr_excl, &lost);
           if (lane_e == 0) {
             cnt_lds[q] = kept;
             if (thr_excl > thr_lds[q]) thr_lds[q] = thr_excl;
-            if ((over || n > CAPW) && p.overflow) p.overflow[qg] = 1;  // (n > CAPW cannot happen: a tile appends at most BM6 keys)
+            if (lost != 0u && p.lost) atomicMax(&p.lost[qg], lost);  // (n > CAPW cannot happen: a tile appends at most BM6 keys)
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1038,8 +1043,11 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
 // carried over from the earlier ladder phases -- and, from it, the admission threshold of the next phase.
 // The band = every key whose score is within band[q] (= 2 delta_q, tavb_rescore.hip) of the query's k-th best score: exactly
 // the rows that can still be in the exact top k once the candidates are rescored with the fp32 query.  Its size is whatever the
-// data makes it (k + a few on isotropic data, a whole cluster of near-duplicates on clustered data), up to kc_max; a bigger
-// band is cut to the strict best k and overflow[q] is set (the caller re-runs that query on the exact tile).
+// data makes it (k + a few on isotropic data, a whole cluster of near-duplicates on clustered data), up to kc_max.  Where a
+// band did not fit on the way (a candidate buffer in the tile kernel, the cache here) the keys were cut to the strict best k and
+// lost[q] holds the highest score level at which rows were dropped; with `verdict` (the last phase) the query is declared
+// incomplete -- verdict[q] = 1, the caller re-runs it on the exact tile -- when the final band does not fit kc_max or reaches
+// down to that level.
 // One workgroup per query, so the selection work of a launch is spread over 1024 workgroups x 256 threads instead of
 // being the serial tail of 256 workgroups.
 //   * the keys of the query (a few hundred after a selective phase; every row of the phase after the cold first one)
@@ -1058,7 +1066,8 @@ constexpr int SEL_PER = SEL_CACHE / 256;
 __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict__ cand, const int* __restrict__ counts, int n_splits, int nq_padded, int k,
                                                           int kc_max, const u64* __restrict__ carried, const int* __restrict__ carried_cnt,
                                                           const float* __restrict__ floor, const float* __restrict__ band, u64* __restrict__ out,
-                                                          int* __restrict__ out_cnt, float* __restrict__ thr_out, int* __restrict__ overflow) {
+                                                          int* __restrict__ out_cnt, float* __restrict__ thr_out, unsigned* __restrict__ lost,
+                                                          int* __restrict__ verdict) {
   extern __shared__ __align__(16) unsigned char sel_smem[];
   u64* cache = reinterpret_cast<u64*>(sel_smem);  // [SEL_CACHE]
   __shared__ int off[260];  // exclusive prefix of the per-split counts (+ the carried band as one more "split")
@@ -1162,21 +1171,22 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
     return true;
   };
   // the cut that goes with the k-th best of the n cached keys (which kth_of_cache leaves in key[]): the band below it, or -- when the
-  // band holds more than `room` keys -- the strict best k; (f_hi, f_lo): keep a key iff score > f_hi or (score == f_hi and low >= f_lo)
-  bool strict = false;  // sticky: once a band did not fit, the query is cut strictly (and flagged)
-  auto cut_of_cache = [&](int n, int room, uint32_t* f_hi, uint32_t* f_lo) -> bool {
+  // band holds more than `room` keys -- the strict best k (*was_strict; the level below which keys were dropped goes to lost_here);
+  // (f_hi, f_lo): keep a key iff score > f_hi or (score == f_hi and low >= f_lo)
+  uint32_t lost_here = 0u;
+  auto cut_of_cache = [&](int n, int room, uint32_t* f_hi, uint32_t* f_lo, bool* was_strict) -> bool {
     uint32_t t_hi = 0u, t_lo = 0u;
-    if (!kth_of_cache(n, k, strict, &t_hi, &t_lo)) return false;
-    if (!strict) {
-      const uint32_t cut = band_cut_bits(t_hi, band_q);
-      if (count([&](u64 kk) { return (uint32_t)(kk >> 32) >= cut; }) <= room) {
-        *f_hi = cut;
-        *f_lo = 0u;
-        return true;
-      }
-      strict = true;
-      kth_of_cache(n, k, true, &t_hi, &t_lo);
+    *was_strict = false;
+    if (!kth_of_cache(n, k, false, &t_hi, &t_lo)) return false;
+    const uint32_t cut = band_cut_bits(t_hi, band_q);
+    if (count([&](u64 kk) { return (uint32_t)(kk >> 32) >= cut; }) <= room) {
+      *f_hi = cut;
+      *f_lo = 0u;
+      return true;
     }
+    *was_strict = true;
+    kth_of_cache(n, k, true, &t_hi, &t_lo);
+    lost_here = max(lost_here, t_hi > 0u ? t_hi : 1u);
     *f_hi = t_hi;
     *f_lo = t_lo;
     return true;
@@ -1194,7 +1204,8 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
     if (n_cached > SEL_CACHE - 256 * UNR) {  // block-uniform (read after a barrier)
       const int n = n_cached;
       __syncthreads();
-      have_filter = cut_of_cache(n, SEL_CACHE / 4, &f_hi, &f_lo);  // n >= k here
+      bool mid_strict;
+      have_filter = cut_of_cache(n, SEL_CACHE / 4, &f_hi, &f_lo, &mid_strict);  // n >= k here
       if (tid == 0) n_cached = 0;
       __syncthreads();
 #pragma unroll
@@ -1226,7 +1237,8 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
   n_keys = n_cached;
   __syncthreads();
   uint32_t t_hi = 0u, t_lo = 0u;
-  const bool enough = cut_of_cache(n_keys, kc_max, &t_hi, &t_lo);  // (fewer than k keys: all of them are the band; key[] is loaded either way)
+  bool strict = false;
+  const bool enough = cut_of_cache(n_keys, kc_max, &t_hi, &t_lo, &strict);  // (fewer than k keys: all of them are the band; key[] is loaded either way)
   // ---- write the band (unsorted) and its size
 #pragma unroll
   for (int j = 0; j < SEL_PER; ++j) {
@@ -1241,11 +1253,17 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
   __syncthreads();
   if (tid == 0) {
     out_cnt[q] = n_picked < kc_max ? n_picked : kc_max;
-    if (strict && overflow != nullptr) overflow[q] = 1;
+    uint32_t lost_all = lost_here;
+    if (lost != nullptr) {
+      if (lost_here != 0u) atomicMax(&lost[q], lost_here);
+      lost_all = max(lost_all, lost[q]);  // (the tile kernels of this and the earlier phases are done: plain read)
+    }
+    // incomplete: the final band itself did not fit, or rows were dropped somewhere at a level the final band reaches (its cut is t_hi when
+    // there are k keys, 0 -- everything counts -- when there are fewer)
+    if (verdict != nullptr) verdict[q] = (strict || (lost_all != 0u && lost_all >= (enough ? t_hi : 0u))) ? 1 : 0;
     if (thr_out != nullptr) {
       float t = -__builtin_inff();
       if (enough && t_hi > 0u) t = __uint_as_float(t_hi - (strict ? 0u : 1u));  // strict: later rows tie-lose (score > t); band: score >= cut
-      if (enough && strict && t_hi == 0u) t = -__builtin_inff();
       if (floor != nullptr && floor[q] > t) t = floor[q];
       thr_out[q] = t;
     }
@@ -1303,13 +1321,13 @@ size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide) {
 
 hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
-                              int* out_cnt, float* thr_out, int* overflow, hipStream_t stream) {
+                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream) {
   if (nq < 1 || k < 1 || k > 64 || n_splits < 1 || n_splits > 256 || nq_padded < nq || kc_max < k || kc_max > SEL_CACHE / 4) return hipErrorInvalidValue;
   constexpr int lds = SEL_CACHE * (int)sizeof(u64);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(select_band_kernel, dim3(nq), dim3(256), lds, stream, cand, counts, n_splits, nq_padded, k, kc_max, carried, carried_cnt, floor, band,
-                     out, out_cnt, thr_out, overflow);
+                     out, out_cnt, thr_out, lost, verdict);
   return hipGetLastError();
 }
 
@@ -1331,7 +1349,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.min_score = p.min_score;
   d.thr_in = p.thr_in;
   d.band = p.band;
-  d.overflow = p.overflow;
+  d.lost = p.lost;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
   const int bm = BM6;
   d.rows_per_split = ((per + bm - 1) / bm) * bm;

@@ -152,14 +152,14 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
 //   * band mode (cand_cnt != nullptr; the 128/256-query tile): cand_cnt[q] <= kBandMax unsorted candidates = every row whose
 //     approximate score is within 2 delta of the approximate k-th best.  A row outside has approx < a_k - 2 delta, so its exact
 //     score is < a_k - delta <= the exact score of each of the k rows that lead the approximate ranking: it cannot be in the
-//     exact top k.  Complete by construction -- unless overflow[q] says that a band did not fit somewhere on the way.
+//     exact top k.  Complete by construction -- unless incomplete[q] (select_band_kernel's verdict) says that a band did not fit somewhere on the way at a level that matters.
 //   * cut mode (cand_cnt == nullptr; the 32/64-query tile over an fp16 shadow): the best `stride` = 64 rows by approximate
 //     score, sorted.  Fewer than 64: nothing was cut.  Else a row outside has approx <= a_63, exact <= a_63 + delta, and is
 //     out when that is below the exact k-th best of the candidates (one delta: the exact k-th is known by now).
 template <typename T>
 __global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corpus, int dim, uint32_t index_base,
                                                       const float* __restrict__ queries, const u64* __restrict__ approx /*[nq, stride]*/, int stride,
-                                                      const int* __restrict__ cand_cnt, const int* __restrict__ overflow,
+                                                      const int* __restrict__ cand_cnt, const int* __restrict__ incomplete,
                                                       const float* __restrict__ delta, float min_score, int k,
                                                       u64* __restrict__ out /*[nq, k]*/, int* __restrict__ n_flagged,
                                                       int* __restrict__ flagged) {
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corp
   // completeness of the candidate set
   bool ok = true;
   if (cand_cnt != nullptr) {
-    ok = (overflow[qi] == 0);
+    ok = (incomplete[qi] == 0);
   } else {
     const u64 a_last = cand[stride - 1];
     if (a_last != 0ull) {  // the set was cut
@@ -311,16 +311,16 @@ hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score
 }
 
 hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
-                          int stride, const int* cand_cnt, const int* overflow, const float* delta, float min_score, int nq, int k,
+                          int stride, const int* cand_cnt, const int* incomplete, const float* delta, float min_score, int nq, int k,
                           unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream) {
-  if (stride < 1 || stride > kBandMax || k < 1 || k > 64 || (cand_cnt != nullptr && overflow == nullptr)) return hipErrorInvalidValue;
+  if (stride < 1 || stride > kBandMax || k < 1 || k > 64 || (cand_cnt != nullptr && incomplete == nullptr)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, stream, n_flagged);
   if (f32_rows)
     hipLaunchKernelGGL(rescore_kernel<float>, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const float*>(corpus), dim, index_base, queries, approx,
-                       stride, cand_cnt, overflow, delta, min_score, k, out, n_flagged, flagged);
+                       stride, cand_cnt, incomplete, delta, min_score, k, out, n_flagged, flagged);
   else
     hipLaunchKernelGGL(rescore_kernel<_Float16>, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(corpus), dim, index_base, queries,
-                       approx, stride, cand_cnt, overflow, delta, min_score, k, out, n_flagged, flagged);
+                       approx, stride, cand_cnt, incomplete, delta, min_score, k, out, n_flagged, flagged);
   return hipGetLastError();
 }
 

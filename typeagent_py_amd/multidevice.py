@@ -15,9 +15,25 @@ answer, ties included.
 
 from __future__ import annotations
 
+import functools
+import threading
+
 import numpy as np
 
 from . import _native
+
+
+def _locked(method):
+    """Hold the group's lock for the whole call: a lookup is `search_begin` on every device followed by `search_end` on every device, and
+    each engine only locks per call -- two threads interleaving those pairs would collect each other's results (or trip the
+    'tavb_search_end does not match the pending tavb_search_begin' check)."""
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        with self._lock:
+            return method(self, *args, **kwargs)
+
+    return wrapper
 
 
 class DeviceGroup:
@@ -26,7 +42,9 @@ class DeviceGroup:
             raise ValueError("devices must name at least one GPU")
         self.devices = [int(d) for d in devices]
         self.engines = [_native.Engine(d) for d in self.devices]
+        self._lock = threading.RLock()
         self.block = 0  # rows per shard (the last shard may hold more)
+        self._outgrown = 0  # block size of the layout that has just been outgrown (the next layout at least doubles it)
         self.bounds = [0] * (len(self.devices) + 1)  # shard g = rows [bounds[g], bounds[g+1])
         self.rows = 0
         self.dim = 0
@@ -73,6 +91,7 @@ class DeviceGroup:
         b = [min(i * block, n) for i in range(g)] + [n]
         return b
 
+    @_locked
     def upload_rows(self, host_rows: np.ndarray, start: int, dtype: int, capacity_hint: int = 0) -> bool:
         """Make rows [start, start + len) of the sharded device copy equal `host_rows`.  Returns False (nothing done) when
         the shard layout has to change and the caller must upload from row 0 instead."""
@@ -83,8 +102,13 @@ class DeviceGroup:
         if fresh and start != 0:
             return False
         if fresh:
-            self.block = max(1, -(-max(n_new, 1) // g))  # balanced now; appends fill the last shard up to twice this
+            # balanced now; appends fill the last shard up to twice this.  A layout that replaces an outgrown one at least doubles its
+            # block: growing an index row by row then re-shards O(log N) times moving O(N) rows in total (ceil(n / g) alone gave a
+            # block only (1 + 1/g) times bigger: ~g ln N re-shards, ~9 N rows moved for 8 devices -- round-2 advice)
+            self.block = max(1, -(-max(n_new, 1) // g), 2 * self._outgrown)
+            self._outgrown = 0
         elif n_new > (g + 1) * self.block:  # the last shard would exceed twice the block: rebalance
+            self._outgrown = self.block
             return False
         bounds = self._layout(n_new, self.block)
         for gi, e in enumerate(self.engines):
@@ -104,6 +128,7 @@ class DeviceGroup:
         self.corpus = True
         return True
 
+    @_locked
     def set_shard_tensors(self, tensors, ordinal_base: int = 0) -> None:
         """Adopt one device tensor per GPU (row shards in order) without a host copy."""
         if len(tensors) != len(self.engines):
@@ -120,10 +145,12 @@ class DeviceGroup:
         self.ordinal_base = ordinal_base
         self.corpus = list(tensors)
 
+    @_locked
     def clear(self) -> None:
         for e in self.engines:
             e.clear()
         self.rows = 0
+        self._outgrown = 0
         self.bounds = [0] * (len(self.engines) + 1)
 
     # -- lookups -------------------------------------------------------------------------------------------------
@@ -133,6 +160,7 @@ class DeviceGroup:
             raise ValueError(f"shapes ({self.rows},{self.dim}) and {tuple(np.shape(q))} not aligned: query must have {self.dim} elements")
         return a
 
+    @_locked
     def _gather(self, queries: np.ndarray, k: int, thrs: np.ndarray) -> np.ndarray:
         """-> merged uint64 [nq, k] keys over all shards"""
         act = self._active()
@@ -159,6 +187,7 @@ class DeviceGroup:
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(thrs, dtype=np.float32), (a.shape[0],)))
         return _native.decode_keys(self._gather(a, k, t))
 
+    @_locked
     def search_all(self, q, thr: np.float32, max_out: int | None = None, subset_rows=None):
         """Every survivor, best first (one emit-all pass per shard, merged on the host)."""
         a = self._query(q)
@@ -183,6 +212,7 @@ class DeviceGroup:
             order = order[:max_out]
         return ids[order], sc[order]
 
+    @_locked
     def search_subset(self, q, rows: np.ndarray, k: int, thr: np.float32):
         """rows: int64 global corpus row per subset position -> (positions int64[m], scores float32[m]); the order is
         (score desc, position asc) like one device's."""

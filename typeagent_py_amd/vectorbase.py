@@ -51,6 +51,96 @@ MODEL_DEFAULT_MIN_SCORES: dict[str, float] = {
 _PAGE = _native.MAX_FUSED_K  # most hits the fused select-while-streaming kernels return; beyond: one emit-all pass + host sort
 
 
+try:  # whole-matrix digests of the "full" host watch
+    from xxhash import xxh3_128_digest as _digest
+except Exception:  # pragma: no cover - xxhash is part of the image
+    import hashlib
+
+    def _digest(data) -> bytes:
+        return hashlib.blake2b(data, digest_size=16).digest()
+
+
+class _Watch:
+    """Dirty flag shared by an index and every view of its host matrix it has handed out (and by the indexes that adopted such a
+    view through deserialize(): `followers`)."""
+
+    __slots__ = ("dirty", "followers")
+
+    def __init__(self) -> None:
+        self.dirty = False
+        self.followers: list[_Watch] = []
+
+    def touch(self) -> None:
+        self.dirty = True
+        for f in self.followers:
+            f.dirty = True
+
+
+class _WatchedMatrix(np.ndarray):
+    """What serialize() / `_vectors` / get_embedding_at() hand out for a matrix this index owns: a plain float32 view of the live
+    host matrix (the reference hands out the live `_vectors`, vectorbase.py:268-271) that remembers being written to.  The
+    reference always scores the live matrix (:176); here the device mirror is refreshed on the next lookup after any write made
+    through numpy -- item / slice assignment, in-place operators and ufunc `out=`, fill / sort / put / ..., np.copyto / np.put /
+    np.place / np.putmask -- on this array or on any view derived from it.  Writers that go around numpy's array API (a base-class
+    view from np.asarray(), memoryview, ctypes pointers, another library writing through the buffer protocol) are not seen:
+    they call `VectorBase.mark_dirty()`."""
+
+    _tavb_watch: _Watch | None = None
+
+    def __array_finalize__(self, obj) -> None:
+        if obj is not None:
+            self._tavb_watch = getattr(obj, "_tavb_watch", None)
+
+    def _touch(self) -> None:
+        w = self._tavb_watch
+        if w is not None:
+            w.touch()
+
+    def __setitem__(self, key, value) -> None:
+        self._touch()
+        super().__setitem__(key, value)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
+        plain = lambda a: a.view(np.ndarray) if isinstance(a, _WatchedMatrix) else a
+        if out is not None:
+            for o in out:
+                if isinstance(o, _WatchedMatrix):
+                    o._touch()
+            kwargs["out"] = tuple(plain(o) for o in out)
+        if method == "at" and isinstance(inputs[0], _WatchedMatrix):
+            inputs[0]._touch()
+        result = getattr(ufunc, method)(*(plain(i) for i in inputs), **kwargs)
+        if out is not None and method == "__call__" and len(out) == 1:
+            return out[0]  # `m *= 2` must rebind m to itself
+        return result  # plain ndarrays: results of arithmetic on the matrix are copies, not watched
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func in _WRITING_FUNCTIONS and args and isinstance(args[0], _WatchedMatrix):
+            args[0]._touch()
+        return super().__array_function__(func, types, args, kwargs)
+
+    def _writing_method(name):  # noqa: N805 -- class-body helper
+        base = getattr(np.ndarray, name)
+
+        def method(self, *args, **kwargs):
+            self._touch()
+            return base(self, *args, **kwargs)
+
+        method.__name__ = name
+        return method
+
+    fill = _writing_method("fill")
+    sort = _writing_method("sort")
+    partition = _writing_method("partition")
+    put = _writing_method("put")
+    setfield = _writing_method("setfield")
+    byteswap = _writing_method("byteswap")
+    del _writing_method
+
+
+_WRITING_FUNCTIONS = {np.copyto, np.put, np.place, np.putmask, np.put_along_axis, np.fill_diagonal}
+
+
 def get_default_min_score(model_name: str) -> float:
     return MODEL_DEFAULT_MIN_SCORES.get(model_name, DEFAULT_MIN_SCORE)
 
@@ -122,6 +212,7 @@ class VectorBase:
         corpus_dtype: str | None = None,
         devices: list[int] | None = None,
         keep_host_copy: bool | None = None,
+        verify_host: str | None = None,
     ):
         self.settings = settings
         self._model = settings.embedding_model
@@ -147,8 +238,18 @@ class VectorBase:
         self._count = 0
         self._dev_rows = 0  # rows of the host matrix already mirrored on the device
         self._dev_valid = True  # False => the device copy must be rebuilt from row 0
-        self._handed_out = False  # the live host matrix is (or may be) in a caller's hands: watch it for in-place edits
+        # The live host matrix can be edited in place by whoever holds it (the reference always scores the live matrix, :176):
+        #  * a matrix this index OWNS is handed out as a _WatchedMatrix view (`_watch` is its dirty flag);
+        #  * a matrix the CALLER owns (deserialize(data) keeps `data` by reference, :287) cannot be wrapped: `_handed_out` turns on a
+        #    fingerprint check per lookup -- "sampled" (default: 32 rows, ~30 us) or "full" (every byte: TYPEAGENT_VB_VERIFY_HOST=full /
+        #    verify_host="full"; ~0.1 ms per MB) -- and mark_dirty() is the explicit form.
+        self._watch = _Watch()
+        self._handed_out = False
         self._dev_fingerprint = None
+        mode = (verify_host or os.environ.get("TYPEAGENT_VB_VERIFY_HOST", "sampled")).lower()
+        if mode not in ("sampled", "full", "off"):
+            raise ValueError("verify_host must be 'sampled', 'full' or 'off'")
+        self._verify_host = mode
         self._device_only = None  # torch tensor when the corpus lives only on the device
         self._row_messages: np.ndarray | None = None  # chunk row -> message ordinal (message re-rank on the device)
         self._row_messages_rows = -1  # rows of the map already on the device
@@ -159,10 +260,14 @@ class VectorBase:
     def _vectors(self) -> NormalizedEmbeddings:
         if self._device_only is not None:
             self._materialize_host()
-        self._handed_out = True
-        if self._embedding_size > 0 and self._host.ndim == 2 and self._count != self._host.shape[0]:
-            return self._host[: self._count]  # the filled part of the growth buffer
-        return self._host  # exactly the adopted / full matrix (same object every time)
+        if self._handed_out:
+            return self._host  # the caller's own matrix, adopted by reference: the same object every time (:271, :287)
+        live = self._host
+        if self._embedding_size > 0 and live.ndim == 2 and self._count != live.shape[0]:
+            live = live[: self._count]  # the filled part of the growth buffer
+        view = live.view(_WatchedMatrix)
+        view._tavb_watch = self._watch
+        return view
 
     @_vectors.setter
     def _vectors(self, value: NormalizedEmbeddings) -> None:
@@ -175,6 +280,9 @@ class VectorBase:
         self._dev_rows = 0
         self._dev_valid = False
         self._handed_out = True  # the caller keeps a reference to `matrix` (deserialize keeps it by reference, :287)
+        other = getattr(matrix, "_tavb_watch", None)
+        if other is not None and other is not self._watch and self._watch not in other.followers:
+            other.followers.append(self._watch)  # another index's serialize() output: writes through it reach this index too
 
     def _materialize_host(self) -> None:
         t, n = self._device_only, self._count
@@ -192,11 +300,16 @@ class VectorBase:
         need = self._count + extra
         if self._host.ndim != 2 or self._host.shape[1] != self._embedding_size:
             self._host = np.zeros((max(need, 4), self._embedding_size), dtype=np.float32)
+            self._handed_out = False
             return
-        if need > self._host.shape[0]:
+        if need > self._host.shape[0] or self._handed_out:
+            # (an adopted matrix is the caller's: appends go to a buffer of our own, like the reference's np.append copy, :128)
+            if self._handed_out and self._dev_valid and self._dev_rows == self._count and self._dev_fingerprint != self._fingerprint():
+                self._dev_valid = False  # edited in place since the last upload: the rows already mirrored are stale too
             grown = np.empty((max(need, 2 * self._host.shape[0], 4), self._embedding_size), dtype=np.float32)
             grown[: self._count] = self._host[: self._count]
             self._host = grown
+            self._handed_out = False
 
     async def get_embedding(self, key: str, cache: bool = True) -> NormalizedEmbedding:
         if cache:
@@ -293,8 +406,11 @@ class VectorBase:
         if self._device_only is not None:
             return eng
         n = self._count
+        if self._watch.dirty:  # a view handed out by serialize() / _vectors / get_embedding_at() was written to
+            self._watch.dirty = False
+            self._dev_valid = False
         if self._handed_out and self._dev_valid and self._dev_rows == n and n > 0 and self._dev_fingerprint != self._fingerprint():
-            self._dev_valid = False  # the matrix handed out by serialize()/deserialize() was edited in place
+            self._dev_valid = False  # the caller's matrix adopted by deserialize() was edited in place
         if not self._dev_valid:
             self._dev_rows = 0
             self._dev_valid = True
@@ -310,18 +426,23 @@ class VectorBase:
         return eng
 
     def _fingerprint(self):
-        """Hash of up to 32 evenly spaced rows of the host matrix (~30 us): a cheap watch on a matrix that a caller holds
-        a reference to.  Whole-matrix edits (re-normalisation, bulk replacement) are caught; an edit confined to rows
-        outside the sample is not -- `mark_dirty()` is the explicit form."""
+        """Watch on a matrix the CALLER owns (adopted by deserialize(), :287).  "sampled": hash of up to 32 evenly spaced rows
+        (~30 us): whole-matrix edits (re-normalisation, bulk replacement) are caught, an edit confined to rows outside the
+        sample is not.  "full": a 128-bit hash of every byte (xxh3, ~0.1 ms per MB on one core; blake2b when xxhash is not
+        installed): nothing is missed, at a per-lookup cost that only small indexes can afford.  `mark_dirty()` is the explicit form."""
         n = self._count
-        if n == 0 or self._host.ndim != 2:
+        if n == 0 or self._host.ndim != 2 or self._verify_host == "off":
             return None
+        if self._verify_host == "full":
+            data = memoryview(np.ascontiguousarray(self._host[:n])).cast("B")
+            return (n, self._host.shape[1], _digest(data))
         idx = np.unique(np.linspace(0, n - 1, num=min(n, 32)).astype(np.int64))
         return hash((n, self._host.shape[1], self._host[idx].tobytes()))
 
     def mark_dirty(self) -> None:
-        """Call after mutating the array returned by serialize()/_vectors in place:
-        the device mirror is rebuilt on the next lookup.  (A sampled fingerprint catches most such edits without it.)"""
+        """Call after writing to the host matrix by a route numpy does not see (raw pointers, memoryview, a base-class view from
+        np.asarray(serialize())), or -- for a matrix adopted by deserialize() under the default sampled watch -- after editing
+        single rows of it: the device mirror is rebuilt on the next lookup."""
         self._dev_valid = False
 
     def adopt_device_corpus(self, tensor, rows: int | None = None, ordinal_base: int = 0) -> None:
@@ -453,8 +574,8 @@ class VectorBase:
         storage/sqlite/schema.py:71-81).  Enables `lookup_messages_by_embedding*`, which run the providers' post-lookup
         aggregation on the device."""
         self._row_messages_src = row_to_message  # identity of the caller's object: callers that pass it every time do not re-upload
-        self._row_messages = np.ascontiguousarray(row_to_message, dtype=np.int64).reshape(-1)
-        self._row_messages_rows = -1
+        self._row_messages = np.array(row_to_message, dtype=np.int64).reshape(-1)  # a snapshot: never an alias of the caller's array
+        self._row_messages_rows = -1  # (re-)uploaded on the next message lookup
 
     def _messages_engine(self):
         """engine with corpus AND map synced, or None when the aggregation has to run on the host (device group)."""
@@ -556,6 +677,7 @@ class VectorBase:
 
     def clear(self) -> None:
         self._device_only = None
+        self._handed_out = False
         self._count = 0
         self._dev_rows = 0
         self._dev_valid = False
