@@ -304,6 +304,11 @@ class Ctx:
 
             self.backend = DeviceShardBackend(self.dev)
             self.eng = self.backend.engine
+            # the exchange of the lookup path is libtavb's own RCCL communicator (tavb_search_allgather); torch.distributed only carries
+            # the rendezvous id, the barriers and the max-over-ranks of the timing
+            self.backend.init_comm(dist.get_rank(), dist.get_world_size())
+            if dist.get_world_size() == 1:
+                self.eng.set_option("comm_force", 1)  # 1-rank dry run of the N > 1 code
         else:
             self.backend = None
             self.eng = _native.Engine(self.dev)
@@ -327,7 +332,7 @@ class Ctx:
 def kernel_times(ctx: Ctx) -> dict:
     n = ctx.native
     ids = {"scan": n.KERNEL_SCAN, "merge": n.KERNEL_MERGE, "mfma_last_phase": n.KERNEL_MFMA, "mfma_earlier_phases": n.KERNEL_MFMA_SAMPLE,
-           "skinny_last_phase": n.KERNEL_SKINNY, "convert": n.KERNEL_CONVERT, "rescore": n.KERNEL_RESCORE}
+           "skinny_last_phase": n.KERNEL_SKINNY, "convert": n.KERNEL_CONVERT, "rescore": n.KERNEL_RESCORE, "exchange": n.KERNEL_EXCHANGE}
     return {name: ctx.eng.profile_read(kid) for name, kid in ids.items()}
 
 
@@ -351,7 +356,7 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         from typeagent_py_amd.sharded import ShardedSearcher
 
         ctx.backend.set_shard(corpus, row_offset=shard_lo)
-        searcher = ShardedSearcher(ctx.backend, always_collective=True)
+        searcher = ShardedSearcher(ctx.backend)
         dq_all = torch.from_numpy(queries).to(torch.device("cuda", ctx.dev))
     else:
         eng.set_corpus_tensor(corpus)
@@ -768,6 +773,36 @@ def respawn_under_torchrun(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def selftest(args) -> int:
+    """`python bench.py --selftest`: prove N = 2 wherever a second GPU shows up.  Runs the headline workload (cfg3, strong scaling) at N = 1
+    and N = 2 as child processes (N = 2: one rank per GPU, the exchange = tavb_search_allgather over RCCL), requires both parity objects
+    to be green and prints one line with both records and the measured speed-up.  With one GPU: a `skipped` line, exit 0."""
+    import torch
+
+    n_gpu = torch.cuda.device_count()
+    if n_gpu < 2:
+        print(json.dumps({"selftest": "skipped", "reason": f"{n_gpu} GPU(s) visible; the N = 2 path needs two", "n_gpus_visible": n_gpu}))
+        return 0
+    lines = {}
+    for n in (1, 2):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--workload", "cfg3", "--no-cpu-baseline", "--steps", str(args.steps or 10)]
+        if args.rows:
+            cmd += ["--rows", str(args.rows)]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        proc = subprocess.run(cmd, env=env, capture_output=True, text=True)
+        out = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or not out:
+            print(json.dumps({"selftest": "failed", "n_gpus": n, "rc": proc.returncode, "stderr_tail": proc.stderr[-1500:]}))
+            return 1
+        lines[n] = json.loads(out[-1])
+    ok = all(lines[n].get("parity", {}).get("ok") for n in (1, 2)) and lines[2]["n_gpus"] == 2
+    print(json.dumps({"selftest": "ok" if ok else "failed", "speedup_n2_over_n1": lines[2]["value"] / lines[1]["value"],
+                      "n1": {k: lines[1][k] for k in ("value", "ms_per_step", "parity", "roofline")},
+                      "n2": {k: lines[2][k] for k in ("value", "ms_per_step", "parity", "roofline", "config")}}))
+    return 0 if ok else 1
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -785,7 +820,10 @@ def main() -> None:
     ap.add_argument("--cfg5-separate", action="store_true", help="cfg5: issue the six lookups as separate synchronous calls")
     ap.add_argument("--min-score", type=float, default=0.0, help="score threshold of the lookups (0.0 = every row survives: worst case for selection; 0.85 = the reference's related-terms default)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (e.g. scan_unroll=4)")
+    ap.add_argument("--selftest", action="store_true", help="on a box with >= 2 GPUs: cfg3 strong scaling at N = 2 over RCCL with full parity, next to N = 1 (one JSON line); skipped on one GPU")
     args = ap.parse_args()
+    if args.selftest:
+        raise SystemExit(selftest(args))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -89,6 +89,8 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "last_shadow"           (get) 1 when the last lookup's corpus pass read the shadow
  *   "mfma_tile"             queries per workgroup tile of the wide fp16 kernel: 0 = auto (128 where that pads less: up to 128, 257..384, 513..640 queries; else 256), 128, 256
  *   "mfma_splits", "mfma_sched", "mfma_ablate"  measurement knobs, see DESIGN.md
+ *   "comm_force"            1: tavb_search_allgather runs its all-gather + merge even in a world of one rank (tests, dry runs)
+ *   "comm_world", "comm_rank" (read only) shape of the context's communicator (0 / -1 without one)
  *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile (exact
  *                   filter + fp32-query rescoring of its candidates), 5 = 32/64-query MFMA tile
  *   "last_flagged" (read only; synchronises) queries of the last 256-query-tile lookup whose candidate set could not be
@@ -228,12 +230,34 @@ int tavb_merge_device(tavb_ctx* ctx, const tavb_key* dev_lists, int32_t n_lists,
 int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* out_ordinals, float* out_scores,
                      int32_t* out_counts);
 
+/* ---- row-sharded corpora: one process per GPU, RCCL over xGMI ------------------------------------------------------------
+ * Every rank holds a contiguous range of the corpus rows in its own context (tavb_set_corpus with ordinal_base = the shard's first
+ * row); a lookup is every rank scanning its shard for the same queries, ONE all-gather of the per-shard [nq, k] key lists
+ * (nq * k * 8 bytes per rank: 256 KiB at 1024 x 32) and a merge kernel on every rank, so that every rank returns the whole-corpus
+ * answer of vectorbase.py:163-190 (keys carry global ordinals and order by (score desc, ordinal asc): the merged answer is the
+ * single-device one, ties included).  The collective is issued by the library itself, on the context's stream, behind the scan and
+ * in front of the merge -- RCCL (librccl.so.1, resolved with dlopen at tavb_comm_init: no link-time dependency) is the only
+ * communication layer; torch.distributed is not needed on the lookup path.
+ *
+ * tavb_comm_unique_id: rank 0 creates the 128-byte rendezvous id (ncclGetUniqueId) and hands it to the other ranks by any means
+ * (a file, a socket, an existing torch.distributed / MPI broadcast).  tavb_comm_init: collective over all `world` ranks
+ * (ncclCommInitRank on the context's device).  One communicator per context; tavb_destroy / tavb_comm_destroy release it. */
+#define TAVB_COMM_ID_BYTES 128
+int tavb_comm_unique_id(void* out_id /* TAVB_COMM_ID_BYTES */);
+int tavb_comm_init(tavb_ctx* ctx, const void* id /* TAVB_COMM_ID_BYTES */, int32_t rank, int32_t world);
+int tavb_comm_destroy(tavb_ctx* ctx);
+/* Collective tavb_search_device: queries (device float32 [nq, dim], the same on every rank) -> out_keys [nq, k] = the merged
+ * whole-corpus lists, on every rank.  out_keys may be device memory or pinned host memory the device can write (the merge kernel
+ * writes it directly).  Asynchronous on the context's stream; tavb_synchronize before reading.  Every rank must call with the same
+ * nq and k.  Without a communicator (or world == 1) this is tavb_search_device. */
+int tavb_search_allgather(tavb_ctx* ctx, const float* dev_queries, int32_t nq, int32_t k, float min_score, tavb_key* out_keys);
+
 /* ---- measurement ------------------------------------------------------------ */
 /* HIP-event timing of the kernels this context launches, on the stream they run on.
  * kernel ids: 0 = streaming scan (dot + score + select), 1 = list merge,
  *             2 = MFMA batched scan (256-query tile: the last phase of the threshold ladder), 3 = normalise,
  *             4 = f32->f16 convert, 5 = the earlier phases of the ladder (either MFMA tile), 6 = 32-query MFMA tile
- *             (last phase), 7 = candidate rescoring of the 256-query tile. */
+ *             (last phase), 7 = candidate rescoring of the 256-query tile, 8 = the all-gather of tavb_search_allgather. */
 #define TAVB_KERNEL_SCAN 0
 #define TAVB_KERNEL_MERGE 1
 #define TAVB_KERNEL_MFMA 2
@@ -242,7 +266,8 @@ int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* 
 #define TAVB_KERNEL_MFMA_SAMPLE 5 /* threshold-seeding phases of the MFMA paths (all ladder phases but the last) */
 #define TAVB_KERNEL_SKINNY 6 /* 32-query MFMA tile (small batches; every batch on fp32 corpora) */
 #define TAVB_KERNEL_RESCORE 7 /* exact fp32-query rescoring of the 256-query tile's candidates (+ query preparation) */
-#define TAVB_KERNEL_COUNT 8
+#define TAVB_KERNEL_EXCHANGE 8 /* the RCCL all-gather of tavb_search_allgather (stream time between its two events: includes waiting for the slowest rank) */
+#define TAVB_KERNEL_COUNT 9
 int tavb_profile_enable(tavb_ctx* ctx, int32_t on);
 int tavb_profile_reset(tavb_ctx* ctx);
 int tavb_profile_read(tavb_ctx* ctx, int32_t kernel_id, double* out_total_ms, int64_t* out_launches);

@@ -63,7 +63,7 @@ def test_native_library_loaded_and_device_is_gfx950():
 
     assert torch.cuda.is_available()
     lib = _native.load_library()
-    assert lib.tavb_version() == 1
+    assert lib.tavb_version() == _native.ABI_VERSION
     assert _native.device_count() >= 1
     eng = _native.Engine(0)
     assert eng.get_option("compute_units") >= 64
@@ -1235,8 +1235,10 @@ def test_shard_search_plus_merge_equals_whole():
 
 
 def test_sharded_searcher_on_one_rank_rccl():
-    """The product's N > 1 code path (DeviceShardBackend + RCCL all-gather + merge kernel) on a
-    one-rank process group: same answer as the plain engine."""
+    """The product's N > 1 code path on a one-rank world: DeviceShardBackend + libtavb's OWN RCCL communicator
+    (tavb_comm_unique_id / tavb_comm_init / tavb_search_allgather: scan -> ncclAllGather on the context's stream -> merge kernel ->
+    pinned host memory), no torch.distributed anywhere; then the same through the torch.distributed fallback the CPU test backend
+    uses.  Same answer as the plain engine."""
     import os
     import socket
 
@@ -1245,6 +1247,45 @@ def test_sharded_searcher_on_one_rank_rccl():
 
     from typeagent_py_amd.sharded import DeviceShardBackend, ShardedSearcher
 
+    v, _ = make_corpus(10_000, 1536, 8100)
+    qs = make_queries(6, 1536, 8101)
+    backend = DeviceShardBackend(0)
+    with torch.cuda.stream(backend.stream):
+        shard = torch.from_numpy(v).cuda()
+    backend.set_shard(shard, row_offset=5_000_000)
+    dq = torch.from_numpy(qs).cuda()
+
+    def check(res):
+        for qi in range(6):
+            m = int(res.counts[qi])
+            assert m == 32
+            vo.check_topk_parity(vo.scores_full(v, qs[qi]), (res.ordinals[qi, :m] - 5_000_000).tolist(), res.scores[qi, :m].tolist(), 32, 0.0)
+
+    # 1. the library's communicator, world of one, the collective forced
+    assert not dist.is_initialized()
+    backend.init_comm(0, 1)
+    eng = backend.engine
+    eng.set_option("comm_force", 1)
+    assert eng.get_option("comm_world") == 1 and eng.get_option("comm_rank") == 0
+    eng.profile_enable(True)
+    eng.profile_reset()
+    searcher = ShardedSearcher(backend)
+    check(searcher.search(dq, 32, 0.0))
+    assert eng.profile_read(_native.KERNEL_EXCHANGE)[1] == 1  # the all-gather ran, inside libtavb
+    # 1024 queries: the wide tile in front of the exchange
+    many = make_queries(1024, 1536, 8102)
+    res = searcher.search(torch.from_numpy(many).cuda(), 32, 0.0)
+    plain = _native.decode_keys(eng.search_device(torch.from_numpy(many).cuda(), 32, 0.0).cpu().numpy())
+    np.testing.assert_array_equal(res.ordinals, plain[0])
+    np.testing.assert_array_equal(res.scores, plain[1])
+    with pytest.raises(ValueError):
+        eng.comm_init(b"x" * 128, 0, 1)  # one communicator per context
+    eng.comm_destroy()
+    assert eng.get_option("comm_world") == 0
+    eng.profile_enable(False)
+    backend.native_comm = False
+
+    # 2. the torch.distributed route (what a backend without a native communicator takes)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -1253,19 +1294,7 @@ def test_sharded_searcher_on_one_rank_rccl():
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        v, _ = make_corpus(10_000, 1536, 8100)
-        qs = make_queries(6, 1536, 8101)
-        backend = DeviceShardBackend(0)
-        with torch.cuda.stream(backend.stream):
-            shard = torch.from_numpy(v).cuda()
-        backend.set_shard(shard, row_offset=5_000_000)
-        searcher = ShardedSearcher(backend, always_collective=True)
-        dq = torch.from_numpy(qs).cuda()
-        res = searcher.search(dq, 32, 0.0)
-        for qi in range(6):
-            m = int(res.counts[qi])
-            assert m == 32
-            vo.check_topk_parity(vo.scores_full(v, qs[qi]), (res.ordinals[qi, :m] - 5_000_000).tolist(), res.scores[qi, :m].tolist(), 32, 0.0)
+        check(ShardedSearcher(backend, always_collective=True).search(dq, 32, 0.0))
     finally:
         dist.destroy_process_group()
 

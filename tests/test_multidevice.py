@@ -170,6 +170,82 @@ def test_gpu_two_real_devices_when_present():
         assert vo.check_topk_parity(vo.scores_full(vv, qs[qi]), [r.item for r in out[qi]], [r.score for r in out[qi]], 32, 0.0).ordinals_bit_exact
 
 
+def _rccl_rank(rank: int, world: int, id_path: str, n: int, ret) -> None:
+    """One process per GPU: shard of the seeded corpus on cuda:<rank>, libtavb's own RCCL communicator (rendezvous id through a
+    file: no torch.distributed anywhere), collective lookups."""
+    import os
+    import time
+
+    try:
+        import torch
+
+        from typeagent_py_amd.sharded import DeviceShardBackend, ShardedSearcher, shard_range
+
+        v, _ = make_corpus(n, 1536, 71)
+        lo, hi = shard_range(n, world, rank)
+        backend = DeviceShardBackend(rank)
+        with torch.cuda.stream(backend.stream):
+            shard = torch.from_numpy(v[lo:hi]).to(f"cuda:{rank}").half()
+        backend.set_shard(shard, row_offset=lo)
+
+        def exchange(uid):
+            if uid is not None:
+                with open(id_path + ".tmp", "wb") as f:
+                    f.write(uid)
+                os.replace(id_path + ".tmp", id_path)
+                return uid
+            for _ in range(600):
+                if os.path.exists(id_path):
+                    return open(id_path, "rb").read()
+                time.sleep(0.05)
+            raise TimeoutError("no rendezvous id")
+
+        backend.init_comm(rank, world, exchange_id=exchange)
+        searcher = ShardedSearcher(backend)
+        out = {}
+        for nq in (1, 40, 130):
+            qs = make_queries(nq, 1536, 72 + nq)
+            res = searcher.search(torch.from_numpy(qs).to(f"cuda:{rank}"), 32, 0.0)
+            out[nq] = (res.ordinals.copy(), res.scores.copy(), res.counts.copy())
+        ret[rank] = out
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+
+        ret[rank] = "ERROR: " + "".join(traceback.format_exception(exc))
+
+
+@pytest.mark.gpu
+def test_gpu_two_ranks_rccl_through_the_c_abi_when_two_gpus_are_present(tmp_path):
+    """N = 2 on real hardware wherever a second GPU shows up: two processes, one per GPU, the exchange = `tavb_search_allgather`
+    (ncclAllGather issued by libtavb on its own stream).  Every rank must return the whole-corpus answer."""
+    if _native.device_count() < 2:
+        pytest.skip("one GPU visible")
+    import torch.multiprocessing as mp
+
+    n = 300_001
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_rccl_rank, args=(r, 2, str(tmp_path / "rccl_id"), n, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(not p.is_alive() and p.exitcode == 0 for p in procs)
+    assert not isinstance(ret[0], str), ret[0]
+    assert not isinstance(ret[1], str), ret[1]
+    v, _ = make_corpus(n, 1536, 71)
+    vv = v.astype(np.float16).astype(np.float32)
+    for nq in (1, 40, 130):
+        for a, b in zip(ret[0][nq], ret[1][nq]):
+            np.testing.assert_array_equal(a, b)  # both ranks: the same answer
+        qs = make_queries(nq, 1536, 72 + nq)
+        ords, scs, cnts = ret[0][nq]
+        for qi in range(0, nq, max(1, nq // 10)):
+            m = int(cnts[qi])
+            assert m == 32
+            vo.check_topk_parity(vo.scores_full(vv, qs[qi]), ords[qi, :m].tolist(), scs[qi, :m].tolist(), 32, 0.0)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # seeded random histories on fake devices: appends of random sizes interleaved with every kind of lookup
 # ------------------------------------------------------------------------------------------------------------------

@@ -22,7 +22,8 @@ TAVB_F16 = 1
 MAX_FUSED_K = 256
 MAX_STREAM_QUERIES = 8
 
-KERNEL_SCAN, KERNEL_MERGE, KERNEL_MFMA, KERNEL_NORMALIZE, KERNEL_CONVERT, KERNEL_MFMA_SAMPLE, KERNEL_SKINNY, KERNEL_RESCORE = range(8)
+KERNEL_SCAN, KERNEL_MERGE, KERNEL_MFMA, KERNEL_NORMALIZE, KERNEL_CONVERT, KERNEL_MFMA_SAMPLE, KERNEL_SKINNY, KERNEL_RESCORE, KERNEL_EXCHANGE = range(9)
+COMM_ID_BYTES = 128
 
 _LIB_NAME = os.environ.get("TAVB_LIBRARY", "libtavb.so")  # "libtavb_debug.so": the ASan/UBSan host build (`make -C csrc debug`)
 _lib = None
@@ -65,6 +66,10 @@ _SIGNATURES = [
     ("tavb_search_subset_device", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     ("tavb_merge_device", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     ("tavb_decode_keys", c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    ("tavb_comm_unique_id", c_int, [c_void_p]),
+    ("tavb_comm_init", c_int, [c_void_p, c_void_p, c_int32, c_int32]),
+    ("tavb_comm_destroy", c_int, [c_void_p]),
+    ("tavb_search_allgather", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     ("tavb_profile_enable", c_int, [c_void_p, c_int32]),
     ("tavb_profile_reset", c_int, [c_void_p]),
     ("tavb_profile_read", c_int, [c_void_p, c_int32, POINTER(c_double), POINTER(c_int64)]),
@@ -477,6 +482,34 @@ class Engine:
         _check(self.lib, rc)
         return out_keys
 
+    # row shards, one process per GPU: the library's own RCCL communicator ----------------------------------
+    def comm_init(self, unique_id: bytes, rank: int, world: int) -> None:
+        """Collective over all ranks: join the communicator named by `unique_id` (from `comm_unique_id()` on rank 0)."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"the rendezvous id is {COMM_ID_BYTES} bytes")
+        buf = ctypes.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        with self._lock:
+            rc = self.lib.tavb_comm_init(self._h, ctypes.cast(buf, c_void_p), int(rank), int(world))
+        _check(self.lib, rc)
+
+    def comm_destroy(self) -> None:
+        with self._lock:
+            rc = self.lib.tavb_comm_destroy(self._h)
+        _check(self.lib, rc)
+
+    def search_allgather(self, dev_queries, k: int, thr: float, out_keys=None):
+        """Collective `search_device`: every rank passes the same queries and gets the merged whole-corpus key lists [nq, k].
+        `out_keys`: a device tensor or a PINNED host tensor (int64 [nq, k]; the merge kernel writes it directly).  Async."""
+        torch = self._torch
+        assert dev_queries.dtype == torch.float32 and dev_queries.is_contiguous() and dev_queries.shape[1] == self.dim
+        nq = dev_queries.shape[0]
+        if out_keys is None:
+            out_keys = torch.empty((nq, k), dtype=torch.int64, device=dev_queries.device)
+        with self._lock:
+            rc = self.lib.tavb_search_allgather(self._h, c_void_p(dev_queries.data_ptr()), nq, k, c_float(float(thr)), c_void_p(out_keys.data_ptr()))
+        _check(self.lib, rc)
+        return out_keys
+
     def merge_device(self, dev_lists, out_keys=None):
         """dev_lists: torch int64 [n_lists, nq, k] -> [nq, k] (async)."""
         torch = self._torch
@@ -488,6 +521,14 @@ class Engine:
             rc = self.lib.tavb_merge_device(self._h, c_void_p(dev_lists.data_ptr()), n_lists, nq, k, c_void_p(out_keys.data_ptr()))
         _check(self.lib, rc)
         return out_keys
+
+
+def comm_unique_id() -> bytes:
+    """A fresh RCCL rendezvous id (rank 0 creates it and hands it to the other ranks)."""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    _check(lib, lib.tavb_comm_unique_id(ctypes.cast(buf, c_void_p)))
+    return buf.raw
 
 
 def make_key(score: float, ordinal: int) -> int:

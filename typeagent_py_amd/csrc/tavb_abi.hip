@@ -3,9 +3,12 @@
 // only -- the kernels live in tavb_scan.hip / tavb_misc.hip / tavb_mfma.hip.
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the functions are resolved with dlsym (tavb_comm_init)
 
 #include <algorithm>
 #include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -139,6 +142,12 @@ struct tavb_ctx {
 
   int last_tier = 0;
   int pending_nq = 0, pending_k = 0;  // shape of the lookup enqueued by tavb_search_begin
+
+  // row-sharded corpora: this context's RCCL communicator (tavb_comm_init) and the buffers of the exchange
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  int64_t comm_force = 0;  // option: run the all-gather + merge even in a world of one (tests, dry runs of the N > 1 path)
+  Buffer d_local, d_gather;  // this shard's [nq, k] lists; the all-gathered [world, nq, k]
 };
 
 namespace {
@@ -373,6 +382,9 @@ int tavb_destroy(tavb_ctx* c) {
   }
   c->h_stage.release();
   c->h_out.release();
+  (void)tavb_comm_destroy(c);
+  c->d_local.release();
+  c->d_gather.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return TAVB_OK;
@@ -442,6 +454,8 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");
     c->mfma_splits = v;
+  } else if (n == "comm_force") {
+    c->comm_force = v ? 1 : 0;
   } else {
     return fail(TAVB_E_INVALID, "unknown option '%s'", name);
   }
@@ -469,6 +483,9 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "skinny_min_batch_f16") *out = c->skinny_min_batch_f16;
   else if (n == "mfma_sample_rows") *out = c->mfma_sample_rows;
   else if (n == "compute_units") *out = c->n_cu;
+  else if (n == "comm_force") *out = c->comm_force;
+  else if (n == "comm_world") *out = c->comm ? c->comm_world : 0;
+  else if (n == "comm_rank") *out = c->comm ? c->comm_rank : -1;
   else if (n == "last_tier") *out = c->last_tier;
   else if (n == "last_flagged") {  // queries of the last 256-query-tile lookup that were re-run on the exact tile (synchronises)
     *out = 0;
@@ -1016,6 +1033,120 @@ int tavb_search_after(tavb_ctx* c, const float* query_host, int32_t k, float min
   if (rc) return rc;
   TAVB_HIP(hipStreamSynchronize(c->stream));
   decode(reinterpret_cast<const u64_t*>(c->h_out.ptr), 1, k, c->ordinal_base, out_ordinals, out_scores, out_count);
+  return TAVB_OK;
+}
+
+// ---- RCCL (resolved at run time: libtavb.so has no link-time dependency on librccl) -------------------------------------------
+namespace {
+struct Rccl {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+std::string g_rccl_error;
+
+int load_rccl() {
+  std::call_once(g_rccl_once, [] {
+    // the copy the process already has (torch ships one with the same SONAME) before a fresh one from the ROCm tree
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* n : names)
+      if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    for (const char* n : names)
+      if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rccl.handle) {
+      const char* e = dlerror();
+      g_rccl_error = std::string("cannot load librccl.so.1: ") + (e ? e : "not found");
+      return;
+    }
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(g_rccl.handle, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(g_rccl.handle, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.handle, "ncclCommDestroy"));
+    g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.handle, "ncclAllGather"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.handle, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
+      g_rccl_error = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
+  });
+  if (!g_rccl_error.empty()) return fail(TAVB_E_UNSUPPORTED, "%s", g_rccl_error.c_str());
+  return TAVB_OK;
+}
+static_assert(TAVB_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the rendezvous id is RCCL's");
+
+#define TAVB_RCCL(expr)                                                                                             \
+  do {                                                                                                              \
+    ncclResult_t r__ = (expr);                                                                                      \
+    if (r__ != ncclSuccess) return fail(TAVB_E_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r__), __FILE__, __LINE__); \
+  } while (0)
+}  // namespace
+
+int tavb_comm_unique_id(void* out_id) {
+  if (!out_id) return fail(TAVB_E_INVALID, "null out_id");
+  if (int rc = load_rccl()) return rc;
+  ncclUniqueId id;
+  TAVB_RCCL(g_rccl.GetUniqueId(&id));
+  memcpy(out_id, id.internal, TAVB_COMM_ID_BYTES);
+  return TAVB_OK;
+}
+
+int tavb_comm_init(tavb_ctx* c, const void* id_bytes, int32_t rank, int32_t world) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!id_bytes) return fail(TAVB_E_INVALID, "null id");
+  if (world < 1 || rank < 0 || rank >= world) return fail(TAVB_E_INVALID, "rank %d out of range for world %d", rank, world);
+  if (c->comm) return fail(TAVB_E_INVALID, "this context already has a communicator (tavb_comm_destroy first)");
+  if (int rc = load_rccl()) return rc;
+  DeviceGuard guard(c->device);
+  ncclUniqueId id;
+  memcpy(id.internal, id_bytes, TAVB_COMM_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  TAVB_RCCL(g_rccl.CommInitRank(&comm, world, id, rank));
+  c->comm = comm;
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return TAVB_OK;
+}
+
+int tavb_comm_destroy(tavb_ctx* c) {
+  if (!c || !c->comm) return TAVB_OK;
+  DeviceGuard guard(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  ncclComm_t comm = c->comm;
+  c->comm = nullptr;
+  c->comm_rank = 0;
+  c->comm_world = 1;
+  if (g_rccl.CommDestroy) TAVB_RCCL(g_rccl.CommDestroy(comm));
+  return TAVB_OK;
+}
+
+int tavb_search_allgather(tavb_ctx* c, const float* dev_queries, int32_t nq, int32_t k, float min_score, tavb_key* out_keys) {
+  if (int rc = check_search_args(c, k)) return rc;
+  if (nq < 1) return fail(TAVB_E_INVALID, "nq must be >= 1");
+  if (!dev_queries || !out_keys) return fail(TAVB_E_INVALID, "null argument");
+  if (!c->comm || (c->comm_world == 1 && !c->comm_force)) return tavb_search_device(c, dev_queries, nq, k, min_score, out_keys);
+  if (c->ordinal_base + c->rows >= 0xFFFFFFFFll)
+    return fail(TAVB_E_UNSUPPORTED, "device-resident keys hold 32-bit ordinals: ordinal_base + rows must be < 2^32 - 1");
+  DeviceGuard guard(c->device);
+  const size_t list_keys = (size_t)nq * k;
+  if (int rc = c->d_local.reserve(list_keys * sizeof(u64_t))) return rc;
+  if (int rc = c->d_gather.reserve(list_keys * sizeof(u64_t) * c->comm_world)) return rc;
+  u64_t* local = reinterpret_cast<u64_t*>(c->d_local.ptr);
+  u64_t* gathered = reinterpret_cast<u64_t*>(c->d_gather.ptr);
+  std::vector<float> ms((size_t)nq, min_score);
+  if (c->rows == 0) {  // an empty shard still takes part in the collective
+    TAVB_HIP(hipMemsetAsync(local, 0, list_keys * sizeof(u64_t), c->stream));
+  } else if (int rc = tavb_search_device_dispatch(c, dev_queries, nq, k, ms.data(), (uint32_t)c->ordinal_base, local)) {
+    return rc;
+  }
+  {
+    Timed t(c, TAVB_KERNEL_EXCHANGE);
+    TAVB_RCCL(g_rccl.AllGather(local, gathered, list_keys, ncclUint64, c->comm, c->stream));
+  }
+  Timed t(c, TAVB_KERNEL_MERGE);
+  hipError_t e = tavb::launch_merge(gathered, c->comm_world, nq, k, /*query_major=*/false, reinterpret_cast<u64_t*>(out_keys), c->stream);
+  if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
   return TAVB_OK;
 }
 

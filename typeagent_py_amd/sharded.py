@@ -14,9 +14,16 @@ Result keys are `(score bits << 32) | (0xFFFFFFFF - global_ordinal)`, so the
 merge is a pure integer max-merge and ties resolve to the smaller global
 ordinal on every rank identically (all ranks return the same answer).
 
+The product backend (`DeviceShardBackend`) issues the exchange from inside
+libtavb: `tavb_search_allgather` = scan kernels -> `ncclAllGather` (RCCL, on the
+context's stream) -> merge kernel, written straight into pinned host memory.
+`torch.distributed` is used ONCE, to hand rank 0's 128-byte RCCL rendezvous id to
+the other ranks (`init_comm`); the lookup path does not touch it.
+
 The compute backend is injected so that the communication pattern can be tested
-on CPU with `gloo` (tests/test_sharded_gloo.py supplies a host backend); the
-product backend below is the only one this package ships and it runs the HIP
+on CPU with `gloo` (tests/test_sharded_gloo.py supplies a host backend: for such
+backends the searcher falls back to `torch.distributed.all_gather_into_tensor`);
+the product backend below is the only one this package ships and it runs the HIP
 kernels.  There is no CPU fallback in the product path.
 """
 
@@ -67,9 +74,38 @@ class DeviceShardBackend:
             self.engine = _native.Engine(self.device, use_torch_stream=True)
         self._pinned: dict = {}
         self._gather: dict = {}
+        self.native_comm = False  # True once init_comm() has joined the library's own RCCL communicator
 
     def set_shard(self, tensor, row_offset: int, rows: int | None = None) -> None:
         self.engine.set_corpus_tensor(tensor, rows=rows, ordinal_base=row_offset)
+
+    def init_comm(self, rank: int, world: int, exchange_id=None) -> None:
+        """Collective: join libtavb's own RCCL communicator (tavb_comm_init).  Rank 0 creates the rendezvous id; `exchange_id(id or None)
+        -> id` distributes it (default: `torch.distributed.broadcast_object_list` over the default group, whatever its backend)."""
+        uid = _native.comm_unique_id() if rank == 0 else None
+        if world > 1 or exchange_id is not None:
+            if exchange_id is None:
+                import torch.distributed as dist
+
+                box = [uid]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+            else:
+                uid = exchange_id(uid)
+        with self.torch.cuda.stream(self.stream):
+            self.engine.comm_init(uid, rank, world)
+        self.native_comm = True
+
+    def search_allgather(self, queries, k: int, thr: float):
+        """scan -> ncclAllGather -> merge inside libtavb, merged keys written into a reused pinned host buffer: -> int64 [nq, k] (host view,
+        valid until the next call)."""
+        shape = (int(queries.shape[0]), int(k))
+        pinned = self._pinned.get(shape)
+        if pinned is None:
+            pinned = self._pinned[shape] = self.torch.empty(shape, dtype=self.torch.int64).pin_memory()
+        self.engine.search_allgather(queries, k, thr, out_keys=pinned)
+        self.engine.synchronize()
+        return pinned.numpy()
 
     def local_search(self, queries, k: int, thr: float):
         with self.torch.cuda.stream(self.stream):
@@ -145,7 +181,13 @@ class ShardedSearcher:
         return self.backend.merge(gathered)
 
     def search(self, queries, k: int, min_score: float = 0.0) -> ShardedResult:
-        keys = self.backend.to_host(self.search_keys(queries, k, min_score))
+        if getattr(self.backend, "native_comm", False) and self.gather_fn is None:
+            # the product path: one C-ABI call (no torch.distributed, no torch op), results land in pinned host memory
+            if not (1 <= k <= _native.MAX_FUSED_K):
+                raise ValueError(f"k must be in 1..{_native.MAX_FUSED_K}")
+            keys = self.backend.search_allgather(queries, k, float(_native.f32_threshold(min_score)))
+        else:
+            keys = self.backend.to_host(self.search_keys(queries, k, min_score))
         ords, scs, cnts = _native.decode_keys(keys)
         return ShardedResult(ords, scs, cnts)
 
@@ -172,8 +214,12 @@ class ShardedVectorBase:
 
     @classmethod
     def from_device_shard(cls, device: int, shard_tensor, row_offset: int, total_rows: int, group=None):
+        import torch.distributed as dist
+
         backend = DeviceShardBackend(device)
         backend.set_shard(shard_tensor, row_offset=row_offset)
+        if dist.is_initialized() and group is None:
+            backend.init_comm(dist.get_rank(), dist.get_world_size())
         return cls(backend, row_offset, shard_tensor.shape[0], total_rows, group=group)
 
     def _queries(self, q):
