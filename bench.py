@@ -228,43 +228,71 @@ def cpu_baseline(host: np.ndarray, queries: np.ndarray, k: int, rows_total: int,
             return vo.lookup(host, q, k, 0.0)
 
     cores = len(os.sched_getaffinity(0))
-    one(queries[0])  # warm-up (BLAS thread pool, page-in)
-    times = []
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover - threadpoolctl is part of the image
+        threadpool_limits = None
+
+    def timed(n_calls: int, first: int = 0) -> list[float]:
+        out = []
+        for j in range(n_calls):
+            t0 = time.perf_counter_ns()
+            one(queries[(first + j) % len(queries)])
+            out.append((time.perf_counter_ns() - t0) / 1e9)
+        return out
+
+    # 20 warm-up calls (BLAS thread pool, page-in of the matrix), then the timed rounds; default threads = all host cores AND
+    # the best thread count of a sweep (OpenBLAS sgemv on a few-GB matrix is memory-bound: 256 threads oversubscribe it)
     t_end = time.perf_counter() + budget_s
-    i = 0
-    while (time.perf_counter() < t_end and i < 400) or i < 3:
-        q = queries[i % len(queries)]
-        t0 = time.perf_counter_ns()
-        one(q)
-        times.append((time.perf_counter_ns() - t0) / 1e9)
-        i += 1
+    warm = timed(20 if host.shape[0] <= 200_000 else 8)
+    per_call = float(np.median(warm))
+    sweep = {}
+    best_threads, best_med = cores, None
+    if threadpool_limits is not None:
+        for th in sorted({1, 4, 8, 16, 32, 64, 128, cores}):
+            if th > cores:
+                continue
+            if th == 1 and per_call * 20 > budget_s:  # (one thread on 1M rows: ~0.6 s per call; measured below with 3 calls)
+                continue
+            with threadpool_limits(limits=th, user_api="blas"):
+                one(queries[0])
+                med = float(np.median(timed(3, 1)))
+            sweep[th] = med
+            if best_med is None or med < best_med:
+                best_threads, best_med = th, med
+    times_default = timed(max(3, min(200, int(max(0.0, t_end - time.perf_counter()) / 2 / max(per_call, 1e-6)))), 4)
+    if threadpool_limits is not None and best_threads != cores:
+        with threadpool_limits(limits=best_threads, user_api="blas"):
+            one(queries[0])
+            times = timed(max(10, min(200, int(max(0.0, t_end - time.perf_counter()) / max(best_med, 1e-6)))), 4)
+    else:
+        times = times_default
     med = float(np.median(times))
+    med_default = float(np.median(times_default))
     scale = rows_total / host.shape[0]
     out = {
         "value": 1.0 / (med * scale),
         "unit": "queries/s",
-        "cores": cores,
+        "cores": best_threads,
+        "host_cores": cores,
         "kind": kind,
-        "sample": f"{len(times)} sequential fuzzy_lookup_embedding calls (numpy {np.__version__} / OpenBLAS sgemv, default threads) on "
-                  f"{host.shape[0]}x{host.shape[1]} fp32 rows of the same corpus, median {med * 1e3:.2f} ms, min {min(times) * 1e3:.2f} ms"
+        "sample": f"{len(times)} sequential fuzzy_lookup_embedding calls (numpy {np.__version__} / OpenBLAS sgemv, {best_threads} BLAS threads = the best of a sweep "
+                  f"over {sorted(sweep)}; {len(warm)} warm-up calls) on {host.shape[0]}x{host.shape[1]} fp32 rows of the same corpus, median {med * 1e3:.2f} ms, min {min(times) * 1e3:.2f} ms"
                   + (f"; per-query time extrapolated x{scale:g} to the {rows_total} rows of the workload (the fp32 host matrix the reference needs, "
                      f"{rows_total * host.shape[1] * 4 / 1e9:.0f} GB, is not materialised)" if scale != 1 else "")
                   + (f"; a {nq}-query batch is {nq} such calls" if nq > 1 else ""),
         "p50_ms_per_query_on_sample": med * 1e3,
+        "thread_sweep_ms": {str(k_): v * 1e3 for k_, v in sorted(sweep.items())},
+        "default_threads": {"value": 1.0 / (med_default * scale), "unit": "queries/s", "cores": cores,
+                            "sample": f"{len(times_default)} calls with OpenBLAS's default of all {cores} host cores, median {med_default * 1e3:.2f} ms, min {min(times_default) * 1e3:.2f} ms"},
     }
-    try:  # also the reference arithmetic on one core
-        from threadpoolctl import threadpool_limits
-
+    if 1 in sweep:
+        out["one_thread"] = {"value": 1.0 / (sweep[1] * scale), "unit": "queries/s", "cores": 1, "sample": f"3 calls, median {sweep[1] * 1e3:.1f} ms on the same sample"}
+    elif threadpool_limits is not None:
         with threadpool_limits(limits=1, user_api="blas"):
-            t1 = []
-            for j in range(3):
-                t0 = time.perf_counter_ns()
-                one(queries[j % len(queries)])
-                t1.append((time.perf_counter_ns() - t0) / 1e9)
+            t1 = timed(3)
         out["one_thread"] = {"value": 1.0 / (float(np.median(t1)) * scale), "unit": "queries/s", "cores": 1,
                              "sample": f"3 calls, median {np.median(t1) * 1e3:.1f} ms on the same sample"}
-    except Exception:
-        pass
     return out
 
 
@@ -289,6 +317,8 @@ class Ctx:
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
+            for var, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):  # (TAVB_BENCH_FORCE_DIST=1 without a launcher)
+                os.environ.setdefault(var, val)
             torch.cuda.set_device(self.local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             self.dist = dist
@@ -585,16 +615,17 @@ def headline_line(ctx: Ctx, rec: dict, name: str, wl: dict, scaling: str, sub: d
     return out
 
 
-def run_cfg5(args, wl) -> None:
-    """BASELINE config 5: user queries/s of the fused multi-index submission (typeagent_py_amd/fused.py)."""
+def run_cfg5(args, wl, emit: bool = True, steps: int | None = None, warmup: int | None = None):
+    """BASELINE config 5: user queries/s of the fused multi-index submission (typeagent_py_amd/fused.py).  `emit=False`: return the
+    record (a sub-record of the north-star suite) instead of printing it."""
     import torch
 
     from typeagent_py_amd import TextEmbeddingIndexSettings, VectorBase, _native
     from typeagent_py_amd.fused import FusedIndexQuery
 
     rows, dim = wl["rows"], wl["dim"]
-    steps = args.steps if args.steps is not None else 30
-    warmup = args.warmup if args.warmup is not None else 3
+    steps = steps if steps is not None else (args.steps if args.steps is not None else 30)
+    warmup = warmup if warmup is not None else (args.warmup if args.warmup is not None else 3)
     fq = FusedIndexQuery(0)
     eng = fq.engine
     with torch.cuda.stream(fq.stream):
@@ -682,6 +713,11 @@ def run_cfg5(args, wl) -> None:
     if not args.no_parity:
         out["parity"] = cfg5_parity(eng, one, user_queries[:2], {"terms": (terms, 50_043), "messages": (msgs, 50_044), "threads": (threads, 50_045)},
                                     dim, wl["dtype"], subset)
+    del terms, msgs, threads
+    fq.close() if hasattr(fq, "close") else None
+    torch.cuda.empty_cache()
+    if not emit:
+        return out
     emit_result(out)
     if out.get("parity") and not out["parity"]["ok"]:
         sys.stderr.write("bench.py: PARITY CHECK FAILED (see the `parity` object in the line above)\n")
@@ -874,6 +910,25 @@ def main() -> None:
         sub["cfg3_q1"] = run_record(ctx, "cfg3_q1", w2, corpus, 0, 40, 5, with_cpu=False)
         del corpus
         torch.cuda.empty_cache()
+        # the headline shape on a clustered corpus (near-duplicate clusters + exact duplicates, queries next to cluster centres): what the
+        # wide tile's band selection is there for; `vs_gaussian` = its rate over the headline's
+        wc = dict(WORKLOADS["cfg3_clustered"])
+        wc["rows_total"] = wc["rows"]
+        cc = gen_rows(ctx.eng, 0, wc["rows"], wc["dim"], wc["seed"], wc["dtype"], "clustered", wc["rows"])
+        sub["cfg3_clustered"] = run_record(ctx, "cfg3_clustered", wc, cc, 0, 10, 2, with_cpu=False)
+        sub["cfg3_clustered"]["vs_gaussian"] = sub["cfg3_clustered"]["queries_per_sec"] / rec["queries_per_sec"]
+        del cc
+        torch.cuda.empty_cache()
+        # one GPU's shard of cfg4 (100M rows over 8 GPUs = 12.5M rows each): the per-GPU work of the weak-scaling config, as a corpus of its own
+        w4 = dict(WORKLOADS["cfg4"])
+        w4["rows_total"] = w4["rows"]
+        c4 = gen_rows(ctx.eng, 0, w4["rows"], w4["dim"], w4["seed"], w4["dtype"])
+        sub["cfg4_shard"] = run_record(ctx, "cfg4", w4, c4, 0, 10, 2, with_cpu=False)
+        sub["cfg4_shard"]["note"] = "rank 0's 12.5M-row shard of cfg4 searched on its own (no exchange: the all-gather + merge of the 8-GPU run add ~0.1 ms per batch)"
+        del c4
+        torch.cuda.empty_cache()
+        # cfg5: the fused multi-index user query (4 term lookups k=50@0.85 + message re-rank k=25@0.7 + thread lookup k=10@0.7; convsettings.py:61-67)
+        sub["cfg5"] = run_cfg5(args, dict(WORKLOADS["cfg5"]), emit=False, steps=20, warmup=3)
         w3 = dict(WORKLOADS["cfg2"])
         w3["rows_total"] = w3["rows"]
         c2 = gen_rows(ctx.eng, 0, w3["rows"], w3["dim"], w3["seed"], w3["dtype"])

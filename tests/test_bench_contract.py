@@ -56,3 +56,26 @@ def test_strong_scaling_shards_cover_the_corpus_once():
         assert all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
         sizes = [hi - lo for lo, hi in bounds]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_committed_pmc_traffic_belongs_to_the_kernels_that_ship():
+    """bench.py reads `roofline.traffic` from profiles/pmc_traffic.json (a separate rocprofv3 --pmc pass: bench.py cannot count HBM bytes
+    itself).  Every entry names the kernels its sum ran over; each must still be a kernel of libtavb.so, and every workload named must
+    still exist with the shape the pass was made for -- so that a stale file fails here instead of riding along silently."""
+    import re
+
+    from typeagent_py_amd import _native
+
+    blob = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    lib = open(_native.library_path(), "rb").read()
+    assert blob, "profiles/pmc_traffic.json is empty"
+    for name, entry in blob.items():
+        assert name in bench.WORKLOADS, f"{name}: not a bench workload any more"
+        assert entry["traffic_bytes_per_step"] > 0 and "FETCH_SIZE" in entry["counter"]
+        assert re.search(rf"--workload {name}\b", entry["source"]), f"{name}: the pass was made for another workload"
+        assert entry.get("kernels"), f"{name}: no kernel list (regenerate with tools/gpu_r3_pmc.sh)"
+        for kern in entry["kernels"]:
+            assert kern.encode() in lib, f"{name}: kernel {kern} is not in libtavb.so any more -- re-run the PMC pass"
+        wl = bench.WORKLOADS[name]
+        corpus_bytes = wl["rows"] * wl["dim"] * (2 if wl["dtype"] == "fp16" else 4)
+        assert 0.9 <= entry["traffic_bytes_per_step"] / corpus_bytes <= 3.0, f"{name}: traffic is not of the order of this workload's corpus"

@@ -1254,6 +1254,9 @@ def test_sharded_searcher_on_one_rank_rccl():
         shard = torch.from_numpy(v).cuda()
     backend.set_shard(shard, row_offset=5_000_000)
     dq = torch.from_numpy(qs).cuda()
+    many = make_queries(1024, 1536, 8102)
+    dmany = torch.from_numpy(many).cuda()
+    torch.cuda.synchronize()  # (the inputs were copied on torch's default stream, the lookups run on the backend's)
 
     def check(res):
         for qi in range(6):
@@ -1273,9 +1276,11 @@ def test_sharded_searcher_on_one_rank_rccl():
     check(searcher.search(dq, 32, 0.0))
     assert eng.profile_read(_native.KERNEL_EXCHANGE)[1] == 1  # the all-gather ran, inside libtavb
     # 1024 queries: the wide tile in front of the exchange
-    many = make_queries(1024, 1536, 8102)
-    res = searcher.search(torch.from_numpy(many).cuda(), 32, 0.0)
-    plain = _native.decode_keys(eng.search_device(torch.from_numpy(many).cuda(), 32, 0.0).cpu().numpy())
+    res = searcher.search(dmany, 32, 0.0)
+    res = type(res)(res.ordinals.copy(), res.scores.copy(), res.counts.copy())
+    keys = eng.search_device(dmany, 32, 0.0)
+    eng.synchronize()
+    plain = _native.decode_keys(keys.cpu().numpy())
     np.testing.assert_array_equal(res.ordinals, plain[0])
     np.testing.assert_array_equal(res.scores, plain[1])
     with pytest.raises(ValueError):

@@ -32,6 +32,8 @@ def main() -> None:
     ap.add_argument("--cmd", default=None, help="the profiled command (for the header)")
     ap.add_argument("--json", default=None)
     ap.add_argument("--name", default=None)
+    ap.add_argument("--round", default="r03", help="prefix of the profiles/ file names this summary is committed under")
+    ap.add_argument("--script", default="tools/gpu_r3_pmc.sh")
     args = ap.parse_args()
     csv.field_size_limit(1 << 30)
     per = collections.defaultdict(lambda: collections.defaultdict(float))  # kernel -> counter -> sum
@@ -74,10 +76,13 @@ def main() -> None:
                     blob = json.load(open(args.json))
                 except Exception:
                     blob = {}
+                lookup_kernels = sorted({re.sub(r"[<(].*$", "", k).strip() for k in per if not any(s_ in k for s_ in SETUP) and per[k].get("FETCH_SIZE", 0.0) > 0})
                 blob[args.name] = {
                     "traffic_bytes_per_step": b,
                     "counter": "FETCH_SIZE (KiB) x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM section), summed over every lookup kernel of a step",
-                    "source": f"rocprofv3 --pmc FETCH_SIZE --kernel-trace pass of `{args.cmd or 'bench.py'}` ({args.steps} lookups in the run), tools/gpu_r2_pmc.sh + tools/pmc_summary.py, profiles/r02_pmc_{args.name}_fetch.md",
+                    "source": f"rocprofv3 --pmc FETCH_SIZE --kernel-trace pass of `{args.cmd or 'bench.py'}` ({args.steps} lookups in the run), {args.script} + tools/pmc_summary.py, profiles/{args.round}_pmc_{args.name}_fetch.md",
+                    # the kernels the sum runs over: tests/test_bench_contract.py checks that each still exists in libtavb.so (a stale file must not go unnoticed)
+                    "kernels": lookup_kernels,
                 }
                 json.dump(blob, open(args.json, "w"), indent=1)
 
