@@ -590,6 +590,48 @@ def test_in_place_edit_of_the_serialized_matrix_is_noticed():
     vo.check_topk_parity(vo.scores_full(x, q), *items_scores(flipped), 3, 0.0)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_small_corpus_lookups_replay_a_captured_graph(dtype):
+    """At the reference's own scale (10k x 1536: 376-417 us per lookup there) a lookup here is launch-bound; single-query lookups on small
+    corpora therefore replay ONE captured HIP graph (query H2D + scan + merge into pinned host memory).  Same answers as the plain
+    path, whatever is replayed: other queries, other (k, min_score) shapes, appends, a corpus too big for the graph path."""
+    v, _ = make_corpus(10_000, 1536, 4500)
+    qs = make_queries(12, 1536, 4501)
+    vb = new_vb(v, dtype=dtype)
+    eng = vb.engine
+    seen = _f16(v) if dtype == "fp16" else v
+    replayed = 0
+    for rep in range(3):
+        for qi in range(12):
+            k, ms = (10, 0.0) if qi % 3 else (32, 0.5)
+            res = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=ms)
+            replayed += eng.get_option("last_graph")
+            vo.check_topk_parity(vo.scores_full(seen, qs[qi]), *items_scores(res), k, ms)
+    assert replayed >= 30  # everything after the first two calls of each of the two shapes
+    eng.set_option("graph_max_bytes", 0)
+    plain = vb.fuzzy_lookup_embedding(qs[1], max_hits=10, min_score=0.0)
+    assert eng.get_option("last_graph") == 0
+    eng.set_option("graph_max_bytes", 256 << 20)
+    again = vb.fuzzy_lookup_embedding(qs[1], max_hits=10, min_score=0.0)
+    assert eng.get_option("last_graph") == 1 and [(r.item, r.score) for r in again] == [(r.item, r.score) for r in plain]
+    # five shapes through four slots, then back to the first
+    for k in (1, 2, 3, 4, 5, 1, 1, 1):
+        for _ in range(3):
+            res = vb.fuzzy_lookup_embedding(qs[2], max_hits=k, min_score=0.0)
+        vo.check_topk_parity(vo.scores_full(seen, qs[2]), *items_scores(res), k, 0.0)
+    assert eng.get_option("last_graph") == 1
+    # an append changes the corpus: the new rows are seen (a new shape: plain, capture, replay)
+    vb.add_embedding(None, qs[3])
+    for _ in range(3):
+        res = vb.fuzzy_lookup_embedding(qs[3], max_hits=10, min_score=0.0)
+        assert res[0].item == 10_000 and abs(res[0].score - 1.0) < 2e-3
+    # with the profiler on the launches are timed one by one: no graph
+    eng.profile_enable(True)
+    vb.fuzzy_lookup_embedding(qs[3], max_hits=10, min_score=0.0)
+    assert eng.get_option("last_graph") == 0
+    eng.profile_enable(False)
+
+
 def test_wrong_query_size_raises_value_error():
     vb = new_vb(np.ones((4, 8), dtype=np.float32))
     with pytest.raises(ValueError):

@@ -55,6 +55,9 @@ struct DeviceGuard {
   }
 };
 
+// bumped by every (re)allocation or release of a workspace: captured HIP graphs hold raw pointers into these buffers
+unsigned long long g_alloc_epoch = 1;
+
 struct Buffer {
   void* ptr = nullptr;
   size_t cap = 0;
@@ -63,6 +66,7 @@ struct Buffer {
     if (bytes <= cap) return TAVB_OK;
     size_t want = std::max(bytes, cap * 2);
     want = (want + 255) & ~(size_t)255;
+    ++g_alloc_epoch;
     if (ptr) {
       hipError_t e = pinned_host ? hipHostFree(ptr) : hipFree(ptr);
       ptr = nullptr;
@@ -78,6 +82,7 @@ struct Buffer {
     return TAVB_OK;
   }
   void release() {
+    if (ptr) ++g_alloc_epoch;
     if (ptr) (void)(pinned_host ? hipHostFree(ptr) : hipFree(ptr));
     ptr = nullptr;
     cap = 0;
@@ -142,6 +147,23 @@ struct tavb_ctx {
 
   int last_tier = 0;
   int pending_nq = 0, pending_k = 0;  // shape of the lookup enqueued by tavb_search_begin
+
+  // small corpora (the reference's own scale: 10k x 1536, 43 us per call as three submissions): the H2D copy of the query, the scan and the merge
+  // of a single-query lookup replayed as ONE captured HIP graph.  A few (corpus, k, min_score) shapes are kept.
+  struct SmallGraph {
+    const void* corpus = nullptr;
+    int64_t rows = 0;
+    int32_t dim = 0, dtype = 0, k = 0;
+    uint32_t thr_bits = 0;
+    unsigned long long epoch = 0, geom_tag = 0;
+    hipGraphExec_t exec = nullptr;
+    int seen = 0;  // calls with this shape so far (the first one runs un-captured: it sizes the workspaces)
+    unsigned long long last_used = 0;
+  };
+  SmallGraph graphs[4];
+  unsigned long long graph_clock = 0;
+  int64_t graph_max_bytes = (int64_t)256 << 20;  // option "graph_max_bytes": single-query lookups on corpora up to this size replay a graph (0 = never)
+  int64_t last_graph = 0;                          // option "last_graph" (get): 1 when the last lookup was a graph replay
 
   // row-sharded corpora: this context's RCCL communicator (tavb_comm_init) and the buffers of the exchange
   ncclComm_t comm = nullptr;
@@ -382,6 +404,8 @@ int tavb_destroy(tavb_ctx* c) {
   }
   c->h_stage.release();
   c->h_out.release();
+  for (auto& g : c->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
   (void)tavb_comm_destroy(c);
   c->d_local.release();
   c->d_gather.release();
@@ -456,6 +480,9 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     c->mfma_splits = v;
   } else if (n == "comm_force") {
     c->comm_force = v ? 1 : 0;
+  } else if (n == "graph_max_bytes") {
+    if (v < 0) return fail(TAVB_E_INVALID, "graph_max_bytes must be >= 0");
+    c->graph_max_bytes = v;
   } else {
     return fail(TAVB_E_INVALID, "unknown option '%s'", name);
   }
@@ -484,6 +511,8 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "mfma_sample_rows") *out = c->mfma_sample_rows;
   else if (n == "compute_units") *out = c->n_cu;
   else if (n == "comm_force") *out = c->comm_force;
+  else if (n == "graph_max_bytes") *out = c->graph_max_bytes;
+  else if (n == "last_graph") *out = c->last_graph;
   else if (n == "comm_world") *out = c->comm ? c->comm_world : 0;
   else if (n == "comm_rank") *out = c->comm ? c->comm_rank : -1;
   else if (n == "last_tier") *out = c->last_tier;
@@ -632,9 +661,78 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
   if (int rc = c->h_out.reserve(obytes)) return rc;
   if (int rc = c->d_queries.reserve(qbytes)) return rc;
   memcpy(c->h_stage.ptr, queries_host, qbytes);
-  TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
-  int rc = tavb_search_device_dispatch(c, reinterpret_cast<const float*>(c->d_queries.ptr), nq, k, min_scores, 0u,
-                                   reinterpret_cast<u64_t*>(c->h_out.ptr));
+  c->last_graph = 0;
+  // ---- small corpus, one query: replay the captured (H2D, scan, merge) graph -- one submission instead of three
+  const int64_t corpus_bytes = c->rows * c->dim * (c->dtype == TAVB_F16 ? 2 : 4);
+  const bool streaming = nq == 1 && !(c->dtype == TAVB_F32 && c->f32_shadow >= 2 && corpus_bytes >= c->f32_shadow_min_bytes);
+  tavb_ctx::SmallGraph* slot = nullptr;
+  if (streaming && !c->profiling && c->graph_max_bytes > 0 && corpus_bytes <= c->graph_max_bytes) {
+    uint32_t thr_bits;
+    memcpy(&thr_bits, &min_scores[0], sizeof thr_bits);
+    const unsigned long long geom_tag = ((unsigned long long)c->geom.blocks << 40) ^ ((unsigned long long)c->geom.waves << 32) ^ ((unsigned long long)c->geom.unroll << 24) ^
+                                        ((unsigned long long)c->geom.nt << 16) ^ ((unsigned long long)c->geom.pipe << 8) ^ (unsigned long long)c->geom.tier;
+    tavb_ctx::SmallGraph* oldest = &c->graphs[0];
+    for (auto& g : c->graphs) {
+      if (g.corpus == c->corpus && g.rows == c->rows && g.dim == c->dim && g.dtype == c->dtype && g.k == k && g.thr_bits == thr_bits && g.geom_tag == geom_tag) slot = &g;
+      if (g.last_used < oldest->last_used) oldest = &g;
+    }
+    if (!slot) {  // a new shape takes the least recently used slot
+      slot = oldest;
+      if (slot->exec) (void)hipGraphExecDestroy(slot->exec);
+      *slot = tavb_ctx::SmallGraph{};
+      slot->corpus = c->corpus;
+      slot->rows = c->rows;
+      slot->dim = c->dim;
+      slot->dtype = c->dtype;
+      slot->k = k;
+      slot->thr_bits = thr_bits;
+      slot->geom_tag = geom_tag;
+    }
+    slot->last_used = ++c->graph_clock;
+    if (slot->exec && slot->epoch != g_alloc_epoch) {  // a workspace moved since the capture: the graph holds stale pointers
+      (void)hipGraphExecDestroy(slot->exec);
+      slot->exec = nullptr;
+      slot->seen = 1;
+    }
+    if (slot->exec) {
+      TAVB_HIP(hipGraphLaunch(slot->exec, c->stream));
+      TAVB_HIP(hipStreamSynchronize(c->stream));
+      c->last_graph = 1;
+      decode(reinterpret_cast<const u64_t*>(c->h_out.ptr), nq, k, c->ordinal_base, out_ordinals, out_scores, out_counts);
+      return TAVB_OK;
+    }
+  }
+  const bool capture = slot != nullptr && slot->seen >= 1;  // (the first call of a shape sizes the workspaces: no allocation may happen inside a capture)
+  if (slot) ++slot->seen;
+  if (capture) TAVB_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  hipError_t copy_err = hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream);
+  int rc = copy_err == hipSuccess ? tavb_search_device_dispatch(c, reinterpret_cast<const float*>(c->d_queries.ptr), nq, k, min_scores, 0u,
+                                                                reinterpret_cast<u64_t*>(c->h_out.ptr))
+                                  : fail(TAVB_E_HIP, "hipMemcpyAsync of the query failed: %s", hipGetErrorString(copy_err));
+  if (capture) {
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc == TAVB_OK && e == hipSuccess && graph) {
+      hipGraphExec_t exec = nullptr;
+      e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (e == hipSuccess) {
+        slot->exec = exec;
+        slot->epoch = g_alloc_epoch;
+      }
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc) return rc;
+    if (!slot->exec) {  // capture or instantiation failed: this shape stays on the plain path
+      (void)hipGetLastError();
+      slot->seen = -1000000;
+      TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
+      if (int rc2 = tavb_search_device_dispatch(c, reinterpret_cast<const float*>(c->d_queries.ptr), nq, k, min_scores, 0u, reinterpret_cast<u64_t*>(c->h_out.ptr)))
+        return rc2;
+    } else {
+      TAVB_HIP(hipGraphLaunch(slot->exec, c->stream));  // nothing ran during the capture: this is the lookup
+      c->last_graph = 1;
+    }
+  }
   if (rc) return rc;
   // no D2H copy: the merge kernel wrote the keys into pinned host memory
   TAVB_HIP(hipStreamSynchronize(c->stream));
