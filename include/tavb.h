@@ -89,9 +89,10 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "last_shadow"           (get) 1 when the last lookup's corpus pass read the shadow
  *   "mfma_tile"             queries per workgroup tile of the wide fp16 kernel: 0 = auto (128 where that pads less: up to 128, 257..384, 513..640 queries; else 256), 128, 256
  *   "mfma_splits", "mfma_sched", "mfma_ablate"  measurement knobs, see DESIGN.md
- *   "graph_max_bytes"       single-query lookups (tavb_search / tavb_search_batch with nq = 1) on corpora of at most this many bytes (default 256 MiB)
- *                           replay ONE captured HIP graph (query H2D, scan, merge into pinned host memory) instead of three submissions; the
- *                           first call of a (corpus, k, min_score) shape runs plain, the second captures, later ones replay; 0 = never
+ *   "graph_max_bytes"       single-query lookups (tavb_search / tavb_search_batch with nq = 1) on corpora of at most this many bytes replay ONE
+ *                           captured HIP graph (query H2D, scan, merge into pinned host memory) instead of three submissions; the first call
+ *                           of a (corpus, k, min_score) shape runs plain, the second captures, later ones replay.  Default 0 = never: on
+ *                           ROCm 7.2 the replay measured SLOWER than the plain submissions (48 vs 41 us at 10k x 1536)
  *   "last_graph"            (get) 1 when the last lookup was such a replay
  *   "comm_force"            1: tavb_search_allgather runs its all-gather + merge even in a world of one rank (tests, dry runs)
  *   "comm_world", "comm_rank" (read only) shape of the context's communicator (0 / -1 without one)

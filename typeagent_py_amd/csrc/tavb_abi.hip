@@ -148,8 +148,10 @@ struct tavb_ctx {
   int last_tier = 0;
   int pending_nq = 0, pending_k = 0;  // shape of the lookup enqueued by tavb_search_begin
 
-  // small corpora (the reference's own scale: 10k x 1536, 43 us per call as three submissions): the H2D copy of the query, the scan and the merge
-  // of a single-query lookup replayed as ONE captured HIP graph.  A few (corpus, k, min_score) shapes are kept.
+  // small corpora (the reference's own scale: 10k x 1536, 41 us per call as three submissions): the H2D copy of the query, the scan and the merge
+  // of a single-query lookup replayed as ONE captured HIP graph.  A few (corpus, k, min_score) shapes are kept.  OFF by default: measured on
+  // MI355X / ROCm 7.2 (profiles/r03_latency_cfg1.md) the replay takes 48.3 us against 41.3 us for the three plain submissions -- hipGraphLaunch
+  // costs more than it saves for a 3-node graph; the GPU-side floor of the lookup is the two kernels (scan 14.8 us + merge 11.8 us).
   struct SmallGraph {
     const void* corpus = nullptr;
     int64_t rows = 0;
@@ -162,7 +164,7 @@ struct tavb_ctx {
   };
   SmallGraph graphs[4];
   unsigned long long graph_clock = 0;
-  int64_t graph_max_bytes = (int64_t)256 << 20;  // option "graph_max_bytes": single-query lookups on corpora up to this size replay a graph (0 = never)
+  int64_t graph_max_bytes = 0;  // option "graph_max_bytes": single-query lookups on corpora up to this size replay a graph (0 = never, the default)
   int64_t last_graph = 0;                          // option "last_graph" (get): 1 when the last lookup was a graph replay
 
   // row-sharded corpora: this context's RCCL communicator (tavb_comm_init) and the buffers of the exchange
@@ -1354,7 +1356,14 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   // stream 163840 unfiltered keys per query: 0.88 of the 6.3 ms of a 128-query batch over 10M rows)
   const int64_t auto_sample = (int64_t)std::min(splits, 64) * 2 * 320;
   const int64_t sample = c->mfma_sample_rows > 0 ? (c->mfma_sample_rows + 255) / 256 * 256 : (c->mfma_sample_rows == 0 ? auto_sample : 0);
-  if (r.ladder && sample > 0 && c->rows >= 8 * sample) {
+  // 32/64-query tile on corpora of a few hundred thousand to ~2M rows: the default ladder's first phases are smaller than one tile per
+  // workgroup (40960 rows = 160 tiles for 512 resident workgroups) and each costs a launch + ~one tile time whatever its size; ONE seeding
+  // phase of exactly one tile per workgroup, then the rest, is faster (1M x 1536 fp32, 32 queries: 1.18 -> 1.07 ms of kernels per batch,
+  // profiles/r03_mid_batch.md); a single un-seeded phase is slower still (1.23 ms: every workgroup pays the cold start)
+  const int64_t one_tile_each = (int64_t)splits * 256;
+  if (r.ladder && r.skinny && c->mfma_sample_rows == 0 && c->rows >= 4 * one_tile_each && c->rows < 50 * auto_sample) {
+    bounds.push_back(one_tile_each);
+  } else if (r.ladder && sample > 0 && c->rows >= 8 * sample) {
     int64_t done = sample;
     bounds.push_back(done);
     const int64_t growth = c->mfma_ladder;
