@@ -256,6 +256,14 @@ int tavb_comm_destroy(tavb_ctx* ctx);
  * writes it directly).  Asynchronous on the context's stream; tavb_synchronize before reading.  Every rank must call with the same
  * nq and k.  Without a communicator (or world == 1) this is tavb_search_device. */
 int tavb_search_allgather(tavb_ctx* ctx, const float* dev_queries, int32_t nq, int32_t k, float min_score, tavb_key* out_keys);
+/* The exchange on its own, for lists a rank produced by other means (its part of a subset search, vectorbase.py:203-230; its survivors
+ * of a predicate, :191-201): dev_local_keys [nq, k] sorted lists with GLOBAL ordinals / positions -> out_keys [nq, k] merged over all
+ * ranks (device or device-writable pinned memory).  Asynchronous; collective. */
+int tavb_allgather_merge(tavb_ctx* ctx, const tavb_key* dev_local_keys, int32_t nq, int32_t k, tavb_key* out_keys);
+/* keys [count] that carry POSITIONS into a list -> the same keys carrying dev_map[position] (int32 [map_len]): a rank's subset search
+ * (tavb_search_subset_device) numbers the part of the caller's subset that lies in its shard; the map leads back to the positions in the
+ * caller's whole list.  In place, asynchronous.  The map must be monotonic for the lists to stay sorted among equal scores. */
+int tavb_remap_key_positions(tavb_ctx* ctx, tavb_key* dev_keys, int64_t count, const int32_t* dev_map, int64_t map_len);
 
 /* ---- measurement ------------------------------------------------------------ */
 /* HIP-event timing of the kernels this context launches, on the stream they run on.

@@ -1327,6 +1327,29 @@ def test_sharded_searcher_on_one_rank_rccl():
     plain = _native.decode_keys(keys.cpu().numpy())
     np.testing.assert_array_equal(res.ordinals, plain[0])
     np.testing.assert_array_equal(res.scores, plain[1])
+    # the other forms of the VectorBase-shaped front end ride the same communicator: tavb_search_subset_device + tavb_remap_key_positions +
+    # tavb_allgather_merge (subset), one emit-all pass + host predicate + tavb_allgather_merge (predicate)
+    from typeagent_py_amd.sharded import ShardedVectorBase
+
+    backend.set_shard(shard, row_offset=0)
+    svb = ShardedVectorBase(backend, 0, 10_000, 10_000)
+    n_exchanges = eng.profile_read(_native.KERNEL_EXCHANGE)[1]
+    subset = np.random.default_rng(8103).integers(-50, 10_000, size=700).tolist() + [17, 17]
+    got = svb.fuzzy_lookup_embedding_in_subset(qs[1], subset, max_hits=20, min_score=0.0)
+    sub_a = np.asarray(subset, dtype=np.int64)
+    vo.check_topk_parity(vo.scores_full(v, qs[1])[sub_a], [r.item for r in got], [r.score for r in got], 20, 0.0, candidate_ordinals=sub_a)
+    assert len(got) == 20
+    pred = lambda i: i % 7 == 3
+    got = svb.fuzzy_lookup_embedding(qs[2], max_hits=12, min_score=0.5, predicate=pred)
+    want = vo.lookup(v, qs[2], 12, 0.5, predicate=pred)
+    assert [r.item for r in got] == [i for i, _ in want]
+    np.testing.assert_allclose([r.score for r in got], [s_ for _, s_ in want], atol=1e-6, rtol=0)
+    msgs = svb.lookup_messages_by_embedding(qs[3], [i // 3 for i in range(10_000)], max_matches=15, threshold_score=0.0)
+    assert len(msgs) <= 15 and len({m.item for m in msgs}) == len(msgs)
+    assert eng.profile_read(_native.KERNEL_EXCHANGE)[1] == n_exchanges + 3
+    with pytest.raises(IndexError):
+        svb.fuzzy_lookup_embedding_in_subset(qs[1], [10_000], max_hits=5)
+    backend.set_shard(shard, row_offset=5_000_000)
     with pytest.raises(ValueError):
         eng.comm_init(b"x" * 128, 0, 1)  # one communicator per context
     eng.comm_destroy()

@@ -207,6 +207,14 @@ def _rccl_rank(rank: int, world: int, id_path: str, n: int, ret) -> None:
             qs = make_queries(nq, 1536, 72 + nq)
             res = searcher.search(torch.from_numpy(qs).to(f"cuda:{rank}"), 32, 0.0)
             out[nq] = (res.ordinals.copy(), res.scores.copy(), res.counts.copy())
+        # subset and predicate forms over the two shards (tavb_search_subset_device + remap + tavb_allgather_merge)
+        from typeagent_py_amd.sharded import ShardedVectorBase
+
+        svb = ShardedVectorBase(backend, lo, hi - lo, n)
+        qs = make_queries(4, 1536, 99)
+        subset = np.random.default_rng(98).integers(-100, n, size=5000).tolist()
+        out["subset"] = [(r.item, r.score) for r in svb.fuzzy_lookup_embedding_in_subset(qs[0], subset, max_hits=32, min_score=0.0)]
+        out["pred"] = [(r.item, r.score) for r in svb.fuzzy_lookup_embedding(qs[1], max_hits=16, min_score=0.52, predicate=lambda i: i % 5 == 2)]
         ret[rank] = out
     except Exception as exc:  # noqa: BLE001
         import traceback
@@ -235,6 +243,12 @@ def test_gpu_two_ranks_rccl_through_the_c_abi_when_two_gpus_are_present(tmp_path
     assert not isinstance(ret[1], str), ret[1]
     v, _ = make_corpus(n, 1536, 71)
     vv = v.astype(np.float16).astype(np.float32)
+    assert ret[0]["subset"] == ret[1]["subset"] and ret[0]["pred"] == ret[1]["pred"]
+    qs4 = make_queries(4, 1536, 99)
+    subset = np.random.default_rng(98).integers(-100, n, size=5000)
+    vo.check_topk_parity(vo.scores_full(vv, qs4[0])[subset], [i for i, _ in ret[0]["subset"]], [s_ for _, s_ in ret[0]["subset"]], 32, 0.0, candidate_ordinals=subset)
+    want = vo.lookup(vv, qs4[1], 16, 0.52, predicate=lambda i: i % 5 == 2)
+    assert [i for i, _ in ret[0]["pred"]] == [i for i, _ in want]
     for nq in (1, 40, 130):
         for a, b in zip(ret[0][nq], ret[1][nq]):
             np.testing.assert_array_equal(a, b)  # both ranks: the same answer

@@ -57,6 +57,29 @@ class HostStandInBackend:
     def empty_gather(self, world, nq, k):
         return torch.empty((world, nq, k), dtype=torch.int64)
 
+    # the forms beside the plain lookup (same contracts as DeviceShardBackend's)
+    def local_search_subset(self, query, local_rows, positions, k, thr):
+        from oracle import vectorbase_oracle as vo
+
+        out = np.zeros((1, k), dtype=np.int64)
+        if len(local_rows):
+            sc = vo.scores_full(self.shard[np.asarray(local_rows)], query)
+            keep = np.flatnonzero(sc >= np.float32(thr))
+            order = keep[np.lexsort((np.asarray(positions)[keep], -sc[keep].astype(np.float64)))][:k]
+            for j, i in enumerate(order):
+                out[0, j] = self.pack(sc[i], int(positions[i]))
+        return torch.from_numpy(out)
+
+    def local_survivors(self, query, thr):
+        from oracle import vectorbase_oracle as vo
+
+        sc = vo.scores_full(self.shard, query)
+        keep = np.flatnonzero(sc >= np.float32(thr))
+        return keep.astype(np.int64) + self.row_offset, sc[keep]
+
+    def keys_to_device(self, keys):
+        return torch.from_numpy(np.ascontiguousarray(keys).view(np.int64))
+
 
 def _free_port() -> int:
     s = socket.socket()
@@ -91,6 +114,28 @@ def _worker(rank: int, world: int, port: int, total_rows: int, dim: int, k: int,
         m = int(res.counts[0])
         assert [h.item for h in hits] == res.ordinals[0, :m].tolist()
         assert [h.score for h in hits] == [float(x) for x in res.scores[0, :m]]
+        # subset form (duplicates, negative ordinals), predicate form, message aggregation: every rank gets the whole-corpus answer
+        from oracle import messages_oracle as mo
+        from oracle import vectorbase_oracle as vo
+
+        rng = np.random.default_rng(5)
+        subset = rng.integers(-min(3, total_rows), total_rows, size=min(60, 4 * total_rows)).tolist() + [0, 0]
+        got = svb.fuzzy_lookup_embedding_in_subset(qs[1], subset, max_hits=k, min_score=min_score)
+        want = vo.lookup_in_subset(v, qs[1], subset, k, min_score)
+        sub_a = np.asarray(subset, dtype=np.int64)
+        assert len(got) == len(want)  # (exact ties -- the same row named twice -- have no defined order in the reference: tie-aware check)
+        vo.check_topk_parity(vo.scores_full(v, qs[1])[sub_a], [h.item for h in got], [h.score for h in got], k, min_score, candidate_ordinals=sub_a)
+        pred = lambda i: i % 3 != 1
+        got = svb.fuzzy_lookup_embedding(qs[2], max_hits=k, min_score=min_score, predicate=pred)
+        want = vo.lookup(v, qs[2], k, min_score, predicate=pred)
+        assert [(h.item, h.score) for h in got] == [(i, s) for i, s in want]
+        row_to_msg = [i // 2 for i in range(total_rows)]
+        got = svb.lookup_messages_by_embedding(qs[3], row_to_msg, max_matches=k, threshold_score=min_score, accept=range(0, total_rows, 2))
+        look = lambda e, kk, t: vo.lookup(v, e, kk, t)
+        want = mo.sqlite_lookup_by_embedding(look, qs[3], row_to_msg, k, min_score, list(range(0, total_rows, 2)))
+        assert [(h.item, h.score) for h in got] == want
+        with pytest.raises(IndexError):
+            svb.fuzzy_lookup_embedding_in_subset(qs[1], [total_rows], max_hits=k)
     finally:
         dist.destroy_process_group()
 

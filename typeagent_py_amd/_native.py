@@ -70,6 +70,8 @@ _SIGNATURES = [
     ("tavb_comm_init", c_int, [c_void_p, c_void_p, c_int32, c_int32]),
     ("tavb_comm_destroy", c_int, [c_void_p]),
     ("tavb_search_allgather", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
+    ("tavb_allgather_merge", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    ("tavb_remap_key_positions", c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64]),
     ("tavb_profile_enable", c_int, [c_void_p, c_int32]),
     ("tavb_profile_reset", c_int, [c_void_p]),
     ("tavb_profile_read", c_int, [c_void_p, c_int32, POINTER(c_double), POINTER(c_int64)]),
@@ -509,6 +511,26 @@ class Engine:
             rc = self.lib.tavb_search_allgather(self._h, c_void_p(dev_queries.data_ptr()), nq, k, c_float(float(thr)), c_void_p(out_keys.data_ptr()))
         _check(self.lib, rc)
         return out_keys
+
+    def allgather_merge(self, dev_local_keys, out_keys=None):
+        """Collective: this rank's sorted lists [nq, k] (global ordinals / positions) -> the lists merged over all ranks (async)."""
+        torch = self._torch
+        assert dev_local_keys.dtype == torch.int64 and dev_local_keys.is_contiguous() and dev_local_keys.dim() == 2
+        nq, k = dev_local_keys.shape
+        if out_keys is None:
+            out_keys = torch.empty((nq, k), dtype=torch.int64, device=dev_local_keys.device)
+        with self._lock:
+            rc = self.lib.tavb_allgather_merge(self._h, c_void_p(dev_local_keys.data_ptr()), nq, k, c_void_p(out_keys.data_ptr()))
+        _check(self.lib, rc)
+        return out_keys
+
+    def remap_key_positions(self, dev_keys, dev_map) -> None:
+        """In place: keys carrying list positions -> keys carrying dev_map[position] (int32 device tensor).  Async."""
+        torch = self._torch
+        assert dev_keys.dtype == torch.int64 and dev_keys.is_contiguous() and dev_map.dtype == torch.int32 and dev_map.is_contiguous()
+        with self._lock:
+            rc = self.lib.tavb_remap_key_positions(self._h, c_void_p(dev_keys.data_ptr()), dev_keys.numel(), c_void_p(dev_map.data_ptr()), dev_map.numel())
+        _check(self.lib, rc)
 
     def merge_device(self, dev_lists, out_keys=None):
         """dev_lists: torch int64 [n_lists, nq, k] -> [nq, k] (async)."""

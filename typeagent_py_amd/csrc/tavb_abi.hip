@@ -1221,6 +1221,21 @@ int tavb_comm_destroy(tavb_ctx* c) {
   return TAVB_OK;
 }
 
+// local [nq, k] lists (device) -> ncclAllGather on the context's stream -> merge kernel -> out_keys [nq, k]
+static int exchange_and_merge(tavb_ctx* c, const u64_t* local, int32_t nq, int32_t k, tavb_key* out_keys) {
+  const size_t list_keys = (size_t)nq * k;
+  if (int rc = c->d_gather.reserve(list_keys * sizeof(u64_t) * c->comm_world)) return rc;
+  u64_t* gathered = reinterpret_cast<u64_t*>(c->d_gather.ptr);
+  {
+    Timed t(c, TAVB_KERNEL_EXCHANGE);
+    TAVB_RCCL(g_rccl.AllGather(local, gathered, list_keys, ncclUint64, c->comm, c->stream));
+  }
+  Timed t(c, TAVB_KERNEL_MERGE);
+  hipError_t e = tavb::launch_merge(gathered, c->comm_world, nq, k, /*query_major=*/false, reinterpret_cast<u64_t*>(out_keys), c->stream);
+  if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
+  return TAVB_OK;
+}
+
 int tavb_search_allgather(tavb_ctx* c, const float* dev_queries, int32_t nq, int32_t k, float min_score, tavb_key* out_keys) {
   if (int rc = check_search_args(c, k)) return rc;
   if (nq < 1) return fail(TAVB_E_INVALID, "nq must be >= 1");
@@ -1231,22 +1246,37 @@ int tavb_search_allgather(tavb_ctx* c, const float* dev_queries, int32_t nq, int
   DeviceGuard guard(c->device);
   const size_t list_keys = (size_t)nq * k;
   if (int rc = c->d_local.reserve(list_keys * sizeof(u64_t))) return rc;
-  if (int rc = c->d_gather.reserve(list_keys * sizeof(u64_t) * c->comm_world)) return rc;
   u64_t* local = reinterpret_cast<u64_t*>(c->d_local.ptr);
-  u64_t* gathered = reinterpret_cast<u64_t*>(c->d_gather.ptr);
   std::vector<float> ms((size_t)nq, min_score);
   if (c->rows == 0) {  // an empty shard still takes part in the collective
     TAVB_HIP(hipMemsetAsync(local, 0, list_keys * sizeof(u64_t), c->stream));
   } else if (int rc = tavb_search_device_dispatch(c, dev_queries, nq, k, ms.data(), (uint32_t)c->ordinal_base, local)) {
     return rc;
   }
-  {
-    Timed t(c, TAVB_KERNEL_EXCHANGE);
-    TAVB_RCCL(g_rccl.AllGather(local, gathered, list_keys, ncclUint64, c->comm, c->stream));
+  return exchange_and_merge(c, local, nq, k, out_keys);
+}
+
+int tavb_allgather_merge(tavb_ctx* c, const tavb_key* dev_local_keys, int32_t nq, int32_t k, tavb_key* out_keys) {
+  if (int rc = check_ctx(c)) return rc;
+  if (nq < 1 || k < 1 || k > TAVB_MAX_FUSED_K) return fail(TAVB_E_INVALID, "bad list shape");
+  if (!dev_local_keys || !out_keys) return fail(TAVB_E_INVALID, "null argument");
+  DeviceGuard guard(c->device);
+  if (!c->comm || (c->comm_world == 1 && !c->comm_force)) {
+    if (reinterpret_cast<const void*>(dev_local_keys) != reinterpret_cast<const void*>(out_keys))
+      TAVB_HIP(hipMemcpyAsync(out_keys, dev_local_keys, (size_t)nq * k * sizeof(u64_t), hipMemcpyDefault, c->stream));
+    return TAVB_OK;
   }
-  Timed t(c, TAVB_KERNEL_MERGE);
-  hipError_t e = tavb::launch_merge(gathered, c->comm_world, nq, k, /*query_major=*/false, reinterpret_cast<u64_t*>(out_keys), c->stream);
-  if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
+  return exchange_and_merge(c, reinterpret_cast<const u64_t*>(dev_local_keys), nq, k, out_keys);
+}
+
+int tavb_remap_key_positions(tavb_ctx* c, tavb_key* dev_keys, int64_t count, const int32_t* dev_map, int64_t map_len) {
+  if (int rc = check_ctx(c)) return rc;
+  if (count < 0 || map_len < 0) return fail(TAVB_E_INVALID, "bad shape");
+  if (count == 0) return TAVB_OK;
+  if (!dev_keys || (map_len > 0 && !dev_map)) return fail(TAVB_E_INVALID, "null argument");
+  DeviceGuard guard(c->device);
+  hipError_t e = tavb::launch_remap_positions(reinterpret_cast<u64_t*>(dev_keys), count, dev_map, map_len, c->stream);
+  if (e != hipSuccess) return fail(TAVB_E_HIP, "remap launch failed: %s", hipGetErrorString(e));
   return TAVB_OK;
 }
 

@@ -277,6 +277,26 @@ __global__ void __launch_bounds__(256) message_rerank_kernel(const u64* __restri
   if (first && pos < max_messages && pos < k) o[pos] = (key & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - (uint32_t)msg);
 }
 
+// keys that carry POSITIONS of a list (0xFFFFFFFF - position in the low word) -> keys that carry map[position]: a shard's subset search
+// returns positions into ITS part of the caller's subset; the exchange needs positions into the caller's whole list
+__global__ void __launch_bounds__(256) remap_positions_kernel(u64* __restrict__ keys, int64_t n, const int32_t* __restrict__ map, int64_t map_len) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const u64 key = keys[i];
+    if (key == 0ull) continue;
+    const int64_t pos = (int64_t)(0xFFFFFFFFu - (uint32_t)key);
+    const uint32_t to = (pos < map_len) ? (uint32_t)map[pos] : 0xFFFFFFFEu;
+    keys[i] = (key & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - to);
+  }
+}
+
+hipError_t launch_remap_positions(unsigned long long* keys, int64_t n, const int32_t* map, int64_t map_len, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(remap_positions_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, keys, n, map, map_len);
+  return hipGetLastError();
+}
+
 hipError_t launch_accept_bitmap(const int32_t* msgs, int64_t n, uint32_t* bits, int64_t n_bits, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   int64_t blocks = (n + 255) / 256;

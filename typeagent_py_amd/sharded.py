@@ -96,6 +96,33 @@ class DeviceShardBackend:
             self.engine.comm_init(uid, rank, world)
         self.native_comm = True
 
+    # -- the forms beside the plain lookup: this shard's part, as keys that already carry GLOBAL positions / ordinals ----------------
+    def local_search_subset(self, query: np.ndarray, local_rows: np.ndarray, positions: np.ndarray, k: int, thr: float):
+        """rows of THIS shard (local numbering) that the caller's subset names, `positions[i]` = where local_rows[i] sits in the
+        caller's list -> keys [1, k] carrying those positions (subset gather kernel + position remap, on the backend's stream)."""
+        torch = self.torch
+        dev = torch.device("cuda", self.device)
+        with torch.cuda.stream(self.stream):
+            if len(local_rows) == 0:
+                return torch.zeros((1, k), dtype=torch.int64, device=dev)
+            dq = torch.from_numpy(np.ascontiguousarray(query, dtype=np.float32)).to(dev, non_blocking=False)
+            rows = torch.from_numpy(np.ascontiguousarray(local_rows, dtype=np.int32)).to(dev)
+            pmap = torch.from_numpy(np.ascontiguousarray(positions, dtype=np.int32)).to(dev)
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            keys = self.engine.search_subset_device(dq, rows, k, thr)
+            self.engine.remap_key_positions(keys, pmap)
+            self._keep = (dq, rows, pmap)  # alive until the next call (the kernels run asynchronously)
+            return keys
+
+    def local_survivors(self, query: np.ndarray, thr: float):
+        """every row of this shard with score >= thr -> (global ordinals int64, scores float32), unsorted (one emit-all pass)."""
+        return self.engine.search_all(np.ascontiguousarray(query, dtype=np.float32), np.float32(thr), None)
+
+    def keys_to_device(self, keys: np.ndarray):
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            return torch.from_numpy(np.ascontiguousarray(keys).view(np.int64)).to(torch.device("cuda", self.device))
+
     def search_allgather(self, queries, k: int, thr: float):
         """scan -> ncclAllGather -> merge inside libtavb, merged keys written into a reused pinned host buffer: -> int64 [nq, k] (host view,
         valid until the next call)."""
@@ -180,6 +207,19 @@ class ShardedSearcher:
             self.dist.all_gather_into_tensor(gathered.view(-1), local.view(-1), group=self.group)
         return self.backend.merge(gathered)
 
+    def exchange(self, local_keys):
+        """this rank's sorted lists [nq, k] (global ordinals / positions) -> the lists merged over all ranks, on every rank."""
+        if getattr(self.backend, "native_comm", False) and self.gather_fn is None:
+            return self.backend.engine.allgather_merge(local_keys)
+        if self.gather_fn is not None:
+            return self.backend.merge(self.gather_fn(local_keys))
+        if self.world == 1 and not (self.always_collective and self.dist.is_initialized()):
+            return local_keys
+        nq, k = local_keys.shape
+        gathered = self.backend.empty_gather(self.world, nq, k)
+        self.dist.all_gather_into_tensor(gathered.view(-1), local_keys.contiguous().view(-1), group=self.group)
+        return self.backend.merge(gathered)
+
     def search(self, queries, k: int, min_score: float = 0.0) -> ShardedResult:
         if getattr(self.backend, "native_comm", False) and self.gather_fn is None:
             # the product path: one C-ABI call (no torch.distributed, no torch op), results land in pinned host memory
@@ -250,5 +290,68 @@ class ShardedVectorBase:
             out.append([ScoredInt(int(o), float(s)) for o, s in zip(res.ordinals[i, :m].tolist(), res.scores[i, :m].tolist())])
         return out
 
-    def fuzzy_lookup_embedding(self, embedding, max_hits: int | None = None, min_score: float | None = None):
-        return self.fuzzy_lookup_embeddings(np.asarray(embedding, dtype=np.float32)[None, :], max_hits, min_score)[0]
+    def fuzzy_lookup_embedding(self, embedding, max_hits: int | None = None, min_score: float | None = None, predicate=None):
+        """vectorbase.py:163-201.  With a predicate (:191-201): every rank applies it to the survivors of ITS shard, in ascending
+        ordinal order (so the predicate is called once per survivor across the job, not once per survivor per rank), keeps its best
+        `max_hits`, and the per-rank lists are merged like any other -- every rank returns the whole-corpus answer."""
+        if predicate is None:
+            return self.fuzzy_lookup_embeddings(np.asarray(embedding, dtype=np.float32)[None, :], max_hits, min_score)[0]
+        from .vectorbase import ScoredInt
+
+        k = 10 if max_hits is None else int(max_hits)
+        if not (1 <= k <= _native.MAX_FUSED_K):
+            raise ValueError(f"max_hits must be in 1..{_native.MAX_FUSED_K} for a sharded lookup with a predicate")
+        thr = _native.f32_threshold(0.0 if min_score is None else min_score)
+        if self.total_rows == 0:
+            return []
+        q = np.ascontiguousarray(embedding, dtype=np.float32)
+        ids, scs = (np.zeros(0, np.int64), np.zeros(0, np.float32)) if self.local_rows == 0 else self.backend.local_survivors(q, thr)
+        order = np.lexsort((ids,))  # ascending ordinal: the order of np.flatnonzero (:193)
+        keep = np.fromiter((bool(predicate(int(i))) for i in ids[order]), dtype=bool, count=len(order))
+        ids, scs = ids[order][keep], scs[order][keep]
+        keys = (scs.astype(np.float32).view(np.uint32).astype(np.uint64) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - ids.astype(np.uint64))
+        local = np.zeros((1, k), dtype=np.uint64)
+        best = np.sort(keys)[::-1][:k]
+        local[0, : len(best)] = best
+        merged = self.backend.to_host(self.searcher.exchange(self.backend.keys_to_device(local)))
+        ords, sc, cnt = _native.decode_keys(merged)
+        return [ScoredInt(int(o), float(s_)) for o, s_ in zip(ords[0, : cnt[0]].tolist(), sc[0, : cnt[0]].tolist())]
+
+    def fuzzy_lookup_embedding_in_subset(self, embedding, ordinals_of_subset, max_hits: int | None = None, min_score: float | None = None):
+        """vectorbase.py:203-230 over the row-sharded corpus: every rank gathers the rows of the caller's subset that lie in its shard,
+        the per-rank top-k lists (keys carrying POSITIONS in the caller's list: duplicates and negative, wrapping ordinals behave as in
+        the reference) are merged over the ranks; returns the caller's ordinals."""
+        from .vectorbase import ScoredInt
+
+        k = 10 if max_hits is None else int(max_hits)
+        if not (1 <= k <= _native.MAX_FUSED_K):
+            raise ValueError(f"max_hits must be in 1..{_native.MAX_FUSED_K} for a sharded subset lookup")
+        thr = float(_native.f32_threshold(0.0 if min_score is None else min_score))
+        if len(ordinals_of_subset) == 0 or self.total_rows == 0:
+            return []
+        subset = np.asarray(ordinals_of_subset)
+        if subset.dtype.kind not in "iu":
+            raise IndexError("arrays used as indices must be of integer (or boolean) type")
+        subset = subset.astype(np.int64, copy=False).reshape(-1)
+        n = self.total_rows
+        rows = np.where(subset < 0, subset + n, subset)  # numpy index wrap (:218)
+        bad = (rows < 0) | (rows >= n)
+        if bad.any():
+            raise IndexError(f"index {int(subset[np.argmax(bad)])} is out of bounds for axis 0 with size {n}")
+        mine = np.flatnonzero((rows >= self.row_offset) & (rows < self.row_offset + self.local_rows))  # ascending positions: lists stay sorted among ties
+        q = np.ascontiguousarray(embedding, dtype=np.float32)
+        local = self.backend.local_search_subset(q, rows[mine] - self.row_offset, mine, k, thr)
+        merged = self.backend.to_host(self.searcher.exchange(local))
+        pos, sc, cnt = _native.decode_keys(merged)
+        return [ScoredInt(int(subset[p]), float(s_)) for p, s_ in zip(pos[0, : cnt[0]].tolist(), sc[0, : cnt[0]].tolist())]
+
+    def lookup_messages_by_embedding(self, embedding, row_to_message, max_matches: int | None = None, threshold_score: float | None = None, accept=None):
+        """`SqliteMessageTextIndex.lookup_by_embedding` / `lookup_in_subset_by_embedding` (storage/sqlite/messageindex.py:296-326, 182-257)
+        over the sharded corpus: the whole-corpus top-`max_matches` chunk rows (collective), THEN the provider's message filter and
+        best-score-per-message aggregation on the merged hits (`row_to_message`: the GLOBAL chunk row -> message map; identical on
+        every rank, so every rank returns the same messages)."""
+        from .adapters import best_score_per_message
+
+        hits = self.fuzzy_lookup_embedding(embedding, max_hits=max_matches, min_score=threshold_score)
+        members = None if accept is None else (accept if callable(accept) else set(int(x) for x in accept).__contains__)
+        return best_score_per_message(hits, row_to_message, max_matches, members)
