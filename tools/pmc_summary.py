@@ -15,7 +15,7 @@ import json
 import re
 import sys
 
-SETUP = ("at::native", "normalize_rows_kernel", "f32_to_f16_kernel", "corpus_max_norm_kernel", "shadow_convert_kernel", "__amd_rocclr_copyBuffer")
+SETUP = ("at::native", "rocprim::", "normalize_rows_kernel", "f32_to_f16_kernel", "corpus_max_norm_kernel", "shadow_convert_kernel", "__amd_rocclr_copyBuffer")
 
 
 def short(name: str) -> str:
@@ -23,6 +23,22 @@ def short(name: str) -> str:
     name = re.sub(r"\(tavb::\w+(?: const)?[&*]?(?:, [^)]*)?\)$", "", name)
     name = name.replace("void ", "").replace("tavb::", "")
     return name if len(name) <= 100 else name[:97] + "..."
+
+
+def kernel_base(name: str) -> str | None:
+    """`scan_fixed_kernel` out of a demangled or mangled libtavb kernel name; None for kernels that are not ours (runtime fills, torch).
+    (rocprofv3 leaves names with _Float16 template arguments mangled, and binutils' c++filt does not know `DF16_` either: the nested name
+    is read off the Itanium length prefixes.)"""
+    if name.startswith("_ZN"):
+        rest, comps = name[3:], []
+        while rest and rest[0].isdigit():
+            digits = re.match(r"\d+", rest).group(0)
+            comps.append(rest[len(digits) : len(digits) + int(digits)])
+            rest = rest[len(digits) + int(digits) :]
+        return comps[-1] if comps and comps[0] == "tavb" and comps[-1].endswith("_kernel") else None
+    name = re.sub(r"\(anonymous namespace\)::", "", name).replace("void ", "")
+    m = re.match(r"(?:tavb::)?([a-z][a-z0-9_]*_kernel)\b", name)
+    return m.group(1) if m else None
 
 
 def main() -> None:
@@ -76,7 +92,7 @@ def main() -> None:
                     blob = json.load(open(args.json))
                 except Exception:
                     blob = {}
-                lookup_kernels = sorted({re.sub(r"[<(].*$", "", k).strip() for k in per if not any(s_ in k for s_ in SETUP) and per[k].get("FETCH_SIZE", 0.0) > 0})
+                lookup_kernels = sorted({kernel_base(k) for k in per if not any(s_ in k for s_ in SETUP) and per[k].get("FETCH_SIZE", 0.0) > 0} - {None})
                 blob[args.name] = {
                     "traffic_bytes_per_step": b,
                     "counter": "FETCH_SIZE (KiB) x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM section), summed over every lookup kernel of a step",
