@@ -79,8 +79,8 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "skinny_min_batch_f32" / "skinny_min_batch_f16"  smallest batch routed to the 32/64-query MFMA tile on fp32 / fp16
  *                   corpora (defaults 5 / 3, the measured break-even; fp32 corpora have no other matrix-core path, fp16 ones use it up to
  *                   mfma_min_batch - 1); smaller batches use the streaming tiers
- *   "mfma_sample_rows", "mfma_ladder"  phases of the MFMA paths' threshold ladder: rows of the first phase (0 = auto: two
- *                   tiles per workgroup; -1 = a single phase, no seeding) and the growth factor of the following ones
+ *   "mfma_sample_rows", "mfma_ladder"  phases of the MFMA paths' threshold ladder: rows of the first phase (0 = auto: one
+ *                   tile per workgroup; -1 = a single phase, no seeding) and the growth factor of the following ones
  *   "f32_shadow"            1 (default): batches of mfma_min_batch+ queries on FP32 corpora run the fp16 tile over an fp16 shadow copy of the corpus
  *                           (built on first use, +50 % device memory, extended on append) and rescore the candidates with the fp32 rows: same
  *                           answers, ~6x the throughput of the fp32 matrix path; 0: fp32 kernels only (the shadow is freed); 2: EVERY lookup

@@ -1380,18 +1380,19 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.active = r.active;
   std::vector<int64_t> bounds;  // phase i scans rows [bounds[i], bounds[i+1])
   bounds.push_back(0);
-  // first phase: `mfma_sample_rows`, or (0 = auto) two tiles per workgroup -- short enough that the 256-query tile's
-  // buffers (3+ tiles deep) never compact while everything is still being admitted
-  // (at most 40960 rows: with one query tile there are 256 row ranges, and select_topk_kernel -- one workgroup per QUERY -- would
-  // stream 163840 unfiltered keys per query: 0.88 of the 6.3 ms of a 128-query batch over 10M rows)
-  const int64_t auto_sample = (int64_t)std::min(splits, 64) * 2 * 320;
+  // first phase: `mfma_sample_rows`, or (0 = auto) ONE tile per workgroup of the 128/256-query kernel -- nothing compacts while everything is
+  // still being admitted, and every unfiltered row of this phase is a key the select kernel has to stream (one workgroup per QUERY: with one
+  // query tile there are 256 row ranges, hence the cap at 64 ranges' worth).  Round 2 used two tiles; one measured the same on the 10M-row
+  // corpus and 4 % faster on a 1.25M-row shard, where the fixed cost of the early phases is what limits strong scaling
+  // (profiles/r03_shard_ladder.md).
+  const int64_t auto_sample = (int64_t)std::min(splits, 64) * 320 * (r.skinny ? 2 : 1);  // (the 32/64-query tile keeps round 2's 40960 rows)
   const int64_t sample = c->mfma_sample_rows > 0 ? (c->mfma_sample_rows + 255) / 256 * 256 : (c->mfma_sample_rows == 0 ? auto_sample : 0);
   // 32/64-query tile on corpora of a few hundred thousand to ~2M rows: the default ladder's first phases are smaller than one tile per
   // workgroup (40960 rows = 160 tiles for 512 resident workgroups) and each costs a launch + ~one tile time whatever its size; ONE seeding
   // phase of exactly one tile per workgroup, then the rest, is faster (1M x 1536 fp32, 32 queries: 1.18 -> 1.07 ms of kernels per batch,
   // profiles/r03_mid_batch.md); a single un-seeded phase is slower still (1.23 ms: every workgroup pays the cold start)
   const int64_t one_tile_each = (int64_t)splits * 256;
-  if (r.ladder && r.skinny && c->mfma_sample_rows == 0 && c->rows >= 4 * one_tile_each && c->rows < 50 * auto_sample) {
+  if (r.ladder && r.skinny && c->mfma_sample_rows == 0 && c->rows >= 4 * one_tile_each && c->rows < 2048000) {
     bounds.push_back(one_tile_each);
   } else if (r.ladder && sample > 0 && c->rows >= 8 * sample) {
     int64_t done = sample;
