@@ -524,7 +524,7 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     except Exception:
         pass
     if shadow:
-        roof["scanned"] = "fp16 shadow of the fp32 corpus (rows x dim x 2 B per pass) as an exact filter; 64 candidates per query rescored with the fp32 rows"
+        roof["scanned"] = "fp16 shadow of the fp32 corpus (rows x dim x 2 B per pass) as an exact filter; the band of candidates per query rescored with the fp32 rows"
     roof.update({
         "kernel": kern_name,
         "kernel_ms_per_step": kern_ms_per_step,

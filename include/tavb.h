@@ -75,7 +75,7 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "scan_nt"       1 = non-temporal corpus loads (default 1)
  *   "scan_pipe"     1 = software-prefetch next rows before reducing current ones
  *   "force_tier"    0 = auto, 1 = fixed-D kernel, 2 = vector kernel, 3 = scalar kernel
- *   "mfma_min_batch" smallest batch routed to the 256-query MFMA tile on f16 corpora (default 65; needs k <= 48, dim % 64 == 0)
+ *   "mfma_min_batch" smallest batch routed to the 256-query MFMA tile on f16 corpora (default 65; needs k <= 64, dim % 64 == 0)
  *   "skinny_min_batch_f32" / "skinny_min_batch_f16"  smallest batch routed to the 32/64-query MFMA tile on fp32 / fp16
  *                   corpora (defaults 5 / 3, the measured break-even; fp32 corpora have no other matrix-core path, fp16 ones use it up to
  *                   mfma_min_batch - 1); smaller batches use the streaming tiers

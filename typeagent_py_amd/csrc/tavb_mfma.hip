@@ -23,9 +23,9 @@
 //   * selection: per (workgroup, query) a candidate buffer of CAPW keys in global memory plus, in LDS, its fill count
 //     and the current admission threshold.  A score that beats the threshold is clipped, packed into a key and
 //     appended (one LDS atomic per lane per block).  A buffer that could overflow on the next tile is compacted to its
-//     best k (`compact_to_kth`: bisection on the score bits, no sort) and the threshold rises to its k-th score.  At the
-//     end of a launch the buffers are left as they are; `select_topk_kernel` (one workgroup per QUERY) picks the best k
-//     over all row ranges and derives the next admission threshold.
+//     BAND (`compact_to_band`: the k-th best score by bisection on the score bits, no sort; everything within 2 delta_q below it
+//     stays) and the threshold rises to the band's cut.  At the end of a launch the buffers are left as they are;
+//     `select_band_kernel` (one workgroup per QUERY) picks the band over all row ranges and derives the next admission threshold.
 //   * the host scans the corpus in phases of growing size (threshold ladder, tavb_abi.hip): the k-th best score after a
 //     phase seeds the admission thresholds of the next (`thr_in`).
 //
@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead LDS-DMA before the block retires
   __syncthreads();
 
-  // the buffers stay unsorted: tavb::select_topk_kernel picks the best k over all workgroups' buffers of a query
+  // the buffers stay unsorted: tavb::select_band_kernel picks the band over all workgroups' buffers of a query
   for (int i = tid; i < BN; i += NT6) my_counts[i] = cnt_lds[i] < CAPW ? cnt_lds[i] : CAPW;
 }
 

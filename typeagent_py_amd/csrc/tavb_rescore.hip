@@ -8,18 +8,22 @@
 //   1. query_prepare_kernel: q16 = fp16(q); delta_q = a rigorous bound on |score_fp16query(x) - score_fp32query(x)| over
 //      every corpus row x:   |x.(q - q16)| <= ||x|| ||q - q16||   (Cauchy-Schwarz), ||x|| <= R = the largest row norm of
 //      the corpus (corpus_max_norm_kernel, cached per corpus), plus the fp32 summation slack of the two dot products.
-//   2. the tile selects the best K' = 64 rows per query by APPROXIMATE score, admitting down to min_score - 2 delta_q.
-//   3. rescore_kernel: the 64 candidates are scored exactly (fp32 query, fp16 row widened, fp32 accumulate -- the
-//      arithmetic of the streaming kernels), filtered by the exact min_score, sorted, and the best k are the answer --
-//      PROVIDED the candidate set provably contains the exact top-k:  fewer than 64 candidates (then it holds every row
-//      with approximate score >= min_score - 2 delta, hence every row whose exact score passes), or
-//           approx(rank 63)  <  approx(rank k-1) - 2 delta_q
-//      (a row outside the set has approx <= approx(rank 63), so exact <= that + delta < approx(rank k-1) - delta <= the
-//      exact score of each of the k rows that lead the approximate ranking: it cannot be in the exact top-k).
-//   4. a query that fails the test (near-duplicate rows around rank k; never on gaussian data: the gap between ranks
-//      32 and 64 of 10M rows is ~8x the bound) is appended to a device-side list; one fixed-shape launch of the
-//      64-query tile with split hi/lo query planes (exact by construction, tavb_mfma.hip) serves the list and returns
-//      at once when it is empty.  No host round trip anywhere: the asynchronous device-resident form stays asynchronous.
+//   2. the tile + select_band_kernel (tavb_mfma.hip) keep, per query, the BAND: every row whose approximate score is within
+//      2 delta_q of the approximate k-th best a_k (and above min_score - 2 delta_q) -- as many rows as the data puts there
+//      (k + 2..3 on isotropic corpora, a whole cluster of near-duplicates on clustered ones), up to kBandMax.
+//   3. rescore_kernel: the band is scored exactly (fp32 query, fp16 row widened, fp32 accumulate -- the arithmetic of the
+//      streaming kernels), filtered by the exact min_score, and its best k by exact key are the answer.  Complete by
+//      construction: a row outside the band has approx < a_k - 2 delta, so exact < a_k - delta <= the exact score of each of
+//      the k rows that lead the approximate ranking -- it cannot be in the exact top-k, however tightly the scores around
+//      rank k are packed.  (Round 2 kept a fixed 64 candidates and had to re-run every query whose 64 best approximate
+//      scores sat inside the bound: a cliff on clustered corpora.)
+//   4. only a band that did not fit (more than kBandMax rows, or more than a candidate buffer holds inside one row range, at
+//      a level the final band reaches: select_band_kernel's verdict) makes a query incomplete; it is appended to a
+//      device-side list; one fixed-shape launch of the 64-query tile with split hi/lo query planes (exact by construction,
+//      tavb_mfma.hip) serves the list and returns at once when it is empty.  No host round trip anywhere: the asynchronous
+//      device-resident form stays asynchronous.
+//   The 32/64-query tile over an fp16 shadow (f32_shadow = 2) still hands over its best 64 by approximate score; there the
+//   set is complete when it was not cut, or when rank 63 + delta is below the exact k-th best (rescore_kernel, cut mode).
 
 //
 // fp32 corpora (the reference's own layout) ride the same filter through an fp16 SHADOW copy of the corpus
