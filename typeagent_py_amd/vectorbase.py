@@ -244,6 +244,7 @@ class VectorBase:
         #    fingerprint check per lookup -- "sampled" (default: 32 rows, ~30 us) or "full" (every byte: TYPEAGENT_VB_VERIFY_HOST=full /
         #    verify_host="full"; ~0.1 ms per MB) -- and mark_dirty() is the explicit form.
         self._watch = _Watch()
+        self._view = None  # (host buffer, row count, the write-tracking view handed out for them)
         self._handed_out = False
         self._dev_fingerprint = None
         mode = (verify_host or os.environ.get("TYPEAGENT_VB_VERIFY_HOST", "sampled")).lower()
@@ -263,10 +264,15 @@ class VectorBase:
         if self._handed_out:
             return self._host  # the caller's own matrix, adopted by reference: the same object every time (:271, :287)
         live = self._host
+        cached = self._view
+        if cached is not None and cached[0] is live and cached[1] == self._count:
+            return cached[2]  # the same object for as long as the matrix is the same (the reference returns its one `_vectors`)
         if self._embedding_size > 0 and live.ndim == 2 and self._count != live.shape[0]:
-            live = live[: self._count]  # the filled part of the growth buffer
-        view = live.view(_WatchedMatrix)
+            view = live[: self._count].view(_WatchedMatrix)  # the filled part of the growth buffer
+        else:
+            view = live.view(_WatchedMatrix)
         view._tavb_watch = self._watch
+        self._view = (live, self._count, view)
         return view
 
     @_vectors.setter
