@@ -96,6 +96,47 @@ def main():
         ok(lib.tavb_search_messages(h, ptr(q), k, c_float(0.0), ptr(acc), acc.size, 10, ptr(om), ptr(sm), byref(cnt)))
         print("messages: count", cnt.value, flush=True)
         ok(lib.tavb_search_messages_subset(h, ptr(q), ptr(rows), rows.size, k, c_float(0.0), 10, ptr(om), ptr(sm), byref(cnt)))
+        # the captured-graph form of the small single-query lookup (plain, capture, replay, replay) -- and back
+        ok(lib.tavb_set_option(h, b"graph_max_bytes", 1 << 30))
+        first = None
+        for rep in range(4):
+            ok(lib.tavb_search(h, ptr(q), k, c_float(0.0), ptr(o), ptr(s), byref(cnt)))
+            first = o.copy() if first is None else first
+            assert (o == first).all()
+        g = c_int64(); ok(lib.tavb_get_option(h, b"last_graph", byref(g)))
+        print("graph replay: last_graph", g.value, flush=True)
+        ok(lib.tavb_set_option(h, b"graph_max_bytes", 0))
+        # row shards: the library's own RCCL communicator, a world of one with the collective forced (round 3)
+        if os.environ.get("TAVB_ASAN_SKIP_RCCL") != "1":
+            uid = ctypes.create_string_buffer(128)
+            ok(lib.tavb_comm_unique_id(uid))
+            ok(lib.tavb_comm_init(h, uid, 0, 1))
+            ok(lib.tavb_set_option(h, b"comm_force", 1))
+            for nq in (1, 40, 200):
+                qq = rng.standard_normal((nq, d)).astype(np.float32)
+                qq /= np.linalg.norm(qq, axis=1, keepdims=True)
+                dq = dmalloc(nq * d * 4); dk = dmalloc(nq * k * 8); dk2 = dmalloc(nq * k * 8)
+                assert hip.hipMemcpy(dq, ptr(qq), nq * d * 4, 1) == 0
+                ok(lib.tavb_search_allgather(h, dq, nq, k, c_float(0.0), dk))
+                ok(lib.tavb_allgather_merge(h, dk, nq, k, dk2))
+                ok(lib.tavb_synchronize(h))
+                keys = np.empty((nq, k), np.uint64); keys2 = np.empty((nq, k), np.uint64)
+                assert hip.hipMemcpy(ptr(keys), dk, nq * k * 8, 2) == 0 and hip.hipMemcpy(ptr(keys2), dk2, nq * k * 8, 2) == 0
+                oo = np.empty((nq, k), np.int64); ss = np.empty((nq, k), np.float32); cc = np.empty(nq, np.int32)
+                ok(lib.tavb_decode_keys(ptr(keys), nq, k, ptr(oo), ptr(ss), ptr(cc)))
+                ref = np.argsort(-scores(vv, qq[0]), kind="stable")[:k]
+                if not ((keys == keys2).all() and cc[0] == k and (oo[0] == ref).mean() > 0.9):
+                    print("MISMATCH allgather", dtype, nq, flush=True); bad.append((dtype, "allgather", nq))
+                # positions -> map[position] (identity + 7)
+                pmap = (np.arange(n, dtype=np.int32) + 7); dm = dmalloc(n * 4)
+                assert hip.hipMemcpy(dm, ptr(pmap), n * 4, 1) == 0
+                ok(lib.tavb_remap_key_positions(h, dk2, nq * k, dm, n)); ok(lib.tavb_synchronize(h))
+                assert hip.hipMemcpy(ptr(keys2), dk2, nq * k * 8, 2) == 0
+                ok(lib.tavb_decode_keys(ptr(keys2), nq, k, ptr(oo), ptr(ss), ptr(cc)))
+                for fr in (dq, dk, dk2, dm): hip.hipFree(fr)
+            ok(lib.tavb_comm_destroy(h))
+            ok(lib.tavb_set_option(h, b"comm_force", 0))
+            print("rccl exchange: ok", flush=True)
         # bad arguments must come back as error codes, not as crashes
         assert lib.tavb_search(h, ptr(q), 100000, c_float(0.0), ptr(o), ptr(s), byref(cnt)) != 0
         assert lib.tavb_set_option(h, b"no_such_option", 1) != 0

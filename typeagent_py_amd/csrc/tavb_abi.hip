@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: the functions are resolved with dlsym (tavb_comm_init)
 
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <mutex>
 #include <cmath>
@@ -56,7 +57,7 @@ struct DeviceGuard {
 };
 
 // bumped by every (re)allocation or release of a workspace: captured HIP graphs hold raw pointers into these buffers
-unsigned long long g_alloc_epoch = 1;
+std::atomic<unsigned long long> g_alloc_epoch{1};  // (contexts on several threads share it)
 
 struct Buffer {
   void* ptr = nullptr;

@@ -105,10 +105,10 @@ class DeviceShardBackend:
         with torch.cuda.stream(self.stream):
             if len(local_rows) == 0:
                 return torch.zeros((1, k), dtype=torch.int64, device=dev)
-            dq = torch.from_numpy(np.ascontiguousarray(query, dtype=np.float32)).to(dev, non_blocking=False)
+            # (the copies run on the backend's stream, in front of the kernels that read them)
+            dq = torch.from_numpy(np.ascontiguousarray(query, dtype=np.float32)).to(dev)
             rows = torch.from_numpy(np.ascontiguousarray(local_rows, dtype=np.int32)).to(dev)
             pmap = torch.from_numpy(np.ascontiguousarray(positions, dtype=np.int32)).to(dev)
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             keys = self.engine.search_subset_device(dq, rows, k, thr)
             self.engine.remap_key_positions(keys, pmap)
             self._keep = (dq, rows, pmap)  # alive until the next call (the kernels run asynchronously)
