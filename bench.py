@@ -244,7 +244,7 @@ def cpu_baseline(host: np.ndarray, queries: np.ndarray, k: int, rows_total: int,
     # 20 warm-up calls (BLAS thread pool, page-in of the matrix), then the timed rounds; default threads = all host cores AND
     # the best thread count of a sweep (OpenBLAS sgemv on a few-GB matrix is memory-bound: 256 threads oversubscribe it)
     t_end = time.perf_counter() + budget_s
-    warm = timed(20 if host.shape[0] <= 200_000 else 8)
+    warm = timed(20)
     per_call = float(np.median(warm))
     sweep = {}
     best_threads, best_med = cores, None
