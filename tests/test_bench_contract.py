@@ -79,3 +79,22 @@ def test_committed_pmc_traffic_belongs_to_the_kernels_that_ship():
         wl = bench.WORKLOADS[name]
         corpus_bytes = wl["rows"] * wl["dim"] * (2 if wl["dtype"] == "fp16" else 4)
         assert 0.9 <= entry["traffic_bytes_per_step"] / corpus_bytes <= 3.0, f"{name}: traffic is not of the order of this workload's corpus"
+
+
+def test_pmc_summary_reads_kernel_names_in_both_forms():
+    """rocprofv3 leaves kernel names with _Float16 template arguments mangled (and binutils' c++filt does not demangle `DF16_`): the PMC
+    summary must name the same kernel either way, and must not claim runtime / torch kernels as ours."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kb = mod.kernel_base
+    assert kb("_ZN4tavb17scan_fixed_kernelIDF16_Li3ELi1ELi1ELi2ELb1ELb0ELi1024EEEvNS_10ScanParamsE") == "scan_fixed_kernel"
+    assert kb("_ZN4tavb12_GLOBAL__N_114rescore_kernelIDF16_EEvPKT_ijPKfPKyiPKiSA_S6_fiPyPiSC_") == "rescore_kernel"
+    assert kb("void tavb::scan_fixed_kernel<float, 6, 1, 1, 2, true, false, 1024>(tavb::ScanParams)") == "scan_fixed_kernel"
+    assert kb("tavb::(anonymous namespace)::select_band_kernel(unsigned long long const*, int const*, int)") == "select_band_kernel"
+    assert kb("mfma_scan_kernel<0, 4, 8, 6, 4>") == "mfma_scan_kernel"
+    assert kb("__amd_rocclr_fillBufferAligned") is None
+    assert kb("void at::native::vectorized_elementwise_kernel<4, at::native::CUDAFunctor_add<float>>") is None
+    assert kb("_ZN2at6native29vectorized_elementwise_kernelILi4EEEvv") is None
