@@ -140,3 +140,27 @@ def test_anisotropic_corpus_batches_against_the_oracle(dtype, nq, k, ms):
         assert float(np.median(ref)) > 0.85  # the whole corpus scores high: dense around rank k
         vo.check_topk_parity(ref, [r.item for r in out[qi]], [r.score for r in out[qi]], k, ms)
     assert out[0][0].item == n // 3
+
+
+@pytest.mark.parametrize("dtype,cluster_rows,nq,k", [("fp16", 100, 130, 32), ("fp32", 100, 300, 32), ("fp16", 200, 1024, 64), ("fp32", 60, 130, 10)])
+def test_clustered_corpus_with_a_threshold_inside_the_cluster(dtype, cluster_rows, nq, k):
+    """min_score set INSIDE the pack of near-equal scores of each query's cluster (the median score of its best cluster_rows rows): the filter
+    admits down to min_score - 2 delta, the rescoring re-tests the exact score against min_score -- every returned row passes it, none that
+    passes is missing, on fp16 corpora and on fp32 ones (fp16 shadow as the filter, fp32 rows for the exact scores)."""
+    n = 50_000
+    v, q, cl, qc = make_clustered_corpus(n, 1536, 4300 + cluster_rows + nq, cluster_rows=cluster_rows, n_queries=nq)
+    seen = v.astype(np.float16).astype(np.float32) if dtype == "fp16" else v
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), corpus_dtype=dtype)
+    vb.add_embeddings(None, v)
+    probe = sorted(set(np.linspace(0, nq - 1, 12).astype(int).tolist()))
+    thresholds = {}
+    for qi in probe:
+        ref = vo.scores_full(seen, q[qi])
+        thresholds[qi] = float(np.sort(ref)[::-1][cluster_rows // 2])
+    ms = float(np.median(list(thresholds.values())))  # one threshold for the batch, inside most clusters' packs
+    out = vb.fuzzy_lookup_embeddings(q, max_hits=k, min_score=ms)
+    assert vb.engine.get_option("last_tier") == 4 and vb.engine.get_option("last_flagged") == 0
+    for qi in probe:
+        ref = vo.scores_full(seen, q[qi])
+        vo.check_topk_parity(ref, [r.item for r in out[qi]], [r.score for r in out[qi]], k, ms)
+        assert all(r.score >= np.float32(ms) for r in out[qi])
