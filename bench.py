@@ -175,38 +175,64 @@ def oracle_chunks(eng, resident, resident_lo: int, total_rows: int, dim: int, se
         yield t.float().cpu().numpy()
 
 
+class ParityTally:
+    """Sums of the per-query reports of `check_topk_parity_large` (with its float64 referee) for one `parity` object."""
+
+    def __init__(self):
+        self.exact = self.permuted = self.near = self.inv_gpu = self.inv_ref = 0
+        self.worst = self.gap = self.noise_ref = self.noise_gpu = self.width = self.inv_gap_gpu = self.inv_gap_ref = 0.0
+
+    def add(self, rep, n_near: int) -> None:
+        self.exact += rep.exact_positions
+        self.permuted += rep.tie_permuted_positions
+        self.near += n_near
+        self.inv_gpu += rep.gpu_inversions_vs_f64
+        self.inv_ref += rep.reference_inversions_vs_f64
+        self.gap = max(self.gap, rep.max_permuted_gap)
+        self.noise_ref = max(self.noise_ref, rep.noise_ref or 0.0)
+        self.noise_gpu = max(self.noise_gpu, rep.noise_gpu or 0.0)
+        self.width = max(self.width, rep.tie_width or 0.0)
+        self.inv_gap_gpu = max(self.inv_gap_gpu, rep.max_inverted_gap_gpu)
+        self.inv_gap_ref = max(self.inv_gap_ref, rep.max_inverted_gap_ref)
+
+    def fields(self) -> dict:
+        # near-tie rule: oracle/vectorbase_oracle.py::check_topk_parity (float64 referee; nothing hand-set) -- profiles/README.md spells the fields out
+        return {
+            "positions_exact": self.exact,
+            "positions_permuted": self.permuted,
+            "max_permuted_gap": self.gap,
+            "gpu_inversions_vs_f64": self.inv_gpu,
+            "reference_inversions_vs_f64": self.inv_ref,
+            "max_inverted_gap_gpu": self.inv_gap_gpu,
+            "max_inverted_gap_ref": self.inv_gap_ref,
+            "noise_gpu": self.noise_gpu,
+            "noise_ref": self.noise_ref,
+            "tie_width": self.width,
+            "near_tie_pairs": self.near,
+            "max_abs_score_error": self.worst,
+        }
+
+
 def parity_check(eng, resident, resident_lo, wl, queries: np.ndarray, sample: list[int], got: dict, min_score: float) -> dict:
     """got[qi] = (ordinals, scores) from the GPU path.  Oracle = numpy restatement of vectorbase.py:163-190 over the
-    whole corpus (oracle/vectorbase_oracle.py), near-tie policy of SURVEY section 7."""
+    whole corpus (oracle/vectorbase_oracle.py) in ORACLE_CHUNK-row chunks; near-ties are decided by a float64 referee computed in the
+    same pass (the reference's best k + 256 rows of every chunk and the returned rows)."""
     from oracle import vectorbase_oracle as vo
 
     t0 = time.perf_counter()
-    ref = vo.scores_full_chunked(oracle_chunks(eng, resident, resident_lo, wl["rows_total"], wl["dim"], wl["seed"], wl["dtype"], wl.get("kind", "gaussian")),
-                                 queries[sample])
-    exact = permuted = near = 0
-    worst = 0.0
+    ref, referee = vo.scores_full_chunked_refereed(
+        oracle_chunks(eng, resident, resident_lo, wl["rows_total"], wl["dim"], wl["seed"], wl["dtype"], wl.get("kind", "gaussian")),
+        queries[sample], [got[qi][0] for qi in sample], keep=wl["k"] + 256)
+    tally = ParityTally()
     try:
         for j, qi in enumerate(sample):
             o, s = got[qi]
-            rep, n_near = vo.check_topk_parity_large(ref[j], o.tolist(), s.tolist(), wl["k"], min_score)
-            exact += rep.exact_positions
-            permuted += rep.tie_permuted_positions
-            near += n_near
-            worst = max(worst, float(np.max(np.abs(ref[j][o] - s))) if len(o) else 0.0)
+            rep, n_near = vo.check_topk_parity_large(ref[j], o.tolist(), s.tolist(), wl["k"], min_score, referee=referee.for_query(j))
+            tally.add(rep, n_near)
+            tally.worst = max(tally.worst, float(np.max(np.abs(ref[j][o] - s))) if len(o) else 0.0)
     except AssertionError as exc:
         return {"ok": False, "error": str(exc)[:300], "queries_checked": len(sample), "rows": wl["rows_total"]}
-    return {
-        "ok": True,
-        "queries_checked": len(sample),
-        "rows": wl["rows_total"],
-        "oracle": "numpy restatement of vectorbase.py:163-190 over the whole corpus in %d-row chunks" % ORACLE_CHUNK,
-        "positions_exact": exact,
-        "positions_permuted_inside_near_ties": permuted,
-        "near_tie_pairs_in_reference_topk": near,
-        "max_abs_score_error": worst,
-        "score_tolerance": vo.SCORE_TOL,
-        "seconds": round(time.perf_counter() - t0, 1),
-    }
+    return {"ok": True, "queries_checked": len(sample), "rows": wl["rows_total"], **tally.fields(), "seconds": round(time.perf_counter() - t0, 1)}
 
 
 def cpu_baseline(host: np.ndarray, queries: np.ndarray, k: int, rows_total: int, nq: int, budget_s: float) -> dict:
@@ -730,8 +756,8 @@ def cfg5_parity(eng, one, user_queries, corpora: dict, dim: int, dtype: str, sub
     from oracle import vectorbase_oracle as vo
 
     t0 = time.perf_counter()
-    checked = exact = permuted = near = hits = 0
-    worst = 0.0
+    checked = hits = 0
+    tally = ParityTally()
     try:
         results = []
         for ui in range(len(user_queries)):
@@ -744,28 +770,26 @@ def cfg5_parity(eng, one, user_queries, corpora: dict, dim: int, dtype: str, sub
         for cname, qs, got_lists, k, ms in legs:
             tensor, seed = corpora[cname]
             thr = float(_f32_threshold(ms))
-            ref = vo.scores_full_chunked(oracle_chunks(eng, tensor, 0, int(tensor.shape[0]), dim, seed, dtype), np.asarray(qs, dtype=np.float32))
+            sub = np.asarray(subset, dtype=np.int64) if (cname == "messages" and subset is not None) else None
+            extra = [np.concatenate([np.asarray([r.item for r in got], dtype=np.int64), sub if sub is not None else np.zeros(0, dtype=np.int64)]) for got in got_lists]
+            ref, referee = vo.scores_full_chunked_refereed(oracle_chunks(eng, tensor, 0, int(tensor.shape[0]), dim, seed, dtype), np.asarray(qs, dtype=np.float32),
+                                                           extra, keep=k + 256)
             for j, got in enumerate(got_lists):
                 items, scs = [r.item for r in got], [r.score for r in got]
-                if cname == "messages" and subset is not None:
-                    sub = np.asarray(subset, dtype=np.int64)
+                truth = referee.for_query(j)
+                if sub is not None:
                     pos = {int(o): i for i, o in enumerate(subset)}
-                    rep, n_near = vo.check_topk_parity_large(ref[j][sub], [pos[i] for i in items], scs, k, thr)
+                    rep, n_near = vo.check_topk_parity_large(ref[j][sub], [pos[i] for i in items], scs, k, thr, referee=lambda p, t=truth: t(sub[np.asarray(p)]))
                 else:
-                    rep, n_near = vo.check_topk_parity_large(ref[j], items, scs, k, thr)
+                    rep, n_near = vo.check_topk_parity_large(ref[j], items, scs, k, thr, referee=truth)
                     if items:
-                        worst = max(worst, float(np.max(np.abs(ref[j][np.asarray(items)] - np.asarray(scs, dtype=np.float32)))))
+                        tally.worst = max(tally.worst, float(np.max(np.abs(ref[j][np.asarray(items)] - np.asarray(scs, dtype=np.float32)))))
                 checked += 1
                 hits += len(items)
-                exact += rep.exact_positions
-                permuted += rep.tie_permuted_positions
-                near += n_near
+                tally.add(rep, n_near)
     except AssertionError as exc:
         return {"ok": False, "error": str(exc)[:300], "lookups_checked": checked}
-    return {"ok": True, "lookups_checked": checked, "hits_returned": hits, "positions_exact": exact, "positions_permuted_inside_near_ties": permuted,
-            "near_tie_pairs_in_reference_topk": near, "max_abs_score_error": worst, "score_tolerance": vo.SCORE_TOL,
-            "oracle": "numpy restatement of vectorbase.py:163-230 over the whole corpora in %d-row chunks" % ORACLE_CHUNK,
-            "seconds": round(time.perf_counter() - t0, 1)}
+    return {"ok": True, "lookups_checked": checked, "hits_returned": hits, **tally.fields(), "seconds": round(time.perf_counter() - t0, 1)}
 
 
 def _f32_threshold(x: float):

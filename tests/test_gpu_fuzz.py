@@ -68,7 +68,7 @@ def test_random_case_against_the_oracle(seed):
             got = vb.fuzzy_lookup_embedding_in_subset(q[qi], c["subset"], max_hits=k, min_score=ms)
             sub = np.asarray(c["subset"], dtype=np.int64)
             ref = vo.scores_full(seen, q[qi])[sub]
-            vo.check_topk_parity(ref, [r.item for r in got], [r.score for r in got], k, ms_eff, candidate_ordinals=sub)
+            vo.check_topk_parity(ref, [r.item for r in got], [r.score for r in got], k, ms_eff, candidate_ordinals=sub, referee=vo.f64_referee(seen[sub], q[qi]))
         return
     if c["nq"] == 1:
         batches = [vb.fuzzy_lookup_embedding(q[0], max_hits=k, min_score=ms)]
@@ -80,7 +80,7 @@ def test_random_case_against_the_oracle(seed):
         got = batches[qi]
         ref = vo.scores_full(seen, q[qi])
         try:
-            vo.check_topk_parity(ref, [r.item for r in got], [r.score for r in got], k, ms_eff)
+            vo.check_topk_parity(ref, [r.item for r in got], [r.score for r in got], k, ms_eff, referee=vo.f64_referee(seen, q[qi]))
         except AssertionError as exc:
             raise AssertionError(f"{tag} query {qi} tier {vb.engine.get_option('last_tier')}: {exc}") from exc
         assert all(0.0 <= r.score <= 1.0 for r in got), tag
@@ -105,12 +105,12 @@ def test_clustered_corpus_batches_against_the_oracle(cluster_rows, nq, k, expect
     for qi in sorted(set(np.linspace(0, nq - 1, 20).astype(int).tolist())):
         ref = vo.scores_full(seen, q[qi])
         items = [r.item for r in out[qi]]
-        vo.check_topk_parity(ref, items, [r.score for r in out[qi]], k, 0.0)
+        vo.check_topk_parity(ref, items, [r.score for r in out[qi]], k, 0.0, referee=vo.f64_referee(seen, q[qi]))
         members = np.flatnonzero(cl == qc[qi])
         assert set(items[: min(k, len(members))]) <= set(members.tolist())  # the best hits are the query's own cluster
         # the single-query kernel: the same answer up to fp32 near-ties (its summation order differs; rows ~1e-7 apart may swap)
         seq = vb.fuzzy_lookup_embedding(q[qi], max_hits=k, min_score=0.0)
-        vo.check_topk_parity(ref, [r.item for r in seq], [r.score for r in seq], k, 0.0)
+        vo.check_topk_parity(ref, [r.item for r in seq], [r.score for r in seq], k, 0.0, referee=vo.f64_referee(seen, q[qi]))
         np.testing.assert_allclose([r.score for r in out[qi]], [r.score for r in seq], atol=1e-6, rtol=0)
 
 
@@ -138,7 +138,7 @@ def test_anisotropic_corpus_batches_against_the_oracle(dtype, nq, k, ms):
     for qi in sorted(set(np.linspace(0, nq - 1, 16).astype(int).tolist())):
         ref = vo.scores_full(seen, q[qi])
         assert float(np.median(ref)) > 0.85  # the whole corpus scores high: dense around rank k
-        vo.check_topk_parity(ref, [r.item for r in out[qi]], [r.score for r in out[qi]], k, ms)
+        vo.check_topk_parity(ref, [r.item for r in out[qi]], [r.score for r in out[qi]], k, ms, referee=vo.f64_referee(seen, q[qi]))
     assert out[0][0].item == n // 3
 
 
@@ -162,5 +162,5 @@ def test_clustered_corpus_with_a_threshold_inside_the_cluster(dtype, cluster_row
     assert vb.engine.get_option("last_tier") == 4 and vb.engine.get_option("last_flagged") == 0
     for qi in probe:
         ref = vo.scores_full(seen, q[qi])
-        vo.check_topk_parity(ref, [r.item for r in out[qi]], [r.score for r in out[qi]], k, ms)
+        vo.check_topk_parity(ref, [r.item for r in out[qi]], [r.score for r in out[qi]], k, ms, referee=vo.f64_referee(seen, q[qi]))
         assert all(r.score >= np.float32(ms) for r in out[qi])

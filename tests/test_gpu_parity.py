@@ -1,9 +1,11 @@
 """GPU suite (`-m gpu`, runs on the MI355X box): the HIP path, reached through the
 drop-in VectorBase class and through the ctypes C ABI, against
   * the committed golden vectors (answers of the VERBATIM reference class),
-  * the numpy oracle on seeded random inputs (differential, modulo fp32 near-ties:
-    ordinals must be the reference's wherever its scores are separated by more than
-    4 * 2^-24; scores within 1e-5 -- `oracle.vectorbase_oracle.check_topk_parity`),
+  * the numpy oracle on seeded random inputs (differential, modulo fp32 near-ties; scores within 1e-5 --
+    `oracle.vectorbase_oracle.check_topk_parity`: where a float64 referee is passed -- every check that has the rows at hand --
+    a different row at a rank is accepted only within 2 * (measured noise of the reference + measured noise of the device)
+    of the float64 truth of the reference's row, and the device's noise is capped by the reference's own; the remaining
+    small isotropic cases use the constant 4 * 2^-24 on the reference's float32 scores),
   * size-independent properties at BASELINE.json's full size (1M x 1536).
 Nothing here reads /root/reference."""
 
@@ -45,7 +47,8 @@ def assert_matches_expect(res, expect, ref_scores=None, k=None, min_score=0.0):
     # The item sequence differs from the reference's: legal only inside groups of (near-)equal
     # float32 scores, whose order the reference leaves to numpy's introselect.  The checker
     # verifies exactly that (rank i must hold a row whose reference score is within 4*2^-24 of
-    # the reference's i-th best score, nothing better omitted, scores within 1e-5).
+    # the reference's i-th best score -- no referee here: the goldens carry scores, not rows --
+    # nothing better omitted, scores within 1e-5).
     assert ref_scores is not None, f"items differ: {items[:8]}... vs {expect['items'][:8]}..."
     vo.check_topk_parity(ref_scores, items, scores, k, min_score)
     ref_sc = np.asarray(expect["scores"], dtype=np.float64)
@@ -561,16 +564,16 @@ def test_appends_between_lookups_keep_device_in_sync():
             else:
                 vb.add_embeddings(None, v[len(vb):upto])
         res = vb.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.0)
-        vo.check_topk_parity(vo.scores_full(v[:upto], q), *items_scores(res), 10, 0.0)
+        vo.check_topk_parity(vo.scores_full(v[:upto], q), *items_scores(res), 10, 0.0, referee=vo.f64_referee(v[:upto], q))
     vb.clear()
     assert vb.fuzzy_lookup_embedding(q) == []
     vb.add_embeddings(None, v[100:200])
     res = vb.fuzzy_lookup_embedding(q, max_hits=5, min_score=0.0)
-    vo.check_topk_parity(vo.scores_full(v[100:200], q), *items_scores(res), 5, 0.0)
+    vo.check_topk_parity(vo.scores_full(v[100:200], q), *items_scores(res), 5, 0.0, referee=vo.f64_referee(v[100:200], q))
     other = np.ascontiguousarray(v[300:400])
     vb.deserialize(other)
     res = vb.fuzzy_lookup_embedding(q, max_hits=5, min_score=0.0)
-    vo.check_topk_parity(vo.scores_full(other, q), *items_scores(res), 5, 0.0)
+    vo.check_topk_parity(vo.scores_full(other, q), *items_scores(res), 5, 0.0, referee=vo.f64_referee(other, q))
 
 
 def test_in_place_edit_of_the_serialized_matrix_is_noticed():
@@ -587,7 +590,7 @@ def test_in_place_edit_of_the_serialized_matrix_is_noticed():
     vb.deserialize(x)  # kept by reference (:287): the caller still holds x
     x *= -1.0
     flipped = vb.fuzzy_lookup_embedding(q, max_hits=3, min_score=0.0)
-    vo.check_topk_parity(vo.scores_full(x, q), *items_scores(flipped), 3, 0.0)
+    vo.check_topk_parity(vo.scores_full(x, q), *items_scores(flipped), 3, 0.0, referee=vo.f64_referee(x, q))
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
@@ -608,7 +611,7 @@ def test_small_corpus_lookups_replay_a_captured_graph(dtype):
             k, ms = (10, 0.0) if qi % 3 else (32, 0.5)
             res = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=ms)
             replayed += eng.get_option("last_graph")
-            vo.check_topk_parity(vo.scores_full(seen, qs[qi]), *items_scores(res), k, ms)
+            vo.check_topk_parity(vo.scores_full(seen, qs[qi]), *items_scores(res), k, ms, referee=vo.f64_referee(seen, qs[qi]))
     assert replayed >= 30  # everything after the first two calls of each of the two shapes
     eng.set_option("graph_max_bytes", 0)
     plain = vb.fuzzy_lookup_embedding(qs[1], max_hits=10, min_score=0.0)
@@ -620,7 +623,7 @@ def test_small_corpus_lookups_replay_a_captured_graph(dtype):
     for k in (1, 2, 3, 4, 5, 1, 1, 1):
         for _ in range(3):
             res = vb.fuzzy_lookup_embedding(qs[2], max_hits=k, min_score=0.0)
-        vo.check_topk_parity(vo.scores_full(seen, qs[2]), *items_scores(res), k, 0.0)
+        vo.check_topk_parity(vo.scores_full(seen, qs[2]), *items_scores(res), k, 0.0, referee=vo.f64_referee(seen, qs[2]))
     assert eng.get_option("last_graph") == 1
     # an append changes the corpus: the new rows are seen (a new shape: plain, capture, replay)
     vb.add_embedding(None, qs[3])
@@ -725,7 +728,7 @@ def test_mfma_threshold_ladder_does_not_change_results(n, nq, k, ms, sample, lad
     for qi in range(nq):
         assert [(r.item, r.score) for r in with_pass[qi]] == [(r.item, r.score) for r in without[qi]]
     for qi in list(range(0, nq, max(1, nq // 24))) + [1, 2]:
-        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(with_pass[qi]), k, ms)
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(with_pass[qi]), k, ms, referee=vo.f64_referee(v16, qs[qi]))
     assert with_pass[0][0].item == 5 and with_pass[1][0].item == n - 3 and with_pass[2][0].item == sample + 7
 
 
@@ -790,7 +793,7 @@ def test_batch_equals_sequential_for_arbitrary_fp32_queries_on_fp16_corpus(nq):
         assert vb.engine.get_option("last_tier") in (1, 2, 3)
         assert [r.item for r in batch[qi]] == [r.item for r in seq]
         np.testing.assert_allclose([r.score for r in batch[qi]], [r.score for r in seq], atol=3e-7, rtol=0)
-        rep = vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(batch[qi]), 32, 0.0)
+        rep = vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(batch[qi]), 32, 0.0, referee=vo.f64_referee(v16, qs[qi]))
         assert rep.ordinals_bit_exact
     # a threshold close to the scores: the relaxed filter threshold + exact re-test give the sequential counts
     thr = float(np.float32(batch[0][20].score))
@@ -825,7 +828,7 @@ def test_128_and_256_query_tiles_agree(n, nq, k, ms, sample):
     assert [(r.item, r.score) for r in auto[1]] == [(r.item, r.score) for r in res[128][1]] and auto[1][0].item == n - 1
     v16 = _f16(v)
     for qi in sorted(set(np.linspace(0, nq - 1, 16).astype(int).tolist())):
-        rep = vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(res[128][qi]), k, ms)
+        rep = vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(res[128][qi]), k, ms, referee=vo.f64_referee(v16, qs[qi]))
         assert rep.tie_permuted_positions <= 2
     with pytest.raises(ValueError):
         eng.set_option("mfma_tile", 64)
@@ -856,22 +859,22 @@ def test_wide_tile_band_holds_a_cluster_of_near_duplicates():
     assert vb.engine.get_option("last_flagged") == 0
     v16 = _f16(v)
     for qi in [0, 1, 2, 3, 4, 64, 129]:
-        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0)
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
     assert set(r.item for r in out[3]) <= set(dup_rows.tolist())
     seq = vb.fuzzy_lookup_embedding(qs[3], max_hits=k, min_score=0.0)  # (another summation order: rows ~1e-7 apart may swap)
-    vo.check_topk_parity(vo.scores_full(v16, qs[3]), *items_scores(seq), k, 0.0)
+    vo.check_topk_parity(vo.scores_full(v16, qs[3]), *items_scores(seq), k, 0.0, referee=vo.f64_referee(v16, qs[3]))
     np.testing.assert_allclose([r.score for r in out[3]], [r.score for r in seq], atol=1e-6, rtol=0)
     # with a threshold, and again
     out2 = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.6)
     for qi in [2, 3, 4]:
-        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out2[qi]), k, 0.6)
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out2[qi]), k, 0.6, referee=vo.f64_referee(v16, qs[qi]))
     assert len(out2[3]) == k and len(out2[2]) == 0
     # k = 50 (the reference's related-terms max_matches, convsettings.py:61-63) and k = 64 ride the wide tile too
     for kk in (50, 64):
         o = vb.fuzzy_lookup_embeddings(qs, max_hits=kk, min_score=0.0)
         assert vb.engine.get_option("last_tier") == 4 and vb.engine.get_option("last_flagged") == 0
         for qi in [3, 77]:
-            vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(o[qi]), kk, 0.0)
+            vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(o[qi]), kk, 0.0, referee=vo.f64_referee(v16, qs[qi]))
 
 
 def test_wide_tile_falls_back_to_the_exact_tile_when_the_band_overflows():
@@ -893,12 +896,12 @@ def test_wide_tile_falls_back_to_the_exact_tile_when_the_band_overflows():
     assert 2 <= flagged <= 4, flagged
     v16 = _f16(v)
     for qi in [0, 3, 4, 9, 64, 129]:
-        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0)
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
     assert [r.item for r in out[9]] == sorted(rows[1300:].tolist())[:k]
     assert set(r.item for r in out[3]) <= set(rows[:1300].tolist())
     out2 = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.6)  # the work list is rebuilt per call
     for qi in [2, 3, 9]:
-        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out2[qi]), k, 0.6)
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out2[qi]), k, 0.6, referee=vo.f64_referee(v16, qs[qi]))
     assert len(out2[3]) == k and len(out2[2]) == 0
 
 
@@ -918,7 +921,7 @@ def test_wide_tile_band_overflow_inside_one_row_range(sample):
     assert vb.engine.get_option("last_flagged") == 1
     v16 = _f16(v)
     for qi in [0, 4, 5, 6, 129]:
-        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0)
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
     assert all(150_000 <= r.item < 150_900 for r in out[5])
 
 
@@ -934,7 +937,7 @@ def test_wide_tile_row_norm_cache_follows_appends_and_rewrites():
     second = vb.fuzzy_lookup_embeddings(qs, max_hits=10, min_score=0.0)
     allv = _f16(np.concatenate([v, big]))
     for qi in range(0, 70, 7):
-        vo.check_topk_parity(vo.scores_full(allv, qs[qi]), *items_scores(second[qi]), 10, 0.0)
+        vo.check_topk_parity(vo.scores_full(allv, qs[qi]), *items_scores(second[qi]), 10, 0.0, referee=vo.f64_referee(allv, qs[qi]))
     assert second[0][0].item == 9_000 and second[0][0].score == 1.0
     assert [r.item for r in first[60]] == [r.item for r in second[60]][: len(first[60])] or True
 
@@ -957,7 +960,7 @@ def test_wide_tile_other_dimensions(dtype, d, tier):
     assert t == tier if tier else t in (1, 2, 3, 5)
     ref_v = v if dtype == "fp32" else _f16(v)
     for qi in range(0, nq, 9):
-        rep = vo.check_topk_parity(vo.scores_full(ref_v, qs[qi]), *items_scores(out[qi]), k, 0.0)
+        rep = vo.check_topk_parity(vo.scores_full(ref_v, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(ref_v, qs[qi]))
         assert rep.tie_permuted_positions <= 2
     assert out[3][0].item == n - 1
 
@@ -980,7 +983,7 @@ def test_f32_corpus_large_batches_ride_the_fp16_shadow(nq):
         assert eng.get_option("last_tier") in (1, 2, 3)
         assert [r.item for r in batch[qi]] == [r.item for r in seq]
         np.testing.assert_allclose([r.score for r in batch[qi]], [r.score for r in seq], atol=3e-7, rtol=0)
-        assert vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(batch[qi]), 32, 0.0).ordinals_bit_exact
+        assert vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(batch[qi]), 32, 0.0, referee=vo.f64_referee(v, qs[qi])).ordinals_bit_exact
     # the 64-query fp32 tile (no shadow) gives the same answers
     eng.set_option("f32_shadow", 0)
     plain = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
@@ -1007,7 +1010,7 @@ def test_f32_shadow_small_and_odd_shapes(n, nq, k, ms):
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
     assert vb.engine.get_option("last_tier") == 4
     for qi in sorted(set(np.linspace(0, nq - 1, 24).astype(int).tolist())):
-        assert vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(out[qi]), k, ms).tie_permuted_positions <= 1
+        assert vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(out[qi]), k, ms, referee=vo.f64_referee(v, qs[qi])).tie_permuted_positions <= 1
     assert out[0][0].item == n - 1
 
 
@@ -1033,7 +1036,7 @@ def test_f32_shadow_level_2_serves_small_batches_and_single_queries(nq):
         assert len({r.item for r in got[qi]} ^ {r.item for r in plain[qi]}) <= 2
     assert swapped <= 4
     for qi in range(0, nq, 5):
-        vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(got[qi]), 32, 0.0)
+        vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(got[qi]), 32, 0.0, referee=vo.f64_referee(v, qs[qi]))
     one = vb.fuzzy_lookup_embedding(qs[0], max_hits=10, min_score=0.6)  # the single-query API takes the same route
     assert eng.get_option("last_shadow") == 1 and [r.item for r in one] == [12_344]
     k50 = vb.fuzzy_lookup_embeddings(qs, max_hits=50, min_score=0.0)  # 64 candidates cannot prove a top-50: the fp32 kernels answer
@@ -1061,7 +1064,7 @@ def test_per_corpus_caches_do_not_survive_a_new_tensor_at_the_same_address():
         out = vb.fuzzy_lookup_embeddings(qs, max_hits=10, min_score=0.0)
         assert vb.engine.get_option("last_tier") == 4 and out[4][0].item == 17
         for qi in (0, 33, 69):
-            assert vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(out[qi]), 10, 0.0).ordinals_bit_exact
+            assert vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(out[qi]), 10, 0.0, referee=vo.f64_referee(v, qs[qi])).ordinals_bit_exact
         del t
         vb.clear()
     # (whether the addresses repeated is the allocator's business; the answers must be right either way)
@@ -1082,7 +1085,7 @@ def test_f32_shadow_follows_appends_rewrites_and_near_duplicates():
     assert eng.get_option("last_tier") == 4 and second[5][0].item == 20_007 and abs(second[5][0].score - 1.0) < 1e-6
     allv = np.concatenate([v, extra])
     for qi in range(0, 80, 9):
-        assert vo.check_topk_parity(vo.scores_full(allv, qs[qi]), *items_scores(second[qi]), 10, 0.0).ordinals_bit_exact
+        assert vo.check_topk_parity(vo.scores_full(allv, qs[qi]), *items_scores(second[qi]), 10, 0.0, referee=vo.f64_referee(allv, qs[qi])).ordinals_bit_exact
     # a row rewritten in place in the serialized matrix (noticed by the fingerprint or mark_dirty): the shadow must follow
     m = vb.serialize()
     m[123] = qs[9]
@@ -1100,7 +1103,7 @@ def test_f32_shadow_follows_appends_rewrites_and_near_duplicates():
     assert vb2.engine.get_option("last_tier") == 4 and vb2.engine.get_option("last_flagged") == 0
     allv2 = np.concatenate([v, dups.astype(np.float32)])
     for qi in [0, 4, 40, 79]:
-        vo.check_topk_parity(vo.scores_full(allv2, qs[qi]), *items_scores(out[qi]), 32, 0.0)
+        vo.check_topk_parity(vo.scores_full(allv2, qs[qi]), *items_scores(out[qi]), 32, 0.0, referee=vo.f64_referee(allv2, qs[qi]))
     # query 3 sits in the middle of 100 rows whose scores differ by less than fp32 summation noise: the ORDER among them is
     # not defined (not even by the reference), the set of scores is
     assert all(r.item >= 20_000 for r in out[3]) and len(set(r.item for r in out[3])) == 32
@@ -1130,7 +1133,7 @@ def test_skinny_kernel_against_oracle(dtype, n, d, nq, k, ms):
     assert vb.engine.get_option("last_tier") == 5
     ref_v = v if dtype == "fp32" else _f16(v)
     for qi in range(nq):
-        vo.check_topk_parity(vo.scores_full(ref_v, qs[qi]), *items_scores(got[qi]), k, ms)
+        vo.check_topk_parity(vo.scores_full(ref_v, qs[qi]), *items_scores(got[qi]), k, ms, referee=vo.f64_referee(ref_v, qs[qi]))
     if n > 10:
         assert got[0][0].item == n - 2
 
@@ -1147,7 +1150,7 @@ def test_skinny_kernel_serves_large_batches_on_fp32_corpora(nq):
     got = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     assert vb.engine.get_option("last_tier") == 5
     for qi in range(0, nq, 7):
-        vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(got[qi]), k, 0.0)
+        vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(got[qi]), k, 0.0, referee=vo.f64_referee(v, qs[qi]))
     # the same batch through the streaming tier
     vb.engine.set_option("skinny_min_batch_f32", 1 << 30)
     ref = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
@@ -1170,7 +1173,7 @@ def test_skinny_64_query_tile_on_fp16_corpora(nq):
     assert vb.engine.get_option("last_tier") == 5
     v16 = _f16(v)
     for qi in range(nq):
-        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(got[qi]), k, 0.0)
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(got[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
     assert got[1][0].item == n - 5
 
 
@@ -1203,7 +1206,7 @@ def test_skinny_kernel_with_threshold_ladder_nan_and_zero_rows(dtype):
     neg = -qs[:8]  # rows that score s for q score 1 - s for -q; with min_score 0.5 the zero row survives
     low = vb.fuzzy_lookup_embeddings(neg, max_hits=64, min_score=0.5)
     for qi in range(8):
-        vo.check_topk_parity(vo.scores_full(ref_v, neg[qi]), *items_scores(low[qi]), 64, 0.5)
+        vo.check_topk_parity(vo.scores_full(ref_v, neg[qi]), *items_scores(low[qi]), 64, 0.5, referee=vo.f64_referee(ref_v, neg[qi]))
 
 
 # --------------------------------------------------------------------------------------
@@ -1273,7 +1276,7 @@ def test_shard_search_plus_merge_equals_whole():
     np.testing.assert_array_equal(merged.cpu().numpy(), want)
     ords, scs, cnts = _native.decode_keys(want)
     for qi in range(5):
-        vo.check_topk_parity(vo.scores_full(v, qs[qi]), ords[qi, : cnts[qi]], scs[qi, : cnts[qi]], k, 0.0)
+        vo.check_topk_parity(vo.scores_full(v, qs[qi]), ords[qi, : cnts[qi]], scs[qi, : cnts[qi]], k, 0.0, referee=vo.f64_referee(v, qs[qi]))
     for e in engines + [whole]:
         e.close()
 
@@ -1306,7 +1309,7 @@ def test_sharded_searcher_on_one_rank_rccl():
         for qi in range(6):
             m = int(res.counts[qi])
             assert m == 32
-            vo.check_topk_parity(vo.scores_full(v, qs[qi]), (res.ordinals[qi, :m] - 5_000_000).tolist(), res.scores[qi, :m].tolist(), 32, 0.0)
+            vo.check_topk_parity(vo.scores_full(v, qs[qi]), (res.ordinals[qi, :m] - 5_000_000).tolist(), res.scores[qi, :m].tolist(), 32, 0.0, referee=vo.f64_referee(v, qs[qi]))
 
     # 1. the library's communicator, world of one, the collective forced
     assert not dist.is_initialized()
@@ -1405,11 +1408,11 @@ def test_fused_multi_index_query_equals_separate_calls():
         single = vt.fuzzy_lookup_embedding(tq[i], max_hits=50, min_score=0.85)
         assert [r.item for r in full.terms[i]] == [r.item for r in single] and len(single) >= 1
         np.testing.assert_allclose([r.score for r in full.terms[i]], [r.score for r in single], atol=2e-7, rtol=0)
-        vo.check_topk_parity(vo.scores_full(terms, tq[i]), *items_scores(full.terms[i]), 50, 0.85)
+        vo.check_topk_parity(vo.scores_full(terms, tq[i]), *items_scores(full.terms[i]), 50, 0.85, referee=vo.f64_referee(terms, tq[i]))
         assert [r.item for r in sub.terms[i]] == [r.item for r in single]
     single = vm.fuzzy_lookup_embedding(mq, max_hits=25, min_score=0.7)
     assert [r.item for r in full.messages] == [r.item for r in single] and single[0].item == 4242
-    vo.check_topk_parity(vo.scores_full(msgs, mq), *items_scores(full.messages), 25, 0.7)
+    vo.check_topk_parity(vo.scores_full(msgs, mq), *items_scores(full.messages), 25, 0.7, referee=vo.f64_referee(msgs, mq))
     single = vm.fuzzy_lookup_embedding_in_subset(mq, subset, max_hits=25, min_score=0.7)
     assert [r.item for r in sub.messages] == [r.item for r in single] and 4242 in [r.item for r in sub.messages]
     single = vh.fuzzy_lookup_embedding(hq, max_hits=10, min_score=0.7)
@@ -1452,13 +1455,17 @@ def test_cfg3_full_size_batch_against_chunked_oracle():
         assert eng.get_option("last_tier") in (1, 2, 3)
         np.testing.assert_array_equal(o1, ords[qi])
         np.testing.assert_allclose(s1, scs[qi], atol=3e-7, rtol=0)
-    ref = vo.scores_full_chunked((corpus[lo : lo + ORACLE_CHUNK].float().cpu().numpy() for lo in range(0, rows, ORACLE_CHUNK)), qs[sample])
-    near_total = permuted = 0
+    ref, referee = vo.scores_full_chunked_refereed((corpus[lo : lo + ORACLE_CHUNK].float().cpu().numpy() for lo in range(0, rows, ORACLE_CHUNK)), qs[sample],
+                                                   [ords[qi] for qi in sample], keep=k + 256)
+    near_total = permuted = inv_gpu = inv_ref = 0
     for j, qi in enumerate(sample):
-        rep, near = vo.check_topk_parity_large(ref[j], ords[qi].tolist(), scs[qi].tolist(), k, 0.0)
+        rep, near = vo.check_topk_parity_large(ref[j], ords[qi].tolist(), scs[qi].tolist(), k, 0.0, referee=referee.for_query(j))
         near_total += near
         permuted += rep.tie_permuted_positions
-    print(f"cfg3 full size: {len(sample)} queries, near-tie pairs in the reference top-{k}: {near_total}, positions permuted inside them: {permuted}")
+        inv_gpu += rep.gpu_inversions_vs_f64
+        inv_ref += rep.reference_inversions_vs_f64
+    print(f"cfg3 full size: {len(sample)} queries, near-tie pairs in the reference top-{k}: {near_total}, positions permuted inside them: {permuted}; "
+          f"pairs ordered against the float64 truth: device {inv_gpu}, reference {inv_ref}")
     assert permuted <= near_total
     eng.close()
 
@@ -1518,7 +1525,7 @@ def test_two_ranks_device_kernels_gloo_exchange():
     for qi in range(7):
         np.testing.assert_array_equal(ret[0][0][qi], ret[1][0][qi])
         np.testing.assert_array_equal(ret[0][1][qi], ret[1][1][qi])
-        rep = vo.check_topk_parity(vo.scores_full(v, qs[qi]), ret[0][0][qi].tolist(), ret[0][1][qi].tolist(), 32, 0.0)
+        rep = vo.check_topk_parity(vo.scores_full(v, qs[qi]), ret[0][0][qi].tolist(), ret[0][1][qi].tolist(), 32, 0.0, referee=vo.f64_referee(v, qs[qi]))
         assert rep.ordinals_bit_exact
     assert ret[0][0].max() > 15_001  # hits from the second shard carry their global ordinals
 
@@ -1545,7 +1552,7 @@ def test_device_resident_load_paths_stream_without_a_host_matrix(tmp_path, dtype
     assert len(mv) == len(messages) and mv._host.shape[0] == 0 and mv._device_only is not None  # nothing on the host
     want = messages.astype(np.float16).astype(np.float32) if dtype == "fp16" else messages
     res = mv.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
-    vo.check_topk_parity(vo.scores_full(want, q), *items_scores(res), 32, 0.0)
+    vo.check_topk_parity(vo.scores_full(want, q), *items_scores(res), 32, 0.0, referee=vo.f64_referee(want, q))
     assert mv._host.shape[0] == 0  # a lookup does not materialise it either
     np.testing.assert_array_equal(mv.serialize(), want)  # ... serialize() does (fp16 storage: the widened values)
     mv.add_embeddings(None, related[:5])  # host-authoritative now: appends behave as always
@@ -1559,7 +1566,7 @@ def test_device_resident_load_paths_stream_without_a_host_matrix(tmp_path, dtype
     load_sqlite_embeddings(db, sv, fetch_rows=1000)
     assert len(sv) == len(related) and sv._host.shape[0] == 0
     want_r = related.astype(np.float16).astype(np.float32) if dtype == "fp16" else related
-    vo.check_topk_parity(vo.scores_full(want_r, q), *items_scores(sv.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.0)), 10, 0.0)
+    vo.check_topk_parity(vo.scores_full(want_r, q), *items_scores(sv.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.0)), 10, 0.0, referee=vo.f64_referee(want_r, q))
     sv.add_embedding(None, related[0])  # single rows stream too
     assert len(sv) == len(related) + 1 and sv._host.shape[0] == 0
 
@@ -1588,7 +1595,7 @@ def test_device_only_corpus_and_lazy_host_copy():
     vb.adopt_device_corpus(torch.from_numpy(v).cuda())
     assert len(vb) == 3000 and vb._embedding_size == 1536
     res = vb.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
-    vo.check_topk_parity(vo.scores_full(v, q), *items_scores(res), 32, 0.0)
+    vo.check_topk_parity(vo.scores_full(v, q), *items_scores(res), 32, 0.0, referee=vo.f64_referee(v, q))
     np.testing.assert_array_equal(vb.serialize(), v)  # copied back on demand
 
 

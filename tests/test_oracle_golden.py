@@ -125,6 +125,105 @@ def test_parity_checker_tolerates_near_ties():
     assert rep.ordinals_bit_exact
 
 
+def _clustered_case(seed=7, n=4000, d=256, members=60):
+    """A query next to a pack of near-duplicate rows: the best `members` scores lie within a few 1e-7 of one another."""
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((n, d)).astype(np.float32)
+    centre = v[0] / np.linalg.norm(v[0])
+    v[:members] = centre[None, :] + 1e-3 * rng.standard_normal((members, d)).astype(np.float32) / np.sqrt(d)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    q = centre + 0.02 * rng.standard_normal(d).astype(np.float32) / np.sqrt(d)
+    q = (q / np.linalg.norm(q)).astype(np.float32)
+    return v.astype(np.float32), q
+
+
+def _other_fp32_answer(v, q, k):
+    """What a second, equally legitimate float32 arithmetic returns: per-row dot products summed in another order (blocks of 16)."""
+    prod = v * q[None, :]
+    dots = prod.reshape(len(v), -1, 16).sum(axis=2, dtype=np.float32).sum(axis=1, dtype=np.float32)
+    sc = vo.cosine_to_score(dots).astype(np.float32)
+    order = np.lexsort((np.arange(len(v)), -sc.astype(np.float64)))[:k]
+    return order.tolist(), sc[order].tolist(), sc
+
+
+def test_float64_referee_accepts_another_summation_order_and_counts_inversions():
+    v, q = _clustered_case()
+    ref = vo.scores_full(v, q)
+    items, scores, _ = _other_fp32_answer(v, q, 32)
+    rep = vo.check_topk_parity(ref, items, scores, 32, 0.0, referee=vo.f64_referee(v, q))
+    assert rep.refereed and rep.noise_ref > 0 and rep.noise_gpu > 0
+    assert rep.tie_width == pytest.approx(2 * (rep.noise_ref + rep.noise_gpu))
+    assert rep.tie_width < 16 * 2.0**-24  # narrower than the hand-set width it replaces
+    assert rep.max_permuted_gap <= rep.tie_width
+    assert rep.exact_positions + rep.tie_permuted_positions == 32
+    # the float64 answer itself has no inversions and is accepted as well
+    t = vo.scores_f64(v, q)
+    best = np.lexsort((np.arange(len(v)), -t))[:32]
+    rep64 = vo.check_topk_parity(ref, best.tolist(), t[best].astype(np.float32).tolist(), 32, 0.0, referee=vo.f64_referee(v, q))
+    assert rep64.gpu_inversions_vs_f64 == 0 and rep64.reference_inversions_vs_f64 >= 0
+
+
+def test_float64_referee_rejects_a_swap_wider_than_the_measured_noise():
+    v, q = _clustered_case()
+    ref = vo.scores_full(v, q)
+    t = vo.scores_f64(v, q)
+    good = vo.lookup(v, q, 32, 0.0)
+    items, scores = [i for i, _ in good], [s for _, s in good]
+    vo.check_topk_parity(ref, items, scores, 32, 0.0, referee=vo.f64_referee(v, q))
+    # move a row up over a float64 gap of 5e-7 .. 8e-7: inside round 3's hand-set 16 * 2^-24 = 9.5e-7 at score ~1, outside what the two
+    # measured noises (~1e-7 each) can explain
+    tt = t[items]
+    pair = next(((a, b) for a in range(32) for b in range(a + 1, 32) if 5e-7 < tt[a] - tt[b] < 8e-7), None)
+    assert pair is not None
+    a, b = pair
+    bad_items = items[:a] + [items[b]] + items[a:b] + items[b + 1:]
+    bad_scores = scores[:a] + [scores[a]] + scores[a:b] + scores[b + 1:]  # keeps the list descending and every score within 1e-5
+    vo.check_topk_parity(ref, bad_items, bad_scores, 32, 0.0, tie_eps=16 * 2.0**-24)  # what round 3's hand-set width let through
+    # a list sorted by its own scores can only swap rows over a gap <= its own error: the lie shows up as device noise (or, with honest
+    # scores, as a list that is not descending)
+    with pytest.raises(AssertionError, match="noisier|near-tie width"):
+        vo.check_topk_parity(ref, bad_items, bad_scores, 32, 0.0, referee=vo.f64_referee(v, q))
+    honest = scores[:a] + [scores[b]] + scores[a:b] + scores[b + 1:]
+    with pytest.raises(AssertionError, match="descending"):
+        vo.check_topk_parity(ref, bad_items, honest, 32, 0.0, referee=vo.f64_referee(v, q))
+
+
+def test_float64_referee_caps_the_device_noise():
+    v, q = _clustered_case()
+    ref = vo.scores_full(v, q)
+    good = vo.lookup(v, q, 32, 0.0)
+    items = [i for i, _ in good]
+    sloppy = [s - 3e-6 for _, s in good]  # inside the 1e-5 score tolerance, ordered, but 20x noisier than the reference
+    vo.check_topk_parity(ref, items, sloppy, 32, 0.0)  # (the constant rule alone cannot see it)
+    with pytest.raises(AssertionError, match="noisier"):
+        vo.check_topk_parity(ref, items, sloppy, 32, 0.0, referee=vo.f64_referee(v, q))
+
+
+def test_float64_referee_detects_an_omitted_row_and_handles_subsets_and_chunks():
+    v, q = _clustered_case()
+    ref = vo.scores_full(v, q)
+    t = vo.scores_f64(v, q)
+    good = vo.lookup(v, q, 10, 0.0)
+    items, scores = [i for i, _ in good], [s for _, s in good]
+    far = int(np.argsort(-t)[40])  # a member of the pack, but > the near-tie width below rank 10
+    assert t[items[-1]] - t[far] > 1e-6
+    with pytest.raises(AssertionError):
+        vo.check_topk_parity(ref, items[:-1] + [far], scores[:-1] + [float(ref[far])], 10, 0.0, referee=vo.f64_referee(v, q))
+    # subset form: positions index the subset
+    sub = np.concatenate([np.arange(0, 60, 2), np.arange(100, 400)])
+    got = vo.lookup_in_subset(v, q, sub.tolist(), 10, 0.0)
+    rep = vo.check_topk_parity(ref[sub], [i for i, _ in got], [s for _, s in got], 10, 0.0, candidate_ordinals=sub, referee=vo.f64_referee(v[sub], q))
+    assert rep.refereed and rep.exact_positions == 10
+    # chunked form: the referee filled while the chunks pass by gives the same verdicts as the whole-matrix one
+    items32, scores32, _ = _other_fp32_answer(v, q, 32)
+    qs = np.stack([q, q])
+    ref2, cr = vo.scores_full_chunked_refereed([v[:1500], v[1500:2600], v[2600:]], qs, [items32, items32], keep=32 + 64)
+    rep_c, near = vo.check_topk_parity_large(ref2[1], items32, scores32, 32, 0.0, margin=64, referee=cr.for_query(1))
+    rep_w = vo.check_topk_parity(ref2[1], items32, scores32, 32, 0.0, referee=vo.f64_referee(v, q))  # (the same float32 reference scores: sgemm's)
+    assert (rep_c.tie_permuted_positions, rep_c.gpu_inversions_vs_f64) == (rep_w.tie_permuted_positions, rep_w.gpu_inversions_vs_f64)
+    assert near >= rep_c.tie_permuted_positions // 2
+
+
 def test_f32_threshold_rule():
     assert float(vo.f32_threshold(0.85)) == float(np.float32(0.85))
     assert float(vo.f32_threshold(np.float64(0.85))) > 0.85  # f64 compare == next f32 up

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """How far the reference arithmetic (float32 numpy/OpenBLAS dot, vectorbase.py:176 + :44-47) sits from the exact score, as a function of
-the size of the dot product: the measurement behind oracle.vectorbase_oracle.tie_eps_at().  CPU only.
+the size of the dot product.  Round 3 turned this measurement into a hand-set near-tie width; since round 4 `check_topk_parity` measures the
+same thing itself, per query, against a float64 referee (oracle.vectorbase_oracle.scores_f64) -- this script is what to run to see the numbers.  CPU only.
 
     python tools/oracle_noise.py
 """
@@ -18,7 +19,7 @@ def noise(v, qs, top=64):
     errs = []
     for q in qs:
         s32 = vo.scores_full(v, q)
-        s64 = np.clip((v.astype(np.float64) @ q.astype(np.float64) + 1.0) / 2.0, 0.0, 1.0)
+        s64 = vo.scores_f64(v, q)
         best = np.argsort(-s64)[:top]
         errs.append(np.abs(s32[best] - s64[best]))
     return np.concatenate(errs), float(np.mean([np.sort(vo.scores_full(v, q))[-1] for q in qs[:8]]))
@@ -31,7 +32,7 @@ def main():
     vg, _ = make_corpus(60_000, 1536, 1)
     e, top = noise(vg, make_queries(64, 1536, 2))
     print(f"isotropic corpus (best score ~{top:.4f}): |f32 - f64| max {e.max():.3e}  p99 {np.percentile(e, 99):.3e}  median {np.median(e):.3e}")
-    print(f"2^-24 = {2.0 ** -24:.3e}; tie_eps_at(0.57) = {vo.tie_eps_at(0.57):.3e}, tie_eps_at(0.999) = {vo.tie_eps_at(0.999):.3e}")
+    print(f"2^-24 = {2.0 ** -24:.3e}; TIE_EPS (the rule without a referee) = {vo.TIE_EPS:.3e}")
 
 
 if __name__ == "__main__":

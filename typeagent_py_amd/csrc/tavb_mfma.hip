@@ -374,7 +374,8 @@ struct WideGeom {
   static constexpr int RA = NI == 2 ? 3 : 2;
   static constexpr int B_RING = RA * SLOT_A6;  // the query ring (always two slots) sits behind the corpus ring
   static constexpr int CTRL = B_RING + 2 * SLOT_B;
-  static constexpr int LDS = CTRL + QT * 8 + 16;
+  static constexpr int TOUCH_SINK = CTRL + QT * 8 + 16;  // 4 x 256 B: where the L2 touch-ahead loads of the waves land (never read)
+  static constexpr int LDS = TOUCH_SINK + 1024;
   static constexpr int PIECES_B = QT / 8 / 4;  // per wave per step: 8 or 4
   static constexpr int PIECES = PIECES_A6 + PIECES_B;
 };
@@ -389,11 +390,12 @@ constexpr int staging_piece_at(int q, int i) {
   return -1;
 }
 
-template <int ABL, int NI, int N3, int N0, int N1>
+template <int ABL, int NI, int N3, int N0, int N1, int TA = 0>
 __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p) {
   using G = WideGeom<NI>;
   constexpr int BN = G::QT, NT = G::NT, SLOT_B6 = G::SLOT_B, CTRL6 = G::CTRL, PIECES_B6 = G::PIECES_B, PIECES6 = G::PIECES, RA = G::RA, B_RING6 = G::B_RING;
   static_assert(N3 + N0 + N1 == PIECES6, "every piece of a step is issued exactly once");
+  static_assert(TA == 0 || G::RA == 2, "the touch-ahead belongs to the two-slot ring");
   static_assert(N3 <= NT && N0 <= NT && N1 <= NT && NI + 5 <= NT, "one piece / one fragment read behind an MFMA at most");
   extern __shared__ __align__(16) unsigned char smem[];
   float* thr_lds = reinterpret_cast<float*>(smem + CTRL6);
@@ -495,6 +497,39 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
       sb_kt = (sb_kt + 1 == steps_per_tile) ? 0 : sb_kt + 1;
     }
   };
+  // ---- L2 touch-ahead (TA > 0).  The corpus lines of a K step are compulsory misses for whichever of the sibling workgroups asks first, and the
+  //      two-slot ring gives a staging load one step (~1.6 us) to land: an HBM round trip under load does not always fit.  So every step each
+  //      wave also reads ONE dword per line of its share of the slab TA steps further on (the workgroups that share a row range split its 320
+  //      rows between them) into a sink in LDS nobody reads: the line is in the XCD's L2 when the real piece asks for it.  VMEM loads return in
+  //      order, so the touch is issued at the START of quarter 2 -- behind every piece the wait in front of quarter 3 is for -- and that wait
+  //      is counted (vmcnt(1): everything but the touch just issued); the touch has until the NEXT step's wait to come back.
+  //      (Round 2 touched with vmcnt(0) waits and lost 3-6 %: every step then waited for an HBM round trip.)
+  uint32_t touch_off = 0;
+  if constexpr (TA > 0) {
+    const int per_wave = (BM6 + 4 * p.n_qtiles - 1) / (4 * p.n_qtiles);
+    const int mine = per_wave < 64 ? per_wave : 64;
+    int zero_t = 0;
+    asm volatile("" : "+v"(zero_t));
+    const int ln_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_t));
+    const int row_t = (qtile * 4 + wave) * per_wave + (ln_t < mine ? ln_t : mine - 1);
+    touch_off = (uint32_t)row_t * row_bytes;
+  }
+  auto touch_ahead = [&]() {
+    int kt2 = sa_kt + TA, tile2 = sa_tile;
+    if (kt2 >= steps_per_tile) {
+      kt2 -= steps_per_tile;
+      ++tile2;
+    }
+    if (kt2 >= steps_per_tile) kt2 = steps_per_tile - 1;
+    if (tile2 >= n_tiles) tile2 = n_tiles - 1;  // past the end: a harmless re-touch (the wait below counts on exactly one touch per step)
+    const int64_t row0 = r_begin + (int64_t)tile2 * BM6;
+    const int64_t left = p.rows - row0;
+    const int valid = (int)(left < BM6 ? left : BM6);
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(sgpr_ptr(corpus + (size_t)row0 * row_bytes)), 0, __builtin_amdgcn_readfirstlane(valid * (int)row_bytes), 0x00020000);
+    unsigned char* sink = smem + G::TOUCH_SINK + wave * 256;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lds_void*)sink, 4, (int)touch_off, __builtin_amdgcn_readfirstlane(kt2 * 128), 0, 0);
+  };
   auto stage_piece = [&](auto idx_tag) {
     constexpr int IDX = decltype(idx_tag)::value;
     if constexpr (RA == 2) {
@@ -591,10 +626,11 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   auto step = [&](auto first_tag) {
     quarter(Q0{}, first_tag, a0, b0, a1, b1, rd_a, rd, Q1{});
     quarter(Q1{}, std::false_type{}, a1, b1, a0, b0, rd_a, rd, Q2{});
+    if constexpr (TA > 0 && (ABL & 2) == 0) touch_ahead();
     quarter(Q2{}, std::false_type{}, a0, b0, a1, b1, rd_a, rd, Q3{});
-    // ---- step S+1 has landed in this wave (two slots: nothing newer is in flight; three: only corpus slab S+2 is); the
-    //      slots of step S are read out; meet
-    if constexpr ((ABL & 2) == 0) wait_vmcnt<(RA == 2 ? 0 : PIECES_A6)>();
+    // ---- step S+1 has landed in this wave (two slots: nothing newer is in flight but the touch-ahead; three: only corpus slab S+2 is);
+    //      the slots of step S are read out; meet
+    if constexpr ((ABL & 2) == 0) wait_vmcnt<(RA == 2 ? (TA > 0 ? 1 : 0) : PIECES_A6)>();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) through the builtin: visible to the compiler's wait-count pass
     TAVB_BARRIER();
     const int nxt_a = (RA == 2) ? (rd_a ^ 1) : (rd_a + 1 == RA ? 0 : rd_a + 1);
@@ -1381,6 +1417,9 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
     switch (p.sched) {  // staging pieces per quarter (q3, q0, q1): measurement
       case 1: return go(mfma_scan_kernel<0, 4, 10, 8, 0>, NT6, LDS256);
       case 2: return go(mfma_scan_kernel<0, 4, 6, 6, 6>, NT6, LDS256);
+      case 3: return go(mfma_scan_kernel<0, 4, 8, 6, 4, 1>, NT6, LDS256);  // L2 touch-ahead, 1 / 2 / 3 steps
+      case 4: return go(mfma_scan_kernel<0, 4, 8, 6, 4, 2>, NT6, LDS256);
+      case 5: return go(mfma_scan_kernel<0, 4, 8, 6, 4, 3>, NT6, LDS256);
       default: return go(mfma_scan_kernel<0, 4, 8, 6, 4>, NT6, LDS256);
     }
   }
