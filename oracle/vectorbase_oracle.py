@@ -187,7 +187,16 @@ def f64_referee(vectors: np.ndarray, query: np.ndarray) -> Callable[[np.ndarray]
     For a subset search pass `vectors[subset]`."""
     def referee(positions: np.ndarray) -> np.ndarray:
         return scores_f64(vectors[np.asarray(positions, dtype=np.int64)], query)
+    referee.dim = int(np.asarray(query).shape[-1])  # lets the checker price legitimate float32 accumulation noise
     return referee
+
+
+def fp32_accumulation_scale(dim: int | None) -> float:
+    """The random-walk scale, in score units, of a float32 dot product of `dim` terms whose partial sums stay within [-1, 1]: every one
+    of the `dim` additions rounds by at most 2^-24 -> sqrt(dim) * 2^-24 on the cosine, half of that on the score (vectorbase.py:44-47
+    halves it).  1.2e-6 at dim = 1536; the worst case (dim * 2^-24) is 40x that.  Measured on the device: 3e-7 for the MFMA tiles at
+    |cos| ~ 1 (96 dependent accumulations of 16-term blocks), 6e-8 for the streaming kernels (24 terms per lane, then a tree)."""
+    return 0.0 if not dim else 0.5 * float(np.sqrt(dim)) * 2.0**-24
 
 
 @dataclass
@@ -265,8 +274,9 @@ def check_topk_parity(
         the reference's row at that rank.  (Order statistics are 1-Lipschitz: the i-th best of scores perturbed by <= e lies within e of
         the i-th best truth, and that row's own truth within another e -- so two correct rankings, one per arithmetic, can differ at a
         rank only by rows this close.  A row swapped over a wider gap is a wrong answer, whatever the noise.)
-        The measured GPU noise itself must stay within max(TIE_EPS, 4 * noise_ref): the device arithmetic may not be sloppier than
-        a few times the reference's own, so "measured" cannot excuse a defect.
+        The measured GPU noise itself must stay within max(TIE_EPS, 4 * noise_ref, fp32_accumulation_scale(dim)): the device may not be
+        sloppier than a few times the reference's own arithmetic or than float32 accumulation of `dim` terms explains (OpenBLAS's
+        blocked sgemv lands anywhere between 4e-8 and 1.6e-7 at |cos| ~ 1, query by query), so "measured" cannot excuse a defect.
         The report also counts, against the truth, the pairs each answer orders wrongly (`gpu_inversions_vs_f64`,
         `reference_inversions_vs_f64`): the returned answer is at least as right as OpenBLAS's when the former <= the latter.
 
@@ -336,8 +346,10 @@ def check_topk_parity(
             noise_gpu = float(np.max(np.abs(got_scores - t_got)))
         else:
             noise_gpu = 0.0
-        assert noise_gpu <= max(TIE_EPS, 4.0 * noise_ref), (
-            f"device scores are noisier than the reference's: max |score - float64| = {noise_gpu:.3e} against {noise_ref:.3e}")
+        noise_cap = max(TIE_EPS, 4.0 * noise_ref, fp32_accumulation_scale(getattr(referee, "dim", None)))
+        assert noise_gpu <= noise_cap, (
+            f"device scores are noisier than float32 arithmetic explains: max |score - float64| = {noise_gpu:.3e} against the reference's "
+            f"{noise_ref:.3e} (cap {noise_cap:.3e})")
         width = 2.0 * (noise_ref + noise_gpu)
         width_eps = width
         thr_eps = max(base_eps, noise_ref + noise_gpu)
@@ -463,7 +475,11 @@ def check_topk_parity_large(
     clean = np.where(np.isnan(ref_scores), np.float32(-1.0), ref_scores)
     top = np.argpartition(-clean, keep - 1)[:keep] if keep < n else np.arange(n)
     top = top[np.lexsort((top, -clean[top].astype(np.float64)))]
-    inner = None if referee is None else (lambda positions: referee(top[np.asarray(positions, dtype=np.int64)]))
+    inner = None
+    if referee is not None:
+        def inner(positions):
+            return referee(top[np.asarray(positions, dtype=np.int64)])
+        inner.dim = getattr(referee, "dim", None)
     rep = check_topk_parity(ref_scores[top], got_items, got_scores, max_hits, min_score, candidate_ordinals=top, referee=inner)
     head = clean[top[: max_hits + 1]].astype(np.float64)
     near_width = rep.tie_width if rep.refereed else TIE_EPS
@@ -497,7 +513,11 @@ class ChunkedReferee:
 
     def for_query(self, j: int) -> Callable[[np.ndarray], np.ndarray]:
         table = self.truth[j]
-        return lambda ordinals: np.array([table[int(o)] for o in np.asarray(ordinals).tolist()], dtype=np.float64)
+
+        def referee(ordinals):
+            return np.array([table[int(o)] for o in np.asarray(ordinals).tolist()], dtype=np.float64)
+        referee.dim = int(self.queries.shape[1])
+        return referee
 
 
 def scores_full_chunked_refereed(chunks: Iterable[np.ndarray], queries: np.ndarray, returned: Sequence[Sequence[int]], keep: int):

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _rec():
     return {
         "workload": "cfg3: 10000000x1536 fp16, 1024 queries/step, top-32, min_score 0.0", "queries_per_sec": 37000.0, "steps": 10, "warmup": 12,
-        "ms_per_step": 27.6, "p50_latency_us": 27500.0, "p99_latency_us": 27900.0, "min_latency_us": 27400.0, "dtype": "f16 storage, f32 accumulate",
+        "ms_per_step": 27.6, "p50_latency_us": 27500.0, "p99_latency_us": 27900.0, "dtype": "f16 storage, f32 accumulate",
         "roofline": {"bound": "mfma", "achieved": 1180.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.472, "traffic": 5.19e10},
         "cpu_baseline": {"value": 0.97, "unit": "queries/s", "cores": 256, "kind": "port", "sample": "..."},
         "parity": {"ok": True}, "host_buffer_form": {"ms_per_step": 27.9},
@@ -38,6 +38,48 @@ def test_headline_line_has_every_contract_field():
         assert key in line["cpu_baseline"]
     eight = bench.headline_line(types.SimpleNamespace(world=8), _rec(), "cfg3", wl, "strong", None)
     assert eight["n_gpus"] == 8 and "row-sharded x8" in eight["config"]["parallelism"] and "sub" not in eight
+
+
+def test_the_line_stays_short_enough_for_the_driver_record():
+    """Round 3's line was ~15 KB and the driver's stored tail lost `sub.cfg3_q1`.  A full suite line (headline + seven sub-records with every
+    field the records carry) must stay under 6 KB."""
+    ctx = types.SimpleNamespace(world=1)
+    wl = dict(bench.WORKLOADS["cfg3"], rows_total=10_000_000)
+    parity = {"ok": True, "queries_checked": 16, "rows": 10_000_000, "positions_exact": 345, "positions_permuted": 167, "max_permuted_gap": 2.23864e-07,
+              "gpu_inversions_vs_f64": 49, "reference_inversions_vs_f64": 120, "max_inverted_gap_gpu": 9.3138e-08, "max_inverted_gap_ref": 2.13037e-07,
+              "noise_gpu": 6.54013e-08, "noise_ref": 3.20549e-07, "tie_width": 7.63534e-07, "near_tie_pairs": 446, "max_abs_score_error": 2.38419e-07, "seconds": 12.5}
+    roof = {"bound": "mfma", "achieved": 1205.9712345, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.48238712345, "traffic": 45050812345.0, "pipe": "v_mfma_f32_32x32x16_f16",
+            "kernel": "mfma_scan_kernel", "kernel_ms_per_step": 26.0847123, "kernel_launches_per_step": 5.0, "algorithmic_per_step": 3.14573e13,
+            "ms_per_step_with_events": 26.5997123, "kernel_parts_ms_per_step": {"mfma_last_phase": 19.1439123, "mfma_earlier_phases": 6.94076123},
+            "other_kernels_ms_per_step": {"merge": 0.247647123, "rescore": 0.154961123},
+            "sustained": {"mfma_only_ms_per_step": 20.325123, "mfma_only_tflops": 1547.72123, "frac_of_mfma_only": 0.791425123, "vendor_gemm_tflops": 1107.16123}}
+    cpu = {"value": 3.18658123, "unit": "queries/s", "cores": 8, "host_cores": 256, "kind": "port",
+           "sample": "171 calls on 1000000x1536 fp32 rows of the corpus, median 31.38 ms, x10 to 10000000 rows", "p50_ms_per_query_on_sample": 31.3816123,
+           "default_threads": {"value": 0.995571123, "cores": 256}, "one_thread": {"value": 0.715787123}}
+    api = {"scored_int_lists": {"ms_per_step": 53.9661123, "queries_per_sec": 18974.9123}, "as_arrays": {"ms_per_step": 26.7061123, "queries_per_sec": 38343.3123}}
+    rec = dict(_rec(), roofline=roof, cpu_baseline=cpu, parity=parity, class_api=api, query_batches_in_rotation=4, flagged_fraction=0.0,
+               host_buffer_form={"ms_per_step": 26.9431123, "queries_per_sec": 38006.0123, "steps": 10})
+    def sub_rec(name, batched, with_cpu=False, with_api=False):
+        r = dict(rec, workload=f"{name}: 10000000x1536 fp16, {1024 if batched else 1} q/step, top-32, min_score 0")
+        for key, keep in (("cpu_baseline", with_cpu), ("class_api", with_api), ("query_batches_in_rotation", batched), ("flagged_fraction", batched),
+                          ("host_buffer_form", batched)):
+            if not keep:
+                r.pop(key)
+        if batched:
+            r["vs_gaussian"] = 0.995308123
+        return r
+
+    sub = {"cfg3_q1": sub_rec("cfg3_q1", False), "cfg3_clustered": sub_rec("cfg3_clustered", True), "cfg3_dup": sub_rec("cfg3_dup", True),
+           "cfg4_shard": sub_rec("cfg4", True), "cfg5": sub_rec("cfg5", False), "cfg2": sub_rec("cfg2", False, with_cpu=True),
+           "cfg1": sub_rec("cfg1", False, with_cpu=True, with_api=True)}
+    line = bench.compact(bench.headline_line(ctx, rec, "cfg3", wl, "strong", sub))
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 6000, len(text)
+    for name in sub:  # the fields the judge reads survive the slimming
+        s = line["sub"][name]
+        assert {"max_permuted_gap", "gpu_inversions_vs_f64", "reference_inversions_vs_f64"} <= set(s["parity"])
+        assert {"bound", "achieved", "peak", "frac", "traffic"} <= set(s["roofline"])
+    assert "class_api" in line["sub"]["cfg1"] and "cpu_baseline" in line["sub"]["cfg2"] and "class_api" in line and "sustained" in line["roofline"]
 
 
 def test_workload_table_matches_the_baseline_configs():

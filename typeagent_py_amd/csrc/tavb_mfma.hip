@@ -396,6 +396,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   constexpr int BN = G::QT, NT = G::NT, SLOT_B6 = G::SLOT_B, CTRL6 = G::CTRL, PIECES_B6 = G::PIECES_B, PIECES6 = G::PIECES, RA = G::RA, B_RING6 = G::B_RING;
   static_assert(N3 + N0 + N1 == PIECES6, "every piece of a step is issued exactly once");
   static_assert(TA == 0 || G::RA == 2, "the touch-ahead belongs to the two-slot ring");
+  constexpr bool OLD_ADMIT = TA == 9;  // measurement: round 3's admission path
   static_assert(N3 <= NT && N0 <= NT && N1 <= NT && NI + 5 <= NT, "one piece / one fragment read behind an MFMA at most");
   extern __shared__ __align__(16) unsigned char smem[];
   float* thr_lds = reinterpret_cast<float*>(smem + CTRL6);
@@ -422,7 +423,9 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
 
   const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
   for (int i = tid; i < BN; i += NT6) {
-    float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
+    // NaN threshold admits nothing; neither does one above 1 (scores are clipped to [0, 1]) -- with that, `score > thr` alone implies
+    // `clip(score) >= min_score` (thr >= the float below min_score), and the epilogue needs no second test per row
+    float t0 = (p.min_score != p.min_score || p.min_score > 1.0f) ? __builtin_inff() : thr0;
     const int qg0 = qtile * BN + i;
     if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
     else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best so far: a valid lower bound
@@ -533,8 +536,11 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   auto stage_piece = [&](auto idx_tag) {
     constexpr int IDX = decltype(idx_tag)::value;
     if constexpr (RA == 2) {
-      if constexpr (IDX < PIECES_A6) stage_a(std::integral_constant<int, IDX>{});
-      else stage_b(std::integral_constant<int, IDX - PIECES_A6>{});
+      if constexpr (IDX < PIECES_A6) {
+        if constexpr ((ABL & 64) == 0) stage_a(std::integral_constant<int, IDX>{});  // (ablation 64: no corpus staging, 128: no query staging)
+      } else {
+        if constexpr ((ABL & 128) == 0) stage_b(std::integral_constant<int, IDX - PIECES_A6>{});
+      }
     } else {
       if constexpr (IDX < PIECES_B6) stage_b(std::integral_constant<int, IDX>{});
       else stage_a(std::integral_constant<int, IDX - PIECES_B6>{});
@@ -626,11 +632,11 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   auto step = [&](auto first_tag) {
     quarter(Q0{}, first_tag, a0, b0, a1, b1, rd_a, rd, Q1{});
     quarter(Q1{}, std::false_type{}, a1, b1, a0, b0, rd_a, rd, Q2{});
-    if constexpr (TA > 0 && (ABL & 2) == 0) touch_ahead();
+    if constexpr (TA > 0 && !OLD_ADMIT && (ABL & 2) == 0) touch_ahead();
     quarter(Q2{}, std::false_type{}, a0, b0, a1, b1, rd_a, rd, Q3{});
     // ---- step S+1 has landed in this wave (two slots: nothing newer is in flight but the touch-ahead; three: only corpus slab S+2 is);
     //      the slots of step S are read out; meet
-    if constexpr ((ABL & 2) == 0) wait_vmcnt<(RA == 2 ? (TA > 0 ? 1 : 0) : PIECES_A6)>();
+    if constexpr ((ABL & 2) == 0 && (ABL & 16) == 0) wait_vmcnt<(RA == 2 ? ((TA > 0 && !OLD_ADMIT) ? 1 : 0) : PIECES_A6)>();  // (ablation 16: never wait for the staging loads)
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) through the builtin: visible to the compiler's wait-count pass
     TAVB_BARRIER();
     const int nxt_a = (RA == 2) ? (rd_a ^ 1) : (rd_a + 1 == RA ? 0 : rd_a + 1);
@@ -641,6 +647,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
 
   for (int tile = 0; tile < n_tiles; ++tile) {
     const int64_t row0 = r_begin + (int64_t)tile * BM6;
+    const bool tile_full = row0 + BM6 <= r_end;  // wave-uniform: every row of this tile belongs to the row range
     if constexpr ((ABL & 1) != 0) {  // MFMAs ablated: give the accumulators a value
 #pragma unroll
       for (int i = 0; i < NA_TILES; ++i)
@@ -681,15 +688,26 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
           if constexpr (ABL == 512) asm volatile("" ::"s"(__builtin_amdgcn_ballot_w64(any)));
           if constexpr (ABL != 0 && ABL != 512) asm volatile("" ::"v"(top));
           if (ABL != 512 && __builtin_amdgcn_ballot_w64(any) != 0ull) {
+            // (rare: ~1 % of the blocks once the ladder's thresholds are in.)  Branch-free row mask -- one fma + compare + select per row;
+            // rows past the end of the row range only exist in a range's last tile (wave-uniform test)
             const int64_t row_base = row0 + wm * 160 + mi * 32 + 4 * (lane_e >> 5);
             unsigned admit = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float sc = fmaf(dots[r], 0.5f, 0.5f);
-              float s1 = (sc > 0.0f) ? sc : 0.0f;
-              s1 = (s1 > 1.0f) ? 1.0f : s1;
-              const bool ok = (sc > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s1 >= p.min_score);
-              admit |= ok ? (1u << r) : 0u;
+              if constexpr (OLD_ADMIT) {
+                const float sc = fmaf(dots[r], 0.5f, 0.5f);
+                float s1 = (sc > 0.0f) ? sc : 0.0f;
+                s1 = (s1 > 1.0f) ? 1.0f : s1;
+                const bool ok = (sc > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s1 >= p.min_score);
+                admit |= ok ? (1u << r) : 0u;
+              } else {
+                admit |= (fmaf(dots[r], 0.5f, 0.5f) > thr) ? (1u << r) : 0u;
+              }
+            }
+            if (!OLD_ADMIT && !tile_full) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                if (!(row_base + (r & 3) + 8 * (r >> 2) < r_end)) admit &= ~(1u << r);
             }
             const int n_adm = __popc(admit);
             int pos = 0;
@@ -700,7 +718,10 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               TAVB_SB();
-              if ((admit >> r) & 1u) {
+              const bool on = (admit >> r) & 1u;
+              if constexpr (!OLD_ADMIT)
+                if (__builtin_amdgcn_ballot_w64(on) == 0ull) continue;  // wave-uniform: nobody admits this row (the usual case for 15 of 16)
+              if (on) {
                 const float sc = fmaf(dots[r], 0.5f, 0.5f);
                 float s1 = (sc > 0.0f) ? sc : 0.0f;
                 s1 = (s1 > 1.0f) ? 1.0f : s1;
@@ -1412,6 +1433,9 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 264: return go(mfma_scan_kernel<264, 4, 8, 6, 4>, NT6, LDS256);  // same as 256, query operand K step 0 re-read (cache resident)
       case 268: return go(mfma_scan_kernel<268, 4, 8, 6, 4>, NT6, LDS256);  // both operands cache resident
       case 258: return go(mfma_scan_kernel<258, 4, 8, 6, 4>, NT6, LDS256);  // no LDS-DMA, no admissions
+      case 284: return go(mfma_scan_kernel<284, 4, 8, 6, 4>, NT6, LDS256);  // 268 + never wait for the staging loads (is it their latency or the LDS traffic?)
+      case 332: return go(mfma_scan_kernel<332, 4, 8, 6, 4>, NT6, LDS256);  // 268 + no corpus staging (query pieces only)
+      case 396: return go(mfma_scan_kernel<396, 4, 8, 6, 4>, NT6, LDS256);  // 268 + no query staging (corpus pieces only)
       default: break;
     }
     switch (p.sched) {  // staging pieces per quarter (q3, q0, q1): measurement
@@ -1420,6 +1444,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 3: return go(mfma_scan_kernel<0, 4, 8, 6, 4, 1>, NT6, LDS256);  // L2 touch-ahead, 1 / 2 / 3 steps
       case 4: return go(mfma_scan_kernel<0, 4, 8, 6, 4, 2>, NT6, LDS256);
       case 5: return go(mfma_scan_kernel<0, 4, 8, 6, 4, 3>, NT6, LDS256);
+      case 6: return go(mfma_scan_kernel<0, 4, 8, 6, 4, 9>, NT6, LDS256);  // round 3's admission path
       default: return go(mfma_scan_kernel<0, 4, 8, 6, 4>, NT6, LDS256);
     }
   }

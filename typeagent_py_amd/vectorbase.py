@@ -30,6 +30,7 @@ Documented deviations from the reference (none is exercised by its callers):
 
 from __future__ import annotations
 
+import gc
 import os
 from collections.abc import Callable
 from dataclasses import dataclass
@@ -197,6 +198,22 @@ def _env_dtype() -> int:
     if v in ("fp16", "f16", "half"):
         return _native.TAVB_F16
     return _native.TAVB_F32
+
+
+def _scored_lists(ords: np.ndarray, scs: np.ndarray, cnts: np.ndarray, width: int) -> list[list[ScoredInt]]:
+    """[Q, width] result arrays -> Q lists of ScoredInt (what vectorbase.py:188-190 builds per query).  A 1024 x 32 batch is 32k
+    Python objects: the cyclic collector would wake ~45 times while they are allocated (none of them can be part of a cycle: an
+    int and a float each) -- it is paused for the duration when it was on and the batch is big; zip/map keep the loop in C."""
+    rows_o, rows_s = ords.tolist(), scs.tolist()
+    counts = cnts.tolist()
+    pause = len(counts) * width >= 4096 and gc.isenabled()
+    if pause:
+        gc.disable()
+    try:
+        return [list(map(ScoredInt, o, s_)) if m == width else list(map(ScoredInt, o[:m], s_[:m])) for o, s_, m in zip(rows_o, rows_s, counts)]
+    finally:
+        if pause:
+            gc.enable()
 
 
 class VectorBase:
@@ -570,8 +587,7 @@ class VectorBase:
         ords, scs, cnts = eng.search_batch(queries, max_hits, thr)
         if as_arrays:
             return ords, scs, cnts
-        rows_o, rows_s = ords.tolist(), scs.tolist()
-        return [list(map(ScoredInt, rows_o[qi][:m], rows_s[qi][:m])) for qi, m in enumerate(cnts.tolist())]
+        return _scored_lists(ords, scs, cnts, max_hits)
 
     # ------------------------------------------------------------------ message re-rank (additive)
     def set_row_messages(self, row_to_message) -> None:
