@@ -688,46 +688,65 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
           if constexpr (ABL == 512) asm volatile("" ::"s"(__builtin_amdgcn_ballot_w64(any)));
           if constexpr (ABL != 0 && ABL != 512) asm volatile("" ::"v"(top));
           if (ABL != 512 && __builtin_amdgcn_ballot_w64(any) != 0ull) {
-            // (rare: ~1 % of the blocks once the ladder's thresholds are in.)  Branch-free row mask -- one fma + compare + select per row;
-            // rows past the end of the row range only exist in a range's last tile (wave-uniform test)
+            // (rare: ~1 % of the blocks once the ladder's thresholds are in -- but each costs the workgroup ~0.3 us, and a batch has a few hundred
+            //  thousand of them.)  One compare per row whose result is a WAVE mask in scalar registers (v_cmp into an SGPR pair: no per-lane
+            //  bit twiddling); a row nobody admits -- 15 of 16 in the usual case -- costs one scalar test.  An admitted row takes its slot
+            //  with one LDS atomic per admitting lane.  Rows past the end of the row range exist only in a range's last tile (wave-uniform).
             const int64_t row_base = row0 + wm * 160 + mi * 32 + 4 * (lane_e >> 5);
-            unsigned admit = 0;
+            if constexpr (OLD_ADMIT) {
+              unsigned admit = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              if constexpr (OLD_ADMIT) {
+              for (int r = 0; r < 16; ++r) {
                 const float sc = fmaf(dots[r], 0.5f, 0.5f);
                 float s1 = (sc > 0.0f) ? sc : 0.0f;
                 s1 = (s1 > 1.0f) ? 1.0f : s1;
                 const bool ok = (sc > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s1 >= p.min_score);
                 admit |= ok ? (1u << r) : 0u;
-              } else {
-                admit |= (fmaf(dots[r], 0.5f, 0.5f) > thr) ? (1u << r) : 0u;
               }
-            }
-            if (!OLD_ADMIT && !tile_full) {
+              const int n_adm = __popc(admit);
+              int pos = 0;
+              if (n_adm > 0) {
+                pos = lds_add_rtn(&cnt_lds[ql], n_adm);
+                if (pos + n_adm > CAPW - BM6) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
+              }
 #pragma unroll
-              for (int r = 0; r < 16; ++r)
-                if (!(row_base + (r & 3) + 8 * (r >> 2) < r_end)) admit &= ~(1u << r);
-            }
-            const int n_adm = __popc(admit);
-            int pos = 0;
-            if (n_adm > 0) {
-              pos = lds_add_rtn(&cnt_lds[ql], n_adm);
-              if (pos + n_adm > CAPW - BM6) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
-            }
+              for (int r = 0; r < 16; ++r) {
+                TAVB_SB();
+                if ((admit >> r) & 1u) {
+                  const float sc = fmaf(dots[r], 0.5f, 0.5f);
+                  float s1 = (sc > 0.0f) ? sc : 0.0f;
+                  s1 = (s1 > 1.0f) ? 1.0f : s1;
+                  if (pos < CAPW)
+                    my_cand[(size_t)ql * CAPW + pos] = make_key(s1, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
+                  ++pos;
+                }
+              }
+            } else {
+              // rows of this block that belong to the row range, seen from this lane's first row (>= 32: all of them)
+              const int64_t left64 = r_end - row_base;
+              const int rows_left = tile_full ? 64 : (int)(left64 < 64 ? left64 : 64);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              TAVB_SB();
-              const bool on = (admit >> r) & 1u;
-              if constexpr (!OLD_ADMIT)
-                if (__builtin_amdgcn_ballot_w64(on) == 0ull) continue;  // wave-uniform: nobody admits this row (the usual case for 15 of 16)
-              if (on) {
-                const float sc = fmaf(dots[r], 0.5f, 0.5f);
-                float s1 = (sc > 0.0f) ? sc : 0.0f;
-                s1 = (s1 > 1.0f) ? 1.0f : s1;
-                if (pos < CAPW)
-                  my_cand[(size_t)ql * CAPW + pos] = make_key(s1, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
-                ++pos;
+              for (int g = 0; g < 4; ++g) {  // four rows at a time: their masks stay in scalar registers
+                float sc[4];
+                u64 m[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  sc[j] = fmaf(dots[4 * g + j], 0.5f, 0.5f);
+                  asm volatile("v_cmp_gt_f32 %0, %1, %2" : "=s"(m[j]) : "v"(sc[j]), "v"(thr));  // (the builtin ballot goes through a 0/1 VGPR and back)
+                }
+                if ((m[0] | m[1] | m[2] | m[3]) == 0ull) continue;  // wave-uniform: nobody admits any of the four
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const int r_off = j + 8 * g;  // row 4 g + j of the accumulator = tile row (r & 3) + 8 (r >> 2) from row_base
+                  if (m[j] == 0ull) continue;
+                  if (((m[j] >> lane_e) & 1ull) != 0ull && r_off < rows_left) {
+                    const int pos = lds_add_rtn(&cnt_lds[ql], 1);
+                    if (pos + 1 > CAPW - BM6) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
+                    float s1 = (sc[j] > 0.0f) ? sc[j] : 0.0f;
+                    s1 = (s1 > 1.0f) ? 1.0f : s1;
+                    if (pos < CAPW) my_cand[(size_t)ql * CAPW + pos] = make_key(s1, (uint32_t)(row_base + r_off) + p.index_base);
+                  }
+                }
               }
             }
           }
@@ -1124,7 +1143,7 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
                                                           int kc_max, const u64* __restrict__ carried, const int* __restrict__ carried_cnt,
                                                           const float* __restrict__ floor, const float* __restrict__ band, u64* __restrict__ out,
                                                           int* __restrict__ out_cnt, float* __restrict__ thr_out, unsigned* __restrict__ lost,
-                                                          int* __restrict__ verdict) {
+                                                          int* __restrict__ verdict, float* __restrict__ level_out) {
   extern __shared__ __align__(16) unsigned char sel_smem[];
   u64* cache = reinterpret_cast<u64*>(sel_smem);  // [SEL_CACHE]
   __shared__ int off[260];  // exclusive prefix of the per-split counts (+ the carried band as one more "split")
@@ -1324,6 +1343,17 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
       if (floor != nullptr && floor[q] > t) t = floor[q];
       thr_out[q] = t;
     }
+    if (level_out != nullptr) {
+      // k keys seen with an approximate score >= a_k (strict: t_hi is a_k itself; band: t_hi is the cut, a_k - 2 delta less an ulp), so with an
+      // EXACT score >= a_k - delta: the level this shard has proven for the whole corpus.  band_q = 2 delta.  Rounded down twice.
+      float lv = -__builtin_inff();
+      if (enough && t_hi > 0u && band_q < __builtin_inff()) {
+        const float a = __uint_as_float(t_hi);
+        lv = strict ? a - 0.5f * band_q : a + 0.5f * band_q;
+        lv = lv > 0.0f ? __uint_as_float(__float_as_uint(lv) - 2u) : -__builtin_inff();
+      }
+      level_out[q] = lv;
+    }
   }
 }
 
@@ -1378,13 +1408,13 @@ size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide) {
 
 hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
-                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream) {
+                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream, float* level_out) {
   if (nq < 1 || k < 1 || k > 64 || n_splits < 1 || n_splits > 256 || nq_padded < nq || kc_max < k || kc_max > SEL_CACHE / 4) return hipErrorInvalidValue;
   constexpr int lds = SEL_CACHE * (int)sizeof(u64);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(select_band_kernel, dim3(nq), dim3(256), lds, stream, cand, counts, n_splits, nq_padded, k, kc_max, carried, carried_cnt, floor, band,
-                     out, out_cnt, thr_out, lost, verdict);
+                     out, out_cnt, thr_out, lost, verdict, level_out);
   return hipGetLastError();
 }
 
