@@ -1374,74 +1374,6 @@ def test_sharded_searcher_on_one_rank_rccl():
         dist.destroy_process_group()
 
 
-def test_thresholds_shared_between_shards_change_no_answer():
-    """tavb_search_allgather on the wide tile: after the first ladder phase the shards all-reduce (max) the score level every query has
-    proven and continue with the k-th best of world x sample rows; the ladder then needs fewer phases.  (a) One GPU standing in for eight
-    shards (`share_emulate_world`: the first phase also runs on seven further row blocks, as the peers would): same keys as the plain
-    lookup, fewer tile launches.  (b) The real exchange on a one-rank communicator (`comm_force`): ncclAllReduce + the level -> threshold
-    kernel run, same keys; a small batch does not exchange."""
-    import torch
-
-    from typeagent_py_amd.sharded import DeviceShardBackend
-
-    n, nq, k = 400_000, 200, 32
-    v, _ = make_corpus(n, 1536, 8200)
-    qs = make_queries(nq, 1536, 8201)
-    rng = np.random.default_rng(8202)
-    _plant_near_duplicates(v, qs, 11, rng.choice(n, size=300, replace=False), rng)  # one query with a band of near-duplicates
-    backend = DeviceShardBackend(0)
-    with torch.cuda.stream(backend.stream):
-        shard = torch.from_numpy(v).cuda().half()
-        dq = torch.from_numpy(qs).cuda()
-    backend.stream.synchronize()
-    backend.set_shard(shard, row_offset=1_000_000)
-    eng = backend.engine
-    eng.profile_enable(True)
-
-    def run(fn):
-        eng.profile_reset()
-        keys = fn()
-        eng.synchronize()
-        out = keys.cpu().numpy().copy() if hasattr(keys, "cpu") else np.array(keys, copy=True)
-        launches = eng.profile_read(_native.KERNEL_MFMA)[1] + eng.profile_read(_native.KERNEL_MFMA_SAMPLE)[1]
-        return out, launches
-
-    plain, n_plain = run(lambda: eng.search_device(dq, k, 0.0))
-    assert eng.get_option("last_tier") == 4 and eng.get_option("last_shared") == 0 and n_plain >= 3
-    v16 = _f16(v)
-    o, s_, c_ = _native.decode_keys(plain)
-    for qi in (0, 11, 199):
-        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), (o[qi, : c_[qi]] - 1_000_000).tolist(), s_[qi, : c_[qi]].tolist(), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
-    # (a) eight emulated shards
-    eng.set_option("share_emulate_world", 8)
-    emu, n_emu = run(lambda: eng.search_device(dq, k, 0.0))
-    eng.set_option("share_emulate_world", 0)
-    assert eng.get_option("last_shared") == 1
-    np.testing.assert_array_equal(emu, plain)
-    assert n_emu - 7 < n_plain  # (seven of the launches were the stand-ins for the peers' first phase)
-    # (b) the real collective, world of one
-    backend.init_comm(0, 1)
-    eng.set_option("comm_force", 1)
-    pinned = torch.empty((nq, k), dtype=torch.int64).pin_memory()
-    real, _ = run(lambda: (eng.search_allgather(dq, k, 0.0, out_keys=pinned), pinned.numpy())[1])
-    assert eng.get_option("last_shared") == 1
-    np.testing.assert_array_equal(real, plain)
-    assert eng.profile_read(_native.KERNEL_EXCHANGE)[1] >= 3  # all-reduce, level -> threshold, all-gather
-    eng.set_option("share_thresholds", 0)
-    off, _ = run(lambda: (eng.search_allgather(dq, k, 0.0, out_keys=pinned), pinned.numpy())[1])
-    assert eng.get_option("last_shared") == 0
-    np.testing.assert_array_equal(off, plain)
-    eng.set_option("share_thresholds", 1)
-    small = torch.empty((6, k), dtype=torch.int64).pin_memory()
-    eng.search_allgather(dq[:6].contiguous(), k, 0.0, out_keys=small)
-    eng.synchronize()
-    assert eng.get_option("last_shared") == 0
-    few = eng.search_device(dq[:6].contiguous(), k, 0.0)  # (a small batch takes other kernels than the wide tile: compare like with like)
-    eng.synchronize()
-    np.testing.assert_array_equal(small.numpy(), few.cpu().numpy())
-    eng.comm_destroy()
-
-
 def test_fused_multi_index_query_equals_separate_calls():
     """cfg5: T term lookups (k=50 @0.85) + message re-rank (k=25 @0.7, full scan and subset) + thread lookup
     (k=10 @0.7) in one submission == the same lookups issued one by one == the oracle."""

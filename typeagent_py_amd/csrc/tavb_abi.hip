@@ -173,16 +173,6 @@ struct tavb_ctx {
   int comm_rank = 0, comm_world = 1;
   int64_t comm_force = 0;  // option: run the all-gather + merge even in a world of one (tests, dry runs of the N > 1 path)
   Buffer d_local, d_gather;  // this shard's [nq, k] lists; the all-gathered [world, nq, k]
-  // Admission thresholds shared between the shards (tavb_search_allgather on the 128/256-query tile): after the first ladder phase every
-  // rank all-reduces (max) the score LEVEL each query has proven on its rows; a rank then starts its next phase with the k-th best of
-  // world x sample rows instead of its own sample, and the ladder needs fewer phases.  Exactly ONE all-reduce per call on every rank
-  // (a rank that runs no ladder contributes -inf), so the collective sequence is the same everywhere whatever the shards hold.
-  int64_t share_thresholds = 1;     // option (must be the same on every rank)
-  int64_t share_emulate_world = 0;  // option, measurement on ONE GPU: stand in for W - 1 peers by running the first phase on W - 1 further
-                                    // row blocks of the local corpus (timed as "exchange"), then ladder as a rank of a world of W would
-  bool share_pending = false;       // this call still owes the communicator its all-reduce
-  int64_t last_shared = 0;          // option "last_shared" (get): queries whose threshold the last exchange raised... (1 = an exchange ran)
-  Buffer d_level, d_floor_shared;   // [nq] levels (in place all-reduce); [nq_pad] per-query floors incl. what the peers proved
 };
 
 namespace {
@@ -493,11 +483,7 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     c->mfma_splits = v;
   } else if (n == "comm_force") {
     c->comm_force = v ? 1 : 0;
-  } else if (n == "share_thresholds") {
-    c->share_thresholds = v ? 1 : 0;
-  } else if (n == "share_emulate_world") {
-    if (v < 0 || v > 64) return fail(TAVB_E_INVALID, "share_emulate_world must be 0..64");
-    c->share_emulate_world = v;
+
   } else if (n == "graph_max_bytes") {
     if (v < 0) return fail(TAVB_E_INVALID, "graph_max_bytes must be >= 0");
     c->graph_max_bytes = v;
@@ -529,9 +515,6 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "mfma_sample_rows") *out = c->mfma_sample_rows;
   else if (n == "compute_units") *out = c->n_cu;
   else if (n == "comm_force") *out = c->comm_force;
-  else if (n == "share_thresholds") *out = c->share_thresholds;
-  else if (n == "share_emulate_world") *out = c->share_emulate_world;
-  else if (n == "last_shared") *out = c->last_shared;
   else if (n == "graph_max_bytes") *out = c->graph_max_bytes;
   else if (n == "last_graph") *out = c->last_graph;
   else if (n == "comm_world") *out = c->comm ? c->comm_world : 0;
@@ -1085,7 +1068,6 @@ int tavb_search_subset_after(tavb_ctx* c, const float* query_host, const int64_t
 
 int tavb_search_device(tavb_ctx* c, const float* dev_queries, int32_t nq, int32_t k, float min_score,
                        tavb_key* dev_out_keys) {
-  if (c) c->share_pending = false;  // (only tavb_search_allgather owes the communicator an exchange)
   if (int rc = check_search_args(c, k)) return rc;
   if (nq < 1) return fail(TAVB_E_INVALID, "nq must be >= 1");
   if (!dev_queries || !dev_out_keys) return fail(TAVB_E_INVALID, "null argument");
@@ -1164,7 +1146,6 @@ struct Rccl {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
-  decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 Rccl g_rccl;
@@ -1188,10 +1169,9 @@ int load_rccl() {
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(g_rccl.handle, "ncclCommInitRank"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.handle, "ncclCommDestroy"));
     g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.handle, "ncclAllGather"));
-    g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(g_rccl.handle, "ncclAllReduce"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.handle, "ncclGetErrorString"));
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.AllReduce || !g_rccl.GetErrorString)
-      g_rccl_error = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclAllReduce / ncclGetErrorString";
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
+      g_rccl_error = "librccl.so.1 lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
   });
   if (!g_rccl_error.empty()) return fail(TAVB_E_UNSUPPORTED, "%s", g_rccl_error.c_str());
   return TAVB_OK;
@@ -1258,24 +1238,6 @@ static int exchange_and_merge(tavb_ctx* c, const u64_t* local, int32_t nq, int32
   return TAVB_OK;
 }
 
-}  // extern "C"
-// The one all-reduce (max) of proven score levels a sharing call owes the communicator.  `level` = device [nq] (in place); nullptr = this rank
-// has nothing to say (no ladder ran: -inf everywhere) and does not use the result.
-static int share_levels(tavb_ctx* c, float* level, int nq) {
-  c->share_pending = false;
-  if (!level) {
-    if (int rc = c->d_level.reserve((size_t)nq * sizeof(float))) return rc;
-    level = reinterpret_cast<float*>(c->d_level.ptr);
-    hipError_t e = tavb::launch_fill_f32(level, -__builtin_inff(), nq, c->stream);
-    if (e != hipSuccess) return fail(TAVB_E_HIP, "fill launch failed: %s", hipGetErrorString(e));
-  }
-  Timed t(c, TAVB_KERNEL_EXCHANGE);
-  TAVB_RCCL(g_rccl.AllReduce(level, level, (size_t)nq, ncclFloat32, ncclMax, c->comm, c->stream));
-  c->last_shared = 1;
-  return TAVB_OK;
-}
-extern "C" {
-
 int tavb_search_allgather(tavb_ctx* c, const float* dev_queries, int32_t nq, int32_t k, float min_score, tavb_key* out_keys) {
   if (int rc = check_search_args(c, k)) return rc;
   if (nq < 1) return fail(TAVB_E_INVALID, "nq must be >= 1");
@@ -1285,16 +1247,12 @@ int tavb_search_allgather(tavb_ctx* c, const float* dev_queries, int32_t nq, int
     return fail(TAVB_E_UNSUPPORTED, "device-resident keys hold 32-bit ordinals: ordinal_base + rows must be < 2^32 - 1");
   DeviceGuard guard(c->device);
   // everything that can fail locally comes BEFORE the collectives, and a local failure still joins them (with an empty list), so that the
-  // peers are never left waiting in ncclAllReduce / ncclAllGather for a rank that has returned an error to its caller
+  // peers are never left waiting in ncclAllGather for a rank that has returned an error to its caller
   const size_t list_keys = (size_t)nq * k;
   if (int rc = c->d_local.reserve(list_keys * sizeof(u64_t))) return rc;
   if (int rc = c->d_gather.reserve(list_keys * sizeof(u64_t) * c->comm_world)) return rc;
-  if (int rc = c->d_level.reserve((size_t)nq * sizeof(float))) return rc;
   u64_t* local = reinterpret_cast<u64_t*>(c->d_local.ptr);
   std::vector<float> ms((size_t)nq, min_score);
-  // one all-reduce of proven score levels per call, decided from the ARGUMENTS only (the same on every rank): batches the wide tile serves
-  c->last_shared = 0;
-  c->share_pending = c->share_thresholds && nq >= c->mfma_min_batch && k <= 64;
   int rc_local = TAVB_OK;
   std::string local_error;
   if (c->rows == 0) {  // an empty shard still takes part in the collectives
@@ -1302,9 +1260,6 @@ int tavb_search_allgather(tavb_ctx* c, const float* dev_queries, int32_t nq, int
   } else if ((rc_local = tavb_search_device_dispatch(c, dev_queries, nq, k, ms.data(), (uint32_t)c->ordinal_base, local)) != TAVB_OK) {
     local_error = g_last_error;
     (void)hipMemsetAsync(local, 0, list_keys * sizeof(u64_t), c->stream);  // this shard contributes nothing; the caller gets the error below
-  }
-  if (c->share_pending) {  // no ladder ran here (streaming / 32-64-query tile / one phase / empty shard / error): a neutral contribution
-    if (int rc = share_levels(c, nullptr, nq)) return rc;
   }
   const int rc_x = exchange_and_merge(c, local, nq, k, out_keys);
   if (rc_local != TAVB_OK) {
@@ -1393,7 +1348,6 @@ struct TileRun {
   int* band_cnt;          // device [nq]: out, keys per query in d_out
   unsigned* lost;         // device [nq_pad]: scratch (zeroed by the caller), score level below which a query lost band rows
   int* verdict;           // device [nq]: out, 1 where the band handed over is not provably complete
-  const float* delta;     // device [nq_pad]: the filter's error bound per query (what turns a peer's proven level into a threshold here)
 };
 
 // Threshold ladder.  The corpus is scanned in phases of growing size -- the first `mfma_sample_rows` rows, then
@@ -1437,11 +1391,6 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.skinny_tile = r.skinny ? r.qt : 0;
   p.wide_tile = r.skinny ? 0 : r.qt;
   p.active = r.active;
-  // thresholds shared between row shards (wide tile inside tavb_search_allgather), or its one-GPU stand-in (option share_emulate_world)
-  const bool can_share = wide && r.ladder && r.band && r.delta && !r.active;
-  const bool share_real = can_share && c->share_pending;
-  const int share_emulated = (can_share && !share_real && c->share_emulate_world > 1) ? (int)c->share_emulate_world : 0;
-  const int64_t share_world = share_real ? c->comm_world : (share_emulated ? share_emulated : 1);
   std::vector<int64_t> bounds;  // phase i scans rows [bounds[i], bounds[i+1])
   bounds.push_back(0);
   // first phase: `mfma_sample_rows`, or (0 = auto) ONE tile per workgroup of the 128/256-query kernel -- nothing compacts while everything is
@@ -1449,7 +1398,9 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   // query tile there are 256 row ranges, hence the cap at 64 ranges' worth).  Round 2 used two tiles; one measured the same on the 10M-row
   // corpus and 4 % faster on a 1.25M-row shard, where the fixed cost of the early phases is what limits strong scaling
   // (profiles/r03_shard_ladder.md).
-  const int64_t auto_sample = (int64_t)std::min(splits, 64) * 320 * (r.skinny ? 2 : 1);  // (the 32/64-query tile keeps round 2's 40960 rows)
+  // Round 4: with one LDS atomic per admitted row (tavb_mfma.hip) the all-admitted first phase is best kept to 32 ranges' worth: 10240 rows --
+  // 1 % faster on a 1.25M-row shard, the same on 10M rows, and half the keys for the select kernel (profiles/r04_cfg3_kernel.md).
+  const int64_t auto_sample = r.skinny ? (int64_t)std::min(splits, 64) * 320 * 2 : (int64_t)std::min(splits, 32) * 320;  // (the 32/64-query tile keeps round 2's 40960 rows)
   const int64_t sample = c->mfma_sample_rows > 0 ? (c->mfma_sample_rows + 255) / 256 * 256 : (c->mfma_sample_rows == 0 ? auto_sample : 0);
   // 32/64-query tile on corpora of a few hundred thousand to ~2M rows: the default ladder's first phases are smaller than one tile per
   // workgroup (40960 rows = 160 tiles for 512 resident workgroups) and each costs a launch + ~one tile time whatever its size; ONE seeding
@@ -1459,14 +1410,11 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   if (r.ladder && r.skinny && c->mfma_sample_rows == 0 && c->rows >= 4 * one_tile_each && c->rows < 2048000) {
     bounds.push_back(one_tile_each);
   } else if (r.ladder && sample > 0 && c->rows >= 8 * sample) {
-    // `seen` = the rows the thresholds of the next phase stand for: everything scanned here so far -- and, when the shards share their
-    // thresholds after the first phase, the peers' samples too (world x sample), so a shard can grow its second phase by that factor
-    int64_t done = sample, seen = sample * share_world;
+    int64_t done = sample;
     bounds.push_back(done);
     const int64_t growth = c->mfma_ladder;
-    while (growth > 0 && (done + seen * growth) * 2 <= c->rows && bounds.size() < 8) {
-      done += seen * growth;
-      seen += seen * growth;
+    while (growth > 0 && done * (growth + 1) * 2 <= c->rows && bounds.size() < 8) {
+      done += done * growth;
       bounds.push_back(done);
     }
   }
@@ -1479,7 +1427,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   }
   p.band = r.band;
   p.lost = r.lost;
-  const float* floor = r.floor;  // per-query thresholds valid for every row; after an exchange: what the peers proved as well
+  const float* floor = r.floor;  // per-query thresholds valid for every row
   const size_t row_bytes = (size_t)c->dim * (r.q32 ? 4 : 2);  // of the corpus operand
   for (int ph = 0; ph < n_phases; ++ph) {
     const bool last = (ph == n_phases - 1);
@@ -1508,55 +1456,13 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
       if (e != hipSuccess) return fail(TAVB_E_HIP, "mfma scan launch failed (phase %d): %s", ph, hipGetErrorString(e));
     }
     if (wide) {
-      const bool exchange = ph == 0 && !last && (share_real || share_emulated);
+      Timed t(c, TAVB_KERNEL_MERGE);
       float* d_thr = reinterpret_cast<float*>(c->d_thr.ptr);
-      {
-        Timed t(c, TAVB_KERNEL_MERGE);
-        if (!last) TAVB_HIP(hipMemsetAsync(d_thr, 0xFF, (size_t)r.nq_pad * sizeof(float), c->stream));  // padding queries: NaN bits, ignored by `>`
-        hipError_t e = tavb::launch_select_band(pp.workspace, pp.counts, pp.n_splits, nq, r.nq_pad, k, kc, carried ? run_in : nullptr, carried ? cnt_in : nullptr,
-                                                floor, r.band, last ? d_out : run_out, last ? r.band_cnt : cnt_out, last ? nullptr : d_thr, r.lost,
-                                                last ? r.verdict : nullptr, c->stream, (exchange && share_real) ? reinterpret_cast<float*>(c->d_level.ptr) : nullptr);
-        if (e != hipSuccess) return fail(TAVB_E_HIP, "select launch failed: %s", hipGetErrorString(e));
-      }
-      if (exchange) {
-        if (int rc = c->d_floor_shared.reserve((size_t)2 * r.nq_pad * sizeof(float))) return rc;
-        float* shared = reinterpret_cast<float*>(c->d_floor_shared.ptr);
-        if (share_real) {
-          // every rank: max over the shards of the level each query has proven -> a threshold here (this shard's own delta)
-          float* level = reinterpret_cast<float*>(c->d_level.ptr);
-          if (int rc = share_levels(c, level, nq)) return rc;
-          Timed t(c, TAVB_KERNEL_EXCHANGE);
-          hipError_t e = tavb::launch_level_to_threshold(level, r.delta, nq, d_thr, c->stream);
-          if (e != hipSuccess) return fail(TAVB_E_HIP, "threshold launch failed: %s", hipGetErrorString(e));
-        } else {
-          // one GPU standing in for `share_emulated` shards: the first phase again on the next row blocks of the local corpus, as the peers
-          // would run it on theirs; their thresholds (same delta: same corpus) are max-ed into ours.  Timed as "exchange": the real thing is
-          // one 4 KiB all-reduce.
-          Timed t(c, TAVB_KERNEL_EXCHANGE);
-          float* peer_thr = shared + r.nq_pad;
-          for (int j = 1; j < share_emulated; ++j) {
-            const int64_t lo = std::min<int64_t>(bounds[1] * j, c->rows - bounds[1]);
-            tavb::MfmaParams pe = pp;
-            pe.lost = nullptr;
-            pe.corpus = reinterpret_cast<const char*>(p.corpus) + (size_t)lo * row_bytes;
-            pe.index_base = r.index_base + (uint32_t)lo;
-            hipError_t e = launch(pe);
-            if (e != hipSuccess) return fail(TAVB_E_HIP, "emulated peer launch failed: %s", hipGetErrorString(e));
-            TAVB_HIP(hipMemsetAsync(peer_thr, 0xFF, (size_t)r.nq_pad * sizeof(float), c->stream));
-            // (band and count outputs go to the buffers of the phase after next: scratch at this point)
-            e = tavb::launch_select_band(pe.workspace, pe.counts, pe.n_splits, nq, r.nq_pad, k, kc, nullptr, nullptr, floor, r.band,
-                                         running + (size_t)((ph + 1) & 1) * nq * kc, run_cnt + (size_t)((ph + 1) & 1) * nq, peer_thr, nullptr, nullptr, c->stream);
-            if (e != hipSuccess) return fail(TAVB_E_HIP, "emulated peer select failed: %s", hipGetErrorString(e));
-            e = tavb::launch_max_f32(d_thr, peer_thr, nq, c->stream);
-            if (e != hipSuccess) return fail(TAVB_E_HIP, "max launch failed: %s", hipGetErrorString(e));
-          }
-          c->last_shared = 1;
-        }
-        // the exchanged threshold holds for every later row: it becomes the floor of the phases to come (select_band_kernel rebuilds its
-        // threshold from the keys it sees; a shard left with fewer than k keys above the peers' level would otherwise fall back to its own floor)
-        TAVB_HIP(hipMemcpyAsync(shared, d_thr, (size_t)r.nq_pad * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-        floor = shared;
-      }
+      if (!last) TAVB_HIP(hipMemsetAsync(d_thr, 0xFF, (size_t)r.nq_pad * sizeof(float), c->stream));  // padding queries: NaN bits, ignored by `>`
+      hipError_t e = tavb::launch_select_band(pp.workspace, pp.counts, pp.n_splits, nq, r.nq_pad, k, kc, carried ? run_in : nullptr, carried ? cnt_in : nullptr,
+                                              floor, r.band, last ? d_out : run_out, last ? r.band_cnt : cnt_out, last ? nullptr : d_thr, r.lost,
+                                              last ? r.verdict : nullptr, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "select launch failed: %s", hipGetErrorString(e));
     } else if (last) {
       Timed t(c, r.active ? TAVB_KERNEL_RESCORE : TAVB_KERNEL_MERGE);
       hipError_t e = scatter ? tavb::launch_merge_scatter(pp.lists, pp.list_stride, nq, k, r.active, scatter, d_out, c->stream)
@@ -1639,7 +1545,6 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   filt.band_cnt = small ? nullptr : d_band_cnt;
   filt.lost = small ? nullptr : d_lost;
   filt.verdict = small ? nullptr : d_verdict;
-  filt.delta = small ? nullptr : d_delta;
   filt.index_base = index_base;
   filt.kernel_min_score = (min_score > 0.0f) ? 0.0f : min_score;  // the per-query relaxed thresholds (floor) do the filtering; NaN stays NaN
   filt.floor = d_floor;
@@ -1684,7 +1589,6 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
 // fp32 corpora), or the 256-query fp16 tile with exact rescoring (large batches on fp16 corpora).  Not part of the public ABI.
 int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores,
                                 uint32_t index_base, u64_t* d_out) {
-  c->last_shared = 0;
   bool uniform_thr = true;
   for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (min_scores[i] == min_scores[0]);
   const bool f16c = (c->dtype == TAVB_F16);

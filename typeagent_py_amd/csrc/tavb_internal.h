@@ -67,10 +67,6 @@ hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score
 hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
                           int stride, const int* cand_cnt, const int* incomplete, const float* delta, float min_score, int nq, int k,
                           unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream);
-// admission thresholds <-> proven score levels (what row shards exchange: tavb_rescore.hip), elementwise max, fill
-hipError_t launch_level_to_threshold(const float* level, const float* delta, int nq, float* thr, hipStream_t stream);
-hipError_t launch_max_f32(float* dst, const float* src, int n, hipStream_t stream);
-hipError_t launch_fill_f32(float* dst, float v, int n, hipStream_t stream);
 hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, float* stats /*[2]*/, hipStream_t stream);
 hipError_t launch_gather_flagged_f32(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, float* out,
                                      float* thr, hipStream_t stream);
@@ -120,9 +116,7 @@ size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide);
 constexpr int kBandMax = 1024;  // candidates per query the rescoring accepts (kc_max; also the most the select kernel's cache keeps when it cuts mid-stream)
 hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
-                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream, float* level_out = nullptr);
-// level_out (optional, [nq]): the score level the query has PROVEN so far -- k rows seen with an exact score >= it (a_k - delta, rounded down;
-// -inf with fewer than k keys) -- what row shards exchange (tavb_rescore.hip::level_to_threshold_kernel)
+                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream);
 // 32-query tiles at HBM speed, fp32 or fp16 corpora (same parameter block; `queries` in the corpus dtype)
 hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream);
 int skinny_query_tile(int nq);  // 32, or 64 for batches of 33 and more

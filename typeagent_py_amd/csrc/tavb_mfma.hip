@@ -374,8 +374,7 @@ struct WideGeom {
   static constexpr int RA = NI == 2 ? 3 : 2;
   static constexpr int B_RING = RA * SLOT_A6;  // the query ring (always two slots) sits behind the corpus ring
   static constexpr int CTRL = B_RING + 2 * SLOT_B;
-  static constexpr int TOUCH_SINK = CTRL + QT * 8 + 16;  // 4 x 256 B: where the L2 touch-ahead loads of the waves land (never read)
-  static constexpr int LDS = TOUCH_SINK + 1024;
+  static constexpr int LDS = CTRL + QT * 8 + 16;
   static constexpr int PIECES_B = QT / 8 / 4;  // per wave per step: 8 or 4
   static constexpr int PIECES = PIECES_A6 + PIECES_B;
 };
@@ -390,13 +389,11 @@ constexpr int staging_piece_at(int q, int i) {
   return -1;
 }
 
-template <int ABL, int NI, int N3, int N0, int N1, int TA = 0>
+template <int ABL, int NI, int N3, int N0, int N1>
 __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p) {
   using G = WideGeom<NI>;
   constexpr int BN = G::QT, NT = G::NT, SLOT_B6 = G::SLOT_B, CTRL6 = G::CTRL, PIECES_B6 = G::PIECES_B, PIECES6 = G::PIECES, RA = G::RA, B_RING6 = G::B_RING;
   static_assert(N3 + N0 + N1 == PIECES6, "every piece of a step is issued exactly once");
-  static_assert(TA == 0 || G::RA == 2, "the touch-ahead belongs to the two-slot ring");
-  constexpr bool OLD_ADMIT = TA == 9;  // measurement: round 3's admission path
   static_assert(N3 <= NT && N0 <= NT && N1 <= NT && NI + 5 <= NT, "one piece / one fragment read behind an MFMA at most");
   extern __shared__ __align__(16) unsigned char smem[];
   float* thr_lds = reinterpret_cast<float*>(smem + CTRL6);
@@ -500,47 +497,11 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
       sb_kt = (sb_kt + 1 == steps_per_tile) ? 0 : sb_kt + 1;
     }
   };
-  // ---- L2 touch-ahead (TA > 0).  The corpus lines of a K step are compulsory misses for whichever of the sibling workgroups asks first, and the
-  //      two-slot ring gives a staging load one step (~1.6 us) to land: an HBM round trip under load does not always fit.  So every step each
-  //      wave also reads ONE dword per line of its share of the slab TA steps further on (the workgroups that share a row range split its 320
-  //      rows between them) into a sink in LDS nobody reads: the line is in the XCD's L2 when the real piece asks for it.  VMEM loads return in
-  //      order, so the touch is issued at the START of quarter 2 -- behind every piece the wait in front of quarter 3 is for -- and that wait
-  //      is counted (vmcnt(1): everything but the touch just issued); the touch has until the NEXT step's wait to come back.
-  //      (Round 2 touched with vmcnt(0) waits and lost 3-6 %: every step then waited for an HBM round trip.)
-  uint32_t touch_off = 0;
-  if constexpr (TA > 0) {
-    const int per_wave = (BM6 + 4 * p.n_qtiles - 1) / (4 * p.n_qtiles);
-    const int mine = per_wave < 64 ? per_wave : 64;
-    int zero_t = 0;
-    asm volatile("" : "+v"(zero_t));
-    const int ln_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_t));
-    const int row_t = (qtile * 4 + wave) * per_wave + (ln_t < mine ? ln_t : mine - 1);
-    touch_off = (uint32_t)row_t * row_bytes;
-  }
-  auto touch_ahead = [&]() {
-    int kt2 = sa_kt + TA, tile2 = sa_tile;
-    if (kt2 >= steps_per_tile) {
-      kt2 -= steps_per_tile;
-      ++tile2;
-    }
-    if (kt2 >= steps_per_tile) kt2 = steps_per_tile - 1;
-    if (tile2 >= n_tiles) tile2 = n_tiles - 1;  // past the end: a harmless re-touch (the wait below counts on exactly one touch per step)
-    const int64_t row0 = r_begin + (int64_t)tile2 * BM6;
-    const int64_t left = p.rows - row0;
-    const int valid = (int)(left < BM6 ? left : BM6);
-    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(sgpr_ptr(corpus + (size_t)row0 * row_bytes)), 0, __builtin_amdgcn_readfirstlane(valid * (int)row_bytes), 0x00020000);
-    unsigned char* sink = smem + G::TOUCH_SINK + wave * 256;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lds_void*)sink, 4, (int)touch_off, __builtin_amdgcn_readfirstlane(kt2 * 128), 0, 0);
-  };
   auto stage_piece = [&](auto idx_tag) {
     constexpr int IDX = decltype(idx_tag)::value;
     if constexpr (RA == 2) {
-      if constexpr (IDX < PIECES_A6) {
-        if constexpr ((ABL & 64) == 0) stage_a(std::integral_constant<int, IDX>{});  // (ablation 64: no corpus staging, 128: no query staging)
-      } else {
-        if constexpr ((ABL & 128) == 0) stage_b(std::integral_constant<int, IDX - PIECES_A6>{});
-      }
+      if constexpr (IDX < PIECES_A6) stage_a(std::integral_constant<int, IDX>{});
+      else stage_b(std::integral_constant<int, IDX - PIECES_A6>{});
     } else {
       if constexpr (IDX < PIECES_B6) stage_b(std::integral_constant<int, IDX>{});
       else stage_a(std::integral_constant<int, IDX - PIECES_B6>{});
@@ -632,11 +593,10 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   auto step = [&](auto first_tag) {
     quarter(Q0{}, first_tag, a0, b0, a1, b1, rd_a, rd, Q1{});
     quarter(Q1{}, std::false_type{}, a1, b1, a0, b0, rd_a, rd, Q2{});
-    if constexpr (TA > 0 && !OLD_ADMIT && (ABL & 2) == 0) touch_ahead();
     quarter(Q2{}, std::false_type{}, a0, b0, a1, b1, rd_a, rd, Q3{});
-    // ---- step S+1 has landed in this wave (two slots: nothing newer is in flight but the touch-ahead; three: only corpus slab S+2 is);
-    //      the slots of step S are read out; meet
-    if constexpr ((ABL & 2) == 0 && (ABL & 16) == 0) wait_vmcnt<(RA == 2 ? ((TA > 0 && !OLD_ADMIT) ? 1 : 0) : PIECES_A6)>();  // (ablation 16: never wait for the staging loads)
+    // ---- step S+1 has landed in this wave (two slots: nothing newer is in flight; three: only corpus slab S+2 is); the
+    //      slots of step S are read out; meet
+    if constexpr ((ABL & 2) == 0) wait_vmcnt<(RA == 2 ? 0 : PIECES_A6)>();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) through the builtin: visible to the compiler's wait-count pass
     TAVB_BARRIER();
     const int nxt_a = (RA == 2) ? (rd_a ^ 1) : (rd_a + 1 == RA ? 0 : rd_a + 1);
@@ -693,59 +653,29 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
             //  bit twiddling); a row nobody admits -- 15 of 16 in the usual case -- costs one scalar test.  An admitted row takes its slot
             //  with one LDS atomic per admitting lane.  Rows past the end of the row range exist only in a range's last tile (wave-uniform).
             const int64_t row_base = row0 + wm * 160 + mi * 32 + 4 * (lane_e >> 5);
-            if constexpr (OLD_ADMIT) {
-              unsigned admit = 0;
+            // rows of this block that belong to the row range, seen from this lane's first row (>= 32: all of them)
+            const int64_t left64 = r_end - row_base;
+            const int rows_left = tile_full ? 64 : (int)(left64 < 64 ? left64 : 64);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const float sc = fmaf(dots[r], 0.5f, 0.5f);
-                float s1 = (sc > 0.0f) ? sc : 0.0f;
-                s1 = (s1 > 1.0f) ? 1.0f : s1;
-                const bool ok = (sc > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s1 >= p.min_score);
-                admit |= ok ? (1u << r) : 0u;
-              }
-              const int n_adm = __popc(admit);
-              int pos = 0;
-              if (n_adm > 0) {
-                pos = lds_add_rtn(&cnt_lds[ql], n_adm);
-                if (pos + n_adm > CAPW - BM6) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
-              }
+            for (int g = 0; g < 4; ++g) {  // four rows at a time: their masks stay in scalar registers
+              float sc[4];
+              u64 m[4];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                TAVB_SB();
-                if ((admit >> r) & 1u) {
-                  const float sc = fmaf(dots[r], 0.5f, 0.5f);
-                  float s1 = (sc > 0.0f) ? sc : 0.0f;
+              for (int j = 0; j < 4; ++j) {
+                sc[j] = fmaf(dots[4 * g + j], 0.5f, 0.5f);
+                asm volatile("v_cmp_gt_f32 %0, %1, %2" : "=s"(m[j]) : "v"(sc[j]), "v"(thr));  // (the builtin ballot goes through a 0/1 VGPR and back)
+              }
+              if ((m[0] | m[1] | m[2] | m[3]) == 0ull) continue;  // wave-uniform: nobody admits any of the four
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int r_off = j + 8 * g;  // row 4 g + j of the accumulator = tile row (r & 3) + 8 (r >> 2) from row_base
+                if (m[j] == 0ull) continue;
+                if (((m[j] >> lane_e) & 1ull) != 0ull && r_off < rows_left) {
+                  const int pos = lds_add_rtn(&cnt_lds[ql], 1);
+                  if (pos + 1 > CAPW - BM6) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
+                  float s1 = (sc[j] > 0.0f) ? sc[j] : 0.0f;
                   s1 = (s1 > 1.0f) ? 1.0f : s1;
-                  if (pos < CAPW)
-                    my_cand[(size_t)ql * CAPW + pos] = make_key(s1, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
-                  ++pos;
-                }
-              }
-            } else {
-              // rows of this block that belong to the row range, seen from this lane's first row (>= 32: all of them)
-              const int64_t left64 = r_end - row_base;
-              const int rows_left = tile_full ? 64 : (int)(left64 < 64 ? left64 : 64);
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {  // four rows at a time: their masks stay in scalar registers
-                float sc[4];
-                u64 m[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  sc[j] = fmaf(dots[4 * g + j], 0.5f, 0.5f);
-                  asm volatile("v_cmp_gt_f32 %0, %1, %2" : "=s"(m[j]) : "v"(sc[j]), "v"(thr));  // (the builtin ballot goes through a 0/1 VGPR and back)
-                }
-                if ((m[0] | m[1] | m[2] | m[3]) == 0ull) continue;  // wave-uniform: nobody admits any of the four
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  const int r_off = j + 8 * g;  // row 4 g + j of the accumulator = tile row (r & 3) + 8 (r >> 2) from row_base
-                  if (m[j] == 0ull) continue;
-                  if (((m[j] >> lane_e) & 1ull) != 0ull && r_off < rows_left) {
-                    const int pos = lds_add_rtn(&cnt_lds[ql], 1);
-                    if (pos + 1 > CAPW - BM6) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
-                    float s1 = (sc[j] > 0.0f) ? sc[j] : 0.0f;
-                    s1 = (s1 > 1.0f) ? 1.0f : s1;
-                    if (pos < CAPW) my_cand[(size_t)ql * CAPW + pos] = make_key(s1, (uint32_t)(row_base + r_off) + p.index_base);
-                  }
+                  if (pos < CAPW) my_cand[(size_t)ql * CAPW + pos] = make_key(s1, (uint32_t)(row_base + r_off) + p.index_base);
                 }
               }
             }
@@ -1143,7 +1073,7 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
                                                           int kc_max, const u64* __restrict__ carried, const int* __restrict__ carried_cnt,
                                                           const float* __restrict__ floor, const float* __restrict__ band, u64* __restrict__ out,
                                                           int* __restrict__ out_cnt, float* __restrict__ thr_out, unsigned* __restrict__ lost,
-                                                          int* __restrict__ verdict, float* __restrict__ level_out) {
+                                                          int* __restrict__ verdict) {
   extern __shared__ __align__(16) unsigned char sel_smem[];
   u64* cache = reinterpret_cast<u64*>(sel_smem);  // [SEL_CACHE]
   __shared__ int off[260];  // exclusive prefix of the per-split counts (+ the carried band as one more "split")
@@ -1343,17 +1273,6 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
       if (floor != nullptr && floor[q] > t) t = floor[q];
       thr_out[q] = t;
     }
-    if (level_out != nullptr) {
-      // k keys seen with an approximate score >= a_k (strict: t_hi is a_k itself; band: t_hi is the cut, a_k - 2 delta less an ulp), so with an
-      // EXACT score >= a_k - delta: the level this shard has proven for the whole corpus.  band_q = 2 delta.  Rounded down twice.
-      float lv = -__builtin_inff();
-      if (enough && t_hi > 0u && band_q < __builtin_inff()) {
-        const float a = __uint_as_float(t_hi);
-        lv = strict ? a - 0.5f * band_q : a + 0.5f * band_q;
-        lv = lv > 0.0f ? __uint_as_float(__float_as_uint(lv) - 2u) : -__builtin_inff();
-      }
-      level_out[q] = lv;
-    }
   }
 }
 
@@ -1408,13 +1327,13 @@ size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide) {
 
 hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
-                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream, float* level_out) {
+                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream) {
   if (nq < 1 || k < 1 || k > 64 || n_splits < 1 || n_splits > 256 || nq_padded < nq || kc_max < k || kc_max > SEL_CACHE / 4) return hipErrorInvalidValue;
   constexpr int lds = SEL_CACHE * (int)sizeof(u64);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(select_band_kernel, dim3(nq), dim3(256), lds, stream, cand, counts, n_splits, nq_padded, k, kc_max, carried, carried_cnt, floor, band,
-                     out, out_cnt, thr_out, lost, verdict, level_out);
+                     out, out_cnt, thr_out, lost, verdict);
   return hipGetLastError();
 }
 
@@ -1463,18 +1382,11 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 264: return go(mfma_scan_kernel<264, 4, 8, 6, 4>, NT6, LDS256);  // same as 256, query operand K step 0 re-read (cache resident)
       case 268: return go(mfma_scan_kernel<268, 4, 8, 6, 4>, NT6, LDS256);  // both operands cache resident
       case 258: return go(mfma_scan_kernel<258, 4, 8, 6, 4>, NT6, LDS256);  // no LDS-DMA, no admissions
-      case 284: return go(mfma_scan_kernel<284, 4, 8, 6, 4>, NT6, LDS256);  // 268 + never wait for the staging loads (is it their latency or the LDS traffic?)
-      case 332: return go(mfma_scan_kernel<332, 4, 8, 6, 4>, NT6, LDS256);  // 268 + no corpus staging (query pieces only)
-      case 396: return go(mfma_scan_kernel<396, 4, 8, 6, 4>, NT6, LDS256);  // 268 + no query staging (corpus pieces only)
       default: break;
     }
     switch (p.sched) {  // staging pieces per quarter (q3, q0, q1): measurement
       case 1: return go(mfma_scan_kernel<0, 4, 10, 8, 0>, NT6, LDS256);
       case 2: return go(mfma_scan_kernel<0, 4, 6, 6, 6>, NT6, LDS256);
-      case 3: return go(mfma_scan_kernel<0, 4, 8, 6, 4, 1>, NT6, LDS256);  // L2 touch-ahead, 1 / 2 / 3 steps
-      case 4: return go(mfma_scan_kernel<0, 4, 8, 6, 4, 2>, NT6, LDS256);
-      case 5: return go(mfma_scan_kernel<0, 4, 8, 6, 4, 3>, NT6, LDS256);
-      case 6: return go(mfma_scan_kernel<0, 4, 8, 6, 4, 9>, NT6, LDS256);  // round 3's admission path
       default: return go(mfma_scan_kernel<0, 4, 8, 6, 4>, NT6, LDS256);
     }
   }

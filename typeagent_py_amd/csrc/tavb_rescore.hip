@@ -289,39 +289,6 @@ __global__ void __launch_bounds__(256) gather_flagged_f32_kernel(const float* __
 
 __global__ void zero_int_kernel(int* p) { *p = 0; }
 
-// ---- admission thresholds shared between row shards (tavb_search_allgather, tavb_abi.hip::run_tile_ladder) -------------------------------
-// After a ladder phase a shard's exclusive admission threshold is just below a_k - 2 delta_q, a_k = the approximate k-th best score over the
-// rows it has scanned.  What the shard has PROVEN is the level  L_q = a_k - delta_q:  k of its rows have an EXACT score >= L_q
-// (select_band_kernel writes it: level_out).  That statement holds for the whole corpus, so the maximum of the shards' levels does too; a row
-// on shard s whose approximate score is <= L - delta_s has an exact score <= L and cannot be in the global top k.
-// delta differs between shards (it carries the shard's largest row norm), hence levels, not thresholds, are what is exchanged.
-// Every step rounds towards the safe side (levels down, thresholds down); an infinite delta proves nothing and is passed over.
-__device__ __forceinline__ float f32_pred(float x) {  // the float below x (x finite or +inf; -inf stays)
-  if (!(x > -__builtin_inff())) return x;
-  if (x == 0.0f) return -1.4e-45f;
-  const uint32_t b = __float_as_uint(x);
-  return __uint_as_float(x > 0.0f ? b - 1u : b + 1u);
-}
-
-__global__ void level_to_threshold_kernel(const float* __restrict__ level, const float* __restrict__ delta, int nq, float* __restrict__ thr) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nq) return;
-  const float d = delta[q], l = level[q];
-  if (!(d < __builtin_inff()) || !(l == l)) return;
-  const float t = f32_pred(f32_pred(l - d));
-  if (t > thr[q]) thr[q] = t;
-}
-
-__global__ void max_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && src[i] > dst[i]) dst[i] = src[i];
-}
-
-__global__ void fill_f32_kernel(float* __restrict__ dst, float v, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = v;
-}
-
 }  // namespace
 
 hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, float* out_sq, hipStream_t stream) {
@@ -337,21 +304,6 @@ hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void
   int64_t blocks = (n + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;
   hipLaunchKernelGGL(shadow_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rows_f32, n, dim, reinterpret_cast<_Float16*>(out_f16), stats);
-  return hipGetLastError();
-}
-
-hipError_t launch_level_to_threshold(const float* level, const float* delta, int nq, float* thr, hipStream_t stream) {
-  hipLaunchKernelGGL(level_to_threshold_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, level, delta, nq, thr);
-  return hipGetLastError();
-}
-
-hipError_t launch_max_f32(float* dst, const float* src, int n, hipStream_t stream) {
-  hipLaunchKernelGGL(max_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dst, src, n);
-  return hipGetLastError();
-}
-
-hipError_t launch_fill_f32(float* dst, float v, int n, hipStream_t stream) {
-  hipLaunchKernelGGL(fill_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dst, v, n);
   return hipGetLastError();
 }
 
