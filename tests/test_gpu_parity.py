@@ -905,10 +905,13 @@ def test_wide_tile_falls_back_to_the_exact_tile_when_the_band_overflows():
     assert len(out2[3]) == k and len(out2[2]) == 0
 
 
-@pytest.mark.parametrize("sample", [-1, 0])
+@pytest.mark.parametrize("sample", [-1, 20480, 0])
 def test_wide_tile_band_overflow_inside_one_row_range(sample):
     """900 near-duplicates in CONSECUTIVE rows: one workgroup's candidate buffer (1024 keys) cannot hold the band while it walks its
-    row range -- the in-kernel compaction falls back to the strict best k and flags the query; everything else stays on the band path."""
+    row range -- the in-kernel compaction falls back to the strict best k and flags the query; everything else stays on the band path.
+    (Whether a buffer overflows depends on how the rows fall into row ranges: one un-seeded phase and round 3's ladder geometry put
+    enough of the 900 into one range; with the default ladder the ranges of the last phase are 640 rows and nothing overflows -- the
+    answers are exact either way.)"""
     n, nq, k = 200_000, 130, 32
     v, _ = make_corpus(n, 1536, 7320)
     qs = make_queries(nq, 1536, 7321)
@@ -918,7 +921,7 @@ def test_wide_tile_band_overflow_inside_one_row_range(sample):
     vb.engine.set_option("mfma_sample_rows", sample)
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     assert vb.engine.get_option("last_tier") == 4
-    assert vb.engine.get_option("last_flagged") == 1
+    assert vb.engine.get_option("last_flagged") == (0 if sample == 0 else 1)
     v16 = _f16(v)
     for qi in [0, 4, 5, 6, 129]:
         vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))

@@ -102,7 +102,8 @@ def _answers_for_current_rows(vb, q):
     return res
 
 
-@pytest.mark.parametrize("write", ["row", "element", "slice_of_view", "row_view", "imul", "ufunc_out", "copyto", "fill", "put", "putmask", "sort"])
+@pytest.mark.parametrize("write", ["row", "element", "slice_of_view", "row_view", "imul", "ufunc_out", "copyto", "fill", "put", "putmask", "sort",
+                                   "flat", "copyto_keywords", "take_out", "dot_out", "bulk_through_asarray", "bulk_through_torch"])
 def test_writes_through_the_serialized_matrix_reach_the_device_mirror(monkeypatch, write):
     """serialize() hands out the live matrix like the reference (vectorbase.py:268-271), which always scores the live matrix (:176).
     Every write numpy can see -- on the array or on views derived from it -- must be answered for on the next lookup, whichever row
@@ -138,6 +139,21 @@ def test_writes_through_the_serialized_matrix_reach_the_device_mirror(monkeypatc
         np.putmask(m, np.broadcast_to(np.arange(50)[:, None] == 17, m.shape), new)
     elif write == "sort":
         m.sort(axis=0)
+    elif write == "flat":  # (round-3 advice: writers the view used to miss)
+        m.flat[17 * 8 : 18 * 8] = new
+    elif write == "copyto_keywords":
+        np.copyto(dst=m, src=-np.asarray(m))
+    elif write == "take_out":
+        np.take(np.asarray(m).copy(), np.arange(50)[::-1], axis=0, out=m)
+    elif write == "dot_out":
+        np.dot(np.asarray(m).copy(), -np.eye(8, dtype=np.float32), out=m)
+    elif write == "bulk_through_asarray":  # a base-class view: numpy tells the view nothing -- the fingerprint of a handed-out matrix does
+        raw = np.asarray(m)
+        raw *= np.float32(-1.0)
+    elif write == "bulk_through_torch":
+        import torch
+
+        torch.from_numpy(np.asarray(m)).mul_(-1.0)
     after = _answers_for_current_rows(vb, q)
     assert len(FakeEngine.instances[-1].uploads) > uploads  # the mirror was refreshed
     assert [(r.item, r.score) for r in after] != [(r.item, r.score) for r in first]
@@ -147,16 +163,30 @@ def test_writes_through_the_serialized_matrix_reach_the_device_mirror(monkeypatc
     _answers_for_current_rows(vb, q)
     assert len(FakeEngine.instances[-1].uploads) == uploads
     assert type(vb.serialize() * 2) is np.ndarray  # arithmetic gives plain copies
+    # arrays that only DERIVE from the matrix own their memory: editing them is nobody's business (round-3 advice: a private copy edited in
+    # place used to trigger a re-upload of the whole corpus)
+    m = vb.serialize()
+    c = m.copy()
+    c *= 2
+    c[3] = 0
+    row = vb.get_embedding_at(4).copy()
+    row /= 3
+    prod = np.dot(m, q)
+    prod[0] = 7
+    assert type(prod) is np.ndarray and type(np.sort(m, axis=0)) is np.ndarray
+    _answers_for_current_rows(vb, q)
+    assert len(FakeEngine.instances[-1].uploads) == uploads
 
 
 def test_raw_writers_use_mark_dirty_and_adopted_matrices_follow_their_watch_mode(monkeypatch):
     vb, rows, rng = _fresh(monkeypatch)
     q = rows[5]
     _answers_for_current_rows(vb, q)
-    raw = np.asarray(vb.serialize())  # a base-class view: numpy no longer tells us about writes (documented residual)
-    raw[5] = -raw[5]
+    raw = np.asarray(vb.serialize())  # a base-class view: numpy no longer tells the view about writes; the sampled fingerprint of a
+    raw[5] = -raw[5]                  # handed-out matrix catches bulk edits (test above), not ONE row outside its 32-row sample:
+    assert 5 not in np.unique(np.linspace(0, 49, num=32).astype(np.int64))
     stale = vb.fuzzy_lookup_embedding(q, max_hits=1, min_score=0.0)
-    assert stale[0].item == 5  # the mirror is stale ...
+    assert stale[0].item == 5  # the mirror is stale (documented residual) ...
     vb.mark_dirty()  # ... until the writer says so
     assert _answers_for_current_rows(vb, q)[0].item != 5
 

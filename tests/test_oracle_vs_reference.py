@@ -3,6 +3,8 @@ class (oracle/ref_loader.py executes /root/reference's vectorbase.py unmodified)
 Skipped where /root/reference does not exist (the GPU box) -- there the committed
 goldens (test_oracle_golden.py) carry the pin."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -86,3 +88,60 @@ def test_host_side_class_matches_reference_bookkeeping():
         assert vb.serialize_embedding_at(-1) is None
         vb.clear()
         assert len(vb) == 0 and vb.serialize().shape == (0, 4)
+
+
+def test_caching_embedding_model_makes_the_reference_calls():
+    """`CachingEmbeddingModel` is registered as typeagent.aitools.embeddings' class by install(): embedders that count, log or bill their
+    calls -- and batch-only ones -- must see the call pattern of the reference's class (aitools/embeddings.py:73-114).  The reference file is
+    executed here with its two PEP 695 `type X = ...` alias statements rewritten as plain assignments (Python 3.10), nothing else touched."""
+    import asyncio
+    import re
+    import types
+
+    from typeagent_py_amd.embeddings import CachingEmbeddingModel
+
+    path = os.path.join(ref_loader.REFERENCE_ROOT, "src", "typeagent", "aitools", "embeddings.py")
+    src = open(path).read()
+    new_src, n_changed = re.subn(r"(?m)^type (\w+) = ", r"\1 = ", src)
+    assert n_changed == 2 and len(new_src.splitlines()) == len(src.splitlines())
+    mod = types.ModuleType("ref_embeddings")
+    exec(compile(new_src, path, "exec"), mod.__dict__)
+
+    class Counting:
+        model_name = "counting"
+
+        def __init__(self):
+            self.calls = []
+
+        async def get_embedding_nocache(self, input):
+            self.calls.append(("one", input))
+            return np.full(3, float(len(input)), dtype=np.float32)
+
+        async def get_embeddings_nocache(self, input):
+            self.calls.append(("many", tuple(input)))
+            return np.stack([np.full(3, float(len(s)), dtype=np.float32) for s in input])
+
+    script = [("one", "a"), ("many", ["a", "bb", "bb", "ccc"]), ("one", "bb"), ("many", ["dddd"]), ("many", ["a", "dddd"]), ("one", "zz"),
+              ("many", ["zz", "yy", "yy"]), ("add", "pre"), ("one", "pre"), ("many", ["pre", "q"])]
+    logs, outs = [], []
+    for cls in (mod.CachingEmbeddingModel, CachingEmbeddingModel):
+        emb = Counting()
+        model = cls(emb)
+        out = []
+        for op, arg in script:
+            if op == "one":
+                out.append(asyncio.run(model.get_embedding(arg)))
+            elif op == "many":
+                out.append(asyncio.run(model.get_embeddings(arg)))
+            else:
+                model.add_embedding(arg, np.full(3, 9.0, dtype=np.float32))
+        logs.append(emb.calls)
+        outs.append(out)
+        assert sorted(model._cache) == sorted({"a", "bb", "ccc", "dddd", "zz", "yy", "pre", "q"})
+    assert logs[0] == logs[1]
+    for a, b in zip(*outs):
+        assert a.dtype == b.dtype and a.shape == b.shape
+        np.testing.assert_array_equal(a, b)
+    for cls in (mod.CachingEmbeddingModel, CachingEmbeddingModel):
+        with pytest.raises(ValueError):
+            asyncio.run(cls(Counting()).get_embeddings([]))

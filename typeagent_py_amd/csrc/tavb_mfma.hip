@@ -806,7 +806,7 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
 
   const float thr0 = (p.min_score > 0.0f) ? __uint_as_float(__float_as_uint(p.min_score) - 1u) : -__builtin_inff();
   if (tid < SQ) {  // SQ <= 64 < S_THREADS
-    float t0 = (p.min_score != p.min_score) ? __builtin_inff() : thr0;  // NaN threshold admits nothing
+    float t0 = (p.min_score != p.min_score || p.min_score > 1.0f) ? __builtin_inff() : thr0;  // NaN threshold admits nothing, nor one above 1 (as in the 256-query tile)
     const int qg0 = qtile * SQ + tid;
     if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
     else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best so far: a valid lower bound
@@ -898,6 +898,7 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
   int rd = 0;
   for (int tile = 0; tile < n_tiles; ++tile) {
     const int64_t row0 = r_begin + (int64_t)tile * BM;
+    const bool tile_full = row0 + BM <= r_end;  // wave-uniform: every row of this tile belongs to the row range
     f32x16 acc[2][NI];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -973,34 +974,31 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
         const bool any = (ABL == 0) && (top > thr_pre);
         if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi][ni]));
         if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-          float sc[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[r] = fmaf(acc[mi][ni][r], 0.5f, 0.5f);
+          // (the admission path of the 256-query tile: wave masks in scalar registers, four rows at a time, one LDS atomic per admitted row)
           const int64_t row_base = row0 + wave * 64 + mi * 32 + 4 * (lane >> 5);
-          unsigned admit = 0;
+          const int64_t left64 = r_end - row_base;
+          const int rows_left = tile_full ? 64 : (int)(left64 < 64 ? left64 : 64);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float s1 = sc[r];
-            s1 = (s1 > 0.0f) ? s1 : 0.0f;
-            s1 = (s1 > 1.0f) ? 1.0f : s1;
-            const bool ok = (sc[r] > thr) && (row_base + (r & 3) + 8 * (r >> 2) < r_end) && (s1 >= p.min_score);
-            admit |= ok ? (1u << r) : 0u;
-          }
-          const int n_adm = __popc(admit);
-          int pos = 0;
-          if (n_adm > 0) {
-            pos = lds_add_rtn(&cnt_lds[ql], n_adm);
-            if (pos + n_adm > CAP - BM) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
-          }
+          for (int g = 0; g < 4; ++g) {
+            float sc[4];
+            u64 m[4];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if ((admit >> r) & 1u) {
-              float s1 = sc[r];
-              s1 = (s1 > 0.0f) ? s1 : 0.0f;
-              s1 = (s1 > 1.0f) ? 1.0f : s1;
-              if (pos < CAP)
-                my_cand[(size_t)ql * CAP + pos] = make_key(s1, (uint32_t)(row_base + (r & 3) + 8 * (r >> 2)) + p.index_base);
-              ++pos;
+            for (int j = 0; j < 4; ++j) {
+              sc[j] = fmaf(acc[mi][ni][4 * g + j], 0.5f, 0.5f);
+              asm volatile("v_cmp_gt_f32 %0, %1, %2" : "=s"(m[j]) : "v"(sc[j]), "v"(thr));
+            }
+            if ((m[0] | m[1] | m[2] | m[3]) == 0ull) continue;  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int r_off = j + 8 * g;
+              if (m[j] == 0ull) continue;
+              if (((m[j] >> lane) & 1ull) != 0ull && r_off < rows_left) {
+                const int pos = lds_add_rtn(&cnt_lds[ql], 1);
+                if (pos + 1 > CAP - BM) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
+                float s1 = (sc[j] > 0.0f) ? sc[j] : 0.0f;
+                s1 = (s1 > 1.0f) ? 1.0f : s1;
+                if (pos < CAP) my_cand[(size_t)ql * CAP + pos] = make_key(s1, (uint32_t)(row_base + r_off) + p.index_base);
+              }
             }
           }
         }

@@ -60,21 +60,23 @@ class CachingEmbeddingModel:
     async def get_embeddings_nocache(self, input: list[str]) -> NormalizedEmbeddings:
         return await self._embedder.get_embeddings_nocache(input)
 
-    # cached forms: compute what is missing (in one embedder call), remember it, answer from the dict
-    async def _fill(self, keys: list[str]) -> None:
-        missing = list(dict.fromkeys(k for k in keys if k not in self._cache))
-        if len(missing) == 1:
-            self._cache[missing[0]] = await self._embedder.get_embedding_nocache(missing[0])
-        elif missing:
-            rows = await self._embedder.get_embeddings_nocache(missing)
-            self._cache.update(zip(missing, rows))
-
+    # cached forms.  The embedder sees exactly the calls the reference's class makes (aitools/embeddings.py:101-114): one
+    # get_embedding_nocache(key) for a single miss, ONE get_embeddings_nocache(missing keys, in order, duplicates included) for a batch --
+    # embedders that count, log or bill their calls, and batch-only ones, cannot tell the two classes apart.
     async def get_embedding(self, key: str) -> NormalizedEmbedding:
-        await self._fill([key])
-        return self._cache[key]
+        hit = self._cache.get(key)
+        if hit is not None:
+            return hit
+        row = await self._embedder.get_embedding_nocache(key)
+        self._cache[key] = row
+        return row
 
     async def get_embeddings(self, keys: list[str]) -> NormalizedEmbeddings:
         if not keys:
             raise ValueError("Cannot embed an empty list")
-        await self._fill(keys)
-        return np.stack([self._cache[k] for k in keys]).astype(np.float32, copy=False)
+        absent = [k for k in keys if k not in self._cache]
+        if absent:
+            rows = await self._embedder.get_embeddings_nocache(absent)
+            for k, row in zip(absent, rows):
+                self._cache[k] = row
+        return np.array([self._cache[k] for k in keys], dtype=np.float32)

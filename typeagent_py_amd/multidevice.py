@@ -44,7 +44,6 @@ class DeviceGroup:
         self.engines = [_native.Engine(d) for d in self.devices]
         self._lock = threading.RLock()
         self.block = 0  # rows per shard (the last shard may hold more)
-        self._outgrown = 0  # block size of the layout that has just been outgrown (the next layout at least doubles it)
         self.bounds = [0] * (len(self.devices) + 1)  # shard g = rows [bounds[g], bounds[g+1])
         self.rows = 0
         self.dim = 0
@@ -102,13 +101,13 @@ class DeviceGroup:
         if fresh and start != 0:
             return False
         if fresh:
-            # balanced now; appends fill the last shard up to twice this.  A layout that replaces an outgrown one at least doubles its
-            # block: growing an index row by row then re-shards O(log N) times moving O(N) rows in total (ceil(n / g) alone gave a
-            # block only (1 + 1/g) times bigger: ~g ln N re-shards, ~9 N rows moved for 8 devices -- round-2 advice)
-            self.block = max(1, -(-max(n_new, 1) // g), 2 * self._outgrown)
-            self._outgrown = 0
+            # balanced: ceil(n / g) rows per shard, every device reserving twice that; appends go to the last shard until it outgrows its
+            # reservation, then the layout is rebuilt balanced.  (Round 3 doubled the BLOCK at a re-shard to re-shard less often: right after
+            # one, 5 of 8 devices held rows and lookups ran ~1.8x slower until the index had doubled -- round-3 advice.  Balanced layouts
+            # re-shard every time the index grows by 1/g: O(g) uploads per appended row when an index is grown row by row, 1 when it is
+            # built in bulk; lookups always run on g equal shards.)
+            self.block = max(1, -(-max(n_new, 1) // g))
         elif n_new > (g + 1) * self.block:  # the last shard would exceed twice the block: rebalance
-            self._outgrown = self.block
             return False
         bounds = self._layout(n_new, self.block)
         for gi, e in enumerate(self.engines):
@@ -122,7 +121,7 @@ class DeviceGroup:
                 continue  # untouched shard
             e.ordinal_base = lo
             local = host_rows[a - start : hi - start] if a < hi else host_rows[:0]
-            cap = self.block if gi < g - 1 else 2 * self.block
+            cap = 2 * self.block
             e.upload_rows(local, a - lo, dtype, capacity_hint=cap if (fresh or e.corpus is None) else 0)
         self.bounds, self.rows, self.dim, self.dtype = bounds, n_new, dim, dtype
         self.corpus = True
@@ -150,7 +149,6 @@ class DeviceGroup:
         for e in self.engines:
             e.clear()
         self.rows = 0
-        self._outgrown = 0
         self.bounds = [0] * (len(self.engines) + 1)
 
     # -- lookups -------------------------------------------------------------------------------------------------

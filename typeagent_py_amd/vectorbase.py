@@ -80,16 +80,22 @@ class _Watch:
 class _WatchedMatrix(np.ndarray):
     """What serialize() / `_vectors` / get_embedding_at() hand out for a matrix this index owns: a plain float32 view of the live
     host matrix (the reference hands out the live `_vectors`, vectorbase.py:268-271) that remembers being written to.  The
-    reference always scores the live matrix (:176); here the device mirror is refreshed on the next lookup after any write made
-    through numpy -- item / slice assignment, in-place operators and ufunc `out=`, fill / sort / put / ..., np.copyto / np.put /
-    np.place / np.putmask -- on this array or on any view derived from it.  Writers that go around numpy's array API (a base-class
-    view from np.asarray(), memoryview, ctypes pointers, another library writing through the buffer protocol) are not seen:
-    they call `VectorBase.mark_dirty()`."""
+    reference always scores the live matrix (:176); here the device mirror is refreshed on the next lookup after a write made
+    through numpy's array API on this array or on a view derived from it: item / slice assignment, in-place operators and ufunc
+    `out=`, fill / sort / put / ..., np.copyto / np.put / np.place / np.putmask, `out=` / `dst=` of any other numpy function, `.flat`
+    (touching `.flat` counts as a write: the iterator it returns assigns behind numpy's back).
+    Arrays that merely DERIVE from the matrix but own their memory (m.copy(), m * 2, a matrix product with it) are plain results: writing to them
+    does not mark anything.  What this class cannot see -- a base-class view from np.asarray(), memoryview, ctypes pointers, torch.from_numpy,
+    another library writing through the buffer protocol -- is caught by the fingerprint the index keeps of a matrix it has handed out
+    (`verify_host`: sampled rows by default, so a bulk rewrite is noticed, a single-row edit by such a route is not): those writers
+    call `VectorBase.mark_dirty()`."""
 
     _tavb_watch: _Watch | None = None
 
     def __array_finalize__(self, obj) -> None:
-        if obj is not None:
+        # only arrays that SHARE the matrix' memory inherit the watch (a copy that owns its data is nobody's mirror: editing it must not
+        # trigger a re-upload of a multi-GB corpus)
+        if obj is not None and not self.flags.owndata:
             self._tavb_watch = getattr(obj, "_tavb_watch", None)
 
     def _touch(self) -> None:
@@ -100,6 +106,16 @@ class _WatchedMatrix(np.ndarray):
     def __setitem__(self, key, value) -> None:
         self._touch()
         super().__setitem__(key, value)
+
+    @property
+    def flat(self):
+        self._touch()  # `m.flat[i] = x` assigns through a np.flatiter: conservative, also for reads
+        return np.ndarray.flat.__get__(self)
+
+    @flat.setter
+    def flat(self, value) -> None:
+        self._touch()
+        np.ndarray.flat.__set__(self, value)
 
     def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
         plain = lambda a: a.view(np.ndarray) if isinstance(a, _WatchedMatrix) else a
@@ -118,7 +134,17 @@ class _WatchedMatrix(np.ndarray):
     def __array_function__(self, func, types, args, kwargs):
         if func in _WRITING_FUNCTIONS and args and isinstance(args[0], _WatchedMatrix):
             args[0]._touch()
-        return super().__array_function__(func, types, args, kwargs)
+        for name in ("out", "dst", "a"):  # np.take(..., out=m), a product written into out=m, np.copyto(dst=m, src=...), np.put(a=m, ...)
+            target = kwargs.get(name)
+            if name == "a" and func not in _WRITING_FUNCTIONS:
+                continue
+            for t in target if isinstance(target, tuple) else (target,):
+                if isinstance(t, _WatchedMatrix):
+                    t._touch()
+        result = super().__array_function__(func, types, args, kwargs)
+        if isinstance(result, _WatchedMatrix) and result.flags.owndata:
+            return result.view(np.ndarray)  # a fresh array (a product, a sorted copy, ...): nobody's mirror
+        return result
 
     def _writing_method(name):  # noqa: N805 -- class-body helper
         base = getattr(np.ndarray, name)
@@ -262,6 +288,7 @@ class VectorBase:
         #    verify_host="full"; ~0.1 ms per MB) -- and mark_dirty() is the explicit form.
         self._watch = _Watch()
         self._view = None  # (host buffer, row count, the write-tracking view handed out for them)
+        self._view_out = False  # a view of a matrix this index owns has been handed out: fingerprint fallback on (round-3 advice)
         self._handed_out = False
         self._dev_fingerprint = None
         mode = (verify_host or os.environ.get("TYPEAGENT_VB_VERIFY_HOST", "sampled")).lower()
@@ -290,6 +317,12 @@ class VectorBase:
             view = live.view(_WatchedMatrix)
         view._tavb_watch = self._watch
         self._view = (live, self._count, view)
+        if not self._view_out:
+            # from now on the lookups also keep the fingerprint of this matrix (writers the view cannot see); nobody has held a
+            # view until now, so the mirror -- if there is one -- matches the matrix as it is
+            self._view_out = True
+            if self._dev_valid and self._dev_rows == self._count:
+                self._dev_fingerprint = self._fingerprint()
         return view
 
     @_vectors.setter
@@ -323,7 +356,7 @@ class VectorBase:
         need = self._count + extra
         if self._host.ndim != 2 or self._host.shape[1] != self._embedding_size:
             self._host = np.zeros((max(need, 4), self._embedding_size), dtype=np.float32)
-            self._handed_out = False
+            self._handed_out = self._view_out = False
             return
         if need > self._host.shape[0] or self._handed_out:
             # (an adopted matrix is the caller's: appends go to a buffer of our own, like the reference's np.append copy, :128)
@@ -332,7 +365,7 @@ class VectorBase:
             grown = np.empty((max(need, 2 * self._host.shape[0], 4), self._embedding_size), dtype=np.float32)
             grown[: self._count] = self._host[: self._count]
             self._host = grown
-            self._handed_out = False
+            self._handed_out = self._view_out = False  # (views of the old buffer are no longer views of this index' matrix)
 
     async def get_embedding(self, key: str, cache: bool = True) -> NormalizedEmbedding:
         if cache:
@@ -432,8 +465,8 @@ class VectorBase:
         if self._watch.dirty:  # a view handed out by serialize() / _vectors / get_embedding_at() was written to
             self._watch.dirty = False
             self._dev_valid = False
-        if self._handed_out and self._dev_valid and self._dev_rows == n and n > 0 and self._dev_fingerprint != self._fingerprint():
-            self._dev_valid = False  # the caller's matrix adopted by deserialize() was edited in place
+        if (self._handed_out or self._view_out) and self._dev_valid and self._dev_rows == n and n > 0 and self._dev_fingerprint != self._fingerprint():
+            self._dev_valid = False  # the caller's matrix adopted by deserialize() -- or a matrix of ours somebody holds a view of -- was edited in place
         if not self._dev_valid:
             self._dev_rows = 0
             self._dev_valid = True
@@ -445,7 +478,7 @@ class VectorBase:
             if done is False:  # a device group has to re-shard: everything again
                 eng.upload_rows(self._host[:n], 0, self._dtype, capacity_hint=self._host.shape[0])
             self._dev_rows = n
-            self._dev_fingerprint = self._fingerprint() if self._handed_out else None
+            self._dev_fingerprint = self._fingerprint() if (self._handed_out or self._view_out) else None
         return eng
 
     def _fingerprint(self):
