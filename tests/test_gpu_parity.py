@@ -637,6 +637,47 @@ def test_small_corpus_lookups_replay_a_captured_graph(dtype):
     eng.profile_enable(False)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("n", [1, 100, 1294, 10_000])
+def test_small_corpus_lookups_take_one_launch(n, dtype):
+    """The scale typeagent itself runs at (the reference's only real fixture is 1294 x 1536; its benchmark 10k x 1536): a single-query
+    lookup on a corpus of up to 128 MiB is ONE launch -- the scan's per-workgroup lists land in pinned host memory and are merged on the
+    host (tavb_merge_keys_host), no merge kernel.  Same answers as the two-launch path for every (k, min_score) the consumers use
+    (k = 10 default, 50 @ 0.85 related terms, 25 @ 0.7 messages), incl. k > rows, k = 256, exact ties, and through the drop-in class."""
+    v, q = make_corpus(n, 1536, 8300 + n)
+    if n >= 100:
+        v[7] = v[3]  # an exact tie
+        q = (v[3] + 0.05 * make_queries(1, 1536, 9)[0]).astype(np.float32)
+        q /= np.linalg.norm(q)
+    vb = new_vb(v, dtype=dtype)
+    eng = vb.engine
+    seen = _f16(v) if dtype == "fp16" else v
+    eng.profile_enable(True)
+    for k, ms in [(10, 0.0), (50, 0.85), (25, 0.7), (1, 0.0), (256, 0.0), (32, 0.5)]:
+        eng.profile_reset()
+        res = vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=ms)
+        assert eng.get_option("last_direct") == 1
+        assert eng.profile_read(_native.KERNEL_SCAN)[1] == 1 and eng.profile_read(_native.KERNEL_MERGE)[1] == 0  # one launch
+        vo.check_topk_parity(vo.scores_full(seen, q), *items_scores(res), k, ms, referee=vo.f64_referee(seen, q))
+        eng.set_option("small_direct_bytes", 0)
+        two = vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=ms)
+        assert eng.get_option("last_direct") == 0
+        eng.set_option("small_direct_bytes", 128 << 20)
+        assert items_scores(res) == items_scores(two)  # the same kernel, the same keys: the host merge and the merge kernel agree exactly
+    if n >= 100:
+        res = vb.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.0)
+        assert [r.item for r in res[:2]] == [3, 7]  # ties by ascending ordinal
+    # a launch geometry forced by option is respected up to the list budget
+    eng.set_option("scan_blocks", 16)
+    res = vb.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.0)
+    vo.check_topk_parity(vo.scores_full(seen, q), *items_scores(res), 10, 0.0, referee=vo.f64_referee(seen, q))
+    eng.set_option("scan_blocks", 0)
+    eng.profile_enable(False)
+    # batches and subset lookups do not take the path (and are unaffected by it)
+    vb.fuzzy_lookup_embeddings(np.stack([q, q]), max_hits=5)
+    assert eng.get_option("last_direct") == 0
+
+
 def test_wrong_query_size_raises_value_error():
     vb = new_vb(np.ones((4, 8), dtype=np.float32))
     with pytest.raises(ValueError):

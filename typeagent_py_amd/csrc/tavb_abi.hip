@@ -139,6 +139,9 @@ struct tavb_ctx {
   int64_t norm_rows = 0;  // rows of the corpus covered by the cached row-norm maxima (d_norm) -- and, for fp32 corpora, by the fp16 shadow
   Buffer h_stage{nullptr, 0, true};
   Buffer h_out{nullptr, 0, true};  // pinned + device-visible: the last kernel of a synchronous lookup writes its keys straight here
+  Buffer h_lists{nullptr, 0, true};  // pinned + device-visible: per-workgroup lists of a small single-query lookup (merged on the host)
+  int64_t small_direct_bytes = (int64_t)128 << 20;  // option: single-query lookups on corpora up to this size take the one-launch path (0 = never)
+  int64_t last_direct = 0;                          // option "last_direct" (get): 1 when the last lookup took it
 
   bool profiling = false;
   double total_ms[TAVB_KERNEL_COUNT] = {0};
@@ -407,6 +410,7 @@ int tavb_destroy(tavb_ctx* c) {
   }
   c->h_stage.release();
   c->h_out.release();
+  c->h_lists.release();
   for (auto& g : c->graphs)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
   (void)tavb_comm_destroy(c);
@@ -481,6 +485,9 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");
     c->mfma_splits = v;
+  } else if (n == "small_direct_bytes") {
+    if (v < 0) return fail(TAVB_E_INVALID, "small_direct_bytes must be >= 0");
+    c->small_direct_bytes = v;
   } else if (n == "comm_force") {
     c->comm_force = v ? 1 : 0;
 
@@ -515,6 +522,8 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "mfma_sample_rows") *out = c->mfma_sample_rows;
   else if (n == "compute_units") *out = c->n_cu;
   else if (n == "comm_force") *out = c->comm_force;
+  else if (n == "small_direct_bytes") *out = c->small_direct_bytes;
+  else if (n == "last_direct") *out = c->last_direct;
   else if (n == "graph_max_bytes") *out = c->graph_max_bytes;
   else if (n == "last_graph") *out = c->last_graph;
   else if (n == "comm_world") *out = c->comm ? c->comm_world : 0;
@@ -666,6 +675,7 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
   if (int rc = c->d_queries.reserve(qbytes)) return rc;
   memcpy(c->h_stage.ptr, queries_host, qbytes);
   c->last_graph = 0;
+  c->last_direct = 0;
   // ---- small corpus, one query: replay the captured (H2D, scan, merge) graph -- one submission instead of three
   const int64_t corpus_bytes = c->rows * c->dim * (c->dtype == TAVB_F16 ? 2 : 4);
   const bool streaming = nq == 1 && !(c->dtype == TAVB_F32 && c->f32_shadow >= 2 && corpus_bytes >= c->f32_shadow_min_bytes);
@@ -705,6 +715,42 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
       decode(reinterpret_cast<const u64_t*>(c->h_out.ptr), nq, k, c->ordinal_base, out_ordinals, out_scores, out_counts);
       return TAVB_OK;
     }
+  }
+  // ---- small corpus, one query (the scale typeagent itself runs at: ~1.3k .. 10k rows): ONE launch.  The scan's per-workgroup lists go
+  //      straight into pinned host memory and are merged here -- the second launch that merged 256 lists on the device cost 11.8 us of a
+  //      41 us lookup (profiles/r03_latency_cfg1.md).  The grid is cut to what keeps the lists within 16 KiB (2048 keys): 204 workgroups
+  //      at k = 10, 64 at k = 32, 40 at k = 50 -- a corpus this small does not need 256 of them.
+  if (streaming && slot == nullptr && c->small_direct_bytes > 0 && corpus_bytes <= c->small_direct_bytes) {
+    tavb::ScanGeometry g = c->geom;
+    if (g.waves < 1) g.waves = 1;
+    if (g.waves > 16) g.waves = 16;
+    g.blocks = std::min(scan_blocks_for(c, c->rows, g.waves, g.unroll), std::max(8, 2048 / k));
+    if (int rc = c->h_lists.reserve((size_t)g.blocks * k * sizeof(u64_t))) return rc;
+    TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
+    tavb::ScanParams p{};
+    p.corpus = c->corpus;
+    p.row_ids = nullptr;
+    p.queries = reinterpret_cast<const float*>(c->d_queries.ptr);
+    p.lists = reinterpret_cast<u64_t*>(c->h_lists.ptr);
+    p.n_pos = c->rows;
+    p.dim = c->dim;
+    p.dtype = c->dtype;
+    p.nq = 1;
+    p.k = k;
+    p.index_base = 0u;
+    p.key_bound = ~0ull;
+    for (int i = 0; i < TAVB_MAX_STREAM_QUERIES; ++i) p.min_score[i] = (i < 1) ? min_scores[0] : INFINITY;
+    {
+      Timed t(c, TAVB_KERNEL_SCAN);
+      hipError_t e = tavb::launch_scan(p, g, c->stream, &c->last_tier);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "scan kernel launch failed: %s", hipGetErrorString(e));
+    }
+    TAVB_HIP(hipStreamSynchronize(c->stream));
+    u64_t merged[TAVB_MAX_FUSED_K];
+    if (int rc = tavb_merge_keys_host(reinterpret_cast<const tavb_key*>(c->h_lists.ptr), g.blocks, 1, k, reinterpret_cast<tavb_key*>(merged))) return rc;
+    decode(merged, 1, k, c->ordinal_base, out_ordinals, out_scores, out_counts);
+    c->last_direct = 1;
+    return TAVB_OK;
   }
   const bool capture = slot != nullptr && slot->seen >= 1;  // (the first call of a shape sizes the workspaces: no allocation may happen inside a capture)
   if (slot) ++slot->seen;
