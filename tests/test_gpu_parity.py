@@ -1418,6 +1418,52 @@ def test_sharded_searcher_on_one_rank_rccl():
         dist.destroy_process_group()
 
 
+def test_sharded_vectorbase_storage_methods_on_the_device():
+    """ShardedVectorBase.add_embedding(s) / serialize / deserialize / clear over a DeviceShardBackend (one rank: the same code every rank of
+    a job runs; the world-2 form of it runs under gloo in tests/test_sharded_gloo.py): appends reach the device shard incrementally -- a
+    shard adopted from the caller's tensor is copied first, the caller's tensor is never written -- and lookups see them under their
+    global ordinals."""
+    import torch
+
+    from typeagent_py_amd.sharded import DeviceShardBackend, ShardedVectorBase
+
+    v, q = make_corpus(3000, 256, 8400)
+    extra, _ = make_corpus(40, 256, 8401)
+    extra[11] = q
+    backend = DeviceShardBackend(0)
+    with torch.cuda.stream(backend.stream):
+        shard = torch.from_numpy(v).cuda()
+    backend.stream.synchronize()
+    backend.set_shard(shard, row_offset=0)
+    svb = ShardedVectorBase(backend, 0, 3000, 3000)
+    first = svb.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.0)
+    vo.check_topk_parity(vo.scores_full(v, q), *items_scores(first), 10, 0.0, referee=vo.f64_referee(v, q))
+    svb.add_embeddings(None, extra[:30])
+    svb.add_embedding("x", extra[30])
+    svb.add_embeddings(["k"] * 9, extra[31:])
+    assert len(svb) == 3040 and svb.local_rows == 3040
+    grown = np.concatenate([v, extra])
+    res = svb.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.0)
+    assert res[0].item == 3011 and abs(res[0].score - 1.0) < 1e-6
+    vo.check_topk_parity(vo.scores_full(grown, q), *items_scores(res), 10, 0.0, referee=vo.f64_referee(grown, q))
+    np.testing.assert_array_equal(shard.cpu().numpy(), v)  # the adopted tensor was not touched
+    np.testing.assert_array_equal(svb.serialize(), grown)
+    batch = svb.fuzzy_lookup_embeddings(np.stack([q, grown[5]]), max_hits=5)
+    assert batch[0][0].item == 3011 and batch[1][0].item == 5
+    svb.deserialize(grown[1000:2000], dtype="fp16")
+    assert len(svb) == 1000 and svb.row_offset == 0
+    seen = _f16(grown[1000:2000])
+    res = svb.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.0)
+    vo.check_topk_parity(vo.scores_full(seen, q), *items_scores(res), 10, 0.0, referee=vo.f64_referee(seen, q))
+    np.testing.assert_array_equal(svb.serialize(), seen)
+    svb.add_embeddings(None, extra[11:12])
+    assert svb.fuzzy_lookup_embedding(q, max_hits=1)[0].item == 1000
+    svb.clear()
+    assert len(svb) == 0 and svb.fuzzy_lookup_embedding(q, max_hits=3) == []
+    svb.add_embeddings(None, extra)  # an index grown from nothing
+    assert svb.fuzzy_lookup_embedding(q, max_hits=1)[0].item == 11
+
+
 def test_fused_multi_index_query_equals_separate_calls():
     """cfg5: T term lookups (k=50 @0.85) + message re-rank (k=25 @0.7, full scan and subset) + thread lookup
     (k=10 @0.7) in one submission == the same lookups issued one by one == the oracle."""

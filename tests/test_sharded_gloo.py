@@ -80,6 +80,18 @@ class HostStandInBackend:
     def keys_to_device(self, keys):
         return torch.from_numpy(np.ascontiguousarray(keys).view(np.int64))
 
+    # storage hooks (same contracts as DeviceShardBackend's)
+    def set_rows(self, rows, row_offset, dtype="fp32"):
+        self.shard = np.ascontiguousarray(rows, dtype=np.float32).reshape(len(rows), -1)
+        self.row_offset = int(row_offset)
+
+    def append_rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        self.shard = rows if self.shard.size == 0 else np.concatenate([self.shard, rows])
+
+    def rows_to_host(self):
+        return self.shard.copy()
+
 
 def _free_port() -> int:
     s = socket.socket()
@@ -136,6 +148,35 @@ def _worker(rank: int, world: int, port: int, total_rows: int, dim: int, k: int,
         assert [(h.item, h.score) for h in got] == want
         with pytest.raises(IndexError):
             svb.fuzzy_lookup_embedding_in_subset(qs[1], [total_rows], max_hits=k)
+        # storage over the shards (vectorbase.py:115-148, 268-287): an append between two lookups lands on the LAST rank, every rank's row
+        # count advances, the next lookup sees the new rows under their global ordinals; serialize() hands out this rank's rows
+        extra, _ = make_corpus(7, dim, 4242)
+        extra[3] = qs[4]  # a planted best hit among the appended rows
+        before = svb.fuzzy_lookup_embedding(qs[4], max_hits=k, min_score=min_score)
+        svb.add_embeddings(None, extra[:5])
+        svb.add_embedding("k", extra[5])
+        svb.add_embeddings(["a"], extra[6:])
+        assert len(svb) == total_rows + 7 and svb.local_rows == (hi - lo) + (7 if rank == world - 1 else 0)
+        grown = np.concatenate([v, extra])
+        after = svb.fuzzy_lookup_embedding(qs[4], max_hits=k, min_score=min_score)
+        want = vo.lookup(grown, qs[4], k, min_score)
+        assert after[0].item == total_rows + 3 and abs(after[0].score - 1.0) < 1e-6 and before[0].item != after[0].item
+        vo.check_topk_parity(vo.scores_full(grown, qs[4]), [h.item for h in after], [h.score for h in after], k, min_score)
+        assert len(after) == len(want)
+        mine = svb.serialize()
+        np.testing.assert_array_equal(mine, grown[svb.row_offset : svb.row_offset + svb.local_rows])
+        with pytest.raises(ValueError):
+            svb.add_embeddings(["one key"], extra[:2])
+        # deserialize: every rank hands in its own rows (here: the two halves swapped in size), offsets are agreed by all-gather
+        cut = 2 * (total_rows + 7) // 3
+        part = grown[:cut] if rank == 0 else grown[cut:]
+        svb.deserialize(part)
+        assert len(svb) == total_rows + 7 and svb.row_offset == (0 if rank == 0 else cut) and svb.local_rows == len(part)
+        again = svb.fuzzy_lookup_embedding(qs[4], max_hits=k, min_score=min_score)
+        assert [(h.item, h.score) for h in again] == [(h.item, h.score) for h in after]
+        svb.clear()
+        assert len(svb) == 0 and svb.fuzzy_lookup_embedding(qs[0], max_hits=k) == []
+        ret[("storage", rank)] = True
     finally:
         dist.destroy_process_group()
 
@@ -149,7 +190,7 @@ def test_two_rank_sharded_search_equals_whole_corpus(total_rows, k, min_score):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), total_rows, dim, k, min_score, ret), nprocs=world, join=True)
-    assert set(ret.keys()) == {0, 1}
+    assert {0, 1} <= set(ret.keys()) and ret[("storage", 0)] and ret[("storage", 1)]
     o0, s0, c0 = ret[0]
     o1, s1, c1 = ret[1]
     np.testing.assert_array_equal(o0[:, :1], o1[:, :1])

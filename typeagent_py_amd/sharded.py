@@ -96,6 +96,33 @@ class DeviceShardBackend:
             self.engine.comm_init(uid, rank, world)
         self.native_comm = True
 
+    # -- storage: this rank's rows (vectorbase.py:115-148, 268-287 over a row-sharded corpus) ------------------------------------------
+    def set_rows(self, rows: np.ndarray, row_offset: int, dtype: str = "fp32") -> None:
+        """Replace this rank's shard by host rows (float32 [n, dim]); uploaded through the pinned ring (tavb_upload_rows)."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        self._dtype_code = _native.TAVB_F16 if dtype == "fp16" else _native.TAVB_F32
+        with self.torch.cuda.stream(self.stream):
+            self.engine.ordinal_base = int(row_offset)
+            if rows.ndim == 2 and rows.shape[1] > 0:
+                self.engine.upload_rows(rows, 0, self._dtype_code, capacity_hint=2 * rows.shape[0])
+            else:
+                self.engine.clear()
+
+    def append_rows(self, rows: np.ndarray) -> None:
+        """Append host rows (float32 [n, dim]) to this rank's shard: only the new rows travel (capacity doubles; a shard adopted from the
+        caller's tensor is copied into a buffer of the backend's own first)."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        code = self.engine.dtype if self.engine.corpus is not None else getattr(self, "_dtype_code", _native.TAVB_F32)
+        with self.torch.cuda.stream(self.stream):
+            self.engine.upload_rows(rows, self.engine.rows if self.engine.corpus is not None else 0, code)
+
+    def rows_to_host(self) -> np.ndarray:
+        """This rank's rows as float32 [n, dim] (fp16 storage widened)."""
+        self.stream.synchronize()
+        if self.engine.corpus is None:
+            return np.zeros((0, 0), dtype=np.float32)
+        return self.engine.corpus[: self.engine.rows].float().cpu().numpy()
+
     # -- the forms beside the plain lookup: this shard's part, as keys that already carry GLOBAL positions / ordinals ----------------
     def local_search_subset(self, query: np.ndarray, local_rows: np.ndarray, positions: np.ndarray, k: int, thr: float):
         """rows of THIS shard (local numbering) that the caller's subset names, `positions[i]` = where local_rows[i] sits in the
@@ -236,8 +263,8 @@ class ShardedVectorBase:
     """VectorBase-shaped front end over a row-sharded corpus: every rank holds rows
     [row_offset, row_offset + local_rows) and every lookup is a collective call (all ranks pass the same
     query, all ranks get the same global answer).  Covers the lookup methods of the reference class
-    (`fuzzy_lookup_embedding`, `fuzzy_lookup_embeddings`, vectorbase.py:163-190); storage methods stay
-    per-rank on the local VectorBase (`.local`)."""
+    (vectorbase.py:163-230: plain, batched, predicate and subset forms) and its storage methods (`add_embedding(s)`: appends go to the
+    last rank's shard; `serialize` / `deserialize`: per-rank matrices; `clear`) -- all collective: every rank makes the same call."""
 
     def __init__(self, backend: ShardBackend, row_offset: int, local_rows: int, total_rows: int, group=None):
         self.backend = backend
@@ -251,6 +278,66 @@ class ShardedVectorBase:
 
     def __bool__(self) -> bool:
         return True
+
+    # ---- storage (collective: every rank makes the same call with the same arguments) ------------------------------------------------
+    @property
+    def _world(self) -> int:
+        return self.searcher.world
+
+    @property
+    def _rank(self) -> int:
+        return self.searcher.rank
+
+    def add_embeddings(self, keys, embeddings) -> None:
+        """vectorbase.py:130-148 over row shards: the new rows get the next global ordinals and go to the LAST rank's shard (contiguous
+        ranges stay contiguous; only that rank uploads anything, and only the new rows); every rank advances its row count.  `keys` is
+        accepted for signature compatibility (the reference caches key -> embedding in its model; there is no model here)."""
+        rows = np.asarray(embeddings, dtype=np.float32)
+        if rows.ndim != 2:
+            raise ValueError(f"Expected 2D embeddings array, got {rows.ndim}D")
+        if keys is not None and len(keys) != len(rows):
+            raise ValueError(f"Number of keys {len(keys)} does not match number of embeddings {len(rows)}")
+        if len(rows) == 0:
+            return
+        if self._rank == self._world - 1:
+            self.backend.append_rows(rows)
+            self.local_rows += len(rows)
+        self.total_rows += len(rows)
+
+    def add_embedding(self, key, embedding) -> None:
+        """vectorbase.py:115-128."""
+        row = np.asarray(embedding, dtype=np.float32)
+        if row.ndim == 1:
+            row = row[None, :]
+        if row.ndim != 2 or row.shape[0] != 1:
+            raise ValueError(f"Expected a single embedding, got shape {row.shape}")
+        self.add_embeddings(None if key is None else [key], row)
+
+    def serialize(self) -> np.ndarray:
+        """vectorbase.py:268-271, per rank: THIS rank's rows [row_offset, row_offset + local_rows) as a float32 matrix (a copy: the rows
+        live on the device); `row_offset`, `local_rows`, `total_rows` place it in the whole.  Concatenating the ranks' matrices in rank
+        order is the reference's `serialize()` of the whole index."""
+        return self.backend.rows_to_host()
+
+    def deserialize(self, local_data, dtype: str = "fp32") -> None:
+        """vectorbase.py:273-287, per rank: every rank hands in ITS rows (float32 [n_r, dim], None or empty for none); the ranks agree on
+        the offsets (an all-gather of the row counts over torch.distributed) and each uploads its own shard."""
+        rows = np.zeros((0, 0), dtype=np.float32) if local_data is None else np.asarray(local_data, dtype=np.float32)
+        if rows.ndim != 2:
+            raise ValueError(f"Expected 2D embeddings array, got {rows.ndim}D")
+        counts = [len(rows)]
+        if self._world > 1:
+            counts = [None] * self._world
+            self.searcher.dist.all_gather_object(counts, len(rows), group=self.searcher.group)
+        self.row_offset = int(sum(counts[: self._rank]))
+        self.local_rows = len(rows)
+        self.total_rows = int(sum(counts))
+        if rows.size or rows.shape[1] > 0:
+            self.backend.set_rows(rows, self.row_offset, dtype)
+
+    def clear(self) -> None:
+        """vectorbase.py:248-255."""
+        self.deserialize(None)
 
     @classmethod
     def from_device_shard(cls, device: int, shard_tensor, row_offset: int, total_rows: int, group=None):
