@@ -992,6 +992,7 @@ def main() -> None:
     ap.add_argument("--cfg5-separate", action="store_true", help="cfg5: issue the six lookups as separate synchronous calls")
     ap.add_argument("--min-score", type=float, default=0.0, help="score threshold of the lookups (0.0 = every row survives: worst case for selection; 0.85 = the reference's related-terms default)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (e.g. scan_unroll=4)")
+    ap.add_argument("--no-calibration", action="store_true", help="skip roofline.sustained (the MFMA-only ablation + vendor GEMM after the headline): counter passes want the lookups only")
     ap.add_argument("--class-api", action="store_true", help="also time the workload through VectorBase.fuzzy_lookup_embedding(s) (always on in the default suite)")
     ap.add_argument("--selftest", action="store_true", help="on a box with >= 2 GPUs: cfg3 strong scaling at N = 2 over RCCL with full parity, next to N = 1 (one JSON line); skipped on one GPU")
     args = ap.parse_args()
@@ -1039,7 +1040,7 @@ def main() -> None:
         corpus = gen_rows(ctx.eng, lo, hi, wl["dim"], wl["seed"], wl["dtype"], wl.get("kind", "gaussian"), wl["rows_total"])
     rec = run_record(ctx, name, wl, corpus, lo, steps, warmup, with_cpu=(ctx.world == 1))
     if ctx.world == 1 and not ctx.distributed and ctx.rank == 0 and not any(o.startswith("mfma_ablate") for o in args.opt):
-        if rec["roofline"]["bound"] == "mfma" and rec["roofline"]["kernel"] == "mfma_scan_kernel" and wl["dtype"] == "fp16":
+        if rec["roofline"]["bound"] == "mfma" and rec["roofline"]["kernel"] == "mfma_scan_kernel" and wl["dtype"] == "fp16" and not args.no_calibration:
             rec["roofline"]["sustained"] = sustained_calibration(ctx, wl, corpus, rec["roofline"]["kernel_ms_per_step"])
         if suite or args.class_api:
             rec["class_api"] = class_api_rates(ctx, wl, corpus, args.min_score, 5 if wl["nq"] > 1 else 50)

@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 /* bumped whenever an entry point, a signature, an option or a kernel id changes incompatibly; the binding refuses a library of another version */
-#define TAVB_ABI_VERSION 3
+#define TAVB_ABI_VERSION 4
 
 #define TAVB_OK 0
 #define TAVB_E_INVALID (-1)     /* bad argument */
@@ -284,6 +284,13 @@ int tavb_remap_key_positions(tavb_ctx* ctx, tavb_key* dev_keys, int64_t count, c
 int tavb_profile_enable(tavb_ctx* ctx, int32_t on);
 int tavb_profile_reset(tavb_ctx* ctx);
 int tavb_profile_read(tavb_ctx* ctx, int32_t kernel_id, double* out_total_ms, int64_t* out_launches);
+
+/* How the library scans a corpus of `rows` rows for a batch of `nq` (>= 65) queries on a part with `n_cu` compute units, with default
+ * options: the phase boundaries of the threshold ladder of the 128/256-query tile (phase i scans rows [out_bounds[i], out_bounds[i+1]);
+ * at most `cap` entries are written, out_bounds may be NULL).  Returns the number of phases = tile-kernel launches per lookup (> 0), or
+ * a negative error code.  No reference counterpart (the reference scans once, vectorbase.py:176); a pure function, needs no context and no
+ * GPU -- what lets a committed profile be checked against the code that ships (tests/test_bench_contract.py). */
+int tavb_plan_ladder(int64_t rows, int32_t nq, int32_t n_cu, int64_t* out_bounds, int32_t cap);
 
 #ifdef __cplusplus
 }

@@ -119,6 +119,12 @@ def test_committed_pmc_traffic_belongs_to_the_kernels_that_ship():
         for kern in entry["kernels"]:
             assert kern.encode() in lib, f"{name}: kernel {kern} is not in libtavb.so any more -- re-run the PMC pass"
         wl = bench.WORKLOADS[name]
+        # ... and the pass must have been made with the launch shape that ships: one tile-kernel launch per ladder phase (round 3's file
+        # was one commit behind the ladder: 4 launches per lookup in the file, 5 in the bench line)
+        launches = entry.get("launches_per_step")
+        assert launches, f"{name}: no launch counts (regenerate with tools/gpu_r4_pmc.sh)"
+        if "mfma_scan_kernel" in launches and wl["nq"] >= 65:
+            assert launches["mfma_scan_kernel"] == len(_native.plan_ladder(wl["rows"], wl["nq"])) - 1, f"{name}: the PMC pass ran another ladder"
         corpus_bytes = wl["rows"] * wl["dim"] * (2 if wl["dtype"] == "fp16" else 4)
         assert 0.9 <= entry["traffic_bytes_per_step"] / corpus_bytes <= 3.0, f"{name}: traffic is not of the order of this workload's corpus"
 

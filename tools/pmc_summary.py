@@ -48,8 +48,8 @@ def main() -> None:
     ap.add_argument("--cmd", default=None, help="the profiled command (for the header)")
     ap.add_argument("--json", default=None)
     ap.add_argument("--name", default=None)
-    ap.add_argument("--round", default="r03", help="prefix of the profiles/ file names this summary is committed under")
-    ap.add_argument("--script", default="tools/gpu_r3_pmc.sh")
+    ap.add_argument("--round", default="r04", help="prefix of the profiles/ file names this summary is committed under")
+    ap.add_argument("--script", default="tools/gpu_r4_pmc.sh")
     args = ap.parse_args()
     csv.field_size_limit(1 << 30)
     per = collections.defaultdict(lambda: collections.defaultdict(float))  # kernel -> counter -> sum
@@ -99,6 +99,8 @@ def main() -> None:
                     "source": f"rocprofv3 --pmc FETCH_SIZE --kernel-trace pass of `{args.cmd or 'bench.py'}` ({args.steps} lookups in the run), {args.script} + tools/pmc_summary.py, profiles/{args.round}_pmc_{args.name}_fetch.md",
                     # the kernels the sum runs over: tests/test_bench_contract.py checks that each still exists in libtavb.so (a stale file must not go unnoticed)
                     "kernels": lookup_kernels,
+                    # launches of each lookup kernel per lookup (the tile kernel: one per ladder phase -- checked against tavb_plan_ladder() by the same test)
+                    "launches_per_step": {kb: round(sum(len(disp[k]) for k in per if kernel_base(k) == kb) / args.steps, 4) for kb in lookup_kernels},
                 }
                 json.dump(blob, open(args.json, "w"), indent=1)
 

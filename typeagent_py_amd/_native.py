@@ -16,7 +16,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 
 import numpy as np
 
-ABI_VERSION = 3  # include/tavb.h TAVB_ABI_VERSION this binding was written against
+ABI_VERSION = 4  # include/tavb.h TAVB_ABI_VERSION this binding was written against
 TAVB_F32 = 0
 TAVB_F16 = 1
 MAX_FUSED_K = 256
@@ -75,9 +75,20 @@ _SIGNATURES = [
     ("tavb_profile_enable", c_int, [c_void_p, c_int32]),
     ("tavb_profile_reset", c_int, [c_void_p]),
     ("tavb_profile_read", c_int, [c_void_p, c_int32, POINTER(c_double), POINTER(c_int64)]),
+    ("tavb_plan_ladder", c_int, [c_int64, c_int32, c_int32, POINTER(c_int64), c_int32]),
 ]
 
 ABI_SYMBOLS = [name for name, _, _ in _SIGNATURES]
+
+
+def plan_ladder(rows: int, nq: int, n_cu: int = 256) -> list[int]:
+    """Phase boundaries of the threshold ladder the library runs for a batch of `nq` (>= 65) queries over `rows` rows with default options
+    (tavb_plan_ladder): len(result) - 1 = tile-kernel launches per lookup.  Needs no GPU."""
+    lib = load_library(preload_torch=False)
+    buf = (c_int64 * 16)()
+    n = lib.tavb_plan_ladder(int(rows), int(nq), int(n_cu), buf, 16)
+    _check(lib, n if n < 0 else 0)
+    return [int(buf[i]) for i in range(n + 1)]
 
 
 def library_path() -> str:

@@ -1396,6 +1396,39 @@ struct TileRun {
   int* verdict;           // device [nq]: out, 1 where the band handed over is not provably complete
 };
 
+// Phase boundaries of the threshold ladder (see run_tile_ladder): phase i scans rows [b[i], b[i+1]).  `sample_opt` / `growth` = the options
+// mfma_sample_rows (0 = auto, -1 = one phase) / mfma_ladder.  A pure function of its arguments: tavb_plan_ladder() hands it to callers that
+// want to know how many tile launches a lookup makes (tests/test_bench_contract.py checks the committed PMC pass against it).
+std::vector<int64_t> ladder_bounds(int64_t rows, int splits, bool skinny, bool ladder, int64_t sample_opt, int64_t growth) {
+  std::vector<int64_t> bounds;
+  bounds.push_back(0);
+  // first phase: `mfma_sample_rows`, or (0 = auto) part of ONE tile per workgroup of the 128/256-query kernel -- nothing compacts while
+  // everything is still being admitted, and every unfiltered row of this phase is a key the select kernel has to stream (one workgroup per
+  // QUERY).  Round 2 used two tiles per workgroup (40960 rows), round 3 one (20480: 4 % faster on a 1.25M-row shard, the same on 10M rows;
+  // profiles/r03_shard_ladder.md).  Round 4: with one LDS atomic per admitted row (tavb_mfma.hip) the all-admitted first phase is best kept
+  // to 32 ranges' worth, 10240 rows -- 1 % faster on the shard, the same on 10M rows, half the keys for the select kernel
+  // (profiles/r04_cfg3_kernel.md).  (The 32/64-query tile keeps round 2's 40960 rows.)
+  const int64_t auto_sample = skinny ? (int64_t)std::min(splits, 64) * 320 * 2 : (int64_t)std::min(splits, 32) * 320;
+  const int64_t sample = sample_opt > 0 ? (sample_opt + 255) / 256 * 256 : (sample_opt == 0 ? auto_sample : 0);
+  // 32/64-query tile on corpora of a few hundred thousand to ~2M rows: the default ladder's first phases are smaller than one tile per
+  // workgroup (40960 rows = 160 tiles for 512 resident workgroups) and each costs a launch + ~one tile time whatever its size; ONE seeding
+  // phase of exactly one tile per workgroup, then the rest, is faster (1M x 1536 fp32, 32 queries: 1.18 -> 1.07 ms of kernels per batch,
+  // profiles/r03_mid_batch.md); a single un-seeded phase is slower still (1.23 ms: every workgroup pays the cold start)
+  const int64_t one_tile_each = (int64_t)splits * 256;
+  if (ladder && skinny && sample_opt == 0 && rows >= 4 * one_tile_each && rows < 2048000) {
+    bounds.push_back(one_tile_each);
+  } else if (ladder && sample > 0 && rows >= 8 * sample) {
+    int64_t done = sample;
+    bounds.push_back(done);
+    while (growth > 0 && done * (growth + 1) * 2 <= rows && bounds.size() < 8) {
+      done += done * growth;
+      bounds.push_back(done);
+    }
+  }
+  bounds.push_back(rows);
+  return bounds;
+}
+
 // Threshold ladder.  The corpus is scanned in phases of growing size -- the first `mfma_sample_rows` rows, then
 // `mfma_ladder` times everything scanned so far, ..., then the rest -- every row exactly once.  After each phase the
 // exact top-k so far is merged; its k-th best score is a valid admission threshold for every later row (the k-th best
@@ -1437,34 +1470,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.skinny_tile = r.skinny ? r.qt : 0;
   p.wide_tile = r.skinny ? 0 : r.qt;
   p.active = r.active;
-  std::vector<int64_t> bounds;  // phase i scans rows [bounds[i], bounds[i+1])
-  bounds.push_back(0);
-  // first phase: `mfma_sample_rows`, or (0 = auto) ONE tile per workgroup of the 128/256-query kernel -- nothing compacts while everything is
-  // still being admitted, and every unfiltered row of this phase is a key the select kernel has to stream (one workgroup per QUERY: with one
-  // query tile there are 256 row ranges, hence the cap at 64 ranges' worth).  Round 2 used two tiles; one measured the same on the 10M-row
-  // corpus and 4 % faster on a 1.25M-row shard, where the fixed cost of the early phases is what limits strong scaling
-  // (profiles/r03_shard_ladder.md).
-  // Round 4: with one LDS atomic per admitted row (tavb_mfma.hip) the all-admitted first phase is best kept to 32 ranges' worth: 10240 rows --
-  // 1 % faster on a 1.25M-row shard, the same on 10M rows, and half the keys for the select kernel (profiles/r04_cfg3_kernel.md).
-  const int64_t auto_sample = r.skinny ? (int64_t)std::min(splits, 64) * 320 * 2 : (int64_t)std::min(splits, 32) * 320;  // (the 32/64-query tile keeps round 2's 40960 rows)
-  const int64_t sample = c->mfma_sample_rows > 0 ? (c->mfma_sample_rows + 255) / 256 * 256 : (c->mfma_sample_rows == 0 ? auto_sample : 0);
-  // 32/64-query tile on corpora of a few hundred thousand to ~2M rows: the default ladder's first phases are smaller than one tile per
-  // workgroup (40960 rows = 160 tiles for 512 resident workgroups) and each costs a launch + ~one tile time whatever its size; ONE seeding
-  // phase of exactly one tile per workgroup, then the rest, is faster (1M x 1536 fp32, 32 queries: 1.18 -> 1.07 ms of kernels per batch,
-  // profiles/r03_mid_batch.md); a single un-seeded phase is slower still (1.23 ms: every workgroup pays the cold start)
-  const int64_t one_tile_each = (int64_t)splits * 256;
-  if (r.ladder && r.skinny && c->mfma_sample_rows == 0 && c->rows >= 4 * one_tile_each && c->rows < 2048000) {
-    bounds.push_back(one_tile_each);
-  } else if (r.ladder && sample > 0 && c->rows >= 8 * sample) {
-    int64_t done = sample;
-    bounds.push_back(done);
-    const int64_t growth = c->mfma_ladder;
-    while (growth > 0 && done * (growth + 1) * 2 <= c->rows && bounds.size() < 8) {
-      done += done * growth;
-      bounds.push_back(done);
-    }
-  }
-  bounds.push_back(c->rows);
+  const std::vector<int64_t> bounds = ladder_bounds(c->rows, splits, r.skinny, r.ladder, c->mfma_sample_rows, c->mfma_ladder);  // phase i scans rows [bounds[i], bounds[i+1])
   const int n_phases = (int)bounds.size() - 1;
   const int kc = wide ? tavb::kBandMax : k;  // keys per query of the running selection between phases
   if (n_phases > 1) {
@@ -1695,3 +1701,14 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   }
   return search_device_impl(c, d_q, nq, k, min_scores, nullptr, c->rows, index_base, d_out);
 }
+
+extern "C" int tavb_plan_ladder(int64_t rows, int32_t nq, int32_t n_cu, int64_t* out_bounds, int32_t cap) {
+  if (rows < 0 || nq < 1 || n_cu < 8) return fail(TAVB_E_INVALID, "bad shape");
+  const int qt = tavb::mfma_query_tile(nq);
+  const int nq_pad = ((nq + qt - 1) / qt) * qt;
+  const int splits = tavb::mfma_pick_splits(rows, nq_pad, qt, n_cu);
+  const std::vector<int64_t> b = ladder_bounds(rows, splits, /*skinny=*/false, /*ladder=*/true, /*sample_opt=*/0, /*growth=*/4);
+  for (size_t i = 0; out_bounds && i < b.size() && (int)i < cap; ++i) out_bounds[i] = b[i];
+  return (int)b.size() - 1;
+}
+
