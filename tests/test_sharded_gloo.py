@@ -82,7 +82,8 @@ class HostStandInBackend:
 
     # storage hooks (same contracts as DeviceShardBackend's)
     def set_rows(self, rows, row_offset, dtype="fp32"):
-        self.shard = np.ascontiguousarray(rows, dtype=np.float32).reshape(len(rows), -1)
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        self.shard = rows if rows.ndim == 2 and rows.shape[1] > 0 else np.zeros((0, self.shard.shape[1]), dtype=np.float32)
         self.row_offset = int(row_offset)
 
     def append_rows(self, rows):

@@ -332,8 +332,7 @@ class ShardedVectorBase:
         self.row_offset = int(sum(counts[: self._rank]))
         self.local_rows = len(rows)
         self.total_rows = int(sum(counts))
-        if rows.size or rows.shape[1] > 0:
-            self.backend.set_rows(rows, self.row_offset, dtype)
+        self.backend.set_rows(rows, self.row_offset, dtype)  # (no rows: the backend drops its shard)
 
     def clear(self) -> None:
         """vectorbase.py:248-255."""
