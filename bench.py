@@ -63,6 +63,9 @@ WORKLOADS = {
     # the same shape on a CLUSTERED corpus (100-row clusters of near-duplicates incl. exact duplicates; every query sits next to a cluster
     # centre, so its top-64 spans < 2e-4 in score -- inside the fp16 filter's error bound): what real embedding corpora do to the wide tile
     "cfg3_clustered": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma", seed=10143, kind="clustered"),
+    # the duplication cliff: clusters of 1500 near-duplicates -- more than a band (1024 candidates) holds, so EVERY query is flagged and re-run
+    # exactly (the 256-query tile's split-plane form: twice the MFMAs of a filter pass on top of the filter pass itself)
+    "cfg3_dup": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma", seed=10243, kind="clustered", cluster_rows=1500),
     # the north star's single-query target on the cfg3 corpus: HBM-bound, 30.72 GB per query
     "cfg3_q1": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm", seed=10043),
     "cfg4": dict(rows=12_500_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma", seed=100043),  # PER GPU (weak scaling)
@@ -86,12 +89,12 @@ CLUSTER_SPREAD = 0.002  # |row - centre| before normalisation: scores inside a c
 CLUSTER_MULT = 7_368_787  # row -> cluster hash (a prime): the rows of a cluster are scattered over the whole corpus
 
 
-def cluster_centres(eng, rows_total: int, dim: int, seed: int):
-    """[rows_total // CLUSTER_ROWS, dim] fp32 unit vectors on the device (same on every rank: one seeded torch generator)."""
+def cluster_centres(eng, rows_total: int, dim: int, seed: int, cluster_rows: int = CLUSTER_ROWS):
+    """[rows_total // cluster_rows, dim] fp32 unit vectors on the device (same on every rank: one seeded torch generator)."""
     import torch
 
     dev = torch.device("cuda", eng.device)
-    n_c = max(1, rows_total // CLUSTER_ROWS)
+    n_c = max(1, rows_total // cluster_rows)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed * 1_000_003 + 999_983)
     c = torch.empty((n_c, dim), dtype=torch.float32, device=dev)
@@ -100,7 +103,7 @@ def cluster_centres(eng, rows_total: int, dim: int, seed: int):
     return c
 
 
-def gen_rows(eng, lo: int, hi: int, dim: int, seed: int, dtype: str, kind: str = "gaussian", rows_total: int | None = None):
+def gen_rows(eng, lo: int, hi: int, dim: int, seed: int, dtype: str, kind: str = "gaussian", rows_total: int | None = None, cluster_rows: int = CLUSTER_ROWS):
     """Rows [lo, hi) of the synthetic corpus `seed` as a device tensor (fp32 or fp16).  Chunk c (CHUNK_ROWS rows) is
     torch.randn with generator seed `seed * 1000003 + c`, L2-normalised by our K1 kernel and (fp16) rounded by our
     convert kernel, so every rank / the parity checker reproduce the same bytes for any row range.
@@ -112,7 +115,7 @@ def gen_rows(eng, lo: int, hi: int, dim: int, seed: int, dtype: str, kind: str =
     dev = torch.device("cuda", eng.device)
     out = torch.empty((hi - lo, dim), dtype=torch.float16 if dtype == "fp16" else torch.float32, device=dev)
     gen = torch.Generator(device=dev)
-    centres = cluster_centres(eng, rows_total if rows_total is not None else hi, dim, seed) if kind == "clustered" else None
+    centres = cluster_centres(eng, rows_total if rows_total is not None else hi, dim, seed, cluster_rows) if kind == "clustered" else None
     c = lo // CHUNK_ROWS
     while c * CHUNK_ROWS < hi:
         c_lo = c * CHUNK_ROWS
@@ -138,9 +141,9 @@ def gen_rows(eng, lo: int, hi: int, dim: int, seed: int, dtype: str, kind: str =
     return out
 
 
-def clustered_queries(eng, count: int, rows_total: int, dim: int, seed: int) -> np.ndarray:
+def clustered_queries(eng, count: int, rows_total: int, dim: int, seed: int, cluster_rows: int = CLUSTER_ROWS) -> np.ndarray:
     """`count` unit queries next to cluster centres of the clustered corpus `seed` (centre + 0.05 * noise: cosine ~0.9988 to the centre)."""
-    centres = cluster_centres(eng, rows_total, dim, seed)
+    centres = cluster_centres(eng, rows_total, dim, seed, cluster_rows)
     rng = np.random.default_rng(seed + 17)
     pick = rng.choice(centres.shape[0], size=count, replace=centres.shape[0] < count)
     q = centres[np.sort(pick)].cpu().numpy() + 0.05 * rng.standard_normal((count, dim)).astype(np.float32) / np.sqrt(dim)
@@ -163,7 +166,7 @@ def host_queries(count: int, dim: int, seed: int) -> np.ndarray:
 # ----------------------------------------------------------------------------------------------------------------
 # CPU legs: parity oracle and the reported baseline
 # ----------------------------------------------------------------------------------------------------------------
-def oracle_chunks(eng, resident, resident_lo: int, total_rows: int, dim: int, seed: int, dtype: str, kind: str = "gaussian"):
+def oracle_chunks(eng, resident, resident_lo: int, total_rows: int, dim: int, seed: int, dtype: str, kind: str = "gaussian", cluster_rows: int = CLUSTER_ROWS):
     """The whole corpus as float32 host chunks of ORACLE_CHUNK rows (fp16 values widened, as the kernels see them):
     rows this rank holds come from the resident tensor, the rest are regenerated on the device."""
     for lo in range(0, total_rows, ORACLE_CHUNK):
@@ -171,7 +174,7 @@ def oracle_chunks(eng, resident, resident_lo: int, total_rows: int, dim: int, se
         if resident is not None and lo >= resident_lo and hi <= resident_lo + resident.shape[0]:
             t = resident[lo - resident_lo : hi - resident_lo]
         else:
-            t = gen_rows(eng, lo, hi, dim, seed, dtype, kind, total_rows)
+            t = gen_rows(eng, lo, hi, dim, seed, dtype, kind, total_rows, cluster_rows)
         yield t.float().cpu().numpy()
 
 
@@ -221,7 +224,7 @@ def parity_check(eng, resident, resident_lo, wl, queries: np.ndarray, sample: li
 
     t0 = time.perf_counter()
     ref, referee = vo.scores_full_chunked_refereed(
-        oracle_chunks(eng, resident, resident_lo, wl["rows_total"], wl["dim"], wl["seed"], wl["dtype"], wl.get("kind", "gaussian")),
+        oracle_chunks(eng, resident, resident_lo, wl["rows_total"], wl["dim"], wl["seed"], wl["dtype"], wl.get("kind", "gaussian"), wl.get("cluster_rows", CLUSTER_ROWS)),
         queries[sample], [got[qi][0] for qi in sample], keep=wl["k"] + 256)
     tally = ParityTally()
     try:
@@ -397,7 +400,7 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     # identical on every rank; arbitrary fp32 values (not fp16-representable).  BATCH_ROTATION different batches take turns in the timed region.
     n_rot = BATCH_ROTATION if nq > 1 else 1
     if wl.get("kind") == "clustered":
-        queries = clustered_queries(eng, max(64, nq * n_rot), rows_total, dim, wl["seed"])
+        queries = clustered_queries(eng, max(64, nq * n_rot), rows_total, dim, wl["seed"], wl.get("cluster_rows", CLUSTER_ROWS))
         queries = queries[np.random.default_rng(7).permutation(len(queries))]  # (neighbouring clusters do not share a query tile)
     else:
         queries = host_queries(max(64, nq * n_rot), dim, 4242)
@@ -443,7 +446,14 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         one_step(n_w)
         n_w += 1
     warmup = n_w
-    # ---- the timed region: exactly `steps` steps, nothing instrumented
+    # ---- the timed region: exactly `steps` steps, nothing instrumented.  The interpreter's cyclic collector is held off for its duration (as
+    #      `timeit` does): a generation-2 collection over torch's module graph takes 30-40 ms -- one such pause inside a 60-step region of
+    #      3.6 ms steps reads as +17 % (found in round 4: the "sporadic host stalls" of the earlier rounds; whether one lands inside the region
+    #      depends on the allocation count up to it, i.e. on the command line).
+    import gc
+
+    gc.collect()
+    gc.disable()
     ctx.barrier()
     lat = []
     t0 = time.perf_counter()
@@ -454,6 +464,7 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     t_loop = time.perf_counter() - t0
     ctx.barrier()
     elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    gc.enable()
     if os.environ.get("TAVB_BENCH_DEBUG"):
         sys.stderr.write(f"[bench debug] {name}: loop {t_loop * 1e3:.2f} ms, sum of steps {sum(lat) / 1e3:.2f} ms, max step {max(lat) / 1e3:.3f} ms, "
                          f"closing barrier {(elapsed - t_loop) * 1e3:.2f} ms\n")
@@ -657,6 +668,9 @@ def class_api_rates(ctx: Ctx, wl: dict, corpus, min_score: float, steps: int) ->
         if nq == 1 and kw:
             continue
         call(0)
+        import gc
+
+        gc.collect()  # (the collector stays ON here: a consumer of the class runs with it; start from a clean slate so that no old garbage is billed to these calls)
         t0 = time.perf_counter()
         for i in range(steps):
             call(1 + i)
@@ -773,6 +787,10 @@ def run_cfg5(args, wl, emit: bool = True, steps: int | None = None, warmup: int 
     for i in range(warmup):
         one(i)
     torch.cuda.synchronize()
+    import gc
+
+    gc.collect()
+    gc.disable()  # (as in run_record: no generation-2 collection inside the timed region)
     lat = []
     t0 = time.perf_counter()
     for i in range(steps):  # the timed region: un-instrumented
@@ -781,6 +799,7 @@ def run_cfg5(args, wl, emit: bool = True, steps: int | None = None, warmup: int 
         lat.append((time.perf_counter_ns() - s0) / 1e3)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if not args.cfg5_separate:  # the same steps again with HIP event pairs around the launches (kernel times)
         eng.profile_enable(True)
         eng.profile_reset()
@@ -1037,7 +1056,7 @@ def main() -> None:
     torch = ctx.torch
     stream_ctx = torch.cuda.stream(ctx.backend.stream) if ctx.backend is not None else torch.cuda.stream(torch.cuda.current_stream(ctx.dev))
     with stream_ctx:
-        corpus = gen_rows(ctx.eng, lo, hi, wl["dim"], wl["seed"], wl["dtype"], wl.get("kind", "gaussian"), wl["rows_total"])
+        corpus = gen_rows(ctx.eng, lo, hi, wl["dim"], wl["seed"], wl["dtype"], wl.get("kind", "gaussian"), wl["rows_total"], wl.get("cluster_rows", CLUSTER_ROWS))
     rec = run_record(ctx, name, wl, corpus, lo, steps, warmup, with_cpu=(ctx.world == 1))
     if ctx.world == 1 and not ctx.distributed and ctx.rank == 0 and not any(o.startswith("mfma_ablate") for o in args.opt):
         if rec["roofline"]["bound"] == "mfma" and rec["roofline"]["kernel"] == "mfma_scan_kernel" and wl["dtype"] == "fp16" and not args.no_calibration:

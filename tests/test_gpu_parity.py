@@ -946,6 +946,41 @@ def test_wide_tile_falls_back_to_the_exact_tile_when_the_band_overflows():
     assert len(out2[3]) == k and len(out2[2]) == 0
 
 
+def test_many_flagged_queries_take_the_wide_exact_fallback():
+    """The duplication cliff, bounded: when MANY queries of a batch (> 64) have more near-duplicates than a band holds, they are re-run on the
+    256-query tile's exact form (fp32 queries as two fp16 planes, the K loop once per plane) instead of 64 at a time on the 64-query exact
+    tile.  100 of 256 queries get 1100 near-duplicate rows each (a band holds 1024): all are flagged; answers are the oracle's either way
+    (`wide_fallback=0`: the 64-query tile, two passes)."""
+    n, nq, k = 130_000, 256, 32
+    v, _ = make_corpus(n, 1536, 8500)
+    qs = make_queries(nq, 1536, 8501)
+    rng = np.random.default_rng(8502)
+    rows = rng.permutation(n)[: 100 * 1100].reshape(100, 1100)
+    for j in range(100):
+        _plant_near_duplicates(v, qs, 2 * j + 1, rows[j], rng)
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    v16 = _f16(v)
+    probe = [0, 1, 3, 77, 101, 199, 200, 255]
+    outs = {}
+    for mode in (1, 0):
+        eng.set_option("wide_fallback", mode)
+        out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+        assert eng.get_option("last_tier") == 4
+        assert 100 <= eng.get_option("last_flagged") <= 160  # (a few more: buffers of other queries that overflowed on the planted rows inside one row range)
+        for qi in probe:
+            vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
+            if qi % 2 == 1 and qi < 200:
+                assert set(r.item for r in out[qi]) <= set(rows[qi // 2].tolist())  # the flagged queries' hits are their planted rows
+        outs[mode] = out
+    for qi in probe:  # the two exact tiles agree up to float32 near-ties
+        np.testing.assert_allclose([r.score for r in outs[1][qi]], [r.score for r in outs[0][qi]], atol=1e-6, rtol=0)
+    # a threshold above the un-planted queries' scores: only the flagged ones return anything, through the same path
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.7)
+    assert len(out[0]) == 0 and len(out[1]) == k
+    vo.check_topk_parity(vo.scores_full(v16, qs[1]), *items_scores(out[1]), k, 0.7, referee=vo.f64_referee(v16, qs[1]))
+
+
 @pytest.mark.parametrize("sample", [-1, 20480, 0])
 def test_wide_tile_band_overflow_inside_one_row_range(sample):
     """900 near-duplicates in CONSECUTIVE rows: one workgroup's candidate buffer (1024 keys) cannot hold the band while it walks its

@@ -140,6 +140,7 @@ struct tavb_ctx {
   Buffer h_stage{nullptr, 0, true};
   Buffer h_out{nullptr, 0, true};  // pinned + device-visible: the last kernel of a synchronous lookup writes its keys straight here
   Buffer h_lists{nullptr, 0, true};  // pinned + device-visible: per-workgroup lists of a small single-query lookup (merged on the host)
+  int64_t wide_fallback = 1;  // option: batches of 256+ queries re-run MANY (> 64) flagged queries on the 256-query tile's exact (split-plane) form
   int64_t small_direct_bytes = (int64_t)128 << 20;  // option: single-query lookups on corpora up to this size take the one-launch path (0 = never)
   int64_t last_direct = 0;                          // option "last_direct" (get): 1 when the last lookup took it
 
@@ -485,6 +486,8 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");
     c->mfma_splits = v;
+  } else if (n == "wide_fallback") {
+    c->wide_fallback = v ? 1 : 0;
   } else if (n == "small_direct_bytes") {
     if (v < 0) return fail(TAVB_E_INVALID, "small_direct_bytes must be >= 0");
     c->small_direct_bytes = v;
@@ -523,6 +526,7 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "compute_units") *out = c->n_cu;
   else if (n == "comm_force") *out = c->comm_force;
   else if (n == "small_direct_bytes") *out = c->small_direct_bytes;
+  else if (n == "wide_fallback") *out = c->wide_fallback;
   else if (n == "last_direct") *out = c->last_direct;
   else if (n == "graph_max_bytes") *out = c->graph_max_bytes;
   else if (n == "last_graph") *out = c->last_graph;
@@ -1388,6 +1392,8 @@ struct TileRun {
   const void* queries;    // operand in the kernel's layout
   const void* corpus;     // corpus operand (nullptr: the context's corpus; the fp16 shadow of an fp32 corpus for the filter pass)
   const int* active;      // optional device-side live-query count (fixed-shape launch over a work list)
+  int active_min, active_max;  // ... served only when active_min < *active <= active_max (0 = no upper bound): two fallbacks share one list
+  int64_t split_plane;    // 128/256-query tile: > 0 = exact form, `queries` = [2][nq_pad][dim] fp16 planes this many bytes apart (final scores, no band)
   bool ladder;            // scan in phases of growing size (else one phase)
   // 128/256-query tile only: band selection (tavb_mfma.hip::select_band_kernel).  d_out then receives [nq, kBandMax] unsorted keys,
   const float* band;      // device [nq_pad]: width of the band below the k-th best
@@ -1470,10 +1476,13 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.skinny_tile = r.skinny ? r.qt : 0;
   p.wide_tile = r.skinny ? 0 : r.qt;
   p.active = r.active;
+  p.active_min = r.active_min;
+  p.active_max = r.active_max;
+  p.split_plane = r.split_plane;
   const std::vector<int64_t> bounds = ladder_bounds(c->rows, splits, r.skinny, r.ladder, c->mfma_sample_rows, c->mfma_ladder);  // phase i scans rows [bounds[i], bounds[i+1])
   const int n_phases = (int)bounds.size() - 1;
   const int kc = wide ? tavb::kBandMax : k;  // keys per query of the running selection between phases
-  if (n_phases > 1) {
+  if (n_phases > 1 || (wide && r.active)) {
     if (int rc = c->d_thr.reserve((size_t)r.nq_pad * sizeof(float))) return rc;
     if (int rc = c->d_sample_keys.reserve((size_t)2 * nq * kc * sizeof(u64_t) + (size_t)2 * nq * sizeof(int))) return rc;  // running selection: two copies (ping-pong) + counts
   }
@@ -1508,13 +1517,20 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
       if (e != hipSuccess) return fail(TAVB_E_HIP, "mfma scan launch failed (phase %d): %s", ph, hipGetErrorString(e));
     }
     if (wide) {
-      Timed t(c, TAVB_KERNEL_MERGE);
+      Timed t(c, r.active ? TAVB_KERNEL_RESCORE : TAVB_KERNEL_MERGE);
       float* d_thr = reinterpret_cast<float*>(c->d_thr.ptr);
       if (!last) TAVB_HIP(hipMemsetAsync(d_thr, 0xFF, (size_t)r.nq_pad * sizeof(float), c->stream));  // padding queries: NaN bits, ignored by `>`
+      // a work-list run (r.active: the SPLIT fallback) ends in its own band buffer; the strict best k of it is scattered to the callers' rows below
+      u64_t* const last_out = r.active ? run_out : d_out;
+      int* const last_cnt = r.active ? cnt_out : r.band_cnt;
       hipError_t e = tavb::launch_select_band(pp.workspace, pp.counts, pp.n_splits, nq, r.nq_pad, k, kc, carried ? run_in : nullptr, carried ? cnt_in : nullptr,
-                                              floor, r.band, last ? d_out : run_out, last ? r.band_cnt : cnt_out, last ? nullptr : d_thr, r.lost,
-                                              last ? r.verdict : nullptr, c->stream);
+                                              floor, r.band, last ? last_out : run_out, last ? last_cnt : cnt_out, last ? nullptr : d_thr, r.lost,
+                                              last ? r.verdict : nullptr, c->stream, r.active, r.active_min, r.active_max > 0 ? r.active_max : 0x7fffffff);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "select launch failed: %s", hipGetErrorString(e));
+      if (last && r.active) {
+        e = tavb::launch_finalize_strict(last_out, last_cnt, kc, nq, k, r.active, r.active_min, r.active_max > 0 ? r.active_max : 0x7fffffff, scatter, d_out, c->stream);
+        if (e != hipSuccess) return fail(TAVB_E_HIP, "finalize launch failed: %s", hipGetErrorString(e));
+      }
     } else if (last) {
       Timed t(c, r.active ? TAVB_KERNEL_RESCORE : TAVB_KERNEL_MERGE);
       hipError_t e = scatter ? tavb::launch_merge_scatter(pp.lists, pp.list_stride, nq, k, r.active, scatter, d_out, c->stream)
@@ -1542,7 +1558,12 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   const bool f32c = (c->dtype == TAVB_F32);
   const int qt = small ? tavb::skinny_query_tile(nq) : (c->mfma_tile > 0 ? (int)c->mfma_tile : tavb::mfma_query_tile(nq));
   const int nq_pad = ((nq + qt - 1) / qt) * qt;
-  const int cap = ((nq + 63) / 64) * 64;  // slots of the work list of queries that need the exact tile
+  // Work list of queries that need an exact pass (a band that did not fit).  Few of them (<= 64): ONE pass of the 64-query exact tile.  Many: the
+  // 256-query tile in its SPLIT form (fp32 queries as two fp16 planes, the K loop run once per plane: twice the MFMAs of a filter pass, exact) --
+  // 16 passes of the 64-query tile per 1024 flagged queries otherwise (round 2-3: "stated, not solved").  Both are fixed-shape
+  // launches over the same device-side list and return at once when it is empty or is the other one's share.
+  const bool wide_fallback = !small && !f32c && nq >= 256 && c->wide_fallback;
+  const int cap = wide_fallback ? ((nq + 255) / 256) * 256 : ((nq + 63) / 64) * 64;  // slots of the work list
   const size_t q16_bytes = (size_t)nq_pad * c->dim * 2 * (small ? 2 : 1);  // small: high and low plane
   if (int rc = c->d_queries_f16.reserve(q16_bytes)) return rc;
   if (int rc = c->d_delta.reserve((size_t)nq_pad * 6 * sizeof(float))) return rc;  // delta, the relaxed thresholds, the band widths; band counts, lost levels, verdicts
@@ -1629,8 +1650,29 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
     ex.floor = fb_thr;
     ex.queries = fb;
     ex.active = d_nflag;
+    ex.active_min = 0;
+    ex.active_max = wide_fallback ? 64 : 0;
     ex.ladder = false;
     if (int rc = run_tile_ladder(c, ex, d_out, d_flagged)) return rc;
+    if (wide_fallback) {
+      TileRun wx{};
+      wx.skinny = false;
+      wx.q32 = false;
+      wx.qt = 256;
+      wx.nq = cap;
+      wx.nq_pad = cap;
+      wx.k = k;
+      wx.index_base = index_base;
+      wx.kernel_min_score = min_score;
+      wx.floor = fb_thr;  // (+inf for the unused slots: they admit nothing)
+      wx.queries = fb;    // [2][cap][dim]: the high plane, then the low plane
+      wx.split_plane = (int64_t)cap * c->dim * 2;
+      wx.active = d_nflag;
+      wx.active_min = 64;
+      wx.active_max = 0;
+      wx.ladder = true;
+      if (int rc = run_tile_ladder(c, wx, d_out, d_flagged)) return rc;
+    }
   }
   return TAVB_OK;
 }

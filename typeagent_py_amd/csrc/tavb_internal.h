@@ -96,7 +96,10 @@ struct MfmaParams {
   int32_t sched;     // measurement: staging schedule of the 256-query tile (1, 2); 9 = 64-byte K steps in the 32/64-query tile
   int32_t ablate;    // measurement only (garbage results): see launch_mfma_scan
   const float* thr_in;  // optional per-query admission thresholds (device, [nq_padded]) from the earlier ladder phases
-  const int* active;    // skinny kernel only, optional: device-side count of live queries (query tiles past it return at once)
+  const int* active;    // optional: device-side count of live queries (query tiles past it return at once) -- a fixed-shape launch over a work list
+  int32_t active_min;   // ... and the whole launch returns at once unless active_min < *active <= active_max (0 = no upper bound)
+  int32_t active_max;
+  int64_t split_plane;  // 256-query kernel only: > 0 = the SPLIT form, queries = [2][nq_padded][dim] fp16 planes this many bytes apart (q = hi + lo)
   int32_t f32;          // skinny kernel only: corpus and queries are fp32 (else fp16)
   int32_t skinny_tile;  // skinny kernel only: queries per tile, 32 or 64
   int32_t wide_tile;    // 128/256-query kernel only: queries per tile, 128 or 256 (0 = 256)
@@ -116,7 +119,11 @@ size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide);
 constexpr int kBandMax = 1024;  // candidates per query the rescoring accepts (kc_max; also the most the select kernel's cache keeps when it cuts mid-stream)
 hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
-                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream);
+                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream, const int* active = nullptr,
+                              int active_min = 0, int active_max = 0x7fffffff);
+// strict best k (ties by ordinal) of every live slot's band, sorted, into row scatter[slot] of out: the last step of the SPLIT fallback
+hipError_t launch_finalize_strict(const unsigned long long* band_keys, const int* band_cnt, int kc, int nq, int k, const int* active, int active_min,
+                                  int active_max, const int* scatter, unsigned long long* out, hipStream_t stream);
 // 32-query tiles at HBM speed, fp32 or fp16 corpora (same parameter block; `queries` in the corpus dtype)
 hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream);
 int skinny_query_tile(int nq);  // 32, or 64 for batches of 33 and more

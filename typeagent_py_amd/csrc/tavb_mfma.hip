@@ -74,6 +74,9 @@ struct MfmaDeviceParams {
   float min_score;
   const float* thr_in;  // optional [nq_padded] admission thresholds from a sample pass (exclusive bound)
   const int* active;    // optional: number of live queries, read on the device; query tiles past it return at once
+  int32_t active_min;   // ... and the launch as a whole returns at once unless active_min < *active <= active_max (two fallbacks share one work list)
+  int32_t active_max;
+  int64_t split_plane;  // 256-query tile, SPLIT form: bytes from the high to the low plane of the queries ([2][nq_padded][dim] fp16); 0 otherwise
   const float* band;    // 128/256-query tile, optional [nq_padded]: keep every key within band[q] below the k-th best (band selection)
   unsigned* lost;       // ... [nq_padded]: atomicMax of the score bits below which a query LOST band rows (a band that did not fit a buffer)
 };
@@ -389,7 +392,10 @@ constexpr int staging_piece_at(int q, int i) {
   return -1;
 }
 
-template <int ABL, int NI, int N3, int N0, int N1>
+// SPLIT: the queries arrive as TWO fp16 planes (q = hi + lo to 2^-22) and a tile runs its K loop twice over the corpus rows, once per plane, into
+// the same accumulators: fp32 query x fp16 row like the 64-query exact tile, at the wide tile's rate -- the bounded fallback for batches in which
+// MANY queries have more near-duplicates than a band holds (tavb_rescore.hip).  Twice the MFMAs; only this instantiation pays for it.
+template <int ABL, int NI, int N3, int N0, int N1, bool SPLIT = false>
 __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p) {
   using G = WideGeom<NI>;
   constexpr int BN = G::QT, NT = G::NT, SLOT_B6 = G::SLOT_B, CTRL6 = G::CTRL, PIECES_B6 = G::PIECES_B, PIECES6 = G::PIECES, RA = G::RA, B_RING6 = G::B_RING;
@@ -412,6 +418,10 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   const int qtile = t % p.n_qtiles;
   const int split = (t / p.n_qtiles) * 8 + xcd;
   if (split >= p.n_splits) return;
+  if (p.active != nullptr) {  // fixed-shape launch over a device-side work list (tavb_rescore.hip): nothing to do, or not this kernel's share
+    const int live = *p.active;
+    if (live <= p.active_min || live > p.active_max || qtile * BN >= live) return;
+  }
   const int64_t r_begin = (int64_t)split * p.rows_per_split;
   const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
   const int logical_block = split * p.n_qtiles + qtile;
@@ -432,7 +442,8 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   if (tid == 0) *need_compact = 0;
 
   const int D = p.dim;
-  const int steps_per_tile = D / 64;
+  const int steps_per_plane = D / 64;
+  const int steps_per_tile = SPLIT ? 2 * steps_per_plane : steps_per_plane;
   const uint32_t row_bytes = (uint32_t)D * 2u;
   const char* corpus = reinterpret_cast<const char*>(p.corpus);
   const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * BN * row_bytes;
@@ -459,7 +470,9 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
     a_lane = (uint32_t)((wm * 160 + frag_row) * 128);              // + mi * 4096
     b_lane = (uint32_t)(B_RING6 + (wn * G::WQ + frag_row) * 128);    // + ni * 4096
   }
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sgpr_ptr(qbase)), 0, (int)(BN * row_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sgpr_ptr(qbase)), 0, (int)(BN * row_bytes) + (SPLIT ? (int)p.split_plane : 0), 0x00020000);
+  const int plane_jump = SPLIT ? (int)p.split_plane - steps_per_plane * 128 : 0;  // K step s >= steps_per_plane reads step s - steps_per_plane of the low plane
 
   // ---- stager.  A "round" is what one K step issues: two slots deep (256-query tile) round S = corpus slab S + 1 then query
   //      slab S + 1; three corpus slots deep (128-query tile) round S = query slab S + 1 FIRST, then corpus slab S + 2, so that
@@ -477,7 +490,8 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
         const_cast<char*>(sgpr_ptr(corpus + (size_t)row0 * row_bytes)), 0, __builtin_amdgcn_readfirstlane(valid * (int)row_bytes), 0x00020000);
     const int pc = wave * PIECES_A6 + J;
     unsigned char* la = smem + sa_slot * SLOT_A6 + pc * 1024;
-    const int soff = __builtin_amdgcn_readfirstlane(sa_kt * 128 + pc * 8 * (int)row_bytes);
+    const int a_kt = (SPLIT && sa_kt >= steps_per_plane) ? sa_kt - steps_per_plane : sa_kt;  // second plane: the same corpus columns again
+    const int soff = __builtin_amdgcn_readfirstlane(a_kt * 128 + pc * 8 * (int)row_bytes);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)la, 16, (J & 1) ? st_odd : st_even, soff, 0, 0);
     if constexpr (J == PIECES_A6 - 1) {
       sa_slot = (sa_slot + 1 == RA) ? 0 : sa_slot + 1;
@@ -490,7 +504,8 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
     constexpr int BJ = decltype(j_tag)::value;
     const int pc = wave * PIECES_B6 + BJ;
     unsigned char* lb = smem + B_RING6 + sb_slot * SLOT_B6 + pc * 1024;
-    const int soff = __builtin_amdgcn_readfirstlane(((ABL & 8) ? 0 : sb_kt * 128) + pc * 8 * (int)row_bytes);  // ablation 8: the query operand's K step 0 every time (cache resident)
+    const int soff = __builtin_amdgcn_readfirstlane(((ABL & 8) ? 0 : sb_kt * 128 + ((SPLIT && sb_kt >= steps_per_plane) ? plane_jump : 0)) +
+                                                    pc * 8 * (int)row_bytes);  // ablation 8: the query operand's K step 0 every time (cache resident)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void*)lb, 16, (BJ & 1) ? st_odd : st_even, soff, 0, 0);
     if constexpr (BJ == PIECES_B6 - 1) {
       sb_slot ^= 1;
@@ -798,7 +813,10 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
   const int qtile = t % p.n_qtiles;
   const int split = (t / p.n_qtiles) * 8 + xcd;
   if (split >= p.n_splits) return;
-  if (p.active != nullptr && qtile * SQ >= *p.active) return;  // fixed-shape launch over a device-side work list (tavb_rescore.hip)
+  if (p.active != nullptr) {  // fixed-shape launch over a device-side work list (tavb_rescore.hip)
+    const int live = *p.active;
+    if (live <= p.active_min || live > p.active_max || qtile * SQ >= live) return;
+  }
   const int64_t r_begin = (int64_t)split * p.rows_per_split;
   const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
   const int logical_block = split * p.n_qtiles + qtile;
@@ -1071,7 +1089,11 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
                                                           int kc_max, const u64* __restrict__ carried, const int* __restrict__ carried_cnt,
                                                           const float* __restrict__ floor, const float* __restrict__ band, u64* __restrict__ out,
                                                           int* __restrict__ out_cnt, float* __restrict__ thr_out, unsigned* __restrict__ lost,
-                                                          int* __restrict__ verdict) {
+                                                          int* __restrict__ verdict, const int* __restrict__ active, int active_min, int active_max) {
+  if (active != nullptr) {  // fixed-shape launch over a device-side work list: slots past it (or a list that is not this fallback's share) have no buffers
+    const int live = *active;
+    if (live <= active_min || live > active_max || (int)blockIdx.x >= live) return;
+  }
   extern __shared__ __align__(16) unsigned char sel_smem[];
   u64* cache = reinterpret_cast<u64*>(sel_smem);  // [SEL_CACHE]
   __shared__ int off[260];  // exclusive prefix of the per-split counts (+ the carried band as one more "split")
@@ -1323,15 +1345,37 @@ size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide) {
   return (size_t)n_splits * (size_t)nq_padded * (wide ? CAPW : CAP) * sizeof(u64);
 }
 
+// The strict best k of every live slot's band (<= kBandMax unsorted keys; ties by ordinal), sorted, scattered to row scatter[slot] of `out`:
+// the last step of the SPLIT fallback, whose scores are final.  One wave per slot.
+__global__ void __launch_bounds__(64) finalize_strict_kernel(const u64* __restrict__ band_keys, const int* __restrict__ band_cnt, int kc, int k,
+                                                             const int* __restrict__ active, int active_min, int active_max,
+                                                             const int* __restrict__ scatter, u64* __restrict__ out) {
+  const int live = *active;
+  const int slot = blockIdx.x;
+  if (live <= active_min || live > active_max || slot >= live) return;
+  const int lane = threadIdx.x;
+  const int n = band_cnt[slot];
+  const WaveTopK<1> best = best_of_buffer(band_keys + (size_t)slot * kc, n < kc ? n : kc, lane);
+  if (lane < k) out[(size_t)scatter[slot] * k + lane] = best.key[0];
+}
+
+hipError_t launch_finalize_strict(const unsigned long long* band_keys, const int* band_cnt, int kc, int nq, int k, const int* active, int active_min,
+                                  int active_max, const int* scatter, unsigned long long* out, hipStream_t stream) {
+  if (nq < 1 || k < 1 || k > 64 || !active || !scatter) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(finalize_strict_kernel, dim3(nq), dim3(64), 0, stream, band_keys, band_cnt, kc, k, active, active_min, active_max, scatter, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
-                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream) {
+                              int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream, const int* active, int active_min,
+                              int active_max) {
   if (nq < 1 || k < 1 || k > 64 || n_splits < 1 || n_splits > 256 || nq_padded < nq || kc_max < k || kc_max > SEL_CACHE / 4) return hipErrorInvalidValue;
   constexpr int lds = SEL_CACHE * (int)sizeof(u64);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(select_band_kernel, dim3(nq), dim3(256), lds, stream, cand, counts, n_splits, nq_padded, k, kc_max, carried, carried_cnt, floor, band,
-                     out, out_cnt, thr_out, lost, verdict);
+                     out, out_cnt, thr_out, lost, verdict, active, active_min, active_max);
   return hipGetLastError();
 }
 
@@ -1354,6 +1398,10 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.thr_in = p.thr_in;
   d.band = p.band;
   d.lost = p.lost;
+  d.active = p.active;
+  d.active_min = p.active_min;
+  d.active_max = p.active_max > 0 ? p.active_max : 0x7fffffff;
+  d.split_plane = p.split_plane;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
   const int bm = BM6;
   d.rows_per_split = ((per + bm - 1) / bm) * bm;
@@ -1373,6 +1421,10 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   {
     if (p.dim % 64 != 0) return hipErrorInvalidValue;
     constexpr int LDS256 = WideGeom<4>::LDS, LDS128 = WideGeom<2>::LDS;
+    if (p.split_plane > 0) {
+      if (tile != BN) return hipErrorInvalidValue;
+      return go(mfma_scan_kernel<0, 4, 8, 6, 4, true>, NT6, LDS256);
+    }
     if (tile == 128) return go(mfma_scan_kernel<0, 2, 6, 4, 4>, NT6, LDS128);
     switch (p.ablate) {
       case 256: return go(mfma_scan_kernel<256, 4, 8, 6, 4>, NT6, LDS256);  // everything except admissions
@@ -1442,6 +1494,8 @@ hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
   d.min_score = p.min_score;
   d.thr_in = p.thr_in;
   d.active = p.active;
+  d.active_min = p.active_min;
+  d.active_max = p.active_max > 0 ? p.active_max : 0x7fffffff;
   d.cand = p.workspace;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
   d.rows_per_split = ((per + BM - 1) / BM) * BM;
