@@ -985,9 +985,8 @@ def test_many_flagged_queries_take_the_wide_exact_fallback():
 def test_wide_tile_band_overflow_inside_one_row_range(sample):
     """900 near-duplicates in CONSECUTIVE rows: one workgroup's candidate buffer (1024 keys) cannot hold the band while it walks its
     row range -- the in-kernel compaction falls back to the strict best k and flags the query; everything else stays on the band path.
-    (Whether a buffer overflows depends on how the rows fall into row ranges: one un-seeded phase and round 3's ladder geometry put
-    enough of the 900 into one range; with the default ladder the ranges of the last phase are 640 rows and nothing overflows -- the
-    answers are exact either way.)"""
+    (Whether a buffer overflows depends on how the rows fall into row ranges: one un-seeded phase and a first phase of 20480 rows put
+    enough of the 900 into one range; the default ladder's geometry is free to change -- the answers are exact either way.)"""
     n, nq, k = 200_000, 130, 32
     v, _ = make_corpus(n, 1536, 7320)
     qs = make_queries(nq, 1536, 7321)
@@ -997,7 +996,7 @@ def test_wide_tile_band_overflow_inside_one_row_range(sample):
     vb.engine.set_option("mfma_sample_rows", sample)
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     assert vb.engine.get_option("last_tier") == 4
-    assert vb.engine.get_option("last_flagged") == (0 if sample == 0 else 1)
+    assert vb.engine.get_option("last_flagged") in ((0, 1) if sample == 0 else (1,))  # (default ladder: whatever its geometry makes of it)
     v16 = _f16(v)
     for qi in [0, 4, 5, 6, 129]:
         vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))

@@ -100,7 +100,10 @@ def main() -> None:
                     # the kernels the sum runs over: tests/test_bench_contract.py checks that each still exists in libtavb.so (a stale file must not go unnoticed)
                     "kernels": lookup_kernels,
                     # launches of each lookup kernel per lookup (the tile kernel: one per ladder phase -- checked against tavb_plan_ladder() by the same test)
-                    "launches_per_step": {kb: round(sum(len(disp[k]) for k in per if kernel_base(k) == kb) / args.steps, 4) for kb in lookup_kernels},
+                    # (the SPLIT instantiation of the tile kernel -- the exact fallback, launched per ladder phase and returning at once when no query is
+                    #  flagged -- is counted apart: `..., true>` in the demangled name)
+                    "launches_per_step": {kb + suffix: round(sum(len(disp[k]) for k in per if kernel_base(k) == kb and (", true>" in k) == (suffix != "")) / args.steps, 4)
+                                          for kb in lookup_kernels for suffix in ("", "_split") if any(kernel_base(k) == kb and (", true>" in k) == (suffix != "") for k in per)},
                 }
                 json.dump(blob, open(args.json, "w"), indent=1)
 

@@ -1405,7 +1405,7 @@ struct TileRun {
 // Phase boundaries of the threshold ladder (see run_tile_ladder): phase i scans rows [b[i], b[i+1]).  `sample_opt` / `growth` = the options
 // mfma_sample_rows (0 = auto, -1 = one phase) / mfma_ladder.  A pure function of its arguments: tavb_plan_ladder() hands it to callers that
 // want to know how many tile launches a lookup makes (tests/test_bench_contract.py checks the committed PMC pass against it).
-std::vector<int64_t> ladder_bounds(int64_t rows, int splits, bool skinny, bool ladder, int64_t sample_opt, int64_t growth) {
+std::vector<int64_t> ladder_bounds(int64_t rows, int splits, int nq_pad, bool skinny, bool ladder, int64_t sample_opt, int64_t growth) {
   std::vector<int64_t> bounds;
   bounds.push_back(0);
   // first phase: `mfma_sample_rows`, or (0 = auto) part of ONE tile per workgroup of the 128/256-query kernel -- nothing compacts while
@@ -1414,7 +1414,8 @@ std::vector<int64_t> ladder_bounds(int64_t rows, int splits, bool skinny, bool l
   // profiles/r03_shard_ladder.md).  Round 4: with one LDS atomic per admitted row (tavb_mfma.hip) the all-admitted first phase is best kept
   // to 32 ranges' worth, 10240 rows -- 1 % faster on the shard, the same on 10M rows, half the keys for the select kernel
   // (profiles/r04_cfg3_kernel.md).  (The 32/64-query tile keeps round 2's 40960 rows.)
-  const int64_t auto_sample = skinny ? (int64_t)std::min(splits, 64) * 320 * 2 : (int64_t)std::min(splits, 32) * 320;
+  // One or two query tiles (up to 256 queries: 128 .. 256 row ranges) keep 64 ranges' worth: 1 - 2 % faster there (profiles/r04_raw/mid_batch.txt).
+  const int64_t auto_sample = skinny ? (int64_t)std::min(splits, 64) * 320 * 2 : (int64_t)std::min(splits, nq_pad >= 512 ? 32 : 64) * 320;
   const int64_t sample = sample_opt > 0 ? (sample_opt + 255) / 256 * 256 : (sample_opt == 0 ? auto_sample : 0);
   // 32/64-query tile on corpora of a few hundred thousand to ~2M rows: the default ladder's first phases are smaller than one tile per
   // workgroup (40960 rows = 160 tiles for 512 resident workgroups) and each costs a launch + ~one tile time whatever its size; ONE seeding
@@ -1479,7 +1480,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.active_min = r.active_min;
   p.active_max = r.active_max;
   p.split_plane = r.split_plane;
-  const std::vector<int64_t> bounds = ladder_bounds(c->rows, splits, r.skinny, r.ladder, c->mfma_sample_rows, c->mfma_ladder);  // phase i scans rows [bounds[i], bounds[i+1])
+  const std::vector<int64_t> bounds = ladder_bounds(c->rows, splits, r.nq_pad, r.skinny, r.ladder, c->mfma_sample_rows, c->mfma_ladder);  // phase i scans rows [bounds[i], bounds[i+1])
   const int n_phases = (int)bounds.size() - 1;
   const int kc = wide ? tavb::kBandMax : k;  // keys per query of the running selection between phases
   if (n_phases > 1 || (wide && r.active)) {
@@ -1749,7 +1750,7 @@ extern "C" int tavb_plan_ladder(int64_t rows, int32_t nq, int32_t n_cu, int64_t*
   const int qt = tavb::mfma_query_tile(nq);
   const int nq_pad = ((nq + qt - 1) / qt) * qt;
   const int splits = tavb::mfma_pick_splits(rows, nq_pad, qt, n_cu);
-  const std::vector<int64_t> b = ladder_bounds(rows, splits, /*skinny=*/false, /*ladder=*/true, /*sample_opt=*/0, /*growth=*/4);
+  const std::vector<int64_t> b = ladder_bounds(rows, splits, nq_pad, /*skinny=*/false, /*ladder=*/true, /*sample_opt=*/0, /*growth=*/4);
   for (size_t i = 0; out_bounds && i < b.size() && (int)i < cap; ++i) out_bounds[i] = b[i];
   return (int)b.size() - 1;
 }
