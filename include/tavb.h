@@ -99,7 +99,12 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile (exact
  *                   filter + fp32-query rescoring of its candidates), 5 = 32/64-query MFMA tile
  *   "last_flagged" (read only; synchronises) queries of the last 256-query-tile lookup whose candidate set could not be
- *                   proven complete and were re-run on the exact 64-query tile (0 on ordinary data)
+ *                   proven complete and were re-run exactly (0 on ordinary data)
+ *   "wide_fallback" 1 (default): when MORE than 64 queries of a batch of 256+ are flagged, they are re-run on the 256-query tile in its
+ *                   exact split-plane form (fp32 queries as two fp16 planes) instead of 64 at a time on the 64-query exact tile; 0 = never
+ *   "small_direct_bytes" single-query host-synchronous lookups (tavb_search, tavb_search_batch with nq = 1) on corpora up to this many
+ *                   bytes (default 128 MiB; 0 = never) are ONE launch: the scan's per-workgroup lists go to pinned host memory and are merged
+ *                   on the host; "last_direct" (read only) = 1 when the last lookup took that path
  */
 int tavb_set_option(tavb_ctx* ctx, const char* name, int64_t value);
 int tavb_get_option(tavb_ctx* ctx, const char* name, int64_t* out_value);
