@@ -78,6 +78,19 @@ def main():
         o = np.empty(k, np.int64); s = np.empty(k, np.float32); cnt = c_int32()
         ok(lib.tavb_search(h, ptr(q), k, c_float(0.0), ptr(o), ptr(s), byref(cnt)))
         print("single search: count", cnt.value, "first", o[0], flush=True)
+        # the one-launch form of the same lookup (round 4: per-workgroup lists into pinned memory, host merge) against the two-launch form
+        two_launch = o.copy()
+        ok(lib.tavb_set_option(h, b"small_direct_bytes", 1 << 30))
+        for kk in (k, 1, 200):
+            o3 = np.empty(kk, np.int64); s3 = np.empty(kk, np.float32)
+            ok(lib.tavb_search(h, ptr(q), kk, c_float(0.0), ptr(o3), ptr(s3), byref(cnt)))
+            dflag = c_int64(); ok(lib.tavb_get_option(h, b"last_direct", byref(dflag)))
+            assert dflag.value == 1 and cnt.value == kk and (o3[: min(k, kk)] == two_launch[: min(k, kk)]).all(), (kk, dflag.value, cnt.value)
+        ok(lib.tavb_set_option(h, b"small_direct_bytes", 128 << 20))
+        bounds = (c_int64 * 16)()
+        phases = lib.tavb_plan_ladder(10_000_000, 1024, 256, bounds, 16)
+        assert phases >= 2 and bounds[0] == 0 and bounds[phases] == 10_000_000 and lib.tavb_plan_ladder(-1, 1024, 256, None, 0) < 0
+        print("one-launch lookup + ladder plan: ok,", phases, "phases", flush=True)
         rows = rng.integers(0, n, 5000).astype(np.int64)
         ok(lib.tavb_search_subset(h, ptr(q), ptr(rows), rows.size, k, c_float(0.0), ptr(o), ptr(s), byref(cnt)))
         print("subset search: count", cnt.value, flush=True)
