@@ -555,7 +555,7 @@ class VectorBase:
                 # more hits than the fused selection holds, or max_hits == 0 (every survivor, sorted: the `[-0:]` quirk,
                 # :186-187): ONE pass emits all survivors, the host sorts them
                 ids, scs = eng.search_all(embedding, thr, None if max_hits == 0 else max_hits)
-            return [ScoredInt(int(i), float(s)) for i, s in zip(ids.tolist(), scs.tolist())]
+            return list(map(ScoredInt, ids.tolist(), scs.tolist()))  # (tolist() yields Python ints / floats: the float32 scores widened, as the reference's float(score))
         # predicate path (:191-201): threshold on the device (one pass, all survivors), then exactly the reference's steps:
         # predicate(ordinal) for EVERY survivor in ascending ordinal order, stable sort by score, cut
         ids, scs = eng.search_all(embedding, thr, None)
