@@ -73,3 +73,26 @@ def test_a_library_of_another_abi_version_is_refused(tmp_path, monkeypatch):
     monkeypatch.setattr(_native, "library_path", lambda: str(so))
     with pytest.raises(RuntimeError, match="C ABI version 1, this binding needs"):
         _native.load_library()
+
+
+def test_plan_ladder_is_a_partition_of_the_rows():
+    """tavb_plan_ladder (no GPU needed): the threshold ladder's phase boundaries start at 0, end at the row count, grow strictly, and a corpus
+    too small for a seeding phase is scanned in one phase; bad shapes come back as errors."""
+    import pytest
+
+    from typeagent_py_amd import _native
+
+    for rows in (1, 319, 10_000, 81_920, 163_840, 1_000_000, 1_250_000, 10_000_000, 100_000_000):
+        for nq in (65, 128, 256, 300, 1024, 4096):
+            b = _native.plan_ladder(rows, nq)
+            assert b[0] == 0 and b[-1] == rows and all(x < y for x, y in zip(b, b[1:])), (rows, nq, b)
+            assert 1 <= len(b) - 1 <= 8
+            if len(b) > 2:
+                assert rows >= 8 * b[1]            # a seeding phase only when the corpus is at least 8 samples long
+                assert b[-1] - b[-2] >= b[-2]      # the last phase is at least as long as everything before it
+    assert len(_native.plan_ladder(50_000, 1024)) == 2
+    assert _native.plan_ladder(10_000_000, 1024) == [0, 10240, 51200, 256000, 1280000, 10_000_000]
+    with pytest.raises(ValueError):
+        _native.plan_ladder(-1, 1024)
+    with pytest.raises(ValueError):
+        _native.plan_ladder(1000, 0)
