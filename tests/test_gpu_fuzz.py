@@ -3,6 +3,8 @@ degenerate rows (duplicates = exact ties, zero rows, un-normalised rows, NaN / i
 tie-aware parity checker against the numpy oracle.  The hand-picked cases live in tests/test_gpu_parity.py; this file is there for the
 combinations nobody thought of.  Nothing here reads /root/reference."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -54,9 +56,12 @@ def _case(seed: int):
     return dict(d=d, n=n, nq=nq, k=k, ms=ms, dtype=dtype, v=v, q=q, subset=subset, flavour=flavour)
 
 
+FUZZ_BASE = int(os.environ.get("TAVB_FUZZ_BASE", "1000"))  # another 250 cases: TAVB_FUZZ_BASE=2000 pytest tests/test_gpu_fuzz.py -m gpu
+
+
 @pytest.mark.parametrize("seed", range(250))
 def test_random_case_against_the_oracle(seed):
-    c = _case(1000 + seed)
+    c = _case(FUZZ_BASE + seed)
     v, q, k, ms = c["v"], c["q"], c["k"], c["ms"]
     vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), corpus_dtype=c["dtype"])
     vb.add_embeddings(None, v)
@@ -164,3 +169,43 @@ def test_clustered_corpus_with_a_threshold_inside_the_cluster(dtype, cluster_row
         ref = vo.scores_full(seen, q[qi])
         vo.check_topk_parity(ref, [r.item for r in out[qi]], [r.score for r in out[qi]], k, ms, referee=vo.f64_referee(seen, q[qi]))
         assert all(r.score >= np.float32(ms) for r in out[qi])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_batches_through_the_threshold_ladder(seed):
+    """The random cases above stay below 20k rows: no threshold ladder, hardly an admission after the first tile.  Here: 170k - 400k rows of
+    64 - 512 dimensions, batches of 33 - 700 queries (64-query tile, 128- and 256-query tiles, fp32 corpora through the fp16 shadow), every k
+    and threshold the consumers use, duplicated rows; several ladder phases, sparse admissions, rescoring -- against the oracle with the float64
+    referee."""
+    rng = np.random.default_rng(7000 + seed)
+    d = int(rng.choice([64, 128, 256, 512]))
+    n = int(rng.choice([170_000, 250_000, 400_000]))
+    nq = int(rng.choice([33, 64, 65, 100, 128, 129, 256, 300, 512, 700]))
+    k = int(rng.choice([1, 10, 25, 32, 50, 64]))
+    ms = [None, 0.0, 0.5, 0.55, 0.6][int(rng.integers(5))]
+    dtype = "fp16" if rng.random() < 0.6 else "fp32"
+    v = rng.standard_normal((n, d)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    src = rng.integers(0, n, size=2000)
+    v[rng.integers(0, n, size=2000)] = v[src]  # exact ties
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0] = v[int(src[0])]
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), corpus_dtype=dtype)
+    vb.add_embeddings(None, v)
+    out = vb.fuzzy_lookup_embeddings(q, max_hits=k, min_score=ms)
+    tag = dict(d=d, n=n, nq=nq, k=k, ms=ms, dtype=dtype, tier=vb.engine.get_option("last_tier"))
+    assert tag["tier"] in (4, 5), tag
+    seen = v.astype(np.float16).astype(np.float32) if dtype == "fp16" else v
+    ms_eff = 0.0 if ms is None else ms
+    for qi in sorted(set([0, nq - 1] + rng.integers(0, nq, size=6).tolist())):
+        ref = vo.scores_full(seen, q[qi])
+        try:
+            vo.check_topk_parity(ref, [r.item for r in out[qi]], [r.score for r in out[qi]], k, ms_eff, referee=vo.f64_referee(seen, q[qi]))
+        except AssertionError as exc:
+            raise AssertionError(f"{tag} query {qi}: {exc}") from exc
+    # the same batch one query at a time (streaming kernels): same hits up to float32 near-ties
+    for qi in (0, nq - 1):
+        one = vb.fuzzy_lookup_embedding(q[qi], max_hits=k, min_score=ms)
+        assert len(one) == len(out[qi]), tag
+        np.testing.assert_allclose([r.score for r in one], [r.score for r in out[qi]], atol=1e-6, rtol=0)
