@@ -1733,6 +1733,12 @@ def test_profile_counters_count_launches():
         vb.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
     ms, n = eng.profile_read(_native.KERNEL_SCAN)
     assert n == 3 and ms > 0
+    assert eng.profile_read(_native.KERNEL_MERGE)[1] == 0  # a corpus this small (123 MB) takes the one-launch path: lists merged on the host
+    eng.set_option("small_direct_bytes", 0)
+    eng.profile_reset()
+    for _ in range(3):
+        vb.fuzzy_lookup_embedding(q, max_hits=32, min_score=0.0)
+    assert eng.profile_read(_native.KERNEL_SCAN)[1] == 3
     ms2, n2 = eng.profile_read(_native.KERNEL_MERGE)
     assert n2 == 3 and ms2 > 0
     eng.profile_enable(False)
