@@ -946,6 +946,30 @@ def test_wide_tile_falls_back_to_the_exact_tile_when_the_band_overflows():
     assert len(out2[3]) == k and len(out2[2]) == 0
 
 
+def test_wide_tile_with_the_query_operand_straight_from_l2():
+    """`mfma_bdirect=1`: the 256-query tile takes its queries in MFMA-fragment-major order straight from L2 into registers (four rotating fragment
+    sets, three corpus slots in the LDS the query ring used to occupy).  Same keys as the default path, incl. padding queries (300 of 512), a
+    threshold, several ladder phases, the band of a near-duplicate cluster, and a second dimension."""
+    for n, d, nq, k, ms in [(200_000, 1536, 300, 32, 0.0), (90_000, 256, 1024, 50, 0.55), (170_000, 768, 257 + 256, 10, 0.0)]:
+        v, _ = make_corpus(n, d, 8600 + d)
+        qs = make_queries(nq, d, 8601 + d)
+        rng = np.random.default_rng(8602)
+        _plant_near_duplicates(v, qs, 7, rng.choice(n, size=200, replace=False), rng)
+        vb = new_vb(v, dtype="fp16")
+        eng = vb.engine
+        base = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms, as_arrays=True)
+        assert eng.get_option("last_tier") == 4
+        eng.set_option("mfma_bdirect", 1)
+        direct = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms, as_arrays=True)
+        eng.set_option("mfma_bdirect", 0)
+        for a, b in zip(base, direct):
+            np.testing.assert_array_equal(a, b)
+        v16 = _f16(v)
+        o, s_, c_ = direct
+        for qi in (0, 7, nq - 1):
+            vo.check_topk_parity(vo.scores_full(v16, qs[qi]), o[qi, : c_[qi]].tolist(), s_[qi, : c_[qi]].tolist(), k, ms, referee=vo.f64_referee(v16, qs[qi]))
+
+
 def test_many_flagged_queries_take_the_wide_exact_fallback():
     """The duplication cliff, bounded: when MANY queries of a batch (> 64) have more near-duplicates than a band holds, they are re-run on the
     256-query tile's exact form (fp32 queries as two fp16 planes, the K loop once per plane) instead of 64 at a time on the 64-query exact

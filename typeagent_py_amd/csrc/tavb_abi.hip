@@ -140,6 +140,7 @@ struct tavb_ctx {
   Buffer h_stage{nullptr, 0, true};
   Buffer h_out{nullptr, 0, true};  // pinned + device-visible: the last kernel of a synchronous lookup writes its keys straight here
   Buffer h_lists{nullptr, 0, true};  // pinned + device-visible: per-workgroup lists of a small single-query lookup (merged on the host)
+  int64_t mfma_bdirect = 0;  // option (measurement for now): the 256-query tile takes its query operand straight from L2 (fragment-major layout), not through LDS
   int64_t wide_fallback = 1;  // option: batches of 256+ queries re-run MANY (> 64) flagged queries on the 256-query tile's exact (split-plane) form
   int64_t small_direct_bytes = (int64_t)128 << 20;  // option: single-query lookups on corpora up to this size take the one-launch path (0 = never)
   int64_t last_direct = 0;                          // option "last_direct" (get): 1 when the last lookup took it
@@ -488,6 +489,8 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     c->mfma_splits = v;
   } else if (n == "wide_fallback") {
     c->wide_fallback = v ? 1 : 0;
+  } else if (n == "mfma_bdirect") {
+    c->mfma_bdirect = v ? 1 : 0;
   } else if (n == "small_direct_bytes") {
     if (v < 0) return fail(TAVB_E_INVALID, "small_direct_bytes must be >= 0");
     c->small_direct_bytes = v;
@@ -527,6 +530,7 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "comm_force") *out = c->comm_force;
   else if (n == "small_direct_bytes") *out = c->small_direct_bytes;
   else if (n == "wide_fallback") *out = c->wide_fallback;
+  else if (n == "mfma_bdirect") *out = c->mfma_bdirect;
   else if (n == "last_direct") *out = c->last_direct;
   else if (n == "graph_max_bytes") *out = c->graph_max_bytes;
   else if (n == "last_graph") *out = c->last_graph;
@@ -1393,6 +1397,7 @@ struct TileRun {
   const void* corpus;     // corpus operand (nullptr: the context's corpus; the fp16 shadow of an fp32 corpus for the filter pass)
   const int* active;      // optional device-side live-query count (fixed-shape launch over a work list)
   int active_min, active_max;  // ... served only when active_min < *active <= active_max (0 = no upper bound): two fallbacks share one list
+  bool bdirect;           // 256-query tile: `queries` are in fragment-major order (straight from L2 into registers)
   int64_t split_plane;    // 128/256-query tile: > 0 = exact form, `queries` = [2][nq_pad][dim] fp16 planes this many bytes apart (final scores, no band)
   bool ladder;            // scan in phases of growing size (else one phase)
   // 128/256-query tile only: band selection (tavb_mfma.hip::select_band_kernel).  d_out then receives [nq, kBandMax] unsorted keys,
@@ -1480,6 +1485,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.active_min = r.active_min;
   p.active_max = r.active_max;
   p.split_plane = r.split_plane;
+  p.bdirect = r.bdirect ? 1 : 0;
   const std::vector<int64_t> bounds = ladder_bounds(c->rows, splits, r.nq_pad, r.skinny, r.ladder, c->mfma_sample_rows, c->mfma_ladder);  // phase i scans rows [bounds[i], bounds[i+1])
   const int n_phases = (int)bounds.size() - 1;
   const int kc = wide ? tavb::kBandMax : k;  // keys per query of the running selection between phases
@@ -1559,6 +1565,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   const bool f32c = (c->dtype == TAVB_F32);
   const int qt = small ? tavb::skinny_query_tile(nq) : (c->mfma_tile > 0 ? (int)c->mfma_tile : tavb::mfma_query_tile(nq));
   const int nq_pad = ((nq + qt - 1) / qt) * qt;
+  const bool bdirect = !small && qt == 256 && c->mfma_bdirect && c->mfma_ablate == 0;
   // Work list of queries that need an exact pass (a band that did not fit).  Few of them (<= 64): ONE pass of the 64-query exact tile.  Many: the
   // 256-query tile in its SPLIT form (fp32 queries as two fp16 planes, the K loop run once per plane: twice the MFMAs of a filter pass, exact) --
   // 16 passes of the 64-query tile per 1024 flagged queries otherwise (round 2-3: "stated, not solved").  Both are fixed-shape
@@ -1601,7 +1608,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
     TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16_bytes, c->stream));  // padding queries
     TAVB_HIP(hipMemsetAsync(d_band, 0, (size_t)nq_pad * 4 * sizeof(float), c->stream));  // band widths of the padding queries, counts, lost levels, verdicts
     hipError_t e = tavb::launch_query_prepare(d_q, nq, c->dim, min_score, small, d_norm, small ? nullptr : c->d_queries_f16.ptr, d_delta, d_floor,
-                                              small ? nullptr : d_band, c->stream);
+                                              small ? nullptr : d_band, c->stream, bdirect);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "query prepare launch failed: %s", hipGetErrorString(e));
     if (small) {
       e = tavb::launch_f32_split_f16(d_q, c->d_queries_f16.ptr, reinterpret_cast<char*>(c->d_queries_f16.ptr) + q16_bytes / 2, (int64_t)nq * c->dim, c->stream);
@@ -1622,6 +1629,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   filt.index_base = index_base;
   filt.kernel_min_score = (min_score > 0.0f) ? 0.0f : min_score;  // the per-query relaxed thresholds (floor) do the filtering; NaN stays NaN
   filt.floor = d_floor;
+  filt.bdirect = bdirect;
   filt.queries = c->d_queries_f16.ptr;
   filt.corpus = f32c ? c->d_shadow.ptr : nullptr;
   filt.ladder = true;

@@ -60,8 +60,9 @@ hipError_t launch_message_rerank(const unsigned long long* hits, int nq, int k, 
 hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, float* out_sq, hipStream_t stream);
 // q16 may be null (rows_only: the filter uses the exact queries, only the rows' rounding enters the bound)
 // band (optional, [nq]): 2 * delta, the width of the band selection
+// frag_major: q16 in MFMA-fragment-major order for 256-query tiles (tavb_mfma.hip, BD) instead of row-major
 hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
-                                float* thr, float* band, hipStream_t stream);
+                                float* thr, float* band, hipStream_t stream, bool frag_major = false);
 // candidates [nq, stride] (+ cand_cnt [nq]: band mode, the set is complete by construction unless incomplete[q]; cand_cnt == nullptr: the
 // sorted best `stride` = 64 by approximate score, complete when rank 63 + delta < the exact k-th best) -> exact top k [nq, k]
 hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
@@ -99,6 +100,7 @@ struct MfmaParams {
   const int* active;    // optional: device-side count of live queries (query tiles past it return at once) -- a fixed-shape launch over a work list
   int32_t active_min;   // ... and the whole launch returns at once unless active_min < *active <= active_max (0 = no upper bound)
   int32_t active_max;
+  int32_t bdirect;      // 256-query kernel only: `queries` are in MFMA-fragment-major order and go straight from L2 into registers (no LDS staging)
   int64_t split_plane;  // 256-query kernel only: > 0 = the SPLIT form, queries = [2][nq_padded][dim] fp16 planes this many bytes apart (q = hi + lo)
   int32_t f32;          // skinny kernel only: corpus and queries are fp32 (else fp16)
   int32_t skinny_tile;  // skinny kernel only: queries per tile, 32 or 64

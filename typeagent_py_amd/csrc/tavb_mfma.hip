@@ -395,10 +395,21 @@ constexpr int staging_piece_at(int q, int i) {
 // SPLIT: the queries arrive as TWO fp16 planes (q = hi + lo to 2^-22) and a tile runs its K loop twice over the corpus rows, once per plane, into
 // the same accumulators: fp32 query x fp16 row like the 64-query exact tile, at the wide tile's rate -- the bounded fallback for batches in which
 // MANY queries have more near-duplicates than a band holds (tavb_rescore.hip).  Twice the MFMAs; only this instantiation pays for it.
-template <int ABL, int NI, int N3, int N0, int N1, bool SPLIT = false>
+// BD ("B direct"): the query operand does not go through LDS at all.  The library lays the fp16 queries out in MFMA-FRAGMENT-MAJOR order (1 KiB per
+// (K step, k16 slice, 32-query block): lane l = query l & 31, halves 8 (l >> 5) .. + 7 of the slice -- query_prepare_kernel), so a fragment is ONE
+// coalesced 16 B-per-lane load out of L2 straight into the registers the MFMA reads; four register sets rotate, the loads run three quarters
+// (~1.2 us) ahead.  Per K step the LDS then moves 120 KiB instead of 216 (no query slab written, no query fragments read); the price is that
+// both row halves of the workgroup load the same fragments (L2 -> CU traffic 104 KiB per step instead of 72).
+template <int ABL, int NI, int N3, int N0, int N1, bool SPLIT = false, bool BD = false>
 __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p) {
   using G = WideGeom<NI>;
-  constexpr int BN = G::QT, NT = G::NT, SLOT_B6 = G::SLOT_B, CTRL6 = G::CTRL, PIECES_B6 = G::PIECES_B, PIECES6 = G::PIECES, RA = G::RA, B_RING6 = G::B_RING;
+  constexpr int BN = G::QT, NT = G::NT, SLOT_B6 = G::SLOT_B, PIECES_B6 = G::PIECES_B, B_RING6 = G::B_RING;
+  // BD: the 64 KiB the query ring occupied pay for a THIRD corpus slot -- a corpus piece then has more than a whole K step (~2 us) to land instead
+  // of 0.4 .. 1 step (the last pieces of a slab are issued in quarter 1 and needed behind quarter 2: an HBM round trip does not fit)
+  constexpr int RA = BD ? 3 : G::RA;
+  constexpr int CTRL6 = BD ? 3 * SLOT_A6 : G::CTRL;
+  constexpr int PIECES6 = BD ? PIECES_A6 : G::PIECES;
+  static_assert(!BD || (NI == 4 && !SPLIT), "the direct query operand is built for the 256-query tile");
   static_assert(N3 + N0 + N1 == PIECES6, "every piece of a step is issued exactly once");
   static_assert(N3 <= NT && N0 <= NT && N1 <= NT && NI + 5 <= NT, "one piece / one fragment read behind an MFMA at most");
   extern __shared__ __align__(16) unsigned char smem[];
@@ -514,7 +525,9 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   };
   auto stage_piece = [&](auto idx_tag) {
     constexpr int IDX = decltype(idx_tag)::value;
-    if constexpr (RA == 2) {
+    if constexpr (BD) {
+      stage_a(std::integral_constant<int, IDX>{});
+    } else if constexpr (RA == 2) {
       if constexpr (IDX < PIECES_A6) stage_a(std::integral_constant<int, IDX>{});
       else stage_b(std::integral_constant<int, IDX - PIECES_A6>{});
     } else {
@@ -553,11 +566,34 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(__builtin_bit_cast(i32x4, A)), "v"(__builtin_bit_cast(i32x4, B)))
 
   f16x8 a0[5], b0[NI], a1[5], b1[NI];
+  f16x8 b2[BD ? NI : 1], b3[BD ? NI : 1];  // BD: four rotating sets of query fragments (quarter q multiplies set q, the loads for quarter q + 3 fill set (q + 3) & 3)
+  constexpr int BQ_SLICE = (BN / 32) * 1024;  // bytes of one k16 slice of the tile's queries in fragment-major order
+  int bq_soff = 0;                            // BD: byte offset (from the tile's queries) of the slice to load next; wraps with the tile
+  const int bq_tile_bytes = BN * (int)row_bytes;
+  int bq_voff = 0;
+  auto bq_load = [&](f16x8(&dst)[BD ? NI : 1]) {  // one slice: this wave's NI fragments (its half of the tile's query blocks)
+    if constexpr (BD) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        dst[ni] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, bq_voff + ni * 1024, bq_soff, 0));
+      bq_soff = (bq_soff + BQ_SLICE == bq_tile_bytes) ? 0 : bq_soff + BQ_SLICE;
+    }
+  };
   {
     const unsigned char* abase = smem + (a_lane + frag_x);
     const unsigned char* bbase = smem + (b_lane + frag_x);
+    if constexpr (BD) {
+      int zero_b = 0;
+      asm volatile("" : "+v"(zero_b));
+      const int ln_b = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero_b));
+      bq_voff = ln_b * 16 + wn * NI * 1024;
+      bq_load(b0);
+      bq_load(b1);
+      bq_load(b2);
+    } else {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) b0[ni] = *reinterpret_cast<const f16x8*>(bbase + ni * 4096);
+      for (int ni = 0; ni < NI; ++ni) b0[ni] = *reinterpret_cast<const f16x8*>(bbase + ni * 4096);
+    }
 #pragma unroll
     for (int mi = 0; mi < 5; ++mi) a0[mi] = *reinterpret_cast<const f16x8*>(abase + mi * 4096);
   }
@@ -589,7 +625,11 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
         }
       }
       if constexpr ((ABL & 32) == 0) {
-        if constexpr (I < NI) nb[I] = *reinterpret_cast<const f16x8*>(bbase + I * 4096);
+        if constexpr (BD) {  // the slice three quarters ahead, straight from L2 into the set the previous quarter has just finished with
+          if constexpr (I < NI) nb[I] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, bq_voff + I * 1024, bq_soff, 0));
+        } else {
+          if constexpr (I < NI) nb[I] = *reinterpret_cast<const f16x8*>(bbase + I * 4096);
+        }
         if constexpr (I >= NI && I < NI + 5) na[I - NI] = *reinterpret_cast<const f16x8*>(abase + (I - NI) * 4096);
       }
       if constexpr ((ABL & 2) == 0) {
@@ -599,6 +639,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
     };
     [&]<int... I>(std::integer_sequence<int, I...>) { (mfma_at(std::integral_constant<int, I>{}), ...); }
     (std::make_integer_sequence<int, NT>{});
+    if constexpr (BD) bq_soff = (bq_soff + BQ_SLICE == bq_tile_bytes) ? 0 : bq_soff + BQ_SLICE;
     if constexpr ((ABL & 1) != 0) asm volatile("" ::"v"(fa[0]), "v"(fa[4]), "v"(fb[0]), "v"(fb[NI - 1]));
   };
   using Q0 = std::integral_constant<int, 0>;
@@ -606,18 +647,32 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   using Q2 = std::integral_constant<int, 2>;
   using Q3 = std::integral_constant<int, 3>;
   auto step = [&](auto first_tag) {
-    quarter(Q0{}, first_tag, a0, b0, a1, b1, rd_a, rd, Q1{});
-    quarter(Q1{}, std::false_type{}, a1, b1, a0, b0, rd_a, rd, Q2{});
-    quarter(Q2{}, std::false_type{}, a0, b0, a1, b1, rd_a, rd, Q3{});
-    // ---- step S+1 has landed in this wave (two slots: nothing newer is in flight; three: only corpus slab S+2 is); the
-    //      slots of step S are read out; meet
-    if constexpr ((ABL & 2) == 0) wait_vmcnt<(RA == 2 ? 0 : PIECES_A6)>();
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) through the builtin: visible to the compiler's wait-count pass
-    TAVB_BARRIER();
-    const int nxt_a = (RA == 2) ? (rd_a ^ 1) : (rd_a + 1 == RA ? 0 : rd_a + 1);
-    quarter(Q3{}, std::false_type{}, a1, b1, a0, b0, nxt_a, rd ^ 1, Q0{});
-    rd ^= 1;
-    rd_a = nxt_a;
+    if constexpr (BD) {
+      quarter(Q0{}, first_tag, a0, b0, a1, b3, rd_a, rd, Q1{});
+      quarter(Q1{}, std::false_type{}, a1, b1, a0, b0, rd_a, rd, Q2{});
+      quarter(Q2{}, std::false_type{}, a0, b2, a1, b1, rd_a, rd, Q3{});
+      // corpus slab S+1 has landed in this wave: behind its last piece (quarter 1 of the PREVIOUS step) came five quarters' query-fragment loads
+      // (5 NI) and the ten pieces of slab S+2, which may all still be in flight (loads return in order: the count is exact)
+      if constexpr ((ABL & 2) == 0) wait_vmcnt<5 * NI + PIECES_A6>();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      TAVB_BARRIER();
+      const int nxt_a = rd_a + 1 == RA ? 0 : rd_a + 1;
+      quarter(Q3{}, std::false_type{}, a1, b3, a0, b2, nxt_a, rd, Q0{});
+      rd_a = nxt_a;
+    } else {
+      quarter(Q0{}, first_tag, a0, b0, a1, b1, rd_a, rd, Q1{});
+      quarter(Q1{}, std::false_type{}, a1, b1, a0, b0, rd_a, rd, Q2{});
+      quarter(Q2{}, std::false_type{}, a0, b0, a1, b1, rd_a, rd, Q3{});
+      // ---- step S+1 has landed in this wave (two slots: nothing newer is in flight; three: only corpus slab S+2 is); the
+      //      slots of step S are read out; meet
+      if constexpr ((ABL & 2) == 0) wait_vmcnt<(RA == 2 ? 0 : PIECES_A6)>();
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) through the builtin: visible to the compiler's wait-count pass
+      TAVB_BARRIER();
+      const int nxt_a = (RA == 2) ? (rd_a ^ 1) : (rd_a + 1 == RA ? 0 : rd_a + 1);
+      quarter(Q3{}, std::false_type{}, a1, b1, a0, b0, nxt_a, rd ^ 1, Q0{});
+      rd ^= 1;
+      rd_a = nxt_a;
+    }
   };
 
   for (int tile = 0; tile < n_tiles; ++tile) {
@@ -1426,6 +1481,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       return go(mfma_scan_kernel<0, 4, 8, 6, 4, true>, NT6, LDS256);
     }
     if (tile == 128) return go(mfma_scan_kernel<0, 2, 6, 4, 4>, NT6, LDS128);
+    if (p.bdirect && p.ablate == 0) return go(mfma_scan_kernel<0, 4, 4, 3, 3, false, true>, NT6, 3 * SLOT_A6 + BN * 8 + 16);  // queries in fragment-major order (query_prepare_kernel)
     switch (p.ablate) {
       case 256: return go(mfma_scan_kernel<256, 4, 8, 6, 4>, NT6, LDS256);  // everything except admissions
       case 260: return go(mfma_scan_kernel<260, 4, 8, 6, 4>, NT6, LDS256);  // same, corpus tile 0 re-read by every block (L2 resident)

@@ -115,17 +115,28 @@ __global__ void __launch_bounds__(256) shadow_convert_kernel(const float* __rest
 // rows_only: the filter multiplies the EXACT queries (split fp16 high + low planes) with the shadow rows: only the rows' rounding counts.
 __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restrict__ q, int nq, int dim, float min_score, int rows_only,
                                                             const float* __restrict__ max_norm_sq /*[2]: max |x16|^2, max |x - x16|^2*/, _Float16* __restrict__ q16,
-                                                            float* __restrict__ delta, float* __restrict__ thr, float* __restrict__ band) {
+                                                            float* __restrict__ delta, float* __restrict__ thr, float* __restrict__ band, int frag_major) {
   const int lane = threadIdx.x & 63;
   const int qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (qi >= nq) return;
   const float* src = q + (size_t)qi * dim;
   _Float16* dst = q16 ? q16 + (size_t)qi * dim : nullptr;
+  // fragment-major (the 256-query tile's direct query operand): 1 KiB per (query tile t, K step s of 64 halves, k16 slice c, 32-query block j);
+  // in it lane l = (half-slice h) * 32 + (query row r & 31) holds halves 8 h .. 8 h + 7 of the slice
+  const int steps = dim / 64;
+  const int qt = qi >> 8, qr = qi & 255;
   float err = 0.f, qq = 0.f;
   for (int i = lane; i < dim; i += 64) {
     const float v = src[i];
     const _Float16 h = (_Float16)v;
-    if (dst) dst[i] = h;
+    if (dst) {
+      if (frag_major) {
+        const int ks = i >> 6, c = (i >> 4) & 3, hs = (i >> 3) & 1, e = i & 7;
+        q16[((((size_t)(qt * steps + ks) * 4 + c) * 8 + (qr >> 5)) * 512) + (size_t)((hs * 32 + (qr & 31)) * 8 + e)] = h;
+      } else {
+        dst[i] = h;
+      }
+    }
     const float d = v - (float)h;
     err = fmaf(d, d, err);
     qq = fmaf(v, v, qq);
@@ -308,9 +319,9 @@ hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void
 }
 
 hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
-                                float* thr, float* band, hipStream_t stream) {
+                                float* thr, float* band, hipStream_t stream, bool frag_major) {
   hipLaunchKernelGGL(query_prepare_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, q, nq, dim, min_score, rows_only ? 1 : 0, max_norm_sq,
-                     reinterpret_cast<_Float16*>(q16), delta, thr, band);
+                     reinterpret_cast<_Float16*>(q16), delta, thr, band, frag_major ? 1 : 0);
   return hipGetLastError();
 }
 
