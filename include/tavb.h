@@ -106,7 +106,8 @@ int tavb_synchronize(tavb_ctx* ctx);
  *                   (no LDS staging; three corpus slots instead of two): measured +0.8 %, kept as an option (profiles/r04_cfg3_kernel.md section 10)
  *   "small_direct_bytes" single-query host-synchronous lookups (tavb_search, tavb_search_batch with nq = 1) on corpora up to this many
  *                   bytes (default 128 MiB; 0 = never) are ONE launch: the scan's per-workgroup lists go to pinned host memory and are merged
- *                   on the host; "last_direct" (read only) = 1 when the last lookup took that path
+ *                   on the host; "last_direct" (read only) = 1 when the last lookup took that path, 2 when in addition the query rode
+ *                   inside the kernel arguments ("inline_query", default 1: 1536-wide queries on the default scan form; no H2D copy before the launch)
  */
 int tavb_set_option(tavb_ctx* ctx, const char* name, int64_t value);
 int tavb_get_option(tavb_ctx* ctx, const char* name, int64_t* out_value);

@@ -656,9 +656,13 @@ def test_small_corpus_lookups_take_one_launch(n, dtype):
     for k, ms in [(10, 0.0), (50, 0.85), (25, 0.7), (1, 0.0), (256, 0.0), (32, 0.5)]:
         eng.profile_reset()
         res = vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=ms)
-        assert eng.get_option("last_direct") == 1
+        assert eng.get_option("last_direct") == 2  # one launch, and the 1536-wide query rode in its kernel arguments: no copy in front of it
         assert eng.profile_read(_native.KERNEL_SCAN)[1] == 1 and eng.profile_read(_native.KERNEL_MERGE)[1] == 0  # one launch
         vo.check_topk_parity(vo.scores_full(seen, q), *items_scores(res), k, ms, referee=vo.f64_referee(seen, q))
+        eng.set_option("inline_query", 0)  # the same launch with the query copied into a device buffer first
+        copied = vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=ms)
+        assert eng.get_option("last_direct") == 1 and items_scores(copied) == items_scores(res)
+        eng.set_option("inline_query", 1)
         eng.set_option("small_direct_bytes", 0)
         two = vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=ms)
         assert eng.get_option("last_direct") == 0
@@ -673,6 +677,17 @@ def test_small_corpus_lookups_take_one_launch(n, dtype):
     vo.check_topk_parity(vo.scores_full(seen, q), *items_scores(res), 10, 0.0, referee=vo.f64_referee(seen, q))
     eng.set_option("scan_blocks", 0)
     eng.profile_enable(False)
+    # a scan form that has no inline-query variant copies the query as before; consecutive lookups with different queries see their own query
+    eng.set_option("scan_unroll", 4)
+    res = vb.fuzzy_lookup_embedding(q, max_hits=10, min_score=0.0)
+    assert eng.get_option("last_direct") == 1
+    vo.check_topk_parity(vo.scores_full(seen, q), *items_scores(res), 10, 0.0, referee=vo.f64_referee(seen, q))
+    eng.set_option("scan_unroll", 2)
+    for seed in range(5):
+        q2 = make_queries(1, 1536, 50 + seed)[0]
+        res = vb.fuzzy_lookup_embedding(q2, max_hits=10, min_score=-1.0)
+        assert eng.get_option("last_direct") == 2
+        vo.check_topk_parity(vo.scores_full(seen, q2), *items_scores(res), 10, -1.0, referee=vo.f64_referee(seen, q2))
     # batches and subset lookups do not take the path (and are unaffected by it)
     vb.fuzzy_lookup_embeddings(np.stack([q, q]), max_hits=5)
     assert eng.get_option("last_direct") == 0

@@ -85,7 +85,7 @@ def main():
             o3 = np.empty(kk, np.int64); s3 = np.empty(kk, np.float32)
             ok(lib.tavb_search(h, ptr(q), kk, c_float(0.0), ptr(o3), ptr(s3), byref(cnt)))
             dflag = c_int64(); ok(lib.tavb_get_option(h, b"last_direct", byref(dflag)))
-            assert dflag.value == 1 and cnt.value == kk and (o3[: min(k, kk)] == two_launch[: min(k, kk)]).all(), (kk, dflag.value, cnt.value)
+            assert dflag.value in (1, 2) and cnt.value == kk and (o3[: min(k, kk)] == two_launch[: min(k, kk)]).all(), (kk, dflag.value, cnt.value)
         ok(lib.tavb_set_option(h, b"small_direct_bytes", 128 << 20))
         bounds = (c_int64 * 16)()
         phases = lib.tavb_plan_ladder(10_000_000, 1024, 256, bounds, 16)

@@ -35,7 +35,11 @@ def main():
     thr = np.float32(ms)
     print("rows", rows, "k", k, "min_score", ms)
     print("host-synchronous search, ONE launch (lists -> pinned, host merge; the default): %.1f us" % med(lambda: eng.search(q, k, thr)))
-    direct = eng.get_option("last_direct") == 1  # (corpora up to small_direct_bytes = 128 MiB)
+    direct = eng.get_option("last_direct") >= 1  # (corpora up to small_direct_bytes = 128 MiB)
+    print("   (query inside the kernel arguments: %s)" % ("yes" if eng.get_option("last_direct") == 2 else "no"))
+    eng.set_option("inline_query", 0)
+    print("   ... with the query copied to a device buffer first (inline_query=0):          %.1f us" % med(lambda: eng.search(q, k, thr)))
+    eng.set_option("inline_query", 1)
     for waves in (2, 4, 8, 16):
         eng.set_option("scan_waves", waves)
         print("   ... with scan_waves=%-2d:                                                       %.1f us" % (waves, med(lambda: eng.search(q, k, thr))))

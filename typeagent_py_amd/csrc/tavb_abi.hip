@@ -143,7 +143,8 @@ struct tavb_ctx {
   int64_t mfma_bdirect = 0;  // option (measurement for now): the 256-query tile takes its query operand straight from L2 (fragment-major layout), not through LDS
   int64_t wide_fallback = 1;  // option: batches of 256+ queries re-run MANY (> 64) flagged queries on the 256-query tile's exact (split-plane) form
   int64_t small_direct_bytes = (int64_t)128 << 20;  // option: single-query lookups on corpora up to this size take the one-launch path (0 = never)
-  int64_t last_direct = 0;                          // option "last_direct" (get): 1 when the last lookup took it
+  int64_t last_direct = 0;                          // option "last_direct" (get): 1 when the last lookup took it, 2 = with the query inside the kernel arguments
+  int inline_query = 1;                             // option: 1536-wide single queries of that path ride in the kernel arguments (no H2D copy before the launch)
 
   bool profiling = false;
   double total_ms[TAVB_KERNEL_COUNT] = {0};
@@ -491,6 +492,8 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     c->wide_fallback = v ? 1 : 0;
   } else if (n == "mfma_bdirect") {
     c->mfma_bdirect = v ? 1 : 0;
+  } else if (n == "inline_query") {
+    c->inline_query = v ? 1 : 0;
   } else if (n == "small_direct_bytes") {
     if (v < 0) return fail(TAVB_E_INVALID, "small_direct_bytes must be >= 0");
     c->small_direct_bytes = v;
@@ -532,6 +535,7 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "wide_fallback") *out = c->wide_fallback;
   else if (n == "mfma_bdirect") *out = c->mfma_bdirect;
   else if (n == "last_direct") *out = c->last_direct;
+  else if (n == "inline_query") *out = c->inline_query;
   else if (n == "graph_max_bytes") *out = c->graph_max_bytes;
   else if (n == "last_graph") *out = c->last_graph;
   else if (n == "comm_world") *out = c->comm ? c->comm_world : 0;
@@ -734,7 +738,6 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
     if (g.waves > 16) g.waves = 16;
     g.blocks = std::min(scan_blocks_for(c, c->rows, g.waves, g.unroll), std::max(8, 2048 / k));
     if (int rc = c->h_lists.reserve((size_t)g.blocks * k * sizeof(u64_t))) return rc;
-    TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
     tavb::ScanParams p{};
     p.corpus = c->corpus;
     p.row_ids = nullptr;
@@ -749,15 +752,25 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
     p.key_bound = ~0ull;
     for (int i = 0; i < TAVB_MAX_STREAM_QUERIES; ++i) p.min_score[i] = (i < 1) ? min_scores[0] : INFINITY;
     {
-      Timed t(c, TAVB_KERNEL_SCAN);
-      hipError_t e = tavb::launch_scan(p, g, c->stream, &c->last_tier);
+      // 1536-wide query (the embedding size typeagent runs at): it rides in the kernel arguments -- one submission, no copy in front of the launch
+      hipError_t e = hipSuccess;
+      bool launched = false;
+      if (c->inline_query) {
+        Timed t(c, TAVB_KERNEL_SCAN);
+        launched = tavb::launch_scan_inline_query(p, g, c->stream, queries_host, &c->last_tier, &e);
+      }
+      if (!launched) {
+        TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
+        Timed t(c, TAVB_KERNEL_SCAN);
+        e = tavb::launch_scan(p, g, c->stream, &c->last_tier);
+      }
       if (e != hipSuccess) return fail(TAVB_E_HIP, "scan kernel launch failed: %s", hipGetErrorString(e));
+      c->last_direct = launched ? 2 : 1;
     }
     TAVB_HIP(hipStreamSynchronize(c->stream));
     u64_t merged[TAVB_MAX_FUSED_K];
     if (int rc = tavb_merge_keys_host(reinterpret_cast<const tavb_key*>(c->h_lists.ptr), g.blocks, 1, k, reinterpret_cast<tavb_key*>(merged))) return rc;
     decode(merged, 1, k, c->ordinal_base, out_ordinals, out_scores, out_counts);
-    c->last_direct = 1;
     return TAVB_OK;
   }
   const bool capture = slot != nullptr && slot->seen >= 1;  // (the first call of a shape sizes the workspaces: no allocation may happen inside a capture)

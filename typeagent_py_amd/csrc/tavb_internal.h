@@ -36,6 +36,10 @@ struct ScanGeometry {
 // returns hipSuccess or the launch error; `*tier_used` reports the kernel family chosen
 hipError_t launch_scan(const ScanParams& p, const ScanGeometry& g, hipStream_t stream, int* tier_used);
 
+// single 1536-wide query handed over INSIDE the kernel arguments (`host_query`: 1536 floats on the host; `p.queries` is not read): no copy in front of
+// the launch.  Returns false -- nothing launched -- when the shape or geometry has no such variant; otherwise `*err` is the launch result.
+bool launch_scan_inline_query(const ScanParams& p, const ScanGeometry& g, hipStream_t stream, const float* host_query, int* tier_used, hipError_t* err);
+
 // every row with score >= min_score[0] (and key < key_bound), unsorted: out[0 .. *counter) (entries past `capacity` are dropped, still counted)
 hipError_t launch_scan_emit(const ScanParams& p, int blocks, unsigned long long* out, unsigned long long capacity, unsigned long long* counter,
                             hipStream_t stream);

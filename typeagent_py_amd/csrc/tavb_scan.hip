@@ -20,6 +20,8 @@
 //   tier 2  scan_vec   : dim a multiple of 16 B, runtime chunk loop, queries in LDS
 //   tier 3  scan_scalar: any dim, element loads (tiny / odd dims of the API tests)
 
+#include <cstring>
+
 #include "tavb_device.h"
 #include "tavb_internal.h"
 
@@ -111,8 +113,16 @@ __device__ __forceinline__ void finish_block(Selector<NQ, KPL>& sel, const ScanP
 // ---------------------------------------------------------------------------
 // tier 1: dim fixed at compile time
 // ---------------------------------------------------------------------------
-template <typename T, int CH, int NQ, int KPL, int U, bool NT, bool PIPE, int MAXT>
-__global__ void __launch_bounds__(MAXT) scan_fixed_kernel(const ScanParams p) {
+// `QA` = InlineQuery: the (single, 1536-wide) query travels inside the kernel arguments instead of through a device buffer -- a small-corpus
+// lookup then is ONE submission (no hipMemcpyAsync in front of the launch: 17.1 -> ~13.4 us of submit + synchronize,
+// profiles/r04_latency_small.md); every wave reads its slice out of the kernarg segment once.
+struct InlineQuery {
+  float v[1536];
+};
+struct NoInlineQuery {};
+
+template <typename T, int CH, int NQ, int KPL, int U, bool NT, bool PIPE, int MAXT, typename QA = NoInlineQuery>
+__global__ void __launch_bounds__(MAXT) scan_fixed_kernel(const ScanParams p, const QA qa) {
   constexpr int EPL = Elem<T>::EPL;
   constexpr int D = CH * 64 * EPL;
   constexpr bool QREG = (NQ == 1);
@@ -132,7 +142,12 @@ __global__ void __launch_bounds__(MAXT) scan_fixed_kernel(const ScanParams p) {
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) qreg[c][e] = p.queries[(c * 64 + lane) * EPL + e];
+      for (int e = 0; e < EPL; ++e) {
+        if constexpr (sizeof(QA) == sizeof(InlineQuery))
+          qreg[c][e] = qa.v[(c * 64 + lane) * EPL + e];
+        else
+          qreg[c][e] = p.queries[(c * 64 + lane) * EPL + e];
+      }
   } else {
     for (int i = threadIdx.x; i < NQ * D; i += blockDim.x) {
       const int q = i / D;
@@ -462,7 +477,21 @@ hipError_t go_fixed(const ScanParams& p, const ScanGeometry& g, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(waves * 64), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(waves * 64), lds, s, p, NoInlineQuery{});
+  return hipGetLastError();
+}
+
+// the default single-query form (2 rows in flight, non-temporal loads) with the query in the kernel arguments
+template <typename T, int CH, int KPL>
+hipError_t go_fixed_inline(const ScanParams& p, const ScanGeometry& g, hipStream_t s, const float* host_query) {
+  static_assert(CH * 64 * Elem<T>::EPL == 1536, "InlineQuery holds 1536 floats");
+  constexpr int MAXT = 1024;
+  int waves = g.waves;
+  if (waves * 64 > MAXT) waves = MAXT / 64;
+  const size_t lds = scratch_bytes(KPL, waves);
+  InlineQuery qa;
+  std::memcpy(qa.v, host_query, sizeof qa.v);
+  hipLaunchKernelGGL((scan_fixed_kernel<T, CH, 1, KPL, 2, true, false, MAXT, InlineQuery>), dim3(g.blocks), dim3(waves * 64), lds, s, p, qa);
   return hipGetLastError();
 }
 
@@ -537,6 +566,18 @@ hipError_t dispatch_scalar(const ScanParams& p, const ScanGeometry& g, hipStream
 }
 
 }  // namespace
+
+bool launch_scan_inline_query(const ScanParams& p, const ScanGeometry& g, hipStream_t stream, const float* host_query, int* tier_used, hipError_t* err) {
+  const bool f16 = p.dtype == TAVB_F16;
+  if (p.nq != 1 || p.dim != 1536 || p.k < 1 || p.k > TAVB_MAX_FUSED_K || ((uintptr_t)p.corpus % 16) != 0) return false;
+  if (!(g.tier == 0 || g.tier == 1) || g.unroll != 2 || !g.nt || g.pipe) return false;  // only the default form of tier 1 has the variant
+  if (tier_used) *tier_used = 1;
+  if (p.k <= 64)
+    *err = f16 ? go_fixed_inline<_Float16, 3, 1>(p, g, stream, host_query) : go_fixed_inline<float, 6, 1>(p, g, stream, host_query);
+  else
+    *err = f16 ? go_fixed_inline<_Float16, 3, 4>(p, g, stream, host_query) : go_fixed_inline<float, 6, 4>(p, g, stream, host_query);
+  return true;
+}
 
 hipError_t launch_scan(const ScanParams& p, const ScanGeometry& g, hipStream_t stream, int* tier_used) {
   if (p.nq < 1 || p.nq > TAVB_MAX_STREAM_QUERIES || p.k < 1 || p.k > TAVB_MAX_FUSED_K || p.dim < 1)
