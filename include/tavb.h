@@ -102,6 +102,9 @@ int tavb_synchronize(tavb_ctx* ctx);
  *                   proven complete and were re-run exactly (0 on ordinary data)
  *   "wide_fallback" 1 (default): when MORE than 64 queries of a batch of 256+ are flagged, they are re-run on the 256-query tile in its
  *                   exact split-plane form (fp32 queries as two fp16 planes) instead of 64 at a time on the 64-query exact tile; 0 = never
+ *   "early_exact"   1 (default): with wide_fallback, a batch MOST of whose queries (> nq / 2) already hold, before the last and biggest filter phase, a band that
+ *                   extrapolates past the band buffer (every query next to more near-duplicates than a band holds) skips that phase, its selection and the
+ *                   rescoring, and all its queries take the exact split-plane form at once; "last_doomed" (read only; synchronises) = that count
  *   "mfma_bdirect"  0 (default) / 1: the 256-query tile takes its query operand in MFMA-fragment-major order straight from L2 into registers
  *                   (no LDS staging; three corpus slots instead of two): measured +0.8 %, kept as an option (profiles/r04_cfg3_kernel.md section 10)
  *   "small_direct_bytes" single-query host-synchronous lookups (tavb_search, tavb_search_batch with nq = 1) on corpora up to this many

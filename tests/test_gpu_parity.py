@@ -1007,6 +1007,7 @@ def test_many_flagged_queries_take_the_wide_exact_fallback():
         out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
         assert eng.get_option("last_tier") == 4
         assert 100 <= eng.get_option("last_flagged") <= 160  # (a few more: buffers of other queries that overflowed on the planted rows inside one row range)
+        assert eng.get_option("last_doomed") <= 128  # not most of the batch: the filter ran to its end
         for qi in probe:
             vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
             if qi % 2 == 1 and qi < 200:
@@ -1018,6 +1019,55 @@ def test_many_flagged_queries_take_the_wide_exact_fallback():
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.7)
     assert len(out[0]) == 0 and len(out[1]) == k
     vo.check_topk_parity(vo.scores_full(v16, qs[1]), *items_scores(out[1]), k, 0.7, referee=vo.f64_referee(v16, qs[1]))
+
+
+def test_a_batch_of_mostly_doomed_bands_skips_the_last_filter_phase():
+    """200 of 256 queries sit next to ONE cluster of 2000 near-duplicate rows spread evenly over the corpus (a band holds 1024): when the phase
+    before the last ends, their bands over the rows seen so far already extrapolate past the buffer -- more than half the batch, so the last
+    (biggest) filter phase, its selection and the rescoring return at once and EVERY query takes the exact split-plane form.  Same answers
+    as with `early_exact=0` (filter to the end, then the exact form for the flagged ones) and as the oracle."""
+    n, nq, k = 170_000, 256, 32
+    v, _ = make_corpus(n, 1536, 8600)
+    qs = make_queries(nq, 1536, 8601)
+    rng = np.random.default_rng(8602)
+    centre = make_queries(1, 1536, 8603)[0]
+    for j in range(200):
+        w = centre + 0.05 * rng.standard_normal(1536).astype(np.float32) / np.sqrt(1536)
+        qs[j] = w / np.linalg.norm(w)
+    rows = rng.permutation(n)[:2000]
+    for r in rows:
+        w = centre + 2e-4 * rng.standard_normal(1536).astype(np.float32) / np.sqrt(1536)
+        v[r] = w / np.linalg.norm(w)
+    bounds = _native.plan_ladder(n, nq)
+    assert len(bounds) >= 3  # at least two phases: there is a phase before the last
+    seen = bounds[-2] / n
+    early_rows = int((rows < bounds[-2]).sum())  # of the cluster, in the phases before the last (~240): every one of the 200 queries holds them all in its band
+    assert early_rows > 1.25 * 1024 * seen + 40 and early_rows > k + 15 + 40  # the extrapolation rule of run_tile_ladder fires with room to spare
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    v16 = _f16(v)
+    probe = [0, 1, 57, 199, 200, 255]
+    outs = {}
+    for early in (1, 0):
+        eng.set_option("early_exact", early)
+        out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+        assert eng.get_option("last_tier") == 4
+        if early:
+            assert 195 <= eng.get_option("last_doomed") <= 200
+            assert eng.get_option("last_flagged") == nq  # nobody was rescored: all of them went to the exact form
+        else:
+            assert eng.get_option("last_doomed") == 0 and 200 <= eng.get_option("last_flagged") < nq
+        for qi in probe:
+            vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
+        assert set(r.item for r in out[0]) <= set(rows.tolist())
+        outs[early] = out
+    for qi in probe:
+        np.testing.assert_allclose([r.score for r in outs[1][qi]], [r.score for r in outs[0][qi]], atol=1e-6, rtol=0)
+    # a threshold: the queries away from the cluster return nothing, through the same skipped-phase path
+    eng.set_option("early_exact", 1)
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.7)
+    assert eng.get_option("last_flagged") == nq and len(out[255]) == 0 and len(out[0]) == k
+    vo.check_topk_parity(vo.scores_full(v16, qs[0]), *items_scores(out[0]), k, 0.7, referee=vo.f64_referee(v16, qs[0]))
 
 
 @pytest.mark.parametrize("sample", [-1, 20480, 0])

@@ -141,6 +141,7 @@ struct tavb_ctx {
   Buffer h_out{nullptr, 0, true};  // pinned + device-visible: the last kernel of a synchronous lookup writes its keys straight here
   Buffer h_lists{nullptr, 0, true};  // pinned + device-visible: per-workgroup lists of a small single-query lookup (merged on the host)
   int64_t mfma_bdirect = 0;  // option (measurement for now): the 256-query tile takes its query operand straight from L2 (fragment-major layout), not through LDS
+  int64_t early_exact = 1;    // option: ... and a batch found to be mostly such queries BEFORE the last filter phase skips that phase (needs wide_fallback)
   int64_t wide_fallback = 1;  // option: batches of 256+ queries re-run MANY (> 64) flagged queries on the 256-query tile's exact (split-plane) form
   int64_t small_direct_bytes = (int64_t)128 << 20;  // option: single-query lookups on corpora up to this size take the one-launch path (0 = never)
   int64_t last_direct = 0;                          // option "last_direct" (get): 1 when the last lookup took it, 2 = with the query inside the kernel arguments
@@ -488,6 +489,8 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");
     c->mfma_splits = v;
+  } else if (n == "early_exact") {
+    c->early_exact = v ? 1 : 0;
   } else if (n == "wide_fallback") {
     c->wide_fallback = v ? 1 : 0;
   } else if (n == "mfma_bdirect") {
@@ -533,6 +536,17 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "comm_force") *out = c->comm_force;
   else if (n == "small_direct_bytes") *out = c->small_direct_bytes;
   else if (n == "wide_fallback") *out = c->wide_fallback;
+  else if (n == "early_exact") *out = c->early_exact;
+  else if (n == "last_doomed") {  // queries of the last 256-query-tile lookup counted by the early verdict (synchronises); above nq / 2 the last filter phase was skipped
+    *out = 0;
+    if (c->d_flag.ptr) {
+      DeviceGuard guard(c->device);
+      int v = 0;
+      TAVB_HIP(hipStreamSynchronize(c->stream));
+      TAVB_HIP(hipMemcpy(&v, reinterpret_cast<const int*>(c->d_flag.ptr) + 1, sizeof v, hipMemcpyDeviceToHost));
+      *out = v;
+    }
+  }
   else if (n == "mfma_bdirect") *out = c->mfma_bdirect;
   else if (n == "last_direct") *out = c->last_direct;
   else if (n == "inline_query") *out = c->inline_query;
@@ -1418,6 +1432,10 @@ struct TileRun {
   int* band_cnt;          // device [nq]: out, keys per query in d_out
   unsigned* lost;         // device [nq_pad]: scratch (zeroed by the caller), score level below which a query lost band rows
   int* verdict;           // device [nq]: out, 1 where the band handed over is not provably complete
+  // ... early verdict on the whole batch: after the phase before the last, queries whose band over the rows seen so far extrapolates to more than
+  // the band buffer are counted in *doomed (zeroed by the caller); with more than doomed_max of them the last phase's launches return at once
+  int* doomed;
+  int doomed_max;
 };
 
 // Phase boundaries of the threshold ladder (see run_tile_ladder): phase i scans rows [b[i], b[i+1]).  `sample_opt` / `growth` = the options
@@ -1521,6 +1539,17 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
     const int carried = ph > 0 ? 1 : 0;  // the running top-k of the earlier phases occupies one more list slot
     pp.list_stride = pp.n_splits + carried;
     pp.thr_in = ph > 0 ? reinterpret_cast<const float*>(c->d_thr.ptr) : floor;
+    // the early verdict (r.doomed): the select launch of the phase before the last counts, the last phase's launches gate themselves on the count
+    const bool doom_count = wide && r.doomed && n_phases >= 2 && ph == n_phases - 2;
+    const bool doom_gate = wide && r.doomed && n_phases >= 2 && last;
+    // a band of c keys over `seen` of `rows` rows grows to about c * rows / seen when its rows are spread evenly (a cluster of near-duplicates around
+    // the k-th best; on ordinary data the band is k plus a key or two whatever the row count): counted when that is 1.25 x the band buffer,
+    // and only with at least 16 keys beyond k in hand
+    const int doom_limit = std::max(k + 15, (int)std::min<int64_t>(1 << 30, (int64_t)(1.25 * kc * (double)bounds[ph + 1] / (double)c->rows)));
+    if (doom_gate) {
+      pp.gate = r.doomed;
+      pp.gate_max = r.doomed_max;
+    }
     u64_t* const running = reinterpret_cast<u64_t*>(c->d_sample_keys.ptr);  // [2][nq][kc] (+ [2][nq] counts); not allocated for a single phase
     const u64_t* const run_in = running ? running + (size_t)((ph + 1) & 1) * nq * kc : nullptr;  // what phase ph - 1 left
     u64_t* const run_out = running ? running + (size_t)(ph & 1) * nq * kc : nullptr;
@@ -1545,7 +1574,8 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
       int* const last_cnt = r.active ? cnt_out : r.band_cnt;
       hipError_t e = tavb::launch_select_band(pp.workspace, pp.counts, pp.n_splits, nq, r.nq_pad, k, kc, carried ? run_in : nullptr, carried ? cnt_in : nullptr,
                                               floor, r.band, last ? last_out : run_out, last ? last_cnt : cnt_out, last ? nullptr : d_thr, r.lost,
-                                              last ? r.verdict : nullptr, c->stream, r.active, r.active_min, r.active_max > 0 ? r.active_max : 0x7fffffff);
+                                              last ? r.verdict : nullptr, c->stream, r.active, r.active_min, r.active_max > 0 ? r.active_max : 0x7fffffff,
+                                              doom_gate ? r.doomed : nullptr, r.doomed_max, doom_count ? r.doomed : nullptr, doom_limit);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "select launch failed: %s", hipGetErrorString(e));
       if (last && r.active) {
         e = tavb::launch_finalize_strict(last_out, last_cnt, kc, nq, k, r.active, r.active_min, r.active_max > 0 ? r.active_max : 0x7fffffff, scatter, d_out, c->stream);
@@ -1646,19 +1676,27 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   filt.queries = c->d_queries_f16.ptr;
   filt.corpus = f32c ? c->d_shadow.ptr : nullptr;
   filt.ladder = true;
+  // a batch MOST of whose bands are not going to fit (every query next to more near-duplicates than a band holds) is found out before the last --
+  // the big -- filter phase and goes straight to the exact split-plane form: the filter's last phase, its selection and the rescoring return at once
+  const bool early = wide_fallback && c->early_exact;
+  TAVB_HIP(hipMemsetAsync(d_nflag, 0, 64 * sizeof(int), c->stream));
+  filt.doomed = early ? d_nflag + 1 : nullptr;
+  filt.doomed_max = nq / 2;
   c->last_shadow = f32c ? 1 : 0;
   if (int rc = run_tile_ladder(c, filt, reinterpret_cast<u64_t*>(c->d_approx.ptr), nullptr)) return rc;
+  char* fb = reinterpret_cast<char*>(c->d_fb_queries.ptr);
+  float* fb_thr = reinterpret_cast<float*>(fb + (size_t)2 * cap * c->dim * 2);
   {
     Timed t(c, TAVB_KERNEL_RESCORE);
     hipError_t e = tavb::launch_rescore(c->corpus, f32c, c->dim, index_base, d_q, reinterpret_cast<const u64_t*>(c->d_approx.ptr), KC,
                                         small ? nullptr : d_band_cnt, small ? nullptr : d_verdict, d_delta, min_score, nq, k, d_out, d_nflag, d_flagged,
-                                        c->stream);
+                                        c->stream, filt.doomed, filt.doomed_max);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "rescore launch failed: %s", hipGetErrorString(e));
-    char* fb = reinterpret_cast<char*>(c->d_fb_queries.ptr);
-    float* fb_thr = reinterpret_cast<float*>(fb + (size_t)2 * cap * c->dim * 2);
     e = f32c ? tavb::launch_gather_flagged_f32(d_q, c->dim, min_score, d_nflag, d_flagged, cap, reinterpret_cast<float*>(fb), fb_thr, c->stream)
              : tavb::launch_gather_flagged(d_q, c->dim, min_score, d_nflag, d_flagged, cap, fb, fb + (size_t)cap * c->dim * 2, fb_thr, c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "gather launch failed: %s", hipGetErrorString(e));
+  }
+  {  // (run_tile_ladder times its own launches, in the same bucket)
     // the exact tile over the work list: returns at once when the list is empty (the normal case)
     TileRun ex{};
     ex.skinny = true;

@@ -71,7 +71,8 @@ hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score
 // sorted best `stride` = 64 by approximate score, complete when rank 63 + delta < the exact k-th best) -> exact top k [nq, k]
 hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
                           int stride, const int* cand_cnt, const int* incomplete, const float* delta, float min_score, int nq, int k,
-                          unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream);
+                          unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream, const int* gate = nullptr, int gate_max = 0);
+// (gate: device-side counter; when *gate > gate_max there are no candidates -- the last filter phase was skipped -- and EVERY query is flagged)
 hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, float* stats /*[2]*/, hipStream_t stream);
 hipError_t launch_gather_flagged_f32(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, float* out,
                                      float* thr, hipStream_t stream);
@@ -104,6 +105,8 @@ struct MfmaParams {
   const int* active;    // optional: device-side count of live queries (query tiles past it return at once) -- a fixed-shape launch over a work list
   int32_t active_min;   // ... and the whole launch returns at once unless active_min < *active <= active_max (0 = no upper bound)
   int32_t active_max;
+  const int* gate;      // 256-query kernel only, optional: device-side counter; the launch returns at once when *gate > gate_max
+  int32_t gate_max;
   int32_t bdirect;      // 256-query kernel only: `queries` are in MFMA-fragment-major order and go straight from L2 into registers (no LDS staging)
   int64_t split_plane;  // 256-query kernel only: > 0 = the SPLIT form, queries = [2][nq_padded][dim] fp16 planes this many bytes apart (q = hi + lo)
   int32_t f32;          // skinny kernel only: corpus and queries are fp32 (else fp16)
@@ -126,7 +129,8 @@ constexpr int kBandMax = 1024;  // candidates per query the rescoring accepts (k
 hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
                               int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream, const int* active = nullptr,
-                              int active_min = 0, int active_max = 0x7fffffff);
+                              int active_min = 0, int active_max = 0x7fffffff, const int* gate = nullptr, int gate_max = 0, int* doomed = nullptr,
+                              int doom_limit = 0);
 // strict best k (ties by ordinal) of every live slot's band, sorted, into row scatter[slot] of out: the last step of the SPLIT fallback
 hipError_t launch_finalize_strict(const unsigned long long* band_keys, const int* band_cnt, int kc, int nq, int k, const int* active, int active_min,
                                   int active_max, const int* scatter, unsigned long long* out, hipStream_t stream);

@@ -77,6 +77,8 @@ struct MfmaDeviceParams {
   int32_t active_min;   // ... and the launch as a whole returns at once unless active_min < *active <= active_max (two fallbacks share one work list)
   int32_t active_max;
   int64_t split_plane;  // 256-query tile, SPLIT form: bytes from the high to the low plane of the queries ([2][nq_padded][dim] fp16); 0 otherwise
+  const int* gate;      // optional device-side counter: the whole launch returns at once when *gate > gate_max (a filter phase of a batch already known to need
+  int32_t gate_max;     // the exact form: tavb_abi.hip::run_tile_ladder)
   const float* band;    // 128/256-query tile, optional [nq_padded]: keep every key within band[q] below the k-th best (band selection)
   unsigned* lost;       // ... [nq_padded]: atomicMax of the score bits below which a query LOST band rows (a band that did not fit a buffer)
 };
@@ -429,6 +431,7 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   const int qtile = t % p.n_qtiles;
   const int split = (t / p.n_qtiles) * 8 + xcd;
   if (split >= p.n_splits) return;
+  if (p.gate != nullptr && *p.gate > p.gate_max) return;  // most of the batch is going to the exact form anyway: this filter phase would be wasted work
   if (p.active != nullptr) {  // fixed-shape launch over a device-side work list (tavb_rescore.hip): nothing to do, or not this kernel's share
     const int live = *p.active;
     if (live <= p.active_min || live > p.active_max || qtile * BN >= live) return;
@@ -1144,7 +1147,9 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
                                                           int kc_max, const u64* __restrict__ carried, const int* __restrict__ carried_cnt,
                                                           const float* __restrict__ floor, const float* __restrict__ band, u64* __restrict__ out,
                                                           int* __restrict__ out_cnt, float* __restrict__ thr_out, unsigned* __restrict__ lost,
-                                                          int* __restrict__ verdict, const int* __restrict__ active, int active_min, int active_max) {
+                                                          int* __restrict__ verdict, const int* __restrict__ active, int active_min, int active_max,
+                                                          const int* __restrict__ gate, int gate_max, int* __restrict__ doomed, int doom_limit) {
+  if (gate != nullptr && *gate > gate_max) return;  // the tile launch in front of this one was skipped too (see MfmaDeviceParams::gate)
   if (active != nullptr) {  // fixed-shape launch over a device-side work list: slots past it (or a list that is not this fallback's share) have no buffers
     const int live = *active;
     if (live <= active_min || live > active_max || (int)blockIdx.x >= live) return;
@@ -1334,6 +1339,9 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
   __syncthreads();
   if (tid == 0) {
     out_cnt[q] = n_picked < kc_max ? n_picked : kc_max;
+    // a band over the rows seen so far that is already this full will not fit at the end (the caller extrapolates: doom_limit): counted, and the
+    // launches of the last filter phase gate themselves on the count
+    if (doomed != nullptr && n_picked > doom_limit) atomicAdd(doomed, 1);
     uint32_t lost_all = lost_here;
     if (lost != nullptr) {
       if (lost_here != 0u) atomicMax(&lost[q], lost_here);
@@ -1424,13 +1432,13 @@ hipError_t launch_finalize_strict(const unsigned long long* band_keys, const int
 hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
                               int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream, const int* active, int active_min,
-                              int active_max) {
+                              int active_max, const int* gate, int gate_max, int* doomed, int doom_limit) {
   if (nq < 1 || k < 1 || k > 64 || n_splits < 1 || n_splits > 256 || nq_padded < nq || kc_max < k || kc_max > SEL_CACHE / 4) return hipErrorInvalidValue;
   constexpr int lds = SEL_CACHE * (int)sizeof(u64);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(select_band_kernel, dim3(nq), dim3(256), lds, stream, cand, counts, n_splits, nq_padded, k, kc_max, carried, carried_cnt, floor, band,
-                     out, out_cnt, thr_out, lost, verdict, active, active_min, active_max);
+                     out, out_cnt, thr_out, lost, verdict, active, active_min, active_max, gate, gate_max, doomed, doom_limit);
   return hipGetLastError();
 }
 
@@ -1457,6 +1465,8 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   d.active_min = p.active_min;
   d.active_max = p.active_max > 0 ? p.active_max : 0x7fffffff;
   d.split_plane = p.split_plane;
+  d.gate = p.gate;
+  d.gate_max = p.gate_max;
   const int64_t per = (p.rows + p.n_splits - 1) / p.n_splits;
   const int bm = BM6;
   d.rows_per_split = ((per + bm - 1) / bm) * bm;

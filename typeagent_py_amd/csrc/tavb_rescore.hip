@@ -177,11 +177,15 @@ __global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corp
                                                       const int* __restrict__ cand_cnt, const int* __restrict__ incomplete,
                                                       const float* __restrict__ delta, float min_score, int k,
                                                       u64* __restrict__ out /*[nq, k]*/, int* __restrict__ n_flagged,
-                                                      int* __restrict__ flagged) {
+                                                      int* __restrict__ flagged, const int* __restrict__ gate, int gate_max) {
   __shared__ u64 exact[kBandMax];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int qi = blockIdx.x;
+  if (gate != nullptr && *gate > gate_max) {  // the last filter phase did not run (most bands were not going to fit): no candidates, every query takes the exact form
+    if (threadIdx.x == 0) flagged[atomicAdd(n_flagged, 1)] = qi;
+    return;
+  }
   const u64* cand = approx + (size_t)qi * stride;
   const float* q = queries + (size_t)qi * dim;
   const int n8 = dim / 8;
@@ -327,15 +331,15 @@ hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score
 
 hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
                           int stride, const int* cand_cnt, const int* incomplete, const float* delta, float min_score, int nq, int k,
-                          unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream) {
+                          unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream, const int* gate, int gate_max) {
   if (stride < 1 || stride > kBandMax || k < 1 || k > 64 || (cand_cnt != nullptr && incomplete == nullptr)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, stream, n_flagged);
   if (f32_rows)
     hipLaunchKernelGGL(rescore_kernel<float>, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const float*>(corpus), dim, index_base, queries, approx,
-                       stride, cand_cnt, incomplete, delta, min_score, k, out, n_flagged, flagged);
+                       stride, cand_cnt, incomplete, delta, min_score, k, out, n_flagged, flagged, gate, gate_max);
   else
     hipLaunchKernelGGL(rescore_kernel<_Float16>, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(corpus), dim, index_base, queries,
-                       approx, stride, cand_cnt, incomplete, delta, min_score, k, out, n_flagged, flagged);
+                       approx, stride, cand_cnt, incomplete, delta, min_score, k, out, n_flagged, flagged, gate, gate_max);
   return hipGetLastError();
 }
 
