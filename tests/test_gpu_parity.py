@@ -1021,11 +1021,13 @@ def test_many_flagged_queries_take_the_wide_exact_fallback():
     vo.check_topk_parity(vo.scores_full(v16, qs[1]), *items_scores(out[1]), k, 0.7, referee=vo.f64_referee(v16, qs[1]))
 
 
-def test_a_batch_of_mostly_doomed_bands_skips_the_last_filter_phase():
+@pytest.mark.parametrize("cluster", [2000, 12_000])
+def test_a_batch_of_mostly_doomed_bands_skips_the_last_filter_phase(cluster):
     """200 of 256 queries sit next to ONE cluster of 2000 near-duplicate rows spread evenly over the corpus (a band holds 1024): when the phase
     before the last ends, their bands over the rows seen so far already extrapolate past the buffer -- more than half the batch, so the last
     (biggest) filter phase, its selection and the rescoring return at once and EVERY query takes the exact split-plane form.  Same answers
-    as with `early_exact=0` (filter to the end, then the exact form for the flagged ones) and as the oracle."""
+    as with `early_exact=0` (filter to the end, then the exact form for the flagged ones) and as the oracle.  (12 000 rows: the band over the
+    first phase alone is past the buffer -- cut to the strict best k there and counted all the same.)"""
     n, nq, k = 170_000, 256, 32
     v, _ = make_corpus(n, 1536, 8600)
     qs = make_queries(nq, 1536, 8601)
@@ -1034,7 +1036,7 @@ def test_a_batch_of_mostly_doomed_bands_skips_the_last_filter_phase():
     for j in range(200):
         w = centre + 0.05 * rng.standard_normal(1536).astype(np.float32) / np.sqrt(1536)
         qs[j] = w / np.linalg.norm(w)
-    rows = rng.permutation(n)[:2000]
+    rows = rng.permutation(n)[:cluster]
     for r in rows:
         w = centre + 2e-4 * rng.standard_normal(1536).astype(np.float32) / np.sqrt(1536)
         v[r] = w / np.linalg.norm(w)

@@ -1341,7 +1341,7 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
     out_cnt[q] = n_picked < kc_max ? n_picked : kc_max;
     // a band over the rows seen so far that is already this full will not fit at the end (the caller extrapolates: doom_limit): counted, and the
     // launches of the last filter phase gate themselves on the count
-    if (doomed != nullptr && n_picked > doom_limit) atomicAdd(doomed, 1);
+    if (doomed != nullptr && (n_picked > doom_limit || strict)) atomicAdd(doomed, 1);  // (strict: it does not even fit now)
     uint32_t lost_all = lost_here;
     if (lost != nullptr) {
       if (lost_here != 0u) atomicMax(&lost[q], lost_here);
