@@ -104,6 +104,26 @@ def test_merge_keys_host_helper():
         np.testing.assert_array_equal(got[q], want)
 
 
+def test_merge_keys_host_random_shapes():
+    """tavb_merge_keys_host (the merge of a one-launch small lookup's per-workgroup lists, of several devices' lists, of begin/end pages) against a
+    plain sort: more lists than k and fewer, lists that are short or empty, exact duplicates across lists, one list, k = 1."""
+    rng = np.random.default_rng(77)
+    shapes = [(204, 1, 10), (40, 1, 50), (64, 1, 32), (8, 1, 256), (1, 3, 5), (300, 2, 1), (3, 2, 64), (17, 4, 17)]
+    shapes += [(int(rng.integers(1, 260)), int(rng.integers(1, 4)), int(rng.integers(1, 70))) for _ in range(200)]
+    for trial, (n_lists, nq, k) in enumerate(shapes):
+        keys = rng.integers(1, (1 << 63) - 1, size=(n_lists, nq, k), dtype=np.int64).astype(np.uint64)
+        if trial % 3 == 0:
+            keys = keys % np.uint64(40) + np.uint64(1)  # many duplicates
+        keys = np.where(rng.random((n_lists, nq, k)) < rng.random(), keys, np.uint64(0))  # holes: sorted to the tails below
+        lists = np.sort(keys, axis=2)[:, :, ::-1].copy()
+        got = _native.merge_keys(lists)
+        for q in range(nq):
+            flat = np.sort(lists[:, q, :].reshape(-1))[::-1]
+            want = np.zeros(k, dtype=np.uint64)
+            want[: min(k, flat.size)] = flat[:k]
+            np.testing.assert_array_equal(got[q], want, err_msg=f"{n_lists} lists, k={k}, query {q}")
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # GPU: several contexts on the visible device(s)
 # ------------------------------------------------------------------------------------------------------------------
