@@ -107,8 +107,9 @@ int tavb_synchronize(tavb_ctx* ctx);
  *                   rescoring, and all its queries take the exact split-plane form at once; "last_doomed" (read only; synchronises) = that count
  *   "mfma_bdirect"  0 (default) / 1: the 256-query tile takes its query operand in MFMA-fragment-major order straight from L2 into registers
  *                   (no LDS staging; three corpus slots instead of two): measured +0.8 %, kept as an option (profiles/r04_cfg3_kernel.md section 10)
- *   "small_direct_bytes" single-query host-synchronous lookups (tavb_search, tavb_search_batch with nq = 1) on corpora up to this many
- *                   bytes (default 128 MiB; 0 = never) are ONE launch: the scan's per-workgroup lists go to pinned host memory and are merged
+ *   "small_direct_bytes" host-synchronous lookups of one query (tavb_search) or a few (tavb_search_batch with nq <= 8; <= 4 for k > 64) on corpora up
+ *                   to this many bytes (default 128 MiB; 0 = never) are ONE launch ("small_direct_keys", default 8192: the most keys the lists may hold
+ *                   -- the grid is cut to fit; twice that for a batch, which goes the usual way when its share would starve the grid): the scan's per-workgroup lists go to pinned host memory and are merged
  *                   on the host; "last_direct" (read only) = 1 when the last lookup took that path, 2 when in addition the query rode
  *                   inside the kernel arguments ("inline_query", default 1: 1536-wide queries on the default scan form; no H2D copy before the launch)
  */

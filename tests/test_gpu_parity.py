@@ -688,9 +688,36 @@ def test_small_corpus_lookups_take_one_launch(n, dtype):
         res = vb.fuzzy_lookup_embedding(q2, max_hits=10, min_score=-1.0)
         assert eng.get_option("last_direct") == 2
         vo.check_topk_parity(vo.scores_full(seen, q2), *items_scores(res), 10, -1.0, referee=vo.f64_referee(seen, q2))
-    # batches and subset lookups do not take the path (and are unaffected by it)
-    vb.fuzzy_lookup_embeddings(np.stack([q, q]), max_hits=5)
-    assert eng.get_option("last_direct") == 0
+    # a FEW queries at once (2 .. 8: batched related-term lookups) take it too -- one launch of the multi-query scan, lists merged on the host per query --
+    # with the answers of single lookups; bigger batches go to the tiles, subset lookups are unaffected
+    qs = np.concatenate([q[None, :], make_queries(8, 1536, 77)])
+    if n >= 100:
+        qs[3] = v[min(n - 1, 50)]
+    for nq in (2, 3, 4, 8, 9):
+        for k, ms in [(10, 0.0), (50, 0.85), (50, -1.0), (200, 0.0)]:
+            eng.profile_enable(True)
+            eng.profile_reset()
+            out = vb.fuzzy_lookup_embeddings(qs[:nq], max_hits=k, min_score=ms)
+            direct = eng.get_option("last_direct")
+            launches = eng.profile_read(_native.KERNEL_SCAN)[1], eng.profile_read(_native.KERNEL_MERGE)[1]
+            eng.profile_enable(False)
+            if nq <= 4 and k <= 50 and n <= 1294:
+                assert direct == 1, (nq, k, direct)  # (bigger shapes: when the list budget still covers the rows in two rounds of the grid)
+            if nq == 9:
+                assert direct == 0
+            if direct:
+                assert launches == (1, 0)
+            for qi in range(nq):
+                vo.check_topk_parity(vo.scores_full(seen, qs[qi]), *items_scores(out[qi]), k, ms, referee=vo.f64_referee(seen, qs[qi]))
+                if qi in (0, nq - 1):  # the single lookup's answer (another kernel: the last bit of a score may differ)
+                    one = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=ms)
+                    np.testing.assert_allclose([r.score for r in out[qi]], [r.score for r in one], atol=1e-6, rtol=0)
+    # per-query thresholds through the C ABI's batch call
+    thr = np.array([0.0, 0.9, -1.0, 0.5], dtype=np.float32)
+    o, s_, c_ = eng.search_batch(qs[:4], 10, thr)
+    assert eng.get_option("last_direct") == (1 if n <= 1294 or dtype == "fp32" else eng.get_option("last_direct"))
+    for qi in range(4):
+        vo.check_topk_parity(vo.scores_full(seen, qs[qi]), o[qi, : c_[qi]].tolist(), s_[qi, : c_[qi]].tolist(), 10, float(thr[qi]), referee=vo.f64_referee(seen, qs[qi]))
 
 
 def test_wrong_query_size_raises_value_error():

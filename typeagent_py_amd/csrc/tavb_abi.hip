@@ -144,6 +144,7 @@ struct tavb_ctx {
   int64_t early_exact = 1;    // option: ... and a batch found to be mostly such queries BEFORE the last filter phase skips that phase (needs wide_fallback)
   int64_t wide_fallback = 1;  // option: batches of 256+ queries re-run MANY (> 64) flagged queries on the 256-query tile's exact (split-plane) form
   int64_t small_direct_bytes = (int64_t)128 << 20;  // option: single-query lookups on corpora up to this size take the one-launch path (0 = never)
+  int64_t small_direct_keys = 8192;                 // option: most keys the per-workgroup lists of such a lookup may hold (the grid is cut to fit; x 2 for a batch of 2 .. 8 queries)
   int64_t last_direct = 0;                          // option "last_direct" (get): 1 when the last lookup took it, 2 = with the query inside the kernel arguments
   int inline_query = 1;                             // option: 1536-wide single queries of that path ride in the kernel arguments (no H2D copy before the launch)
 
@@ -495,6 +496,9 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     c->wide_fallback = v ? 1 : 0;
   } else if (n == "mfma_bdirect") {
     c->mfma_bdirect = v ? 1 : 0;
+  } else if (n == "small_direct_keys") {
+    if (v < 64 || v > (1 << 20)) return fail(TAVB_E_INVALID, "small_direct_keys must be 64 .. 1048576");
+    c->small_direct_keys = v;
   } else if (n == "inline_query") {
     c->inline_query = v ? 1 : 0;
   } else if (n == "small_direct_bytes") {
@@ -550,6 +554,7 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "mfma_bdirect") *out = c->mfma_bdirect;
   else if (n == "last_direct") *out = c->last_direct;
   else if (n == "inline_query") *out = c->inline_query;
+  else if (n == "small_direct_keys") *out = c->small_direct_keys;
   else if (n == "graph_max_bytes") *out = c->graph_max_bytes;
   else if (n == "last_graph") *out = c->last_graph;
   else if (n == "comm_world") *out = c->comm ? c->comm_world : 0;
@@ -742,50 +747,62 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
       return TAVB_OK;
     }
   }
-  // ---- small corpus, one query (the scale typeagent itself runs at: ~1.3k .. 10k rows): ONE launch.  The scan's per-workgroup lists go
-  //      straight into pinned host memory and are merged here -- the second launch that merged 256 lists on the device cost 11.8 us of a
-  //      41 us lookup (profiles/r03_latency_cfg1.md).  The grid is cut to what keeps the lists within 16 KiB (2048 keys): 204 workgroups
-  //      at k = 10, 64 at k = 32, 40 at k = 50 -- a corpus this small does not need 256 of them.
-  if (streaming && slot == nullptr && c->small_direct_bytes > 0 && corpus_bytes <= c->small_direct_bytes) {
+  // ---- small corpus (the scale typeagent itself runs at: ~1.3k .. 10k rows), one query or a FEW (batched related-term lookups,
+  //      adapters.install_batched_lookup_terms): ONE launch.  The scan's per-workgroup lists go straight into pinned host memory and are merged
+  //      here -- the second launch that merged them on the device cost 11.8 us of a 41 us lookup (profiles/r03_latency_cfg1.md), and a batch of
+  //      2 .. 8 queries took 36 .. 110 us through the device merge or the 32-query MFMA tile (profiles/r04_latency_small.md).  The grid is cut to
+  //      what keeps the lists within `small_direct_keys` keys (8192 = 64 KiB over PCIe; twice that for a batch): 163 workgroups at k = 50,
+  //      all of them at k <= 32.  A batch takes this path when its share of that budget still covers the rows in two rounds of the grid, and on
+  //      fp16 corpora up to 4 queries: beyond that the multi-query scan (6 us more per query) loses to the 32-query tile (measured).
+  const int direct_nq_max = (k > 64) ? 4 : TAVB_MAX_STREAM_QUERIES;  // queries one pass of the streaming kernels serves
+  const bool few = nq >= 2 && nq <= direct_nq_max && !(c->dtype == TAVB_F32 && c->f32_shadow >= 2 && corpus_bytes >= c->f32_shadow_min_bytes);
+  if ((streaming || few) && slot == nullptr && c->small_direct_bytes > 0 && corpus_bytes <= c->small_direct_bytes) {
     tavb::ScanGeometry g = c->geom;
     if (g.waves < 1) g.waves = 1;
     if (g.waves > 16) g.waves = 16;
-    g.blocks = std::min(scan_blocks_for(c, c->rows, g.waves, g.unroll), std::max(8, 2048 / k));
-    if (int rc = c->h_lists.reserve((size_t)g.blocks * k * sizeof(u64_t))) return rc;
-    tavb::ScanParams p{};
-    p.corpus = c->corpus;
-    p.row_ids = nullptr;
-    p.queries = reinterpret_cast<const float*>(c->d_queries.ptr);
-    p.lists = reinterpret_cast<u64_t*>(c->h_lists.ptr);
-    p.n_pos = c->rows;
-    p.dim = c->dim;
-    p.dtype = c->dtype;
-    p.nq = 1;
-    p.k = k;
-    p.index_base = 0u;
-    p.key_bound = ~0ull;
-    for (int i = 0; i < TAVB_MAX_STREAM_QUERIES; ++i) p.min_score[i] = (i < 1) ? min_scores[0] : INFINITY;
-    {
-      // 1536-wide query (the embedding size typeagent runs at): it rides in the kernel arguments -- one submission, no copy in front of the launch
-      hipError_t e = hipSuccess;
-      bool launched = false;
-      if (c->inline_query) {
-        Timed t(c, TAVB_KERNEL_SCAN);
-        launched = tavb::launch_scan_inline_query(p, g, c->stream, queries_host, &c->last_tier, &e);
+    const int64_t budget = c->small_direct_keys * (nq > 1 ? 2 : 1);
+    g.blocks = std::min(scan_blocks_for(c, c->rows, g.waves, g.unroll), (int)std::max<int64_t>(8, budget / ((int64_t)k * nq)));
+    const int64_t rounds = (c->rows + (int64_t)g.blocks * g.waves * g.unroll - 1) / ((int64_t)g.blocks * g.waves * g.unroll);
+    if (nq == 1 || (rounds <= 2 && (c->dtype == TAVB_F32 || nq <= 4))) {
+      const size_t list_keys = (size_t)nq * g.blocks * k;
+      if (int rc = c->h_lists.reserve((list_keys + (size_t)nq * k) * sizeof(u64_t))) return rc;  // + the merged keys
+      tavb::ScanParams p{};
+      p.corpus = c->corpus;
+      p.row_ids = nullptr;
+      p.queries = reinterpret_cast<const float*>(c->d_queries.ptr);
+      p.lists = reinterpret_cast<u64_t*>(c->h_lists.ptr);  // [nq][blocks][k]
+      p.n_pos = c->rows;
+      p.dim = c->dim;
+      p.dtype = c->dtype;
+      p.nq = nq;
+      p.k = k;
+      p.index_base = 0u;
+      p.key_bound = ~0ull;
+      for (int i = 0; i < TAVB_MAX_STREAM_QUERIES; ++i) p.min_score[i] = (i < nq) ? min_scores[i] : INFINITY;
+      {
+        // one 1536-wide query (the embedding size typeagent runs at): it rides in the kernel arguments -- one submission, no copy in front of the launch
+        hipError_t e = hipSuccess;
+        bool launched = false;
+        if (c->inline_query && nq == 1) {
+          Timed t(c, TAVB_KERNEL_SCAN);
+          launched = tavb::launch_scan_inline_query(p, g, c->stream, queries_host, &c->last_tier, &e);
+        }
+        if (!launched) {
+          TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
+          Timed t(c, TAVB_KERNEL_SCAN);
+          e = tavb::launch_scan(p, g, c->stream, &c->last_tier);
+        }
+        if (e != hipSuccess) return fail(TAVB_E_HIP, "scan kernel launch failed: %s", hipGetErrorString(e));
+        c->last_direct = launched ? 2 : 1;
       }
-      if (!launched) {
-        TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
-        Timed t(c, TAVB_KERNEL_SCAN);
-        e = tavb::launch_scan(p, g, c->stream, &c->last_tier);
-      }
-      if (e != hipSuccess) return fail(TAVB_E_HIP, "scan kernel launch failed: %s", hipGetErrorString(e));
-      c->last_direct = launched ? 2 : 1;
+      TAVB_HIP(hipStreamSynchronize(c->stream));
+      tavb_key* merged = reinterpret_cast<tavb_key*>(c->h_lists.ptr) + list_keys;
+      for (int q = 0; q < nq; ++q)
+        if (int rc = tavb_merge_keys_host(reinterpret_cast<const tavb_key*>(c->h_lists.ptr) + (size_t)q * g.blocks * k, g.blocks, 1, k, merged + (size_t)q * k))
+          return rc;
+      decode(reinterpret_cast<const u64_t*>(merged), nq, k, c->ordinal_base, out_ordinals, out_scores, out_counts);
+      return TAVB_OK;
     }
-    TAVB_HIP(hipStreamSynchronize(c->stream));
-    u64_t merged[TAVB_MAX_FUSED_K];
-    if (int rc = tavb_merge_keys_host(reinterpret_cast<const tavb_key*>(c->h_lists.ptr), g.blocks, 1, k, reinterpret_cast<tavb_key*>(merged))) return rc;
-    decode(merged, 1, k, c->ordinal_base, out_ordinals, out_scores, out_counts);
-    return TAVB_OK;
   }
   const bool capture = slot != nullptr && slot->seen >= 1;  // (the first call of a shape sizes the workspaces: no allocation may happen inside a capture)
   if (slot) ++slot->seen;
