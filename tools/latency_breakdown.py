@@ -46,7 +46,7 @@ def main():
     eng.set_option("scan_waves", 16)
     for blocks in ((8, 16, 32, 64, 128, 256) if direct else ()):
         eng.set_option("scan_blocks", blocks)
-        print("   ... with scan_blocks=%-3d (lists merged on the host: min(blocks, 2048 / k)):   %.1f us" % (blocks, med(lambda: eng.search(q, k, thr))))
+        print("   ... with scan_blocks=%-3d (lists merged on the host; capped by small_direct_keys / k):  %.1f us" % (blocks, med(lambda: eng.search(q, k, thr))))
     eng.set_option("scan_blocks", 0)
     eng.set_option("small_direct_bytes", 0)
     print("host-synchronous search, two launches (scan + device merge -> pinned; round 3): %.1f us" % med(lambda: eng.search(q, k, thr)))
