@@ -86,6 +86,14 @@ def main():
             ok(lib.tavb_search(h, ptr(q), kk, c_float(0.0), ptr(o3), ptr(s3), byref(cnt)))
             dflag = c_int64(); ok(lib.tavb_get_option(h, b"last_direct", byref(dflag)))
             assert dflag.value in (1, 2) and cnt.value == kk and (o3[: min(k, kk)] == two_launch[: min(k, kk)]).all(), (kk, dflag.value, cnt.value)
+        # ... and a FEW queries at once through it (the multi-query scan's lists merged per query on the host), every k and count, per-query thresholds
+        for nq3, kk in ((2, k), (3, 1), (4, 200), (8, k)):
+            q3 = v[5 : 5 + nq3].copy()
+            o3 = np.empty((nq3, kk), np.int64); s3 = np.empty((nq3, kk), np.float32); c3 = np.empty(nq3, np.int32)
+            thr3 = np.linspace(0.0, 0.5, nq3).astype(np.float32)
+            ok(lib.tavb_search_batch(h, ptr(q3), nq3, kk, ptr(thr3), ptr(o3), ptr(s3), ptr(c3)))
+            dflag = c_int64(); ok(lib.tavb_get_option(h, b"last_direct", byref(dflag)))
+            assert (o3[:, 0] == np.arange(5, 5 + nq3)).all() and (c3 >= 1).all(), (nq3, kk, dflag.value, o3[:, 0], c3)
         ok(lib.tavb_set_option(h, b"small_direct_bytes", 128 << 20))
         bounds = (c_int64 * 16)()
         phases = lib.tavb_plan_ladder(10_000_000, 1024, 256, bounds, 16)
