@@ -1325,6 +1325,7 @@ def test_skinny_kernel_against_oracle(dtype, n, d, nq, k, ms):
     if n > 10:
         qs[0] = v[n - 2]  # exact self-match in the last rows
     vb = new_vb(v, dtype=dtype)
+    vb.engine.set_option("small_direct_bytes", 0)  # (up to 8 queries on a corpus this small would take the one-launch streaming path: this test is about the tile)
     got = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
     assert vb.engine.get_option("last_tier") == 5
     ref_v = v if dtype == "fp32" else _f16(v)
