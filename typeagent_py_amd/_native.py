@@ -84,6 +84,14 @@ ABI_SYMBOLS = [name for name, _, _ in _SIGNATURES]
 _AS_POINTER = ctypes.c_char * 0  # `_AS_POINTER.from_buffer(ndarray)`: a ctypes object at the array's address, passed where a pointer is expected
 
 
+def _addr(arr: np.ndarray):
+    """The array's address as a ctypes argument: 0.25 us through the buffer protocol (writable arrays) against ~2 us for `ndarray.ctypes.data_as()`."""
+    try:
+        return _AS_POINTER.from_buffer(arr)
+    except (TypeError, ValueError, BufferError):  # read-only (or otherwise not exportable) buffer
+        return arr.ctypes.data_as(c_void_p)
+
+
 def plan_ladder(rows: int, nq: int, n_cu: int = 256) -> list[int]:
     """Phase boundaries of the threshold ladder the library runs for a batch of `nq` (>= 65) queries over `rows` rows with default options
     (tavb_plan_ladder): len(result) - 1 = tile-kernel launches per lookup.  Needs no GPU."""
@@ -307,7 +315,7 @@ class Engine:
             src = np.ascontiguousarray(host_rows, dtype=np.float32)
             torch.cuda.current_stream(self.device).synchronize()  # the allocation / copy of old rows above ran on torch's stream
             dst = self.corpus.data_ptr() + start * dim * (2 if dtype == TAVB_F16 else 4)
-            _check(self.lib, self.lib.tavb_upload_rows(self._h, src.ctypes.data_as(c_void_p), src.shape[0], dim, c_void_p(dst), dtype))
+            _check(self.lib, self.lib.tavb_upload_rows(self._h, _addr(src), src.shape[0], dim, c_void_p(dst), dtype))
         self.set_corpus_tensor(self.corpus, rows=n_new, ordinal_base=self.ordinal_base, _owned=True)
         _check(self.lib, self.lib.tavb_corpus_modified(self._h, int(start)))  # rows [start, n_new) were (re)written
         return True
@@ -368,7 +376,7 @@ class Engine:
         try:
             pa = _AS_POINTER.from_buffer(a)  # 0.25 us; needs a writable buffer
         except (TypeError, ValueError):
-            pa = a.ctypes.data_as(c_void_p)
+            pa = _addr(a)
         with self._lock:
             ords, scs, p_ords, p_scs, cnt = self._out_buffers(k)
             if after is None:
@@ -390,12 +398,12 @@ class Engine:
         cnt = c_int32(0)
         with self._lock:
             if after is None:
-                rc = self.lib.tavb_search_subset(self._h, a.ctypes.data_as(c_void_p), r.ctypes.data_as(c_void_p), r.shape[0], k,
-                                                 c_float(float(thr)), pos.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt))
+                rc = self.lib.tavb_search_subset(self._h, _addr(a), _addr(r), r.shape[0], k,
+                                                 c_float(float(thr)), _addr(pos), _addr(scs), byref(cnt))
             else:
-                rc = self.lib.tavb_search_subset_after(self._h, a.ctypes.data_as(c_void_p), r.ctypes.data_as(c_void_p), r.shape[0], k,
+                rc = self.lib.tavb_search_subset_after(self._h, _addr(a), _addr(r), r.shape[0], k,
                                                        c_float(float(thr)), c_float(after[0]), int(after[1]),
-                                                       pos.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt))
+                                                       _addr(pos), _addr(scs), byref(cnt))
         _check(self.lib, rc)
         m = int(cnt.value)
         return pos[:m], scs[:m]
@@ -411,11 +419,11 @@ class Engine:
         cnt, total = c_int64(0), c_int64(0)
         with self._lock:
             if r is None:
-                rc = self.lib.tavb_search_all(self._h, a.ctypes.data_as(c_void_p), c_float(float(thr)), cap, items.ctypes.data_as(c_void_p),
-                                              scs.ctypes.data_as(c_void_p), byref(cnt), byref(total))
+                rc = self.lib.tavb_search_all(self._h, _addr(a), c_float(float(thr)), cap, _addr(items),
+                                              _addr(scs), byref(cnt), byref(total))
             else:
-                rc = self.lib.tavb_search_subset_all(self._h, a.ctypes.data_as(c_void_p), r.ctypes.data_as(c_void_p), r.shape[0], c_float(float(thr)), cap,
-                                                     items.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt), byref(total))
+                rc = self.lib.tavb_search_subset_all(self._h, _addr(a), _addr(r), r.shape[0], c_float(float(thr)), cap,
+                                                     _addr(items), _addr(scs), byref(cnt), byref(total))
         _check(self.lib, rc)
         m = int(cnt.value)
         return items[:m], scs[:m]
@@ -430,9 +438,8 @@ class Engine:
         ords = np.empty((nq, k), dtype=np.int64)
         scs = np.empty((nq, k), dtype=np.float32)
         cnts = np.zeros(nq, dtype=np.int32)
-        with self._lock:
-            rc = self.lib.tavb_search_batch(self._h, a.ctypes.data_as(c_void_p), nq, k, t.ctypes.data_as(c_void_p),
-                                            ords.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), cnts.ctypes.data_as(c_void_p))
+        with self._lock:  # (five `ndarray.ctypes.data_as()` were 10 us of a 32 us two-query lookup on a small corpus)
+            rc = self.lib.tavb_search_batch(self._h, _addr(a), nq, k, _addr(t), _addr(ords), _addr(scs), _addr(cnts))
         _check(self.lib, rc)
         return ords, scs, cnts
 
@@ -458,14 +465,14 @@ class Engine:
         with self._lock:
             if subset_rows is not None:
                 r = np.ascontiguousarray(subset_rows, dtype=np.int64)
-                rc = self.lib.tavb_search_messages_subset(self._h, a.ctypes.data_as(c_void_p), r.ctypes.data_as(c_void_p), r.shape[0], k, c_float(float(thr)),
-                                                          int(max_messages), msgs.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt))
+                rc = self.lib.tavb_search_messages_subset(self._h, _addr(a), _addr(r), r.shape[0], k, c_float(float(thr)),
+                                                          int(max_messages), _addr(msgs), _addr(scs), byref(cnt))
             else:
                 acc = None if accept is None else np.ascontiguousarray(accept, dtype=np.int32)
-                rc = self.lib.tavb_search_messages(self._h, a.ctypes.data_as(c_void_p), k, c_float(float(thr)),
-                                                   acc.ctypes.data_as(c_void_p) if acc is not None and acc.size else None,
+                rc = self.lib.tavb_search_messages(self._h, _addr(a), k, c_float(float(thr)),
+                                                   _addr(acc) if acc is not None and acc.size else None,
                                                    -1 if acc is None else acc.shape[0], int(max_messages),
-                                                   msgs.ctypes.data_as(c_void_p), scs.ctypes.data_as(c_void_p), byref(cnt))
+                                                   _addr(msgs), _addr(scs), byref(cnt))
         _check(self.lib, rc)
         m = int(cnt.value)
         return msgs[:m], scs[:m]
@@ -477,14 +484,14 @@ class Engine:
         if cursor_key is not None:
             cur = (c_uint64 * 1)(int(cursor_key))
         with self._lock:
-            rc = self.lib.tavb_search_begin(self._h, queries.ctypes.data_as(c_void_p), queries.shape[0], k, thrs.ctypes.data_as(c_void_p),
+            rc = self.lib.tavb_search_begin(self._h, _addr(queries), queries.shape[0], k, _addr(thrs),
                                             ctypes.cast(cur, c_void_p) if cur is not None else None)
         _check(self.lib, rc)
 
     def search_end(self, nq: int, k: int, out_keys: np.ndarray) -> None:
         """out_keys: uint64 [nq, k] (contiguous) <- sorted key lists with global ordinals."""
         with self._lock:
-            rc = self.lib.tavb_search_end(self._h, nq, k, out_keys.ctypes.data_as(c_void_p))
+            rc = self.lib.tavb_search_end(self._h, nq, k, _addr(out_keys))
         _check(self.lib, rc)
 
     # device-resident forms ---------------------------------------------------
@@ -595,7 +602,7 @@ def merge_keys(lists: np.ndarray) -> np.ndarray:
     a = np.ascontiguousarray(lists, dtype=np.uint64)
     n_lists, nq, k = a.shape
     out = np.empty((nq, k), dtype=np.uint64)
-    _check(lib, lib.tavb_merge_keys_host(a.ctypes.data_as(c_void_p), n_lists, nq, k, out.ctypes.data_as(c_void_p)))
+    _check(lib, lib.tavb_merge_keys_host(_addr(a), n_lists, nq, k, _addr(out)))
     return out
 
 
@@ -609,6 +616,6 @@ def decode_keys(keys: np.ndarray):
     ords = np.empty((nq, k), dtype=np.int64)
     scs = np.empty((nq, k), dtype=np.float32)
     cnts = np.zeros(nq, dtype=np.int32)
-    _check(lib, lib.tavb_decode_keys(a.ctypes.data_as(c_void_p), nq, k, ords.ctypes.data_as(c_void_p),
-                                     scs.ctypes.data_as(c_void_p), cnts.ctypes.data_as(c_void_p)))
+    _check(lib, lib.tavb_decode_keys(_addr(a), nq, k, _addr(ords),
+                                     _addr(scs), _addr(cnts)))
     return ords, scs, cnts
