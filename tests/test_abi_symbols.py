@@ -96,3 +96,33 @@ def test_plan_ladder_is_a_partition_of_the_rows():
         _native.plan_ladder(-1, 1024)
     with pytest.raises(ValueError):
         _native.plan_ladder(1000, 0)
+
+
+def test_array_arguments_go_through_the_buffer_protocol_or_fall_back():
+    """`_native._addr`: the address ctypes receives is the array's own, for writable arrays (buffer protocol), read-only ones, empty ones and
+    views that cannot export a contiguous buffer (the `ndarray.ctypes` fallback)."""
+    import ctypes
+
+    import numpy as np
+
+    from typeagent_py_amd import _native
+
+    def address(arg):
+        return ctypes.cast(arg, ctypes.c_void_p).value if not isinstance(arg, ctypes.c_void_p) else arg.value
+
+    a = np.arange(12, dtype=np.float32).reshape(3, 4)
+    assert address(_native._addr(a)) == a.ctypes.data
+    ro = a.copy()
+    ro.setflags(write=False)
+    assert address(_native._addr(ro)) == ro.ctypes.data
+    assert address(_native._addr(a[1:])) == a[1:].ctypes.data  # a contiguous slice: its own start
+    strided = a[:, ::2]
+    assert address(_native._addr(strided)) == strided.ctypes.data
+    empty = np.empty(0, dtype=np.int64)
+    _native._addr(empty)  # (nothing to read or write: any pointer does; must not raise)
+    # and the library reads / writes through it
+    lib = _native.load_library(preload_torch=False)
+    lists = np.array([[[9, 4, 1]], [[7, 6, 0]]], dtype=np.uint64)
+    out = np.zeros((1, 3), dtype=np.uint64)
+    assert lib.tavb_merge_keys_host(_native._addr(lists), 2, 1, 3, _native._addr(out)) == 0
+    assert out.tolist() == [[9, 7, 6]]
