@@ -1,5 +1,5 @@
 """CPU suite: the N > 1 path (row-sharded corpus, all-gather of per-shard top-k keys,
-merge) with world_size = 2 over gloo.  The communication pattern, shard ranges, ordinal
+merge) with world_size = 2 and 3 (uneven and empty shards) over gloo.  The communication pattern, shard ranges, ordinal
 offsets and key packing are the product's (typeagent_py_amd/sharded.py); only the two
 compute hooks of the backend are replaced by host stand-ins, because there is no GPU in
 this container (the same hooks run the HIP kernels in tests/test_gpu_parity.py and in
@@ -169,12 +169,14 @@ def _worker(rank: int, world: int, port: int, total_rows: int, dim: int, k: int,
         with pytest.raises(ValueError):
             svb.add_embeddings(["one key"], extra[:2])
         # deserialize: every rank hands in its own rows (here: the two halves swapped in size), offsets are agreed by all-gather
-        cut = 2 * (total_rows + 7) // 3
-        part = grown[:cut] if rank == 0 else grown[cut:]
+        n_all = total_rows + 7
+        cuts = [0, 2 * n_all // 3] + [2 * n_all // 3 + (i + 1) * (n_all - 2 * n_all // 3) // (world - 1) for i in range(world - 1)]  # rank 0 holds two thirds
+        part = grown[cuts[rank] : cuts[rank + 1]]
         svb.deserialize(part)
-        assert len(svb) == total_rows + 7 and svb.row_offset == (0 if rank == 0 else cut) and svb.local_rows == len(part)
+        assert len(svb) == n_all and svb.row_offset == cuts[rank] and svb.local_rows == len(part)
         again = svb.fuzzy_lookup_embedding(qs[4], max_hits=k, min_score=min_score)
-        assert [(h.item, h.score) for h in again] == [(h.item, h.score) for h in after]
+        assert [h.item for h in again] == [h.item for h in after], (rank, again, after)
+        np.testing.assert_allclose([h.score for h in again], [h.score for h in after], atol=1e-6, rtol=0)  # (numpy's sgemv on other row ranges: the last bit may move)
         svb.clear()
         assert len(svb) == 0 and svb.fuzzy_lookup_embedding(qs[0], max_hits=k) == []
         ret[("storage", rank)] = True
@@ -205,6 +207,33 @@ def test_two_rank_sharded_search_equals_whole_corpus(total_rows, k, min_score):
         sc = vo.scores_full(v, qs[qi])
         rep = vo.check_topk_parity(sc, o0[qi, :m].tolist(), s0[qi, :m].tolist(), k, min_score)
         assert rep.ordinals_bit_exact  # same numpy arithmetic on both sides here
+
+
+@pytest.mark.parametrize("total_rows,k,min_score", [(1000, 16, 0.0), (2, 4, 0.0)])
+def test_three_rank_sharded_search_equals_whole_corpus(total_rows, k, min_score):
+    """Uneven shards (334 / 333 / 333 rows) and a world with an EMPTY shard (2 rows over 3 ranks): every rank ends up with the whole corpus's answer."""
+    from oracle import vectorbase_oracle as vo
+    from tests.synth import make_corpus, make_queries
+
+    world, dim = 3, 48
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), total_rows, dim, k, min_score, ret), nprocs=world, join=True)
+    assert all(r in ret and ret[("storage", r)] for r in range(world))
+    v, _ = make_corpus(total_rows, dim, 31337)
+    qs = make_queries(5, dim, 31338)
+    o0, s0, c0 = ret[0]
+    for r in (1, 2):
+        o, s, c = ret[r]
+        np.testing.assert_array_equal(c0, c)
+        for qi in range(5):
+            m = int(c0[qi])
+            np.testing.assert_array_equal(o0[qi, :m], o[qi, :m])
+            np.testing.assert_array_equal(s0[qi, :m], s[qi, :m])
+    for qi in range(5):
+        m = int(c0[qi])
+        rep = vo.check_topk_parity(vo.scores_full(v, qs[qi]), o0[qi, :m].tolist(), s0[qi, :m].tolist(), k, min_score)
+        assert rep.ordinals_bit_exact
 
 
 def test_shard_ranges_partition_the_rows():
