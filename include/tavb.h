@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 /* bumped whenever an entry point, a signature, an option or a kernel id changes incompatibly; the binding refuses a library of another version */
-#define TAVB_ABI_VERSION 4
+#define TAVB_ABI_VERSION 5
 
 #define TAVB_OK 0
 #define TAVB_E_INVALID (-1)     /* bad argument */
@@ -45,6 +45,7 @@ extern "C" {
 #define TAVB_E_NO_CORPUS (-3)   /* search before tavb_set_corpus */
 #define TAVB_E_UNSUPPORTED (-4) /* shape outside what the kernels cover (see message) */
 #define TAVB_E_NOMEM (-5)
+#define TAVB_E_PEER (-6)        /* tavb_decode_keys: the lists come from a collective lookup in which a rank's local search failed (they lead with TAVB_KEY_PEER_FAILED) */
 
 #define TAVB_F32 0
 #define TAVB_F16 1
@@ -75,7 +76,8 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "scan_nt"       1 = non-temporal corpus loads (default 1)
  *   "scan_pipe"     1 = software-prefetch next rows before reducing current ones
  *   "force_tier"    0 = auto, 1 = fixed-D kernel, 2 = vector kernel, 3 = scalar kernel
- *   "mfma_min_batch" smallest batch routed to the 256-query MFMA tile on f16 corpora (default 65; needs k <= 64, dim % 64 == 0)
+ *   "mfma_min_batch" smallest batch routed to the 256-query MFMA tile on f16 corpora (default 65; needs dim % 64 == 0; k up to 64 on fp32 corpora
+ *                   (through their fp16 shadow), up to TAVB_MAX_FUSED_K on fp16 ones; thresholds may differ per query)
  *   "skinny_min_batch_f32" / "skinny_min_batch_f16"  smallest batch routed to the 32/64-query MFMA tile on fp32 / fp16
  *                   corpora (defaults 5 / 3, the measured break-even; fp32 corpora have no other matrix-core path, fp16 ones use it up to
  *                   mfma_min_batch - 1); smaller batches use the streaming tiers
@@ -95,6 +97,9 @@ int tavb_synchronize(tavb_ctx* ctx);
  *                           ROCm 7.2 the replay measured SLOWER than the plain submissions (48 vs 41 us at 10k x 1536)
  *   "last_graph"            (get) 1 when the last lookup was such a replay
  *   "comm_force"            1: tavb_search_allgather runs its all-gather + merge even in a world of one rank (tests, dry runs)
+ *   "comm_fail_rank"        fault injection (default -1 = off): on the rank of the communicator with this number the local search of
+ *                           tavb_search_allgather fails as a launch or an allocation inside it would -- that rank still joins the all-gather
+ *                           (with TAVB_KEY_PEER_FAILED lists) and returns its error, every other rank's lists decode to TAVB_E_PEER
  *   "comm_world", "comm_rank" (read only) shape of the context's communicator (0 / -1 without one)
  *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile (exact
  *                   filter + fp32-query rescoring of its candidates), 5 = 32/64-query MFMA tile
@@ -151,6 +156,10 @@ int tavb_convert_f32_to_f16(tavb_ctx* ctx, const float* dev_in, void* dev_out, i
 /* A packed result key: (float32 score bits << 32) | (0xFFFFFFFF - ordinal); 0 = empty
  * slot.  Bigger key = better hit, so per-shard lists merge with integer compares. */
 typedef uint64_t tavb_key;
+/* Not a result: what a rank whose local search FAILED contributes to the all-gather of tavb_search_allgather, in every slot of its lists.  All
+ * bits set sorts above every real key (scores are in [0, 1]), so it leads every merged list on every rank: no rank can mistake a result that
+ * is missing a shard for an answer.  tavb_decode_keys returns TAVB_E_PEER for lists that carry it. */
+#define TAVB_KEY_PEER_FAILED (~(tavb_key)0)
 
 /* ---- synchronous lookups (host in, host out) ---------------------------------- */
 /* fuzzy_lookup_embedding without predicate (vectorbase.py:163-190):
@@ -168,7 +177,8 @@ int tavb_search_subset(tavb_ctx* ctx, const float* query_host, const int64_t* ro
 
 /* Q independent lookups in one submission (the batching the reference leaves as a TODO,
  * storage/sqlite/reltermsindex.py:259-271).  Semantics == Q calls of tavb_search.
- * queries_host: float32 [nq, dim].  min_scores: nq thresholds.  Outputs [nq, k] / [nq]. */
+ * queries_host: float32 [nq, dim].  min_scores: nq thresholds -- one per query, as Q calls of the reference have Q `min_score`
+ * arguments (vectorbase.py:163-173); a mixed batch runs on the same kernels as a uniform one.  Outputs [nq, k] / [nq]. */
 int tavb_search_batch(tavb_ctx* ctx, const float* queries_host, int32_t nq, int32_t k, const float* min_scores,
                       int64_t* out_ordinals, float* out_scores, int32_t* out_counts);
 
@@ -252,7 +262,10 @@ int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* 
  * row); a lookup is every rank scanning its shard for the same queries, ONE all-gather of the per-shard [nq, k] key lists
  * (nq * k * 8 bytes per rank: 256 KiB at 1024 x 32) and a merge kernel on every rank, so that every rank returns the whole-corpus
  * answer of vectorbase.py:163-190 (keys carry global ordinals and order by (score desc, ordinal asc): the merged answer is the
- * single-device one, ties included).  The collective is issued by the library itself, on the context's stream, behind the scan and
+ * single-device one, ties included).  A rank whose local search fails still joins the all-gather -- the peers are never left waiting -- with
+ * TAVB_KEY_PEER_FAILED lists, returns its own error, and every other rank's merged lists decode to TAVB_E_PEER (tavb_decode_keys): a lookup
+ * either returns the whole-corpus answer on a rank or an error, never an answer that silently misses a shard.
+ * The collective is issued by the library itself, on the context's stream, behind the scan and
  * in front of the merge -- RCCL (librccl.so.1, resolved with dlopen at tavb_comm_init: no link-time dependency) is the only
  * communication layer; torch.distributed is not needed on the lookup path.
  *

@@ -483,13 +483,20 @@ def test_lookup_texts_batched_equals_sequential_fuzzy_lookup():
         queries = ["term number 17 about cats", "dogs", "something else entirely", words[150]]
         batched = await lookup_texts_batched(vb, queries)
         sequential = [await vb.fuzzy_lookup(q) for q in queries]
-        return batched, sequential
+        return batched, sequential, await vb.get_embeddings(queries)
 
-    batched, sequential = asyncio.run(go())
+    batched, sequential, embedded = asyncio.run(go())
     assert len(batched) == 4
-    for b, s in zip(batched, sequential):
+    corpus = np.asarray(vb.serialize(), dtype=np.float32)
+    for b, s, e in zip(batched, sequential, embedded):
         assert [r.item for r in b] == [r.item for r in s] and len(b) <= 7
         np.testing.assert_allclose([r.score for r in b], [r.score for r in s], atol=2e-7, rtol=0)
+        # ... and against the oracle's restatement of what the reference's loop does per text (storage/memory/reltermsindex.py:320-337 ->
+        # vectorbase.py:232-246 -> :163-190 with the settings' defaults: max_matches 7, min_score 0.3)
+        want = vo.lookup(corpus, np.asarray(e, dtype=np.float32), 7, 0.3)
+        vo.check_topk_parity(vo.scores_full(corpus, np.asarray(e, dtype=np.float32)), *items_scores(b), 7, 0.3, referee=vo.f64_referee(corpus, np.asarray(e, dtype=np.float32)))
+        assert len(b) == len(want)
+        np.testing.assert_allclose([r.score for r in b], [s_ for _, s_ in want], atol=SCORE_TOL, rtol=0)
     assert batched[0][0].item == 17 and batched[3][0].item == 150
     assert asyncio.run(lookup_texts_batched(vb, [])) == []
 
@@ -1040,8 +1047,16 @@ def test_many_flagged_queries_take_the_wide_exact_fallback():
             if qi % 2 == 1 and qi < 200:
                 assert set(r.item for r in out[qi]) <= set(rows[qi // 2].tolist())  # the flagged queries' hits are their planted rows
         outs[mode] = out
-    for qi in probe:  # the two exact tiles agree up to float32 near-ties
-        np.testing.assert_allclose([r.score for r in outs[1][qi]], [r.score for r in outs[0][qi]], atol=1e-6, rtol=0)
+    # both exact fallbacks hand their best rows (+ a band below the k-th) to the rescoring kernel, whose arithmetic is the streaming kernels':
+    # the wide split-plane form, the 64-query tile and `fuzzy_lookup_embedding` on its own return the same float32 scores in the same order
+    for qi in probe:
+        seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=0.0)
+        assert eng.get_option("last_tier") in (1, 2, 3)
+        assert [(r.item, r.score) for r in outs[1][qi]] == [(r.item, r.score) for r in seq], qi
+        if qi % 2 == 0 or qi >= 200:  # (un-flagged queries; a flagged one on the 64-query tile has 64 - k ranks of slack, not a score band: near-ties of a
+            assert [(r.item, r.score) for r in outs[0][qi]] == [(r.item, r.score) for r in seq], qi  # 1100-row cluster packed inside 1e-5 may permute)
+        else:
+            np.testing.assert_allclose([r.score for r in outs[0][qi]], [r.score for r in seq], atol=3e-7, rtol=0)
     # a threshold above the un-planted queries' scores: only the flagged ones return anything, through the same path
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.7)
     assert len(out[0]) == 0 and len(out[1]) == k
@@ -1119,6 +1134,144 @@ def test_wide_tile_band_overflow_inside_one_row_range(sample):
     for qi in [0, 4, 5, 6, 129]:
         vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
     assert all(150_000 <= r.item < 150_900 for r in out[5])
+
+
+def _plant_clusters(v, qs, query_ids, rows_per_query, rng, eps=2e-4):
+    """vectorised `_plant_near_duplicates` for MANY queries: query_ids[j] gets rows_per_query rows next to it (scores within ~1e-5 of one another)"""
+    d = v.shape[1]
+    rows = rng.permutation(v.shape[0])[: len(query_ids) * rows_per_query].reshape(len(query_ids), rows_per_query)
+    for j, qi in enumerate(query_ids):
+        base = qs[qi] + 0.3 * rng.standard_normal(d).astype(np.float32) / np.sqrt(d)
+        base /= np.linalg.norm(base)
+        w = base[None, :] + eps * rng.standard_normal((rows_per_query, d)).astype(np.float32) / np.sqrt(d)
+        v[rows[j]] = w / np.linalg.norm(w, axis=1, keepdims=True)
+    return rows
+
+
+def test_unused_slots_of_the_wide_fallback_admit_nothing():
+    """The wide split-plane fallback runs over a work list padded to whole 256-query tiles.  The unused slots of the last live tile hold zero
+    queries (every row scores 0.5): with `min_score` below that they used to admit every row of the big ladder phases from the second phase on
+    (their per-phase threshold is NaN: the select kernel skips them) -- correct answers, several times the time.  300 flagged queries (one full
+    tile + 44 slots of the next) must cost about what 480 (two nearly full tiles) cost, and the answers are the oracle's.  (A few un-planted
+    queries are flagged too: a planted cluster that happens to score in their top k is 1100 rows inside their band.)"""
+    import time
+
+    n, d, nq, k = 560_000, 512, 1024, 32
+    v, _ = make_corpus(n, d, 8700)
+    qs = make_queries(nq, d, 8701)
+    rng = np.random.default_rng(8702)
+    rows = _plant_clusters(v, qs, list(range(480)), 1100, rng)
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    eng.set_option("early_exact", 0)  # (the filter runs to its end in both batches: the fallback's cost is what is compared)
+    plain = make_queries(nq, d, 8703)
+    batches = {}
+    for flagged_queries in (300, 480):
+        b = plain.copy()
+        b[:flagged_queries] = qs[:flagged_queries]
+        batches[flagged_queries] = b
+    times = {}
+    v16 = _f16(v)
+    for m, b in batches.items():
+        out = vb.fuzzy_lookup_embeddings(b, max_hits=k, min_score=0.0, as_arrays=True)
+        assert eng.get_option("last_tier") == 4
+        assert m <= eng.get_option("last_flagged") <= min(m + 120, 512), eng.get_option("last_flagged")  # both batches: two tiles of the work list
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            vb.fuzzy_lookup_embeddings(b, max_hits=k, min_score=0.0, as_arrays=True)
+            best = min(best, time.perf_counter() - t0)
+        times[m] = best
+        o, s_, c_ = out
+        for qi in (0, 255, 256, m - 1, m, 1023):
+            vo.check_topk_parity(vo.scores_full(v16, b[qi]), o[qi, : c_[qi]].tolist(), s_[qi, : c_[qi]].tolist(), k, 0.0, referee=vo.f64_referee(v16, b[qi]))
+            if qi < m:
+                assert set(o[qi, : c_[qi]].tolist()) <= set(rows[qi].tolist())
+    assert times[300] < 1.3 * times[480], times
+
+
+@pytest.mark.parametrize("nq", [40, 130, 1024])
+def test_per_query_thresholds_ride_the_tiles(nq):
+    """A batch whose `min_score`s differ per query (Q calls of the reference have Q of them, vectorbase.py:163-173) takes the same kernels as a
+    uniform one -- the 32/64-query tile at 40 queries, the 128/256-query tile + rescoring beyond -- and returns, query by query, what the
+    single-query kernel returns with that query's threshold (NaN and > 1 thresholds included: nothing passes)."""
+    n, d, k = 60_000, 1536, 32
+    v, _ = make_corpus(n, d, 8710)
+    qs = make_queries(nq, d, 8711)
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    v16 = _f16(v)
+    ref0 = vo.scores_full(v16, qs[0])
+    levels = np.sort(ref0)[::-1]
+    thr = np.full(nq, 0.0, dtype=np.float64)
+    thr[1::4] = float(levels[10])   # ~11 rows of query 0 pass; other queries: about as many
+    thr[2::4] = float(levels[200])
+    thr[3::4] = 0.4
+    thr[5] = float("nan")
+    thr[6] = 1.5
+    thr[7] = float(levels[0])  # exactly the best score of query 0 (for query 7: usually nothing)
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=thr.tolist())
+    assert eng.get_option("last_tier") == (4 if nq >= 65 else 5)
+    assert len(out[5]) == 0 and len(out[6]) == 0
+    for qi in sorted(set([0, 1, 2, 3, 4, 5, 6, 7, 9, nq // 2, nq - 1])):
+        t = thr[qi]
+        seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=None if t != t else float(t)) if t == t else []
+        assert eng.get_option("last_tier") in (1, 2, 3) or t != t
+        assert [r.item for r in out[qi]] == [r.item for r in seq], qi
+        if nq >= 65:  # rescored with the streaming kernels' arithmetic: the same float32 values (the 32/64-query tile returns its own accumulation order)
+            assert [r.score for r in out[qi]] == [r.score for r in seq], qi
+        else:
+            np.testing.assert_allclose([r.score for r in out[qi]], [r.score for r in seq], atol=3e-7, rtol=0)
+        if t == t:
+            vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, float(np.float32(t)), referee=vo.f64_referee(v16, qs[qi]))
+    # the uniform form of the same call still means the same thing
+    uni = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.4)
+    assert [(r.item, r.score) for r in uni[3]] == [(r.item, r.score) for r in out[3]]
+    assert eng.get_option("last_tier") == (4 if nq >= 65 else 5)
+    # through the C ABI with a float32 array, on an fp32 corpus (32/64-query fp32 tile; the fp16 shadow + fp32 rescoring from 65 queries on)
+    vb32 = new_vb(v[:20_000], dtype="fp32")
+    t32 = np.where(np.arange(nq) % 2 == 0, np.float32(0.0), np.float32(0.5)).astype(np.float32)
+    o, s_, c_ = vb32.engine.search_batch(qs, k, t32)
+    assert vb32.engine.get_option("last_tier") == (4 if nq >= 65 else 5)
+    for qi in (0, 1, nq - 2, nq - 1):
+        seq = vb32.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=float(t32[qi]))
+        assert o[qi, : c_[qi]].tolist() == [r.item for r in seq]
+        np.testing.assert_allclose(s_[qi, : c_[qi]], [r.score for r in seq], atol=3e-7, rtol=0)
+
+
+@pytest.mark.parametrize("nq,k", [(1024, 100), (130, 256), (300, 65)])
+def test_wide_tile_serves_k_beyond_64(nq, k):
+    """`max_hits` up to 256 rides the 128/256-query tile on fp16 corpora (the band selection holds any k the fused selections serve): a
+    1024-query batch with k = 100 used to fall to the streaming kernel, 8 queries per corpus pass.  One query sits on a cluster of 1300
+    near-duplicates (a band that does not fit): beyond k = 64 the flagged query goes to the wide split-plane form whatever the count."""
+    n, d = 150_000, 1536
+    v, _ = make_corpus(n, d, 8720 + k)
+    qs = make_queries(nq, d, 8721 + k)
+    rng = np.random.default_rng(8722)
+    dup = rng.choice(n, size=1300, replace=False)
+    _plant_near_duplicates(v, qs, 3, dup, rng)
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert eng.get_option("last_tier") == 4
+    assert 1 <= eng.get_option("last_flagged") <= 3
+    v16 = _f16(v)
+    for qi in sorted(set([0, 1, 3, 4, nq // 2, nq - 1])):
+        assert len(out[qi]) == k
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
+        if qi != 3:
+            seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=0.0)
+            assert [(r.item, r.score) for r in out[qi]] == [(r.item, r.score) for r in seq], qi
+    assert set(r.item for r in out[3]) <= set(dup.tolist())
+    # with a threshold that leaves fewer than k rows
+    thr = float(np.float32(out[0][k // 2].score))
+    out2 = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=thr)
+    assert len(out2[0]) == k // 2 + 1 and [r.item for r in out2[0]] == [r.item for r in out[0][: k // 2 + 1]]
+    # fp32 corpora have no exact tile beyond k = 64: the batch takes the streaming kernels, same answers
+    vb32 = new_vb(v[:30_000], dtype="fp32")
+    o32 = vb32.fuzzy_lookup_embeddings(qs[:70], max_hits=k, min_score=0.0)
+    assert vb32.engine.get_option("last_tier") in (1, 2, 3)
+    vo.check_topk_parity(vo.scores_full(v[:30_000], qs[5]), *items_scores(o32[5]), k, 0.0, referee=vo.f64_referee(v[:30_000], qs[5]))
 
 
 def test_wide_tile_row_norm_cache_follows_appends_and_rewrites():
@@ -1550,6 +1703,24 @@ def test_sharded_searcher_on_one_rank_rccl():
     with pytest.raises(IndexError):
         svb.fuzzy_lookup_embedding_in_subset(qs[1], [10_000], max_hits=5)
     backend.set_shard(shard, row_offset=5_000_000)
+    # fault injection: the local search of this rank "fails" -- it still joins the all-gather (the exchange runs: peers are never left waiting),
+    # returns ITS error, and what the merge left in the output decodes to TAVB_E_PEER: no rank can take a result that misses a shard for an answer
+    n_exchanges = eng.profile_read(_native.KERNEL_EXCHANGE)[1]
+    pinned = torch.empty((6, 32), dtype=torch.int64).pin_memory()
+    eng.set_option("comm_fail_rank", 0)
+    with pytest.raises(_native.TavbError, match="injected failure"):
+        eng.search_allgather(dq, 32, 0.0, out_keys=pinned)
+    eng.synchronize()
+    assert eng.profile_read(_native.KERNEL_EXCHANGE)[1] == n_exchanges + 1
+    assert (pinned.numpy().view(np.uint64) == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    with pytest.raises(_native.TavbError, match="rank of the collective lookup failed"):
+        _native.decode_keys(pinned.numpy())
+    with pytest.raises(_native.TavbError):
+        searcher.search(dq, 32, 0.0)
+    eng.set_option("comm_fail_rank", 3)  # another rank's number: nothing happens here
+    check(searcher.search(dq, 32, 0.0))
+    eng.set_option("comm_fail_rank", -1)
+    check(searcher.search(dq, 32, 0.0))
     with pytest.raises(ValueError):
         eng.comm_init(b"x" * 128, 0, 1)  # one communicator per context
     eng.comm_destroy()

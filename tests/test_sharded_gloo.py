@@ -236,6 +236,68 @@ def test_three_rank_sharded_search_equals_whole_corpus(total_rows, k, min_score)
         assert rep.ordinals_bit_exact
 
 
+def _failing_worker(rank: int, world: int, port: int, fail_rank: int, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.synth import make_corpus, make_queries
+        from typeagent_py_amd.sharded import PeerFailedError, ShardedSearcher, ShardedVectorBase, shard_range
+
+        v, _ = make_corpus(900, 48, 31337)
+        qs = make_queries(4, 48, 31338)
+        lo, hi = shard_range(900, world, rank)
+
+        class Flaky(HostStandInBackend):
+            broken = False
+
+            def local_search(self, queries, k, thr):
+                if self.broken:
+                    raise RuntimeError(f"injected failure of the local search on rank {rank}")
+                return super().local_search(queries, k, thr)
+
+        backend = Flaky(v[lo:hi], lo)
+        searcher = ShardedSearcher(backend)
+        first = searcher.search(torch.from_numpy(qs), 8, 0.0)
+        backend.broken = rank == fail_rank
+        try:
+            searcher.search(torch.from_numpy(qs), 8, 0.0)
+            outcome = "answer"
+        except PeerFailedError:
+            outcome = "peer"
+        except RuntimeError as exc:
+            outcome = "own" if "injected failure" in str(exc) else f"other: {exc}"
+        backend.broken = False
+        again = searcher.search(torch.from_numpy(qs), 8, 0.0)  # nobody was left behind in the all-gather: the next collective lines up
+        np.testing.assert_array_equal(first.ordinals, again.ordinals)
+        # imbalance / rebalance of the VectorBase-shaped front end: appends land on the last rank, a rebalance re-deals the rows
+        svb = ShardedVectorBase(Flaky(v[lo:hi].copy(), lo), lo, hi - lo, 900)
+        extra, _ = make_corpus(600, 48, 4242)
+        svb.add_embeddings(None, extra)
+        imb = svb.imbalance()
+        before = svb.fuzzy_lookup_embedding(qs[1], max_hits=8)
+        svb.rebalance()
+        after = svb.fuzzy_lookup_embedding(qs[1], max_hits=8)
+        ret[rank] = (outcome, imb, svb.imbalance(), svb.local_rows, [(r.item, r.score) for r in before] == [(r.item, r.score) for r in after], len(svb))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_whose_local_search_fails_still_joins_the_exchange_and_every_rank_gets_an_error():
+    """The protocol of `tavb_search_allgather` (include/tavb.h), on the torch.distributed route: the failing rank contributes
+    TAVB_KEY_PEER_FAILED lists, joins the all-gather and raises ITS error; the others find the key at the head of their merged lists and
+    raise `PeerFailedError` -- nobody hangs, nobody returns an answer that misses a shard, and the next lookup works."""
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_failing_worker, args=(world, _free_port(), 1, ret), nprocs=world, join=True)
+    assert [ret[r][0] for r in range(world)] == ["peer", "own", "peer"]
+    for r in range(world):
+        _, imb, imb_after, local_rows, same, total = ret[r]
+        assert abs(imb - 900 / 500) < 1e-9 and imb_after == 1.0 and local_rows == 500 and same and total == 1500
+
+
 def test_shard_ranges_partition_the_rows():
     from typeagent_py_amd.sharded import shard_range
 

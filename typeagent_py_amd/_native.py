@@ -16,7 +16,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 
 import numpy as np
 
-ABI_VERSION = 4  # include/tavb.h TAVB_ABI_VERSION this binding was written against
+ABI_VERSION = 5  # include/tavb.h TAVB_ABI_VERSION this binding was written against
 TAVB_F32 = 0
 TAVB_F16 = 1
 MAX_FUSED_K = 256

@@ -123,6 +123,8 @@ struct tavb_ctx {
   Buffer d_queries, d_queries_f16, d_lists, d_out, d_rows, d_cand, d_thr, d_sample_keys;
   Buffer d_counts;  // 256-query tile: keys left per candidate buffer
   Buffer d_delta, d_approx, d_flag, d_fb_queries, d_norm;  // exact rescoring of the 256-query tile (tavb_rescore.hip)
+  Buffer d_minscores;      // per-query thresholds of a batch on the device: [nq_pad] min_scores, then [nq_pad] exclusive admission floors (the tile paths)
+  Buffer d_fb_cand;        // what the 64-query exact tile ranked highest for the flagged queries: [slots][64] keys, rescored into the callers' rows
   Buffer d_shadow;         // fp32 corpora: fp16 shadow copy of rows [0, norm_rows), the filter operand of the 128/256-query tile
   int64_t f32_shadow = 1;  // option: 1 = batches of mfma_min_batch+ queries on fp32 corpora go through that shadow (+50 % HBM); 2 = every lookup on
                            // fp32 corpora of f32_shadow_min_bytes and more (half the bytes per pass); 0 = never
@@ -180,6 +182,7 @@ struct tavb_ctx {
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 1;
   int64_t comm_force = 0;  // option: run the all-gather + merge even in a world of one (tests, dry runs of the N > 1 path)
+  int64_t comm_fail_rank = -1;  // option (fault injection): the local search of tavb_search_allgather "fails" on this rank of the communicator
   Buffer d_local, d_gather;  // this shard's [nq, k] lists; the all-gathered [world, nq, k]
 };
 
@@ -405,6 +408,8 @@ int tavb_destroy(tavb_ctx* c) {
   c->d_flag.release();
   c->d_fb_queries.release();
   c->d_norm.release();
+  c->d_minscores.release();
+  c->d_fb_cand.release();
   c->d_accept.release();
   c->d_bits.release();
   c->d_emit.release();
@@ -506,7 +511,9 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     c->small_direct_bytes = v;
   } else if (n == "comm_force") {
     c->comm_force = v ? 1 : 0;
-
+  } else if (n == "comm_fail_rank") {
+    if (v < -1) return fail(TAVB_E_INVALID, "comm_fail_rank must be >= -1");
+    c->comm_fail_rank = v;
   } else if (n == "graph_max_bytes") {
     if (v < 0) return fail(TAVB_E_INVALID, "graph_max_bytes must be >= 0");
     c->graph_max_bytes = v;
@@ -538,6 +545,7 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "mfma_sample_rows") *out = c->mfma_sample_rows;
   else if (n == "compute_units") *out = c->n_cu;
   else if (n == "comm_force") *out = c->comm_force;
+  else if (n == "comm_fail_rank") *out = c->comm_fail_rank;
   else if (n == "small_direct_bytes") *out = c->small_direct_bytes;
   else if (n == "wide_fallback") *out = c->wide_fallback;
   else if (n == "early_exact") *out = c->early_exact;
@@ -761,9 +769,12 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
     if (g.waves < 1) g.waves = 1;
     if (g.waves > 16) g.waves = 16;
     const int64_t budget = c->small_direct_keys * (nq > 1 ? 2 : 1);
-    g.blocks = std::min(scan_blocks_for(c, c->rows, g.waves, g.unroll), (int)std::max<int64_t>(8, budget / ((int64_t)k * nq)));
+    const int full_blocks = scan_blocks_for(c, c->rows, g.waves, g.unroll);
+    g.blocks = std::min(full_blocks, (int)std::max<int64_t>(8, budget / ((int64_t)k * nq)));
     const int64_t rounds = (c->rows + (int64_t)g.blocks * g.waves * g.unroll - 1) / ((int64_t)g.blocks * g.waves * g.unroll);
-    if (nq == 1 || (rounds <= 2 && (c->dtype == TAVB_F32 || nq <= 4))) {
+    // one query: only while the cut grid keeps at least half of the full one (k = 256 would leave 32 workgroups to stream up to 128 MiB: slower
+    // than the full grid + the device merge; measured at k <= 50, where 163+ of 204 workgroups stay)
+    if ((nq == 1 && 2 * g.blocks >= full_blocks) || (nq > 1 && rounds <= 2 && (c->dtype == TAVB_F32 || nq <= 4))) {
       const size_t list_keys = (size_t)nq * g.blocks * k;
       if (int rc = c->h_lists.reserve((list_keys + (size_t)nq * k) * sizeof(u64_t))) return rc;  // + the merged keys
       tavb::ScanParams p{};
@@ -1210,6 +1221,13 @@ int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* 
   if (nq < 0 || k < 1) return fail(TAVB_E_INVALID, "bad shape");
   if (nq == 0) return TAVB_OK;
   if (!keys_host || !out_ordinals || !out_scores || !out_counts) return fail(TAVB_E_INVALID, "null argument");
+  // a rank whose local search failed joins the collective with TAVB_KEY_PEER_FAILED in every slot of its lists; the key sorts above every
+  // real one, so it leads every merged list on every rank: the answer is missing a shard and must not be used
+  for (int q = 0; q < nq; ++q)
+    if (keys_host[(size_t)q * k] == TAVB_KEY_PEER_FAILED) {
+      for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+      return fail(TAVB_E_PEER, "a rank of the collective lookup failed in its local search: the merged lists are missing its shard");
+    }
   decode(reinterpret_cast<const u64_t*>(keys_host), nq, k, 0, out_ordinals, out_scores, out_counts);
   return TAVB_OK;
 }
@@ -1357,11 +1375,18 @@ int tavb_search_allgather(tavb_ctx* c, const float* dev_queries, int32_t nq, int
   std::vector<float> ms((size_t)nq, min_score);
   int rc_local = TAVB_OK;
   std::string local_error;
-  if (c->rows == 0) {  // an empty shard still takes part in the collectives
+  if (c->comm_fail_rank >= 0 && c->comm_fail_rank == c->comm_rank) {  // fault injection (option "comm_fail_rank"): what a failed launch / allocation inside the local search looks like
+    rc_local = fail(TAVB_E_HIP, "injected failure of the local search on rank %d (option comm_fail_rank)", c->comm_rank);
+  } else if (c->rows == 0) {  // an empty shard still takes part in the collectives
     TAVB_HIP(hipMemsetAsync(local, 0, list_keys * sizeof(u64_t), c->stream));
-  } else if ((rc_local = tavb_search_device_dispatch(c, dev_queries, nq, k, ms.data(), (uint32_t)c->ordinal_base, local)) != TAVB_OK) {
+  } else {
+    rc_local = tavb_search_device_dispatch(c, dev_queries, nq, k, ms.data(), (uint32_t)c->ordinal_base, local);
+  }
+  if (rc_local != TAVB_OK) {
     local_error = g_last_error;
-    (void)hipMemsetAsync(local, 0, list_keys * sizeof(u64_t), c->stream);  // this shard contributes nothing; the caller gets the error below
+    // this shard's lists = TAVB_KEY_PEER_FAILED (all bits set) in every slot: it sorts above every real key, so it leads every merged list on
+    // EVERY rank -- the peers' answers would silently miss this shard otherwise; tavb_decode_keys turns it into TAVB_E_PEER
+    (void)hipMemsetAsync(local, 0xFF, list_keys * sizeof(u64_t), c->stream);
   }
   const int rc_x = exchange_and_merge(c, local, nq, k, out_keys);
   if (rc_local != TAVB_OK) {
@@ -1457,7 +1482,17 @@ struct TileRun {
   // the band buffer are counted in *doomed (zeroed by the caller); with more than doomed_max of them the last phase's launches return at once
   int* doomed;
   int doomed_max;
+  // a work-list run of the 128/256-query tile (r.active: the SPLIT fallback) ends with its candidates rescored by the streaming kernels' arithmetic
+  // (tavb_rescore.hip, slot mode): the callers' fp32 queries [*, dim], their thresholds [*] (device), indexed by scatter[slot]
+  const float* rs_queries;
+  const float* rs_min_scores;
 };
+
+// Width (in score) of the band the exact fallbacks keep below their k-th best before the candidates are scored again with the streaming
+// kernels' arithmetic: the two arithmetics (fp32 accumulation inside the matrix pipe vs the streaming kernels' per-lane fma chains) differ by
+// a few 1e-7 on unit vectors of 1536 dimensions (measured: <= 4e-7 against float64), the hi + lo split of a query carries it to 2^-22.
+// Ten times that: a row the streaming arithmetic ranks in the top k is inside the band unless the two disagree by more than 4e-6.
+constexpr float kExactBand = 4e-6f;
 
 // Phase boundaries of the threshold ladder (see run_tile_ladder): phase i scans rows [b[i], b[i+1]).  `sample_opt` / `growth` = the options
 // mfma_sample_rows (0 = auto, -1 = one phase) / mfma_ladder.  A pure function of its arguments: tavb_plan_ladder() hands it to callers that
@@ -1500,8 +1535,8 @@ std::vector<int64_t> ladder_bounds(int64_t rows, int splits, int nq_pad, bool sk
 // whatever comes first and compacting, and the running top-k rides along as one more list of the next phase's merge.
 // Expected admissions per query drop from k * rows / sample (one seeding phase) to ~k * ladder per phase.  Results do
 // not depend on the phase boundaries.  Output: sorted key lists [nq, k] at `d_out` (or, with `scatter`, rows
-// scatter[slot] of it for the slots below *active).
-int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scatter) {
+// scatter[slot] of it for the slots below *active; a work-list run of the wide tile rescoring its band first: TileRun::rs_queries).
+int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scatter, bool scatter_identity = false) {
   auto pick_splits = [&](int64_t rows) {
     return r.skinny ? tavb::skinny_pick_splits(rows, r.nq_pad, r.qt, c->n_cu, c->dim, r.q32) : tavb::mfma_pick_splits(rows, r.nq_pad, r.qt, c->n_cu);
   };
@@ -1598,14 +1633,16 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
                                               last ? r.verdict : nullptr, c->stream, r.active, r.active_min, r.active_max > 0 ? r.active_max : 0x7fffffff,
                                               doom_gate ? r.doomed : nullptr, r.doomed_max, doom_count ? r.doomed : nullptr, doom_limit);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "select launch failed: %s", hipGetErrorString(e));
-      if (last && r.active) {
-        e = tavb::launch_finalize_strict(last_out, last_cnt, kc, nq, k, r.active, r.active_min, r.active_max > 0 ? r.active_max : 0x7fffffff, scatter, d_out, c->stream);
-        if (e != hipSuccess) return fail(TAVB_E_HIP, "finalize launch failed: %s", hipGetErrorString(e));
+      if (last && r.active) {  // the band of every live slot, scored again the streaming kernels' way: its best k go to the caller's row scatter[slot]
+        e = tavb::launch_rescore_slots(c->corpus, /*f32_rows=*/false, c->dim, r.index_base, r.rs_queries, last_out, kc, last_cnt, r.rs_min_scores, nq, k, d_out,
+                                       scatter, r.active, r.active_min, r.active_max > 0 ? r.active_max : 0x7fffffff, c->stream);
+        if (e != hipSuccess) return fail(TAVB_E_HIP, "fallback rescore launch failed: %s", hipGetErrorString(e));
       }
     } else if (last) {
       Timed t(c, r.active ? TAVB_KERNEL_RESCORE : TAVB_KERNEL_MERGE);
-      hipError_t e = scatter ? tavb::launch_merge_scatter(pp.lists, pp.list_stride, nq, k, r.active, scatter, d_out, c->stream)
-                             : tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true, d_out, c->stream);
+      // (scatter_identity: a work-list run whose lists stay slot-indexed -- merged only for the live slots)
+      hipError_t e = (scatter || scatter_identity) ? tavb::launch_merge_scatter(pp.lists, pp.list_stride, nq, k, r.active, scatter, d_out, c->stream)
+                                                    : tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true, d_out, c->stream);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
     } else {
       hipError_t e = tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true, run_out, c->stream);
@@ -1618,31 +1655,86 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   return TAVB_OK;
 }
 
+// The lowest threshold of a batch (NaN thresholds aside; NaN when every one is NaN): the ONE threshold a tile launch takes -- the per-query
+// thresholds ride in the `floor` array.
+float lowest_min_score(const float* min_scores, int nq) {
+  float lo = NAN;
+  for (int i = 0; i < nq; ++i)
+    if (min_scores[i] == min_scores[i]) lo = (lo != lo || min_scores[i] < lo) ? min_scores[i] : lo;
+  return lo;
+}
+
+// min_scores (host, [nq]) -> c->d_minscores: [nq_pad] the thresholds themselves (padding: +inf), then [nq_pad] the exclusive admission floors
+// that go with them (`score > floor` <=> `score >= min_score`; +inf for NaN / > 1 / padding).  A uniform batch -- every caller of the reference --
+// is filled by a kernel (no host buffer in flight: the device-resident forms stay asynchronous); a mixed one is copied from pageable memory
+// (staged by the runtime before the call returns).
+int upload_min_scores(tavb_ctx* c, const float* min_scores, int nq, int nq_pad, const float** d_ms_out, const float** d_floor_out) {
+  if (int rc = c->d_minscores.reserve((size_t)2 * nq_pad * sizeof(float))) return rc;
+  float* d_ms = reinterpret_cast<float*>(c->d_minscores.ptr);
+  float* d_floor = d_ms + nq_pad;
+  auto floor_of = [](float ms) {
+    if (ms != ms || ms > 1.0f) return INFINITY;
+    if (!(ms > 0.0f)) return -INFINITY;
+    uint32_t bits;
+    memcpy(&bits, &ms, sizeof bits);
+    --bits;
+    float f;
+    memcpy(&f, &bits, sizeof f);
+    return f;
+  };
+  bool uniform = true;
+  for (int i = 1; i < nq; ++i) uniform = uniform && (memcmp(&min_scores[i], &min_scores[0], sizeof(float)) == 0);
+  if (uniform) {
+    hipError_t e = tavb::launch_fill_thresholds(d_ms, d_floor, nq, nq_pad, min_scores[0], floor_of(min_scores[0]), c->stream);
+    if (e != hipSuccess) return fail(TAVB_E_HIP, "threshold fill launch failed: %s", hipGetErrorString(e));
+  } else {
+    std::vector<float> h((size_t)2 * nq_pad, INFINITY);
+    for (int i = 0; i < nq; ++i) {
+      h[i] = min_scores[i];
+      h[(size_t)nq_pad + i] = floor_of(min_scores[i]);
+    }
+    TAVB_HIP(hipMemcpyAsync(d_ms, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    TAVB_HIP(hipStreamSynchronize(c->stream));  // (pageable source: be sure the runtime is done with `h` before it goes out of scope)
+  }
+  *d_ms_out = d_ms;
+  *d_floor_out = d_floor;
+  return TAVB_OK;
+}
+
 // The 128/256-query fp16 tile as an exact filter + fp32-query rescoring of its candidates (tavb_rescore.hip).  fp32 corpora:
 // the filter reads the fp16 shadow (d_shadow, reserved by the caller), the rescoring and the fallback tile the fp32 rows.
 // `small` (fp32 corpora only): the filter is the 32/64-query tile over the shadow with the EXACT queries (split fp16 planes), for batches
 // below the wide tile's range -- half the bytes of an fp32 pass.
-int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_score, uint32_t index_base, u64_t* d_out, bool small = false) {
+// min_scores: host [nq], one threshold per query (the reference takes `min_score` per call, vectorbase.py:163-173: a batch of Q calls has Q of them).
+int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores, uint32_t index_base, u64_t* d_out, bool small = false) {
   // candidates per query handed to the rescoring: the wide tile selects a BAND (every row within 2 delta of the approximate k-th best: as many
   // as the data makes it, up to kBandMax), the 32/64-query tile (`small`) the best 64 by approximate score
   const int KC = small ? 64 : tavb::kBandMax;
   const bool f32c = (c->dtype == TAVB_F32);
+  const bool big_k = k > 64;  // beyond what the 64-query exact tile ranks: every flagged query goes to the wide split-plane form (fp16 corpora only: the caller checked)
   const int qt = small ? tavb::skinny_query_tile(nq) : (c->mfma_tile > 0 ? (int)c->mfma_tile : tavb::mfma_query_tile(nq));
   const int nq_pad = ((nq + qt - 1) / qt) * qt;
   const bool bdirect = !small && qt == 256 && c->mfma_bdirect && c->mfma_ablate == 0;
   // Work list of queries that need an exact pass (a band that did not fit).  Few of them (<= 64): ONE pass of the 64-query exact tile.  Many: the
   // 256-query tile in its SPLIT form (fp32 queries as two fp16 planes, the K loop run once per plane: twice the MFMAs of a filter pass, exact) --
   // 16 passes of the 64-query tile per 1024 flagged queries otherwise (round 2-3: "stated, not solved").  Both are fixed-shape
-  // launches over the same device-side list and return at once when it is empty or is the other one's share.
-  const bool wide_fallback = !small && !f32c && nq >= 256 && c->wide_fallback;
+  // launches over the same device-side list and return at once when it is empty or is the other one's share.  Either one hands its best rows
+  // (and a small band below them) to the rescoring kernel in slot mode: a query served by a fallback gets the streaming kernels' float32 scores.
+  const bool wide_fallback = !small && !f32c && c->wide_fallback && (nq >= 256 || big_k);
+  if (big_k && !wide_fallback) return fail(TAVB_E_UNSUPPORTED, "k > 64 on the batched tile needs an fp16 corpus and the wide_fallback option");
   const int cap = wide_fallback ? ((nq + 255) / 256) * 256 : ((nq + 63) / 64) * 64;  // slots of the work list
   const size_t q16_bytes = (size_t)nq_pad * c->dim * 2 * (small ? 2 : 1);  // small: high and low plane
   if (int rc = c->d_queries_f16.reserve(q16_bytes)) return rc;
   if (int rc = c->d_delta.reserve((size_t)nq_pad * 6 * sizeof(float))) return rc;  // delta, the relaxed thresholds, the band widths; band counts, lost levels, verdicts
   if (int rc = c->d_approx.reserve((size_t)nq * KC * sizeof(u64_t))) return rc;
   if (int rc = c->d_flag.reserve((size_t)(cap + 64) * sizeof(int))) return rc;
-  if (int rc = c->d_fb_queries.reserve((size_t)2 * cap * c->dim * 2 + (size_t)cap * sizeof(float))) return rc;
+  if (int rc = c->d_fb_queries.reserve((size_t)2 * cap * c->dim * 2 + (size_t)2 * cap * sizeof(float))) return rc;  // + per-slot thresholds, per-slot band widths
+  if (!big_k)
+    if (int rc = c->d_fb_cand.reserve((size_t)cap * 64 * sizeof(u64_t))) return rc;
   if (int rc = c->d_norm.reserve(256)) return rc;
+  const float *d_ms = nullptr, *d_ms_floor = nullptr;
+  if (int rc = upload_min_scores(c, min_scores, nq, nq_pad, &d_ms, &d_ms_floor)) return rc;
+  const float ms_lo = lowest_min_score(min_scores, nq);
   float* d_norm = reinterpret_cast<float*>(c->d_norm.ptr);
   float* d_delta = reinterpret_cast<float*>(c->d_delta.ptr);
   float* d_floor = d_delta + nq_pad;
@@ -1671,7 +1763,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
     }
     TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16_bytes, c->stream));  // padding queries
     TAVB_HIP(hipMemsetAsync(d_band, 0, (size_t)nq_pad * 4 * sizeof(float), c->stream));  // band widths of the padding queries, counts, lost levels, verdicts
-    hipError_t e = tavb::launch_query_prepare(d_q, nq, c->dim, min_score, small, d_norm, small ? nullptr : c->d_queries_f16.ptr, d_delta, d_floor,
+    hipError_t e = tavb::launch_query_prepare(d_q, nq, c->dim, d_ms, small, d_norm, small ? nullptr : c->d_queries_f16.ptr, d_delta, d_floor,
                                               small ? nullptr : d_band, c->stream, bdirect);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "query prepare launch failed: %s", hipGetErrorString(e));
     if (small) {
@@ -1691,7 +1783,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   filt.lost = small ? nullptr : d_lost;
   filt.verdict = small ? nullptr : d_verdict;
   filt.index_base = index_base;
-  filt.kernel_min_score = (min_score > 0.0f) ? 0.0f : min_score;  // the per-query relaxed thresholds (floor) do the filtering; NaN stays NaN
+  filt.kernel_min_score = (ms_lo > 0.0f) ? 0.0f : ms_lo;  // the per-query relaxed thresholds (floor) do the filtering; NaN stays NaN
   filt.floor = d_floor;
   filt.bdirect = bdirect;
   filt.queries = c->d_queries_f16.ptr;
@@ -1707,34 +1799,47 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
   if (int rc = run_tile_ladder(c, filt, reinterpret_cast<u64_t*>(c->d_approx.ptr), nullptr)) return rc;
   char* fb = reinterpret_cast<char*>(c->d_fb_queries.ptr);
   float* fb_thr = reinterpret_cast<float*>(fb + (size_t)2 * cap * c->dim * 2);
+  float* fb_band = fb_thr + cap;
   {
     Timed t(c, TAVB_KERNEL_RESCORE);
     hipError_t e = tavb::launch_rescore(c->corpus, f32c, c->dim, index_base, d_q, reinterpret_cast<const u64_t*>(c->d_approx.ptr), KC,
-                                        small ? nullptr : d_band_cnt, small ? nullptr : d_verdict, d_delta, min_score, nq, k, d_out, d_nflag, d_flagged,
+                                        small ? nullptr : d_band_cnt, small ? nullptr : d_verdict, d_delta, d_ms, nq, k, d_out, d_nflag, d_flagged,
                                         c->stream, filt.doomed, filt.doomed_max);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "rescore launch failed: %s", hipGetErrorString(e));
-    e = f32c ? tavb::launch_gather_flagged_f32(d_q, c->dim, min_score, d_nflag, d_flagged, cap, reinterpret_cast<float*>(fb), fb_thr, c->stream)
-             : tavb::launch_gather_flagged(d_q, c->dim, min_score, d_nflag, d_flagged, cap, fb, fb + (size_t)cap * c->dim * 2, fb_thr, c->stream);
+    e = f32c ? tavb::launch_gather_flagged_f32(d_q, c->dim, d_ms, d_nflag, d_flagged, cap, reinterpret_cast<float*>(fb), fb_thr, c->stream)
+             : tavb::launch_gather_flagged(d_q, c->dim, d_ms, d_nflag, d_flagged, cap, fb, fb + (size_t)cap * c->dim * 2, fb_thr, c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "gather launch failed: %s", hipGetErrorString(e));
+    if (wide_fallback) {
+      e = tavb::launch_fill_f32(fb_band, cap, kExactBand, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "band fill launch failed: %s", hipGetErrorString(e));
+    }
   }
   {  // (run_tile_ladder times its own launches, in the same bucket)
-    // the exact tile over the work list: returns at once when the list is empty (the normal case)
-    TileRun ex{};
-    ex.skinny = true;
-    ex.q32 = f32c;
-    ex.qt = 64;
-    ex.nq = cap;
-    ex.nq_pad = cap;
-    ex.k = k;
-    ex.index_base = index_base;
-    ex.kernel_min_score = min_score;
-    ex.floor = fb_thr;
-    ex.queries = fb;
-    ex.active = d_nflag;
-    ex.active_min = 0;
-    ex.active_max = wide_fallback ? 64 : 0;
-    ex.ladder = false;
-    if (int rc = run_tile_ladder(c, ex, d_out, d_flagged)) return rc;
+    if (!big_k) {
+      // the exact tile over the work list: returns at once when the list is empty (the normal case).  It ranks 64 rows per slot whatever k: the
+      // rows beyond the k-th are the band the rescoring (slot mode) re-orders with the streaming kernels' arithmetic
+      TileRun ex{};
+      ex.skinny = true;
+      ex.q32 = f32c;
+      ex.qt = 64;
+      ex.nq = cap;
+      ex.nq_pad = cap;
+      ex.k = 64;
+      ex.index_base = index_base;
+      ex.kernel_min_score = ms_lo;
+      ex.floor = fb_thr;
+      ex.queries = fb;
+      ex.active = d_nflag;
+      ex.active_min = 0;
+      ex.active_max = wide_fallback ? 64 : 0;
+      ex.ladder = false;
+      u64_t* fb_cand = reinterpret_cast<u64_t*>(c->d_fb_cand.ptr);
+      if (int rc = run_tile_ladder(c, ex, fb_cand, nullptr, /*scatter_identity=*/true)) return rc;
+      Timed t(c, TAVB_KERNEL_RESCORE);
+      hipError_t e = tavb::launch_rescore_slots(c->corpus, f32c, c->dim, index_base, d_q, fb_cand, 64, nullptr, d_ms, wide_fallback ? 64 : cap, k, d_out,
+                                                d_flagged, d_nflag, 0, wide_fallback ? 64 : 0x7fffffff, c->stream);
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "fallback rescore launch failed: %s", hipGetErrorString(e));
+    }
     if (wide_fallback) {
       TileRun wx{};
       wx.skinny = false;
@@ -1744,14 +1849,17 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
       wx.nq_pad = cap;
       wx.k = k;
       wx.index_base = index_base;
-      wx.kernel_min_score = min_score;
+      wx.kernel_min_score = ms_lo;
       wx.floor = fb_thr;  // (+inf for the unused slots: they admit nothing)
+      wx.band = fb_band;  // kExactBand below the k-th best: what the rescoring re-orders
       wx.queries = fb;    // [2][cap][dim]: the high plane, then the low plane
       wx.split_plane = (int64_t)cap * c->dim * 2;
       wx.active = d_nflag;
-      wx.active_min = 64;
+      wx.active_min = big_k ? 0 : 64;
       wx.active_max = 0;
       wx.ladder = true;
+      wx.rs_queries = d_q;
+      wx.rs_min_scores = d_ms;
       if (int rc = run_tile_ladder(c, wx, d_out, d_flagged)) return rc;
     }
   }
@@ -1762,17 +1870,20 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, float min_sc
 
 // Routes a device-resident query batch: streaming scan (few queries), 32/64-query tile (small batches; every batch on
 // fp32 corpora), or the 256-query fp16 tile with exact rescoring (large batches on fp16 corpora).  Not part of the public ABI.
+// min_scores: one threshold per query -- the tiles take them per query (a batch of Q `fuzzy_lookup_embedding` calls has Q of them,
+// vectorbase.py:163-173), so a mixed batch takes the same route as a uniform one.
 int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores,
                                 uint32_t index_base, u64_t* d_out) {
   bool uniform_thr = true;
-  for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (min_scores[i] == min_scores[0]);
+  for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (memcmp(&min_scores[i], &min_scores[0], sizeof(float)) == 0);
   const bool f16c = (c->dtype == TAVB_F16);
-  // the wide tile keeps a band below the k-th best (any k the tiles serve: the reference's max_matches = 50, convsettings.py:61-63, included)
-  bool wide = (f16c || c->f32_shadow) && c->corpus && nq >= c->mfma_min_batch && uniform_thr && tavb::mfma_supported(c->dim, k) &&
-              c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c);
+  // the wide tile keeps a band below the k-th best (any k the fused selections serve: the reference's max_matches = 50, convsettings.py:61-63,
+  // included).  Its flagged queries need an exact tile: the 64-query one up to k = 64, beyond that the wide split-plane form (fp16 corpora).
+  const bool exact_tile = (k <= 64) ? tavb::skinny_supported(c->dim, k, !f16c) : (f16c && c->wide_fallback != 0);
+  bool wide = (f16c || c->f32_shadow) && c->corpus && nq >= c->mfma_min_batch && tavb::mfma_supported(c->dim, k) && c->rows > 0 && exact_tile;
   // f32_shadow = 2: smaller batches (and single queries) on big fp32 corpora filter on the shadow too, with the 32/64-query tile
   // (it keeps the best 64 candidates per query: k up to 48 leaves the slack the completeness test needs)
-  bool shadow_small = !wide && !f16c && c->f32_shadow >= 2 && c->corpus && nq <= 64 && uniform_thr && tavb::mfma_supported(c->dim, 64) && k <= 48 &&
+  bool shadow_small = !wide && !f16c && c->f32_shadow >= 2 && c->corpus && nq <= 64 && tavb::mfma_supported(c->dim, 64) && k <= 48 &&
                       tavb::skinny_supported(c->dim, k, false) && (int64_t)c->rows * c->dim * 4 >= c->f32_shadow_min_bytes;
   if ((wide || shadow_small) && !f16c) {  // fp32 corpus: the filter needs the fp16 shadow; without the memory for it the fp32 kernels serve the batch
     const size_t need = (size_t)c->rows * c->dim * 2;
@@ -1784,14 +1895,14 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   c->last_shadow = 0;
   if (shadow_small) {
     c->last_tier = 5;
-    return search_wide_exact(c, d_q, nq, k, min_scores[0], index_base, d_out, /*small=*/true);
+    return search_wide_exact(c, d_q, nq, k, min_scores, index_base, d_out, /*small=*/true);
   }
   // 32/64-query tiles at HBM speed: small batches on fp16 corpora, every batch from `skinny_min_batch_f32` up on fp32 ones
-  const bool skinny = !wide && c->corpus && uniform_thr && c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c) &&
+  const bool skinny = !wide && c->corpus && c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c) &&
                       nq >= (f16c ? c->skinny_min_batch_f16 : c->skinny_min_batch_f32);
   if (wide) {
     c->last_tier = 4;  // 1-3 = streaming tiers, 4 = 256-query MFMA tile, 5 = 32/64-query MFMA tile
-    return search_wide_exact(c, d_q, nq, k, min_scores[0], index_base, d_out);
+    return search_wide_exact(c, d_q, nq, k, min_scores, index_base, d_out);
   }
   if (skinny) {
     const int qt = tavb::skinny_query_tile(nq);
@@ -1800,6 +1911,9 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     const size_t plane = (size_t)nq_pad * c->dim * (q32 ? 4 : 2);
     const size_t qbytes = plane * (q32 ? 1 : 2);
     if (int rc = c->d_queries_f16.reserve(qbytes)) return rc;
+    const float *d_ms = nullptr, *d_ms_floor = nullptr;
+    if (!uniform_thr)  // per-query thresholds: exclusive admission floors valid from the first row on
+      if (int rc = upload_min_scores(c, min_scores, nq, nq_pad, &d_ms, &d_ms_floor)) return rc;
     TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, qbytes, c->stream));
     if (q32) {
       TAVB_HIP(hipMemcpyAsync(c->d_queries_f16.ptr, d_q, (size_t)nq * c->dim * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -1817,7 +1931,8 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     r.nq_pad = nq_pad;
     r.k = k;
     r.index_base = index_base;
-    r.kernel_min_score = min_scores[0];
+    r.kernel_min_score = uniform_thr ? min_scores[0] : lowest_min_score(min_scores, nq);
+    r.floor = d_ms_floor;
     r.queries = c->d_queries_f16.ptr;
     r.ladder = true;
     return run_tile_ladder(c, r, d_out, nullptr);

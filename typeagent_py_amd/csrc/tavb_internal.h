@@ -47,7 +47,7 @@ hipError_t launch_scan_emit(const ScanParams& p, int blocks, unsigned long long*
 // lists: [n_lists, nq, k] (list-major) or [nq, n_lists, k] (query-major) sorted keys -> out [nq, k]
 hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, int k, bool query_major,
                         unsigned long long* out, hipStream_t stream);
-// the same over a device-side work list: query slot s is merged only if s < *active, into out[scatter[s]]
+// the same over a device-side work list: query slot s is merged only if s < *active, into out[scatter[s]] (scatter == nullptr: out[s])
 hipError_t launch_merge_scatter(const unsigned long long* lists, int n_lists, int nq, int k, const int* active, const int* scatter,
                                 unsigned long long* out, hipStream_t stream);
 
@@ -65,18 +65,27 @@ hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, floa
 // q16 may be null (rows_only: the filter uses the exact queries, only the rows' rounding enters the bound)
 // band (optional, [nq]): 2 * delta, the width of the band selection
 // frag_major: q16 in MFMA-fragment-major order for 256-query tiles (tavb_mfma.hip, BD) instead of row-major
-hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
+// min_scores: device [nq], the callers' thresholds per query (float32 values, NaN allowed)
+hipError_t launch_query_prepare(const float* q, int nq, int dim, const float* min_scores, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
                                 float* thr, float* band, hipStream_t stream, bool frag_major = false);
+hipError_t launch_fill_f32(float* p, int n, float v, hipStream_t stream);
+hipError_t launch_fill_thresholds(float* a, float* b, int n, int n_pad, float va, float vb, hipStream_t stream);  // a[i] = va, b[i] = vb (i < n), +inf up to n_pad
 // candidates [nq, stride] (+ cand_cnt [nq]: band mode, the set is complete by construction unless incomplete[q]; cand_cnt == nullptr: the
 // sorted best `stride` = 64 by approximate score, complete when rank 63 + delta < the exact k-th best) -> exact top k [nq, k]
 hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
-                          int stride, const int* cand_cnt, const int* incomplete, const float* delta, float min_score, int nq, int k,
+                          int stride, const int* cand_cnt, const int* incomplete, const float* delta, const float* min_scores, int nq, int k,
                           unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream, const int* gate = nullptr, int gate_max = 0);
+// the same scoring over the device-side work list of flagged queries: slot s (live when s < *slot_active, slot_min < *slot_active <= slot_max) holds
+// the candidates an exact tile ranked highest for query slot_query[s] (cand [n_slots, stride]; cand_cnt [n_slots] or nullptr = `stride` each);
+// their best k by the streaming kernels' arithmetic go to row slot_query[s] of out [nq, k]
+hipError_t launch_rescore_slots(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* cand,
+                                int stride, const int* cand_cnt, const float* min_scores, int n_slots, int k, unsigned long long* out,
+                                const int* slot_query, const int* slot_active, int slot_min, int slot_max, hipStream_t stream);
 // (gate: device-side counter; when *gate > gate_max there are no candidates -- the last filter phase was skipped -- and EVERY query is flagged)
 hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, float* stats /*[2]*/, hipStream_t stream);
-hipError_t launch_gather_flagged_f32(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, float* out,
+hipError_t launch_gather_flagged_f32(const float* queries, int dim, const float* min_scores, const int* n_flagged, const int* flagged, int cap, float* out,
                                      float* thr, hipStream_t stream);
-hipError_t launch_gather_flagged(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, void* hi, void* lo,
+hipError_t launch_gather_flagged(const float* queries, int dim, const float* min_scores, const int* n_flagged, const int* flagged, int cap, void* hi, void* lo,
                                  float* thr, hipStream_t stream);
 
 hipError_t launch_normalize_f32(const float* in, float* out, int64_t rows, int dim, hipStream_t stream);
@@ -131,9 +140,6 @@ hipError_t launch_select_band(const unsigned long long* cand, const int* counts,
                               int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream, const int* active = nullptr,
                               int active_min = 0, int active_max = 0x7fffffff, const int* gate = nullptr, int gate_max = 0, int* doomed = nullptr,
                               int doom_limit = 0);
-// strict best k (ties by ordinal) of every live slot's band, sorted, into row scatter[slot] of out: the last step of the SPLIT fallback
-hipError_t launch_finalize_strict(const unsigned long long* band_keys, const int* band_cnt, int kc, int nq, int k, const int* active, int active_min,
-                                  int active_max, const int* scatter, unsigned long long* out, hipStream_t stream);
 // 32-query tiles at HBM speed, fp32 or fp16 corpora (same parameter block; `queries` in the corpus dtype)
 hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream);
 int skinny_query_tile(int nq);  // 32, or 64 for batches of 33 and more

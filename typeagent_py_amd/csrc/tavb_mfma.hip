@@ -432,9 +432,11 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
   const int split = (t / p.n_qtiles) * 8 + xcd;
   if (split >= p.n_splits) return;
   if (p.gate != nullptr && *p.gate > p.gate_max) return;  // most of the batch is going to the exact form anyway: this filter phase would be wasted work
-  if (p.active != nullptr) {  // fixed-shape launch over a device-side work list (tavb_rescore.hip): nothing to do, or not this kernel's share
+  int live_q = p.nq;  // queries that exist: the batch, or -- for a fixed-shape launch over a device-side work list (tavb_rescore.hip) -- the slots in use
+  if (p.active != nullptr) {  // nothing to do, or not this kernel's share
     const int live = *p.active;
     if (live <= p.active_min || live > p.active_max || qtile * BN >= live) return;
+    live_q = live < live_q ? live : live_q;
   }
   const int64_t r_begin = (int64_t)split * p.rows_per_split;
   const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
@@ -448,7 +450,10 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
     // `clip(score) >= min_score` (thr >= the float below min_score), and the epilogue needs no second test per row
     float t0 = (p.min_score != p.min_score || p.min_score > 1.0f) ? __builtin_inff() : thr0;
     const int qg0 = qtile * BN + i;
-    if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
+    // padding queries -- and the unused slots of the last live tile of a work list: zero queries, every row scores 0.5, and from the second
+    // ladder phase on their thr_in is NaN (the select kernel skips them), so without this they would admit every row of the big phases --
+    // admit nothing
+    if (qg0 >= live_q) t0 = __builtin_inff();
     else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best so far: a valid lower bound
     thr_lds[i] = t0;
     cnt_lds[i] = 0;
@@ -871,9 +876,11 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
   const int qtile = t % p.n_qtiles;
   const int split = (t / p.n_qtiles) * 8 + xcd;
   if (split >= p.n_splits) return;
+  int live_q = p.nq;
   if (p.active != nullptr) {  // fixed-shape launch over a device-side work list (tavb_rescore.hip)
     const int live = *p.active;
     if (live <= p.active_min || live > p.active_max || qtile * SQ >= live) return;
+    live_q = live < live_q ? live : live_q;
   }
   const int64_t r_begin = (int64_t)split * p.rows_per_split;
   const int64_t r_end = (r_begin + p.rows_per_split < p.rows) ? r_begin + p.rows_per_split : p.rows;
@@ -884,7 +891,7 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
   if (tid < SQ) {  // SQ <= 64 < S_THREADS
     float t0 = (p.min_score != p.min_score || p.min_score > 1.0f) ? __builtin_inff() : thr0;  // NaN threshold admits nothing, nor one above 1 (as in the 256-query tile)
     const int qg0 = qtile * SQ + tid;
-    if (qg0 >= p.nq) t0 = __builtin_inff();  // padding queries admit nothing
+    if (qg0 >= live_q) t0 = __builtin_inff();  // padding queries (and unused work-list slots) admit nothing
     else if (p.thr_in && p.thr_in[qg0] > t0) t0 = p.thr_in[qg0];  // k-th best so far: a valid lower bound
     thr_lds[tid] = t0;
     cnt_lds[tid] = 0;
@@ -1389,7 +1396,9 @@ int mfma_query_tile(int nq) {
   return ((n128 & 1) && n128 <= 5) ? 128 : BN;
 }
 
-bool mfma_supported(int dim, int k) { return dim % BK == 0 && dim >= BK && dim <= 16384 && k >= 1 && k <= 64; }
+// k: the band selection holds any k the fused selections serve (a band of k + its 2-delta neighbourhood has to fit the 640 keys a candidate
+// buffer keeps between compactions and the 1024 of the select kernel: k = 256 leaves the same slack as k = 32 on isotropic data)
+bool mfma_supported(int dim, int k) { return dim % BK == 0 && dim >= BK && dim <= 16384 && k >= 1 && k <= TAVB_MAX_FUSED_K; }
 
 int mfma_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu) {
   // One workgroup per CU and all of them resident at once: the grid is (groups of 8 row ranges) x query tiles x 8, so the
@@ -1408,32 +1417,11 @@ size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide) {
   return (size_t)n_splits * (size_t)nq_padded * (wide ? CAPW : CAP) * sizeof(u64);
 }
 
-// The strict best k of every live slot's band (<= kBandMax unsorted keys; ties by ordinal), sorted, scattered to row scatter[slot] of `out`:
-// the last step of the SPLIT fallback, whose scores are final.  One wave per slot.
-__global__ void __launch_bounds__(64) finalize_strict_kernel(const u64* __restrict__ band_keys, const int* __restrict__ band_cnt, int kc, int k,
-                                                             const int* __restrict__ active, int active_min, int active_max,
-                                                             const int* __restrict__ scatter, u64* __restrict__ out) {
-  const int live = *active;
-  const int slot = blockIdx.x;
-  if (live <= active_min || live > active_max || slot >= live) return;
-  const int lane = threadIdx.x;
-  const int n = band_cnt[slot];
-  const WaveTopK<1> best = best_of_buffer(band_keys + (size_t)slot * kc, n < kc ? n : kc, lane);
-  if (lane < k) out[(size_t)scatter[slot] * k + lane] = best.key[0];
-}
-
-hipError_t launch_finalize_strict(const unsigned long long* band_keys, const int* band_cnt, int kc, int nq, int k, const int* active, int active_min,
-                                  int active_max, const int* scatter, unsigned long long* out, hipStream_t stream) {
-  if (nq < 1 || k < 1 || k > 64 || !active || !scatter) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(finalize_strict_kernel, dim3(nq), dim3(64), 0, stream, band_keys, band_cnt, kc, k, active, active_min, active_max, scatter, out);
-  return hipGetLastError();
-}
-
 hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
                               int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream, const int* active, int active_min,
                               int active_max, const int* gate, int gate_max, int* doomed, int doom_limit) {
-  if (nq < 1 || k < 1 || k > 64 || n_splits < 1 || n_splits > 256 || nq_padded < nq || kc_max < k || kc_max > SEL_CACHE / 4) return hipErrorInvalidValue;
+  if (nq < 1 || k < 1 || k > TAVB_MAX_FUSED_K || n_splits < 1 || n_splits > 256 || nq_padded < nq || kc_max < k || kc_max > SEL_CACHE / 4) return hipErrorInvalidValue;
   constexpr int lds = SEL_CACHE * (int)sizeof(u64);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;

@@ -67,7 +67,7 @@ hipError_t launch_merge(const unsigned long long* lists, int n_lists, int nq, in
 
 hipError_t launch_merge_scatter(const unsigned long long* lists, int n_lists, int nq, int k, const int* active, const int* scatter,
                                 unsigned long long* out, hipStream_t stream) {
-  if (n_lists < 1 || nq < 1 || k < 1 || k > 64 || !active || !scatter) return hipErrorInvalidValue;
+  if (n_lists < 1 || nq < 1 || k < 1 || k > 64 || !active) return hipErrorInvalidValue;
   int waves = 16;
   while (waves > 1 && waves / 2 >= n_lists) waves /= 2;
   const size_t lds = (size_t)((waves + 1) / 2) * 64 * sizeof(u64);

@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) shadow_convert_kernel(const float* __rest
 // One wave per query.  q16 <- fp16(q); delta <- score-units bound described above; thr <- the exclusive admission
 // threshold of the approximate pass (just below min_score - 2 delta; -inf when every row qualifies; +inf for NaN).
 // rows_only: the filter multiplies the EXACT queries (split fp16 high + low planes) with the shadow rows: only the rows' rounding counts.
-__global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restrict__ q, int nq, int dim, float min_score, int rows_only,
+__global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restrict__ q, int nq, int dim, const float* __restrict__ min_scores /*[nq]*/, int rows_only,
                                                             const float* __restrict__ max_norm_sq /*[2]: max |x16|^2, max |x - x16|^2*/, _Float16* __restrict__ q16,
                                                             float* __restrict__ delta, float* __restrict__ thr, float* __restrict__ band, int frag_major) {
   const int lane = threadIdx.x & 63;
@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
     delta[qi] = d;
     if (band) band[qi] = 2.0f * d;
     float t;
+    const float min_score = min_scores[qi];
     if (min_score != min_score) {
       t = __builtin_inff();
     } else {
@@ -171,25 +172,39 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
 //   * cut mode (cand_cnt == nullptr; the 32/64-query tile over an fp16 shadow): the best `stride` = 64 rows by approximate
 //     score, sorted.  Fewer than 64: nothing was cut.  Else a row outside has approx <= a_63, exact <= a_63 + delta, and is
 //     out when that is below the exact k-th best of the candidates (one delta: the exact k-th is known by now).
-template <typename T>
+//   * SLOT mode (slot_query != nullptr): the workgroup serves slot blockIdx.x of the device-side work list of flagged queries (live when
+//     slot < *slot_active and slot_min < *slot_active <= slot_max): the candidates at approx[slot] / cand_cnt[slot] are what an EXACT
+//     tile (fp32 query as hi + lo fp16 planes, or fp32 MFMAs) ranked highest -- its best k and every row within a small band below the
+//     k-th (tavb_abi.hip: kExactBand) -- and belong to query slot_query[slot].  Their scores come out of the matrix pipe's accumulation
+//     order; scoring them again HERE gives them the streaming kernels' arithmetic, so that a query served by a fallback returns the
+//     same float32 scores (and the same order among near-ties) as `fuzzy_lookup_embedding` on its own.  Nothing is flagged.
+// KPL: result keys per lane (1: k <= 64, 4: k <= 256).
+template <typename T, int KPL>
 __global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corpus, int dim, uint32_t index_base,
                                                       const float* __restrict__ queries, const u64* __restrict__ approx /*[nq, stride]*/, int stride,
                                                       const int* __restrict__ cand_cnt, const int* __restrict__ incomplete,
-                                                      const float* __restrict__ delta, float min_score, int k,
+                                                      const float* __restrict__ delta, const float* __restrict__ min_scores /*[nq]*/, int k,
                                                       u64* __restrict__ out /*[nq, k]*/, int* __restrict__ n_flagged,
-                                                      int* __restrict__ flagged, const int* __restrict__ gate, int gate_max) {
+                                                      int* __restrict__ flagged, const int* __restrict__ gate, int gate_max,
+                                                      const int* __restrict__ slot_query, const int* __restrict__ slot_active, int slot_min, int slot_max) {
   __shared__ u64 exact[kBandMax];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int qi = blockIdx.x;
-  if (gate != nullptr && *gate > gate_max) {  // the last filter phase did not run (most bands were not going to fit): no candidates, every query takes the exact form
+  const int slot = blockIdx.x;
+  int qi = slot;
+  if (slot_query != nullptr) {
+    const int live = *slot_active;
+    if (live <= slot_min || live > slot_max || slot >= live) return;
+    qi = slot_query[slot];
+  } else if (gate != nullptr && *gate > gate_max) {  // the last filter phase did not run (most bands were not going to fit): no candidates, every query takes the exact form
     if (threadIdx.x == 0) flagged[atomicAdd(n_flagged, 1)] = qi;
     return;
   }
-  const u64* cand = approx + (size_t)qi * stride;
+  const u64* cand = approx + (size_t)slot * stride;
   const float* q = queries + (size_t)qi * dim;
+  const float min_score = min_scores[qi];
   const int n8 = dim / 8;
-  int n_cand = cand_cnt ? cand_cnt[qi] : stride;
+  int n_cand = cand_cnt ? cand_cnt[slot] : stride;
   if (n_cand > kBandMax) n_cand = kBandMax;
   for (int c = wave; c < n_cand; c += 4) {
     const u64 key = cand[c];  // wave-uniform
@@ -231,17 +246,23 @@ __global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corp
   }
   __syncthreads();
   if (wave != 0) return;
-  // best 64 of the exact keys, sorted best first (rank r in lane r)
-  WaveTopK<1> best;
+  // best 64 * KPL of the exact keys, sorted best first (rank r in slot r / 64 of lane r % 64)
+  WaveTopK<KPL> best;
   best.clear();
   for (int off = 0; off < n_cand; off += 64) {
-    WaveTopK<1> chunk;
-    chunk.key[0] = sort64_ascending((off + lane < n_cand) ? exact[off + lane] : 0ull, lane);  // ascending == "reversed best-first"
+    WaveTopK<KPL> chunk;
+    chunk.clear();
+    chunk.key[KPL - 1] = sort64_ascending((off + lane < n_cand) ? exact[off + lane] : 0ull, lane);  // ascending == "reversed best-first", zero-extended to 64 * KPL
     best.merge_reversed(chunk, lane);
   }
-  const u64 mine = best.key[0];
-  const float my_score = __uint_as_float((uint32_t)(mine >> 32));
-  if (lane < k) out[(size_t)qi * k + lane] = (mine != 0ull && my_score >= min_score) ? mine : 0ull;  // sorted by score: the rows that fail are a tail
+#pragma unroll
+  for (int s_ = 0; s_ < KPL; ++s_) {
+    const u64 mine = best.key[s_];
+    const float my_score = __uint_as_float((uint32_t)(mine >> 32));
+    const int r = s_ * 64 + lane;
+    if (r < k) out[(size_t)qi * k + r] = (mine != 0ull && my_score >= min_score) ? mine : 0ull;  // sorted by score: the rows that fail are a tail
+  }
+  if (slot_query != nullptr) return;
   // completeness of the candidate set
   bool ok = true;
   if (cand_cnt != nullptr) {
@@ -250,20 +271,20 @@ __global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corp
     const u64 a_last = cand[stride - 1];
     if (a_last != 0ull) {  // the set was cut
       const float a_cut = __uint_as_float((uint32_t)(a_last >> 32));
-      const u64 kth = readlane_u64(mine, k - 1);
+      const u64 kth = best.at(k - 1);
       const float e_k = __uint_as_float((uint32_t)(kth >> 32));
       ok = (kth != 0ull) && (a_cut + delta[qi] < e_k);  // false for delta = inf
     }
   }
   if (!ok && lane == 0) {
-    const int slot = atomicAdd(n_flagged, 1);
-    flagged[slot] = qi;
+    const int slot_f = atomicAdd(n_flagged, 1);
+    flagged[slot_f] = qi;
   }
 }
 
 // Compact the flagged queries into the operand of the exact 64-query tile: split hi / lo fp16 planes [2, cap, dim]
 // (unused slots zero) and per-slot exclusive thresholds (+inf for unused slots: they admit nothing).
-__global__ void __launch_bounds__(256) gather_flagged_kernel(const float* __restrict__ queries, int dim, float min_score,
+__global__ void __launch_bounds__(256) gather_flagged_kernel(const float* __restrict__ queries, int dim, const float* __restrict__ min_scores,
                                                              const int* __restrict__ n_flagged, const int* __restrict__ flagged, int cap,
                                                              _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* __restrict__ thr) {
   const int n = *n_flagged;
@@ -271,6 +292,7 @@ __global__ void __launch_bounds__(256) gather_flagged_kernel(const float* __rest
   const int slot = blockIdx.x;
   if (slot >= cap) return;
   const bool used = slot < n;
+  const float min_score = used ? min_scores[flagged[slot]] : 0.0f;
   const float thr0 = (min_score > 0.0f) ? __uint_as_float(__float_as_uint(min_score) - 1u) : -__builtin_inff();
   if (threadIdx.x == 0) thr[slot] = used ? ((min_score != min_score) ? __builtin_inff() : thr0) : __builtin_inff();
   const float* src = used ? queries + (size_t)flagged[slot] * dim : nullptr;
@@ -288,7 +310,7 @@ __global__ void __launch_bounds__(256) gather_flagged_kernel(const float* __rest
 }
 
 // the same for the exact fp32 tile: plain fp32 queries [cap, dim]
-__global__ void __launch_bounds__(256) gather_flagged_f32_kernel(const float* __restrict__ queries, int dim, float min_score,
+__global__ void __launch_bounds__(256) gather_flagged_f32_kernel(const float* __restrict__ queries, int dim, const float* __restrict__ min_scores,
                                                                  const int* __restrict__ n_flagged, const int* __restrict__ flagged, int cap,
                                                                  float* __restrict__ out, float* __restrict__ thr) {
   const int n = *n_flagged;
@@ -296,6 +318,7 @@ __global__ void __launch_bounds__(256) gather_flagged_f32_kernel(const float* __
   const int slot = blockIdx.x;
   if (slot >= cap) return;
   const bool used = slot < n;
+  const float min_score = used ? min_scores[flagged[slot]] : 0.0f;
   const float thr0 = (min_score > 0.0f) ? __uint_as_float(__float_as_uint(min_score) - 1u) : -__builtin_inff();
   if (threadIdx.x == 0) thr[slot] = used ? ((min_score != min_score) ? __builtin_inff() : thr0) : __builtin_inff();
   const float* src = used ? queries + (size_t)flagged[slot] * dim : nullptr;
@@ -303,6 +326,20 @@ __global__ void __launch_bounds__(256) gather_flagged_f32_kernel(const float* __
 }
 
 __global__ void zero_int_kernel(int* p) { *p = 0; }
+
+__global__ void fill_f32_kernel(float* __restrict__ p, int n, float v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// a uniform batch's thresholds: a[i] = va, b[i] = vb for i < n, +inf for the padding up to n_pad
+__global__ void fill_thresholds_kernel(float* __restrict__ a, float* __restrict__ b, int n, int n_pad, float va, float vb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) {
+    a[i] = i < n ? va : __builtin_inff();
+    b[i] = i < n ? vb : __builtin_inff();
+  }
+}
 
 }  // namespace
 
@@ -322,36 +359,77 @@ hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void
   return hipGetLastError();
 }
 
-hipError_t launch_query_prepare(const float* q, int nq, int dim, float min_score, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
+hipError_t launch_fill_f32(float* p, int n, float v, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, v);
+  return hipGetLastError();
+}
+
+hipError_t launch_fill_thresholds(float* a, float* b, int n, int n_pad, float va, float vb, hipStream_t stream) {
+  if (n_pad <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_thresholds_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, stream, a, b, n, n_pad, va, vb);
+  return hipGetLastError();
+}
+
+hipError_t launch_query_prepare(const float* q, int nq, int dim, const float* min_scores, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
                                 float* thr, float* band, hipStream_t stream, bool frag_major) {
-  hipLaunchKernelGGL(query_prepare_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, q, nq, dim, min_score, rows_only ? 1 : 0, max_norm_sq,
+  hipLaunchKernelGGL(query_prepare_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, q, nq, dim, min_scores, rows_only ? 1 : 0, max_norm_sq,
                      reinterpret_cast<_Float16*>(q16), delta, thr, band, frag_major ? 1 : 0);
   return hipGetLastError();
 }
 
+namespace {
+template <typename T>
+void launch_rescore_t(const void* corpus, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx, int stride,
+                      const int* cand_cnt, const int* incomplete, const float* delta, const float* min_scores, int n_blocks, int k, unsigned long long* out,
+                      int* n_flagged, int* flagged, hipStream_t stream, const int* gate, int gate_max, const int* slot_query, const int* slot_active,
+                      int slot_min, int slot_max) {
+  if (k <= 64)
+    hipLaunchKernelGGL((rescore_kernel<T, 1>), dim3(n_blocks), dim3(256), 0, stream, reinterpret_cast<const T*>(corpus), dim, index_base, queries, approx,
+                       stride, cand_cnt, incomplete, delta, min_scores, k, out, n_flagged, flagged, gate, gate_max, slot_query, slot_active, slot_min, slot_max);
+  else
+    hipLaunchKernelGGL((rescore_kernel<T, 4>), dim3(n_blocks), dim3(256), 0, stream, reinterpret_cast<const T*>(corpus), dim, index_base, queries, approx,
+                       stride, cand_cnt, incomplete, delta, min_scores, k, out, n_flagged, flagged, gate, gate_max, slot_query, slot_active, slot_min, slot_max);
+}
+}  // namespace
+
 hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
-                          int stride, const int* cand_cnt, const int* incomplete, const float* delta, float min_score, int nq, int k,
+                          int stride, const int* cand_cnt, const int* incomplete, const float* delta, const float* min_scores, int nq, int k,
                           unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream, const int* gate, int gate_max) {
-  if (stride < 1 || stride > kBandMax || k < 1 || k > 64 || (cand_cnt != nullptr && incomplete == nullptr)) return hipErrorInvalidValue;
+  if (stride < 1 || stride > kBandMax || k < 1 || k > TAVB_MAX_FUSED_K || (cand_cnt != nullptr && incomplete == nullptr) || !min_scores) return hipErrorInvalidValue;
+  if (cand_cnt == nullptr && k > 64) return hipErrorInvalidValue;  // cut mode hands over 64 candidates
   hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, stream, n_flagged);
   if (f32_rows)
-    hipLaunchKernelGGL(rescore_kernel<float>, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const float*>(corpus), dim, index_base, queries, approx,
-                       stride, cand_cnt, incomplete, delta, min_score, k, out, n_flagged, flagged, gate, gate_max);
+    launch_rescore_t<float>(corpus, dim, index_base, queries, approx, stride, cand_cnt, incomplete, delta, min_scores, nq, k, out, n_flagged, flagged, stream,
+                            gate, gate_max, nullptr, nullptr, 0, 0);
   else
-    hipLaunchKernelGGL(rescore_kernel<_Float16>, dim3(nq), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(corpus), dim, index_base, queries,
-                       approx, stride, cand_cnt, incomplete, delta, min_score, k, out, n_flagged, flagged, gate, gate_max);
+    launch_rescore_t<_Float16>(corpus, dim, index_base, queries, approx, stride, cand_cnt, incomplete, delta, min_scores, nq, k, out, n_flagged, flagged,
+                               stream, gate, gate_max, nullptr, nullptr, 0, 0);
   return hipGetLastError();
 }
 
-hipError_t launch_gather_flagged_f32(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, float* out,
+hipError_t launch_rescore_slots(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* cand,
+                                int stride, const int* cand_cnt, const float* min_scores, int n_slots, int k, unsigned long long* out,
+                                const int* slot_query, const int* slot_active, int slot_min, int slot_max, hipStream_t stream) {
+  if (stride < 1 || stride > kBandMax || k < 1 || k > TAVB_MAX_FUSED_K || n_slots < 1 || !slot_query || !slot_active || !min_scores) return hipErrorInvalidValue;
+  if (f32_rows)
+    launch_rescore_t<float>(corpus, dim, index_base, queries, cand, stride, cand_cnt, nullptr, nullptr, min_scores, n_slots, k, out, nullptr, nullptr, stream,
+                            nullptr, 0, slot_query, slot_active, slot_min, slot_max);
+  else
+    launch_rescore_t<_Float16>(corpus, dim, index_base, queries, cand, stride, cand_cnt, nullptr, nullptr, min_scores, n_slots, k, out, nullptr, nullptr, stream,
+                               nullptr, 0, slot_query, slot_active, slot_min, slot_max);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_flagged_f32(const float* queries, int dim, const float* min_scores, const int* n_flagged, const int* flagged, int cap, float* out,
                                      float* thr, hipStream_t stream) {
-  hipLaunchKernelGGL(gather_flagged_f32_kernel, dim3(cap), dim3(256), 0, stream, queries, dim, min_score, n_flagged, flagged, cap, out, thr);
+  hipLaunchKernelGGL(gather_flagged_f32_kernel, dim3(cap), dim3(256), 0, stream, queries, dim, min_scores, n_flagged, flagged, cap, out, thr);
   return hipGetLastError();
 }
 
-hipError_t launch_gather_flagged(const float* queries, int dim, float min_score, const int* n_flagged, const int* flagged, int cap, void* hi, void* lo,
+hipError_t launch_gather_flagged(const float* queries, int dim, const float* min_scores, const int* n_flagged, const int* flagged, int cap, void* hi, void* lo,
                                  float* thr, hipStream_t stream) {
-  hipLaunchKernelGGL(gather_flagged_kernel, dim3(cap), dim3(256), 0, stream, queries, dim, min_score, n_flagged, flagged, cap,
+  hipLaunchKernelGGL(gather_flagged_kernel, dim3(cap), dim3(256), 0, stream, queries, dim, min_scores, n_flagged, flagged, cap,
                      reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo), thr);
   return hipGetLastError();
 }

@@ -58,6 +58,33 @@ class ShardBackend(Protocol):
     def empty_gather(self, world: int, nq: int, k: int):  # tensor int64 [world, nq, k] on the backend's device
         ...
 
+    # the forms beside the plain lookup (ShardedVectorBase: subset, predicate) -------------------------------------------------------
+    def local_search_subset(self, query: np.ndarray, local_rows: np.ndarray, positions: np.ndarray, k: int, thr: float):  # -> tensor int64 [1, k], keys carrying `positions`
+        ...
+
+    def local_survivors(self, query: np.ndarray, thr: float):  # -> (global ordinals int64, scores float32) of every row of the shard with score >= thr
+        ...
+
+    def keys_to_device(self, keys: np.ndarray):  # uint64 / int64 [nq, k] host keys -> tensor on the backend's device
+        ...
+
+    # storage (ShardedVectorBase.add_embedding(s) / serialize / deserialize / clear) --------------------------------------------------
+    def set_rows(self, rows: np.ndarray, row_offset: int, dtype: str = "fp32") -> None:  # replace this rank's shard (float32 [n, dim]; no rows: drop it)
+        ...
+
+    def append_rows(self, rows: np.ndarray) -> None:  # append float32 [n, dim] to this rank's shard
+        ...
+
+    def rows_to_host(self) -> np.ndarray:  # this rank's rows as float32 [n, dim]
+        ...
+
+
+PEER_FAILED_KEY = -1  # TAVB_KEY_PEER_FAILED (all bits set) seen as int64: what a rank whose local search failed contributes to the exchange
+
+
+class PeerFailedError(RuntimeError):
+    """Another rank's local search failed during a collective lookup: the merged lists would be missing its shard."""
+
 
 class DeviceShardBackend:
     """HIP kernels on this rank's GPU, launched on a dedicated torch stream so that
@@ -219,20 +246,36 @@ class ShardedSearcher:
         if not (1 <= k <= _native.MAX_FUSED_K):
             raise ValueError(f"k must be in 1..{_native.MAX_FUSED_K}")
         thr = float(_native.f32_threshold(min_score))
-        local = self.backend.local_search(queries, k, thr)
-        if self.world == 1 and not (self.always_collective and self.dist.is_initialized()):
+        collective = not (self.world == 1 and not (self.always_collective and self.dist.is_initialized()))
+        failure = None
+        try:
+            local = self.backend.local_search(queries, k, thr)
+        except Exception as exc:  # noqa: BLE001 -- whatever the backend raised: the peers must not be left waiting in the all-gather
+            if not collective:
+                raise
+            # the protocol of tavb_search_allgather (include/tavb.h): this rank joins the exchange with TAVB_KEY_PEER_FAILED in every slot -- it
+            # sorts above every real key, so it leads every merged list on every rank -- and raises its own error afterwards
+            failure = exc
+            nq = int(queries.shape[0])
+            local = self.backend.empty_gather(1, nq, k)[0]
+            local.fill_(PEER_FAILED_KEY)
+        if not collective:
             return local
         nq = local.shape[0]
         if self.gather_fn is not None:
-            return self.backend.merge(self.gather_fn(local))
-        gathered = self.backend.empty_gather(self.world, nq, k)
-        stream = getattr(self.backend, "stream", None)
-        if stream is not None:
-            with self.backend.torch.cuda.stream(stream):
-                self.dist.all_gather_into_tensor(gathered.view(-1), local.view(-1), group=self.group)
+            merged = self.backend.merge(self.gather_fn(local))
         else:
-            self.dist.all_gather_into_tensor(gathered.view(-1), local.view(-1), group=self.group)
-        return self.backend.merge(gathered)
+            gathered = self.backend.empty_gather(self.world, nq, k)
+            stream = getattr(self.backend, "stream", None)
+            if stream is not None:
+                with self.backend.torch.cuda.stream(stream):
+                    self.dist.all_gather_into_tensor(gathered.view(-1), local.contiguous().view(-1), group=self.group)
+            else:
+                self.dist.all_gather_into_tensor(gathered.view(-1), local.contiguous().view(-1), group=self.group)
+            merged = self.backend.merge(gathered)
+        if failure is not None:
+            raise failure
+        return merged
 
     def exchange(self, local_keys):
         """this rank's sorted lists [nq, k] (global ordinals / positions) -> the lists merged over all ranks, on every rank."""
@@ -255,6 +298,8 @@ class ShardedSearcher:
             keys = self.backend.search_allgather(queries, k, float(_native.f32_threshold(min_score)))
         else:
             keys = self.backend.to_host(self.search_keys(queries, k, min_score))
+        if keys.size and (np.asarray(keys).reshape(keys.shape[0], -1)[:, 0].view(np.int64) == PEER_FAILED_KEY).any():
+            raise PeerFailedError("a rank of the collective lookup failed in its local search: the merged lists are missing its shard")
         ords, scs, cnts = _native.decode_keys(keys)
         return ShardedResult(ords, scs, cnts)
 
@@ -303,6 +348,32 @@ class ShardedVectorBase:
             self.backend.append_rows(rows)
             self.local_rows += len(rows)
         self.total_rows += len(rows)
+        # Appends always land on the last rank: contiguous ranges stay contiguous and nothing already placed moves -- but every collective
+        # lookup waits for the largest shard, so an index GROWN by appends drifts towards single-GPU speed.  `imbalance()` says how far it has
+        # drifted; `rebalance()` re-deals the rows (a collective: every rank hands its rows to `deserialize` of the balanced layout).
+
+    def imbalance(self) -> float:
+        """Collective: largest shard / mean shard (1.0 = balanced)."""
+        if self.total_rows == 0 or self._world == 1:
+            return 1.0
+        counts = [None] * self._world
+        self.searcher.dist.all_gather_object(counts, self.local_rows, group=self.searcher.group)
+        return max(counts) / (self.total_rows / self._world)
+
+    def rebalance(self, dtype: str = "fp32") -> None:
+        """Collective: re-deal the rows into balanced contiguous shards (`shard_range`).  Every rank serialises its rows, the ranks exchange
+        them over torch.distributed (host side, every rank sees the whole matrix for a moment: a maintenance step for corpora that fit host memory,
+        not the lookup path -- bigger ones are re-sharded from their source with `deserialize`) and each keeps its new range."""
+        mine = self.serialize()
+        if self._world == 1:
+            return
+        parts = [None] * self._world
+        self.searcher.dist.all_gather_object(parts, (self.row_offset, mine), group=self.searcher.group)
+        parts = [p for p in parts if p[1].size]
+        dim = parts[0][1].shape[1] if parts else 0
+        whole = np.concatenate([p[1] for p in sorted(parts, key=lambda t: t[0])]) if parts else np.zeros((0, dim), np.float32)
+        lo, hi = shard_range(len(whole), self._world, self._rank)
+        self.deserialize(whole[lo:hi], dtype)
 
     def add_embedding(self, key, embedding) -> None:
         """vectorbase.py:115-128."""

@@ -600,13 +600,24 @@ class VectorBase:
     ):
         """Batch form: equals [fuzzy_lookup_embedding(e, max_hits, min_score) for e in embeddings],
         served by one device submission (the reference loops, storage/memory/reltermsindex.py:320-332).
+        `min_score` may be a sequence with one threshold per query.
         `as_arrays=True` (1 <= max_hits <= 256) returns (ordinals int64 [Q, max_hits], scores float32 [Q, max_hits], counts
         int32 [Q]) instead of Q lists of ScoredInt: building 32k Python objects takes as long as a third of the 1024-query
         lookup over 10M rows itself."""
         queries = np.asarray(embeddings, dtype=np.float32)
         if queries.ndim != 2:
             raise ValueError(f"Expected 2D embeddings array, got {queries.ndim}D")
-        max_hits, thr = self._limits(max_hits, min_score)
+        if min_score is not None and not np.isscalar(min_score) and np.ndim(min_score) == 1:
+            # one threshold per query (Q calls of the reference have Q `min_score` arguments, :163-173): same kernels as a uniform batch
+            if len(min_score) != len(queries):
+                raise ValueError(f"Number of thresholds {len(min_score)} does not match number of embeddings {len(queries)}")
+            per_query = list(min_score)
+            max_hits, _ = self._limits(max_hits, 0.0)
+            thr = np.asarray([_native.f32_threshold(0.0 if m is None else m) for m in per_query], dtype=np.float32)
+            min_score = None
+        else:
+            per_query = None
+            max_hits, thr = self._limits(max_hits, min_score)
         if as_arrays and not (1 <= max_hits <= _PAGE):
             raise ValueError(f"as_arrays needs 1 <= max_hits <= {_PAGE}")
         if self._count == 0 or len(queries) == 0:
@@ -615,7 +626,7 @@ class VectorBase:
                 return np.zeros((nq, max_hits), np.int64), np.zeros((nq, max_hits), np.float32), np.zeros(nq, np.int32)
             return [[] for _ in range(len(queries))]
         if not (1 <= max_hits <= _PAGE):
-            return [self.fuzzy_lookup_embedding(q, max_hits, min_score) for q in queries]
+            return [self.fuzzy_lookup_embedding(q, max_hits, min_score if per_query is None else per_query[i]) for i, q in enumerate(queries)]
         eng = self._sync_device()
         ords, scs, cnts = eng.search_batch(queries, max_hits, thr)
         if as_arrays:
