@@ -309,6 +309,9 @@ def cpu_baseline(host: np.ndarray, queries: np.ndarray, k: int, rows_total: int,
         "sample": f"{len(times)} calls on {host.shape[0]}x{host.shape[1]} fp32 rows of the corpus, median {med * 1e3:.2f} ms"
                   + (f", x{scale:g} to {rows_total} rows" if scale != 1 else ""),
         "p50_ms_per_query_on_sample": med * 1e3,
+        # `value` = the CPU's best: the thread count (`cores`) that won a BLAS thread sweep.  What the reference gets out of the box --
+        # OpenBLAS's default of one thread per host core, SURVEY 8d's stated baseline -- is `default_threads` (oversubscribed on a 256-core host)
+        "value_is": "best thread count of a BLAS thread sweep; default_threads = OpenBLAS default (all host cores)",
         "default_threads": {"value": 1.0 / (med_default * scale), "cores": cores},
     }
     if 1 in sweep:
@@ -340,11 +343,19 @@ class Ctx:
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            if "MASTER_PORT" not in os.environ:
+                # only the launcher-less one-rank dry run gets here (TAVB_BENCH_FORCE_DIST=1): a free port of this host, so that two benches
+                # on one node cannot collide (a launcher -- the driver's torch.distributed.run, or respawn_under_torchrun -- hands the port down)
+                if self.world > 1:
+                    raise SystemExit("bench.py: WORLD_SIZE > 1 without MASTER_PORT (launch through torch.distributed.run, or `python bench.py --gpus N`)")
+                os.environ["MASTER_PORT"] = str(free_port())
             for var, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):  # (TAVB_BENCH_FORCE_DIST=1 without a launcher)
                 os.environ.setdefault(var, val)
             torch.cuda.set_device(self.local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            import datetime
+
+            # (rank 0 checks parity against the CPU oracle over the WHOLE corpus -- 100M rows at N = 8 take minutes -- while the others wait in a barrier)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank), timeout=datetime.timedelta(minutes=45))
             self.dist = dist
             if dist.get_world_size() != args.gpus:
                 raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
@@ -395,7 +406,7 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     args, eng, torch = ctx.args, ctx.eng, ctx.torch
     dim, k, nq = wl["dim"], wl["k"], wl["nq"]
     rows_local, rows_total = int(corpus.shape[0]), wl["rows_total"]
-    min_score = args.min_score
+    min_score = wl.get("min_score", args.min_score)
     thr = float(ctx.native.f32_threshold(min_score))
     # identical on every rank; arbitrary fp32 values (not fp16-representable).  BATCH_ROTATION different batches take turns in the timed region.
     n_rot = BATCH_ROTATION if nq > 1 else 1
@@ -480,6 +491,24 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     elapsed_with_events = ctx.max_over_ranks(time.perf_counter() - e0)
     kt = kernel_times(ctx)
     eng.profile_enable(False)
+    dist_extra = None
+    if ctx.dist is not None:
+        # every rank's own scan time and what it spent in the exchange (ncclAllGather inside tavb_search_allgather, HIP events on the library's
+        # stream: a rank that finishes its scan early waits there for the slowest one, so the MINIMUM over ranks is the cost of the exchange
+        # itself and max - min of the scan times is the skew)
+        scan_ms = sum(kt[p][0] for p in ("scan", "mfma_last_phase", "mfma_earlier_phases", "skinny_last_phase")) / steps
+        mine = torch.tensor([scan_ms, kt["exchange"][0] / steps, kt["merge"][0] / steps, float(rows_local)], dtype=torch.float64, device=torch.device("cuda", ctx.dev))
+        every = [torch.zeros_like(mine) for _ in range(ctx.dist.get_world_size())]
+        ctx.dist.all_gather(every, mine)
+        per = torch.stack(every).cpu().numpy()
+        dist_extra = {
+            "scan_ms_per_rank": [float(x) for x in per[:, 0]],
+            "rank_skew_ms": float(per[:, 0].max() - per[:, 0].min()),
+            "exchange_ms": float(per[:, 1].min()),           # all-gather of the per-shard [nq, k] key lists (256 KiB per rank at 1024 x 32)
+            "exchange_ms_incl_wait": float(per[:, 1].max()), # ... on the rank that waited longest for its peers
+            "merge_ms": float(per[:, 2].max()),
+            "rows_per_rank": [int(x) for x in per[:, 3]],
+        }
     host_form = None
     if searcher is None and nq > 1:  # the same batch handed over as a host buffer (what VectorBase.fuzzy_lookup_embeddings does): PCIe-inclusive
         one_step(0, True)
@@ -592,6 +621,8 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
                              "filter_phases_ms_per_step": kern_ms_per_step})
     if host_form:
         rec["host_buffer_form"] = host_form
+    if dist_extra:
+        rec["exchange"] = dist_extra
     if not args.no_parity:
         rec["parity"] = parity_check(eng, corpus, shard_lo, wl, queries, sample, got, min_score)
     if with_cpu and not args.no_cpu_baseline:
@@ -726,17 +757,20 @@ def headline_line(ctx: Ctx, rec: dict, name: str, wl: dict, scaling: str, sub: d
         out["parity"] = {k: v for k, v in rec["parity"].items() if k not in ("rows", "seconds", "max_inverted_gap_gpu", "max_inverted_gap_ref")}
     if "host_buffer_form" in rec:
         out["host_buffer_form"] = rec["host_buffer_form"]  # PCIe-inclusive rate of the same batch (never `value`)
-    for key in ("query_batches_in_rotation", "flagged_fraction", "class_api"):
+    for key in ("query_batches_in_rotation", "flagged_fraction", "class_api", "exchange"):
         if key in rec:
             out[key] = rec[key]
     if scaling == "weak" and ctx.world >= 1:
         out["row_queries_per_sec"] = rec["queries_per_sec"] * wl["rows_total"]
     if sub:
-        out["sub"] = {k: slim_sub(v) for k, v in sub.items()}
+        # the driver's record keeps the top-level contract fields and the last 2000 characters of the line: the records a reader is most likely
+        # to look for there (this round's: the mid-batch tiles, cfg5's variants) go last
+        last = [k for k in ("cfg5", "cfg2_b32", "cfg3_b32", "cfg3_b128", "cfg4_weak") if k in sub]
+        out["sub"] = {k: slim_sub(sub[k]) for k in [k for k in sub if k not in last] + last}
     return out
 
 
-def run_cfg5(args, wl, emit: bool = True, steps: int | None = None, warmup: int | None = None):
+def run_cfg5(args, wl, emit: bool = True, steps: int | None = None, warmup: int | None = None, variants: bool = False):
     """BASELINE config 5: user queries/s of the fused multi-index submission (typeagent_py_amd/fused.py).  `emit=False`: return the
     record (a sub-record of the north-star suite) instead of printing it."""
     import torch
@@ -768,47 +802,57 @@ def run_cfg5(args, wl, emit: bool = True, steps: int | None = None, warmup: int 
     for u in range(8):
         tq = np.stack([near(terms, int(rng.integers(rows)), 0.3) for _ in range(4)])
         user_queries.append((tq, near(msgs, int(rng.integers(rows)), 0.6), near(threads, int(rng.integers(1000)), 0.6)))
-    subset = np.random.default_rng(99).choice(rows, size=args.cfg5_subset, replace=False).tolist() if args.cfg5_subset else None
+    def make_one(separate: bool, subset):
+        if separate:
+            def one(i):
+                tq, mq, hq = user_queries[i % len(user_queries)]
+                out = [vbs[0].fuzzy_lookup_embedding(q, max_hits=50, min_score=0.85) for q in tq]
+                if subset is None:
+                    out.append(vbs[1].fuzzy_lookup_embedding(mq, max_hits=25, min_score=0.7))
+                else:
+                    out.append(vbs[1].fuzzy_lookup_embedding_in_subset(mq, subset, max_hits=25, min_score=0.7))
+                out.append(vbs[2].fuzzy_lookup_embedding(hq, max_hits=10, min_score=0.7))
+                return out
+        else:
+            def one(i):
+                tq, mq, hq = user_queries[i % len(user_queries)]
+                return fq.run(tq, mq, hq, message_subset=subset)
+        return one
 
-    if args.cfg5_separate:
+    def subset_of(n: int):
+        return np.random.default_rng(99).choice(rows, size=n, replace=False).tolist() if n else None
+
+    vbs = []
+    if args.cfg5_separate or variants:
         class _Null:
             model_name = "bench"
-        vbs = []
         for t in (terms, msgs, threads):
             vb = VectorBase(TextEmbeddingIndexSettings(_Null()), device=0)
             vb.adopt_device_corpus(t)
             vbs.append(vb)
 
-        def one(i):
-            tq, mq, hq = user_queries[i % len(user_queries)]
-            out = [vbs[0].fuzzy_lookup_embedding(q, max_hits=50, min_score=0.85) for q in tq]
-            if subset is None:
-                out.append(vbs[1].fuzzy_lookup_embedding(mq, max_hits=25, min_score=0.7))
-            else:
-                out.append(vbs[1].fuzzy_lookup_embedding_in_subset(mq, subset, max_hits=25, min_score=0.7))
-            out.append(vbs[2].fuzzy_lookup_embedding(hq, max_hits=10, min_score=0.7))
-            return out
-    else:
-        def one(i):
-            tq, mq, hq = user_queries[i % len(user_queries)]
-            return fq.run(tq, mq, hq, message_subset=subset)
-
-    for i in range(warmup):
-        one(i)
-    torch.cuda.synchronize()
     import gc
 
-    gc.collect()
-    gc.disable()  # (as in run_record: no generation-2 collection inside the timed region)
-    lat = []
-    t0 = time.perf_counter()
-    for i in range(steps):  # the timed region: un-instrumented
-        s0 = time.perf_counter_ns()
-        one(warmup + i)
-        lat.append((time.perf_counter_ns() - s0) / 1e3)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+    def time_mode(one, n_steps: int, n_warm: int):
+        for i in range(n_warm):
+            one(i)
+        torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()  # (as in run_record: no generation-2 collection inside the timed region)
+        lat = []
+        t0 = time.perf_counter()
+        for i in range(n_steps):  # the timed region: un-instrumented
+            s0 = time.perf_counter_ns()
+            one(n_warm + i)
+            lat.append((time.perf_counter_ns() - s0) / 1e3)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        gc.enable()
+        return el, lat
+
+    subset = subset_of(args.cfg5_subset)
+    one = make_one(args.cfg5_separate, subset)
+    elapsed, lat = time_mode(one, steps, warmup)
     if not args.cfg5_separate:  # the same steps again with HIP event pairs around the launches (kernel times)
         eng.profile_enable(True)
         eng.profile_reset()
@@ -816,7 +860,11 @@ def run_cfg5(args, wl, emit: bool = True, steps: int | None = None, warmup: int 
             one(warmup + i)
         torch.cuda.synchronize()
     esize = 2 if wl["dtype"] == "fp16" else 4
-    alg = rows * dim * esize + (len(subset) if subset else rows) * dim * esize + 1000 * dim * esize
+
+    def alg_bytes(sub_):
+        return rows * dim * esize + (len(sub_) if sub_ else rows) * dim * esize + 1000 * dim * esize
+
+    alg = alg_bytes(subset)
     out = {
         "metric": "user queries/sec + p50 latency, fused multi-index VectorBase lookups (cfg5)",
         "value": steps / elapsed, "unit": "user-queries/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
@@ -834,6 +882,22 @@ def run_cfg5(args, wl, emit: bool = True, steps: int | None = None, warmup: int 
         out["roofline"]["scan_kernel_ms_per_user_query"] = ms / steps
         out["roofline"]["scan_launches_per_user_query"] = n / steps
         eng.profile_enable(False)
+    if variants:
+        # SURVEY 8d cfg5, the other forms on the same corpora: the memory provider's message re-rank over a subset of 1000 ordinals
+        # (tools/benchmark_vectorbase.py:133-136), and the six lookups as separate synchronous calls through the drop-in class
+        sub1000 = subset_of(1000)
+        one_s = make_one(False, sub1000)
+        el_s, lat_s = time_mode(one_s, steps, warmup)
+        a_s = alg_bytes(sub1000)
+        out["variants"] = {"subset1000": {"value": steps / el_s, "ms_per_step": el_s / steps * 1e3, "hbm_frac": a_s / (el_s / steps) / 1e9 / HBM_PEAK_GBS}}
+        if not args.no_parity:
+            pa = cfg5_parity(eng, one_s, user_queries[:1], {"terms": (terms, 50_043), "messages": (msgs, 50_044), "threads": (threads, 50_045)}, dim, wl["dtype"], sub1000,
+                             only=("messages",))
+            out["variants"]["subset1000"]["parity"] = {k: pa[k] for k in ("ok", "error", "lookups_checked", "hits_returned") if k in pa}
+        one_x = make_one(True, None)
+        el_x, _ = time_mode(one_x, max(5, steps // 2), 2)
+        n_x = max(5, steps // 2)
+        out["variants"]["separate_calls"] = {"value": n_x / el_x, "ms_per_step": el_x / n_x * 1e3, "fused_speedup": (steps / elapsed) / (n_x / el_x)}
     if not args.no_parity:
         out["parity"] = cfg5_parity(eng, one, user_queries[:2], {"terms": (terms, 50_043), "messages": (msgs, 50_044), "threads": (threads, 50_045)},
                                     dim, wl["dtype"], subset)
@@ -848,7 +912,7 @@ def run_cfg5(args, wl, emit: bool = True, steps: int | None = None, warmup: int 
         raise SystemExit(3)
 
 
-def cfg5_parity(eng, one, user_queries, corpora: dict, dim: int, dtype: str, subset) -> dict:
+def cfg5_parity(eng, one, user_queries, corpora: dict, dim: int, dtype: str, subset, only=None) -> dict:
     """Two user queries (12 lookups) of the cfg5 submission against the oracle over the WHOLE corpora (10M-row passes in
     ORACLE_CHUNK-row chunks): term lookups k=50 @0.85, message re-rank k=25 @0.7 (full scan or subset), thread lookup k=10 @0.7."""
     from oracle import vectorbase_oracle as vo
@@ -866,6 +930,8 @@ def cfg5_parity(eng, one, user_queries, corpora: dict, dim: int, dtype: str, sub
                 ("messages", np.stack([u[1] for u in user_queries]), [r[1] for r in results], 25, 0.7),
                 ("threads", np.stack([u[2] for u in user_queries]), [r[2] for r in results], 10, 0.7)]
         for cname, qs, got_lists, k, ms in legs:
+            if only is not None and cname not in only:
+                continue
             tensor, seed = corpora[cname]
             thr = float(_f32_threshold(ms))
             sub = np.asarray(subset, dtype=np.int64) if (cname == "messages" and subset is not None) else None
@@ -916,17 +982,21 @@ def slim_sub(rec: dict) -> dict:
     """A sub-record of the suite without what the headline already says or profiles/README.md explains: the line has to stay under ~6 KB for
     the driver's record to hold every sub-record (round 3's 15 KB line lost `sub.cfg3_q1`)."""
     out = {}
-    for key in ("workload", "queries_per_sec", "value", "unit", "ms_per_step", "p50_latency_us", "flagged_fraction", "vs_gaussian", "class_api"):
+    for key in ("workload", "queries_per_sec", "value", "unit", "ms_per_step", "p50_latency_us", "flagged_fraction", "vs_gaussian", "class_api",
+                "variants", "exchange", "row_queries_per_sec", "scaling"):
         if key in rec:
             out[key] = rec[key]
     if "config" in rec and "workload" not in out:
         out["workload"] = rec["config"]["workload"]
     if "workload" in out:
         out["workload"] = out["workload"].split(": ", 1)[-1].replace(", min_score 0", "")  # (the key already names the workload)
-    if rec.get("query_batches_in_rotation"):
-        out.pop("p50_latency_us", None)  # a batch's latency is its ms_per_step
+    if rec.get("query_batches_in_rotation") or out.get("ms_per_step", 0) > 0.2:
+        out.pop("p50_latency_us", None)  # a batch's latency is its ms_per_step; so is a long single lookup's (kept for the launch-bound cfg1)
     ro = rec.get("roofline") or {}
-    keep = {k: ro[k] for k in ("bound", "achieved", "peak", "frac", "traffic", "kernel", "kernel_ms_per_step", "scan_kernel_ms_per_user_query", "scanned") if k in ro}
+    # (`peak` is the headline's for the same `bound`: 8000 GB/s hbm, 2500 TFLOP/s fp16 mfma)
+    keep = {k: ro[k] for k in ("bound", "achieved", "frac", "traffic", "kernel", "kernel_ms_per_step", "scan_kernel_ms_per_user_query", "scanned") if k in ro}
+    if keep.get("traffic") is None:
+        keep.pop("traffic", None)
     if "exact" not in str(keep.get("kernel", "exact")):
         keep.pop("kernel")  # (named only where it is not the workload's usual kernel)
     if ro.get("other_kernels_ms_per_step"):
@@ -936,6 +1006,9 @@ def slim_sub(rec: dict) -> dict:
     if pa:
         out["parity"] = {k: pa[k] for k in ("ok", "error", "lookups_checked", "positions_exact", "positions_permuted", "max_permuted_gap",
                                             "gpu_inversions_vs_f64", "reference_inversions_vs_f64", "noise_gpu", "noise_ref") if k in pa}
+        if out["parity"].get("positions_permuted") == 0:  # every position exact: nothing permuted, nothing inverted (on either side)
+            for key in ("max_permuted_gap", "gpu_inversions_vs_f64", "reference_inversions_vs_f64"):
+                out["parity"].pop(key, None)
     cb = rec.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "cores", "kind", "p50_ms_per_query_on_sample") if k in cb}
@@ -962,12 +1035,17 @@ def emit_result(line: dict) -> None:
         os.write(_RESULT_FD, data)
 
 
-def respawn_under_torchrun(args) -> int:
-    """`python bench.py --gpus N` with N > 1 and no rank environment: become the launcher (one rank per GPU)."""
+def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def respawn_under_torchrun(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no rank environment: become the launcher (one rank per GPU)."""
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -1076,11 +1154,16 @@ def main() -> None:
             rec["class_api"] = class_api_rates(ctx, wl, corpus, args.min_score, 5 if wl["nq"] > 1 else 50)
 
     sub = None
-    if suite and ctx.world == 1 and not args.no_sub:
+    if suite and not ctx.distributed and not args.no_sub:
         sub = {}
         # the single-query target on the same 10M-row corpus
         w2 = dict(WORKLOADS["cfg3_q1"], rows_total=wl["rows_total"], rows=wl["rows"])
         sub["cfg3_q1"] = run_record(ctx, "cfg3_q1", w2, corpus, 0, 40, 5, with_cpu=False)
+        # middle batch sizes on the same corpus (what a batched `lookup_terms` lands on: storage/sqlite/reltermsindex.py:259-271): one HBM pass
+        # serves the whole batch -- 32 queries on the 32/64-query tile, 128 on the 128-query tile
+        for mid in ("cfg3_b32", "cfg3_b128"):
+            wm = dict(WORKLOADS[mid], rows_total=wl["rows_total"], rows=wl["rows"])
+            sub[mid] = run_record(ctx, mid, wm, corpus, 0, 20, 3, with_cpu=False)
         del corpus
         torch.cuda.empty_cache()
         # (the two small corpora next: measured right after big ones have come and gone, cfg2 reads 6 % slower -- where its 6 GB land in HBM)
@@ -1088,6 +1171,11 @@ def main() -> None:
         w3["rows_total"] = w3["rows"]
         c2 = gen_rows(ctx.eng, 0, w3["rows"], w3["dim"], w3["seed"], w3["dtype"])
         sub["cfg2"] = run_record(ctx, "cfg2", w3, c2, 0, 100, 10, with_cpu=True)
+        # the same lookup at the reference's related-terms threshold (min_score 0.85, knowpro/convsettings.py:61-63): nothing of a gaussian
+        # corpus survives it -- the scan without any selection work
+        sub["cfg2_ms085"] = run_record(ctx, "cfg2", dict(w3, min_score=0.85), c2, 0, 100, 10, with_cpu=False)
+        wb = dict(WORKLOADS["cfg2_b32"], rows_total=w3["rows"])
+        sub["cfg2_b32"] = run_record(ctx, "cfg2_b32", wb, c2, 0, 40, 5, with_cpu=False)
         del c2
         # BASELINE config 1: the reference's own scale (10k x 1536 fp32, one query, top-10) -- launch-bound; with the class-level rate
         w1 = dict(WORKLOADS["cfg1"])
@@ -1126,7 +1214,27 @@ def main() -> None:
         del c4
         torch.cuda.empty_cache()
         # cfg5: the fused multi-index user query (4 term lookups k=50@0.85 + message re-rank k=25@0.7 + thread lookup k=10@0.7; convsettings.py:61-67)
-        sub["cfg5"] = run_cfg5(args, dict(WORKLOADS["cfg5"]), emit=False, steps=20, warmup=3)
+        # + the memory provider's 1000-ordinal message subset and the six lookups as separate synchronous calls, on the same corpora
+        sub["cfg5"] = run_cfg5(args, dict(WORKLOADS["cfg5"]), emit=False, steps=20, warmup=3, variants=True)
+    elif suite and ctx.distributed and not args.no_sub:  # (also the one-rank dry run of this code, TAVB_BENCH_FORCE_DIST=1)
+        # N > 1: beside the strong-scaling headline, BASELINE configs[3] as the north star words it -- 12.5M rows PER GPU (100M rows at N = 8),
+        # the same 1024-query batches; `row_queries_per_sec` is the weak-scaling figure (rows x queries per second over all ranks)
+        del corpus
+        torch.cuda.empty_cache()
+        w4 = dict(WORKLOADS["cfg4"])
+        if args.rows:
+            w4["rows"] = args.rows
+        w4["rows_total"] = w4["rows"] * ctx.world
+        lo4 = ctx.rank * w4["rows"]
+        with stream_ctx:
+            c4 = gen_rows(ctx.eng, lo4, lo4 + w4["rows"], w4["dim"], w4["seed"], w4["dtype"], "gaussian", w4["rows_total"])
+        r4 = run_record(ctx, "cfg4", w4, c4, lo4, 10, 2, with_cpu=False)
+        if ctx.rank == 0:
+            r4["row_queries_per_sec"] = r4["queries_per_sec"] * w4["rows_total"]
+            r4["scaling"] = "weak"
+            sub = {"cfg4_weak": r4}
+        del c4
+        torch.cuda.empty_cache()
     ok = True
     if ctx.rank == 0:
         line = headline_line(ctx, rec, name, wl, scaling, sub)

@@ -1,0 +1,93 @@
+#!/bin/bash
+# The one GPU-box script (run through gpurun).  Usage:  bash tools/gpu.sh LABEL STEP [STEP ...]
+# Output -> gpurun_out/LABEL/.  Steps:
+#   suite            the whole `-m gpu` test suite (-x)                          -> gpu_suite.log
+#   tests:EXPR       pytest -m gpu -k EXPR                                       -> gpu_tests.log
+#   smoke            __graft_entry__.smoke()
+#   bench            the driver's command (bench.py --gpus 1 --steps 20 --warmup 5) + a digest of the line  -> bench_default.json
+#   dist1            the N > 1 code path on a one-rank communicator (TAVB_BENCH_FORCE_DIST=1)               -> bench_dist1.json
+#   variants:FILE    bench.py variants listed one per line ("name: args") in FILE, one child process each   -> bench_<name>.json, variants.txt
+#   ab:ARGS          interleaved A/B on this box: A = cfg3 as shipped, B = the same + ARGS (3 rounds)
+#   pmc              FETCH_SIZE passes for every workload of profiles/pmc_traffic.json + the MFMA counters of cfg3 -> pmc_*.md, pmc_traffic.json
+#   pmcw             WRITE_SIZE pass of cfg3
+#   trace            rocprofv3 --kernel-trace --stats of the driver's command (fewer steps) and of the headline alone -> trace_*.md
+#   power            rocm-smi power / sclk samples under a 400-step cfg3 loop    -> smi.txt
+set -u
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd "$R"
+LABEL=$1; shift
+O=$R/gpurun_out/$LABEL; mkdir -p "$O"
+Q="--no-cpu-baseline --no-parity --no-sub --no-calibration"
+
+digest() { # file
+python - "$1" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+def show(n, r):
+    ro = r.get("roofline", {}); pa = r.get("parity") or {}
+    print(f"{n:16s} value {r.get('value', r.get('queries_per_sec', 0)):10.1f} ms/step {r.get('ms_per_step', 0):8.4f} frac {ro.get('frac', 0):.4f} {ro.get('bound')} "
+          f"kern {ro.get('kernel_ms_per_step', 0) or 0:.3f} parity {pa.get('ok')} {pa.get('positions_exact')}/{pa.get('positions_permuted')} inv {pa.get('gpu_inversions_vs_f64')}/{pa.get('reference_inversions_vs_f64')} "
+          f"noise {pa.get('noise_gpu')}/{pa.get('noise_ref')} {pa.get('error') or ''} flagged {r.get('flagged_fraction')} {r.get('class_api') or ''} {r.get('variants') or ''}")
+show("headline", d); print("sustained", d["roofline"].get("sustained")); print("cpu", d.get("cpu_baseline"))
+for n, r in (d.get("sub") or {}).items(): show(n, r)
+PY
+}
+
+pmc() { # name pmc_traffic-key|"" workload-args counters...
+  local name=$1 key=$2 wl="$3"; shift 3
+  ( cd /tmp && timeout -k 5 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/raw_$name -- python $R/bench.py $Q $wl > $O/pmc_$name.log 2>&1 )
+  echo "pmc $name rc=$? $(date -u +%T)"
+  local total=$(grep -o "[0-9]* lookups in this process" $O/pmc_$name.log | head -1 | cut -d" " -f1)
+  python tools/pmc_summary.py $O/raw_$name/*/*_counter_collection.csv --steps ${total:-1} --cmd "bench.py $Q $wl" ${key:+--json $O/pmc_traffic.json --name $key} > $O/pmc_$name.md 2>> $O/pmc_err.log
+  rm -rf $O/raw_$name
+}
+
+for step in "$@"; do
+  arg=${step#*:}; S=$(date +%s)
+  case ${step%%:*} in
+    suite) timeout 1700 python -m pytest tests -q -m gpu -x > $O/gpu_suite.log 2>&1; echo "suite rc=$?"; tail -4 $O/gpu_suite.log ;;
+    tests) timeout 1200 python -m pytest tests -q -m gpu -x -k "$arg" > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -15 $O/gpu_tests.log ;;
+    smoke) timeout 180 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+    bench)
+      timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+      echo "bench rc=$? in $(( $(date +%s) - S )) s, line bytes: $(wc -c < $O/bench_default.json)"; tail -3 $O/bench_default.err; digest $O/bench_default.json ;;
+    dist1)
+      TAVB_BENCH_FORCE_DIST=1 timeout 900 python bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_dist1.json 2> $O/bench_dist1.err
+      echo "dist1 rc=$? line bytes: $(wc -c < $O/bench_dist1.json)"; tail -3 $O/bench_dist1.err; digest $O/bench_dist1.json ;;
+    variants) mapfile -t specs < <(grep -v '^#' "$arg" | grep .); timeout 1700 python tools/bench_variants.py $O "${specs[@]}" 2>&1 | tee -a $O/variants.txt ;;
+    ab)
+      specs=(); for i in 1 2 3; do specs+=("A$i: $Q --workload cfg3 --steps 20 --warmup 5" "B$i: $Q --workload cfg3 --steps 20 --warmup 5 $arg"); done
+      timeout 1700 python tools/bench_variants.py $O "${specs[@]}" 2>&1 | tee -a $O/variants.txt ;;
+    pmc)
+      rm -f $O/pmc_traffic.json
+      pmc cfg3_fetch cfg3 "--workload cfg3 --steps 2 --warmup 1" FETCH_SIZE
+      pmc cfg3_mfma "" "--workload cfg3 --steps 2 --warmup 1" GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU
+      pmc cfg3_clustered_fetch cfg3_clustered "--workload cfg3_clustered --steps 2 --warmup 1" FETCH_SIZE
+      pmc cfg3_q1_fetch cfg3_q1 "--workload cfg3_q1 --steps 5 --warmup 1" FETCH_SIZE
+      pmc cfg2_fetch cfg2 "--workload cfg2 --steps 10 --warmup 2" FETCH_SIZE
+      pmc cfg4_fetch cfg4 "--workload cfg4 --steps 2 --warmup 1" FETCH_SIZE
+      pmc cfg3_b128_fetch cfg3_b128 "--workload cfg3_b128 --steps 2 --warmup 1" FETCH_SIZE
+      pmc cfg2_b32_fetch cfg2_b32 "--workload cfg2_b32 --steps 5 --warmup 1" FETCH_SIZE
+      pmc cfg3_b32_fetch cfg3_b32 "--workload cfg3_b32 --steps 2 --warmup 1" FETCH_SIZE
+      python -c "import json; d=json.load(open('$O/pmc_traffic.json')); print({k:(round(v['traffic_bytes_per_step']/1e9,3), v['launches_per_step']) for k,v in d.items()})" ;;
+    pmcw) pmc cfg3_write "" "--workload cfg3 --steps 2 --warmup 1" WRITE_SIZE; tail -12 $O/pmc_cfg3_write.md ;;
+    trace)
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_default -o x -- python $R/bench.py --no-cpu-baseline --no-parity --steps 4 --warmup 1 > $O/trace_default.log 2>&1; echo "trace default rc=$?"
+        timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_headline -o x -- python $R/bench.py $Q --steps 20 --warmup 5 > $O/trace_headline.log 2>&1; echo "trace headline rc=$?" )
+      for t in default headline; do
+        db=$(find $O/trace_$t -name "*results.db" 2>/dev/null | head -1); [ -n "$db" ] && python tools/rocpd_summary.py $db > $O/trace_$t.md 2>> $O/trace_err.log
+      done
+      rm -rf $O/trace_default/ $O/trace_headline/
+      grep -o '"kernel_ms_per_step":[0-9.]*' $O/trace_headline.log | head -2; head -12 $O/trace_headline.md ;;
+    power)
+      python bench.py --workload cfg3 $Q --steps 400 --warmup 2 > $O/power_bench.json 2> $O/power_bench.err &
+      BP=$!
+      while kill -0 $BP 2>/dev/null; do
+        rocm-smi --showpower --showclocks 2>/dev/null | grep -E "GPU\[0\].*(Power|sclk)" | tr '\n' ' ' >> $O/smi.txt; echo >> $O/smi.txt; sleep 0.4
+      done
+      rocm-smi --showmaxpower 2>/dev/null | grep -E "GPU\[0\]" >> $O/smi.txt; tail -3 $O/smi.txt ;;
+    *) echo "unknown step $step" ;;
+  esac
+  echo "[$step: $(( $(date +%s) - S )) s]"
+done
