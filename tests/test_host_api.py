@@ -307,3 +307,41 @@ def test_batch_lookup_as_arrays_and_shadow_env_knob_on_a_fake_engine(monkeypatch
     vb0.add_embeddings(None, v)
     vb0.fuzzy_lookup_embedding(qs[0])
     assert FakeEngine.instances[-1].options.get("f32_shadow") == 0
+
+
+def test_hit_lists_built_in_c_equal_the_python_loop(monkeypatch):
+    """`_tavb_pyhits.build` (csrc/tavb_pyhits.c) against the interpreter's loop: same classes, values, list shapes; bad shapes and
+    classes without the two slots are refused."""
+    import typeagent_py_amd.vectorbase as mod
+
+    assert mod._tavb_pyhits is not None, "typeagent_py_amd/_tavb_pyhits.so is not built (make -C typeagent_py_amd/csrc)"
+    rng = np.random.default_rng(3)
+    o = rng.integers(0, 2**40, (37, 9)).astype(np.int64)
+    s = rng.random((37, 9)).astype(np.float32)
+    c = rng.integers(0, 10, 37).astype(np.int32)
+    c[0], c[1] = 0, 9
+    fast = mod._scored_lists(o, s, c, 9)
+    monkeypatch.setattr(mod, "_tavb_pyhits", None)
+    slow = mod._scored_lists(o, s, c, 9)
+    assert fast == slow and [len(x) for x in fast] == c.tolist()
+    assert all(type(h) is mod.ScoredInt and type(h.item) is int and type(h.score) is float for row in fast for h in row)
+    assert fast[1][0].score == float(s[1, 0]) and fast[1][8].item == int(o[1, 8])
+    h = fast[1][0]
+    h.item = 5  # ordinary instances: writable, comparable, printable
+    assert h == mod.ScoredInt(5, float(s[1, 0])) and repr(h).startswith("ScoredInt(item=5, score=")
+    from typeagent_py_amd import _tavb_pyhits as ph
+
+    with pytest.raises(ValueError):
+        ph.build(mod.ScoredInt, o, s, c[:5], 9)
+    with pytest.raises((TypeError, AttributeError)):
+        ph.build(dict, o, s, c, 9)
+
+    class Plain:  # no slots: refused, not corrupted
+        item = 0
+        score = 0.0
+
+    with pytest.raises(TypeError):
+        ph.build(Plain, o, s, c, 9)
+    # strided / wrongly typed arrays take the Python loop
+    monkeypatch.undo()
+    assert mod._scored_lists(o[:, ::1], s, c.astype(np.int64).astype(np.int32), 9) == slow
