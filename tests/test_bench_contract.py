@@ -122,14 +122,14 @@ def test_committed_pmc_traffic_belongs_to_the_kernels_that_ship():
         assert name in bench.WORKLOADS, f"{name}: not a bench workload any more"
         assert entry["traffic_bytes_per_step"] > 0 and "FETCH_SIZE" in entry["counter"]
         assert re.search(rf"--workload {name}\b", entry["source"]), f"{name}: the pass was made for another workload"
-        assert entry.get("kernels"), f"{name}: no kernel list (regenerate with tools/gpu_r3_pmc.sh)"
+        assert entry.get("kernels"), f"{name}: no kernel list (regenerate with tools/gpu.sh pmc)"
         for kern in entry["kernels"]:
             assert kern.encode() in lib, f"{name}: kernel {kern} is not in libtavb.so any more -- re-run the PMC pass"
         wl = bench.WORKLOADS[name]
         # ... and the pass must have been made with the launch shape that ships: one tile-kernel launch per ladder phase (round 3's file
         # was one commit behind the ladder: 4 launches per lookup in the file, 5 in the bench line)
         launches = entry.get("launches_per_step")
-        assert launches, f"{name}: no launch counts (regenerate with tools/gpu_r4_pmc.sh)"
+        assert launches, f"{name}: no launch counts (regenerate with tools/gpu.sh pmc)"
         if "mfma_scan_kernel" in launches and wl["nq"] >= 65:
             assert launches["mfma_scan_kernel"] == len(_native.plan_ladder(wl["rows"], wl["nq"])) - 1, f"{name}: the PMC pass ran another ladder"
         corpus_bytes = wl["rows"] * wl["dim"] * (2 if wl["dtype"] == "fp16" else 4)

@@ -1157,9 +1157,10 @@ def _plant_clusters(v, qs, query_ids, rows_per_query, rng, eps=2e-4):
 def test_unused_slots_of_the_wide_fallback_admit_nothing():
     """The wide split-plane fallback runs over a work list padded to whole 256-query tiles.  The unused slots of the last live tile hold zero
     queries (every row scores 0.5): with `min_score` below that they used to admit every row of the big ladder phases from the second phase on
-    (their per-phase threshold is NaN: the select kernel skips them) -- correct answers, several times the time.  300 flagged queries (one full
-    tile + 44 slots of the next) must cost about what 480 (two nearly full tiles) cost, and the answers are the oracle's.  (A few un-planted
-    queries are flagged too: a planted cluster that happens to score in their top k is 1100 rows inside their band.)"""
+    (their per-phase threshold is NaN: the select kernel skips them) -- correct answers, several times the time.  Two batches whose work lists
+    need the SAME number of tiles, one leaving most of its last tile unused, one filling it, must cost about the same, and the answers are
+    the oracle's.  (The planted clusters are most of this corpus, so about a third of the un-planted queries are flagged too: a cluster that
+    scores inside their top k is 1100 rows inside their band.)"""
     import time
 
     n, d, nq, k = 560_000, 512, 1024, 32
@@ -1172,16 +1173,17 @@ def test_unused_slots_of_the_wide_fallback_admit_nothing():
     eng.set_option("early_exact", 0)  # (the filter runs to its end in both batches: the fallback's cost is what is compared)
     plain = make_queries(nq, d, 8703)
     batches = {}
-    for flagged_queries in (300, 480):
+    for planted in (230, 480):
         b = plain.copy()
-        b[:flagged_queries] = qs[:flagged_queries]
-        batches[flagged_queries] = b
-    times = {}
+        b[:planted] = qs[:planted]
+        batches[planted] = b
+    times, flagged = {}, {}
     v16 = _f16(v)
     for m, b in batches.items():
         out = vb.fuzzy_lookup_embeddings(b, max_hits=k, min_score=0.0, as_arrays=True)
         assert eng.get_option("last_tier") == 4
-        assert m <= eng.get_option("last_flagged") <= min(m + 120, 512), eng.get_option("last_flagged")  # both batches: two tiles of the work list
+        flagged[m] = int(eng.get_option("last_flagged"))
+        assert m <= flagged[m] <= m + (nq - m) * 6 // 10, flagged  # the planted queries + up to ~half of the others
         best = 1e9
         for _ in range(3):
             t0 = time.perf_counter()
@@ -1189,11 +1191,18 @@ def test_unused_slots_of_the_wide_fallback_admit_nothing():
             best = min(best, time.perf_counter() - t0)
         times[m] = best
         o, s_, c_ = out
-        for qi in (0, 255, 256, m - 1, m, 1023):
+        for qi in (0, 229, 230, m - 1, m, 1023):
             vo.check_topk_parity(vo.scores_full(v16, b[qi]), o[qi, : c_[qi]].tolist(), s_[qi, : c_[qi]].tolist(), k, 0.0, referee=vo.f64_referee(v16, b[qi]))
             if qi < m:
                 assert set(o[qi, : c_[qi]].tolist()) <= set(rows[qi].tolist())
-    assert times[300] < 1.3 * times[480], times
+    tiles = {m: (f + 255) // 256 for m, f in flagged.items()}
+    unused = {m: tiles[m] * 256 - f for m, f in flagged.items()}
+    assert min(flagged.values()) > 64, flagged  # both batches are served by the wide form
+    if tiles[230] == tiles[480]:
+        assert unused[230] > unused[480] + 64, (flagged, "the batches were meant to differ in unused slots")
+        assert times[230] < 1.3 * times[480], (times, flagged)
+    else:  # (another tile count: the emptier work list must at least not cost more per tile)
+        assert times[230] / tiles[230] < 1.3 * times[480] / tiles[480], (times, flagged)
 
 
 @pytest.mark.parametrize("nq", [40, 130, 1024])
@@ -1223,11 +1232,17 @@ def test_per_query_thresholds_ride_the_tiles(nq):
         t = thr[qi]
         seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=None if t != t else float(t)) if t == t else []
         assert eng.get_option("last_tier") in (1, 2, 3) or t != t
-        assert [r.item for r in out[qi]] == [r.item for r in seq], qi
-        if nq >= 65:  # rescored with the streaming kernels' arithmetic: the same float32 values (the 32/64-query tile returns its own accumulation order)
+        if nq >= 65:  # rescored with the streaming kernels' arithmetic: the same float32 values, so the same order
+            assert [r.item for r in out[qi]] == [r.item for r in seq], qi
             assert [r.score for r in out[qi]] == [r.score for r in seq], qi
         else:
+            # the 32/64-query tile returns its own accumulation order: scores within float32 summation noise of the streaming kernel's, and two
+            # rows closer than that may trade places (query 39 of the 40-query case: ranks 15 / 16 are 4.9e-8 apart in float64) -- the
+            # refereed check below decides whether that is all a different order is
+            assert len(out[qi]) == len(seq), qi
             np.testing.assert_allclose([r.score for r in out[qi]], [r.score for r in seq], atol=3e-7, rtol=0)
+            if [r.item for r in out[qi]] != [r.item for r in seq]:
+                assert sorted(r.item for r in out[qi]) == sorted(r.item for r in seq) or len(seq) == k, qi
         if t == t:
             vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, float(np.float32(t)), referee=vo.f64_referee(v16, qs[qi]))
     # the uniform form of the same call still means the same thing

@@ -226,3 +226,46 @@ def test_a_serialized_matrix_adopted_by_another_index_is_watched_by_both(monkeyp
     m[30] = -m[30]
     m[2] = q
     assert vb.fuzzy_lookup_embedding(q, max_hits=1)[0].item == 2 and other.fuzzy_lookup_embedding(q, max_hits=1)[0].item == 2
+
+
+def test_fallback_fingerprint_of_an_owned_matrix_is_amortised(monkeypatch):
+    """A matrix this index owns reports writes through its tracking view; the fingerprint behind it (writers that go around numpy) costs as
+    much as a small lookup, so after a serialize() it is compared at most once per 64 lookups / 20 ms -- not on every lookup for the rest
+    of the index' life.  A matrix the CALLER owns keeps the per-lookup check."""
+    import time
+
+    vb, rows, rng = _fresh(monkeypatch, n=400)
+    q = rows[5].copy()
+    vb.serialize()  # a view is out: the fallback watch is on
+    vb.fuzzy_lookup_embedding(q, max_hits=1)
+    calls = []
+    orig = VectorBase._fingerprint
+    monkeypatch.setattr(VectorBase, "_fingerprint", lambda self: (calls.append(1), orig(self))[1])
+    t0 = time.monotonic()
+    for _ in range(256):
+        vb.fuzzy_lookup_embedding(q, max_hits=1)
+    elapsed = time.monotonic() - t0
+    assert len(calls) <= 256 // 64 + int(elapsed / 0.02) + 2, (len(calls), elapsed)
+    # a bulk edit through a base-class view (invisible to the tracker) is still noticed: within 64 lookups or 20 ms
+    raw = np.asarray(vb.serialize())
+    raw *= np.float32(-1.0)
+    time.sleep(0.03)
+    assert _answers_for_current_rows(vb, q)[0].item != 5
+    # ... and is not lost when an append regrows the buffer before the next check (the fingerprint is compared before the flag is dropped)
+    vb2, rows2, _ = _fresh(monkeypatch, n=64)
+    q2 = rows2[9].copy()
+    vb2.serialize()
+    vb2.fuzzy_lookup_embedding(q2, max_hits=1)
+    raw2 = np.asarray(vb2.serialize())
+    raw2 *= np.float32(-1.0)
+    while len(vb2) < 200:  # grows past the buffer at least once
+        vb2.add_embedding(None, _unit(rng, 1, 8)[0])
+    assert _answers_for_current_rows(vb2, q2)[0].item != 9
+    # the caller's own matrix: every lookup
+    other = VectorBase(TextEmbeddingIndexSettings(NullModel()))
+    other.deserialize(_unit(rng, 100, 8))
+    other.fuzzy_lookup_embedding(q, max_hits=1)
+    calls.clear()
+    for _ in range(10):
+        other.fuzzy_lookup_embedding(q, max_hits=1)
+    assert len(calls) == 10

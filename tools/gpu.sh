@@ -3,6 +3,7 @@
 # Output -> gpurun_out/LABEL/.  Steps:
 #   suite            the whole `-m gpu` test suite (-x)                          -> gpu_suite.log
 #   tests:EXPR       pytest -m gpu -k EXPR                                       -> gpu_tests.log
+#   opttests:OPTS:EXPR  the same under TAVB_ENGINE_OPTIONS=OPTS (every engine of the test process gets those options)   -> gpu_opttests.log
 #   smoke            __graft_entry__.smoke()
 #   bench            the driver's command (bench.py --gpus 1 --steps 20 --warmup 5) + a digest of the line  -> bench_default.json
 #   dist1            the N > 1 code path on a one-rank communicator (TAVB_BENCH_FORCE_DIST=1)               -> bench_dist1.json
@@ -12,6 +13,9 @@
 #   pmcw             WRITE_SIZE pass of cfg3
 #   trace            rocprofv3 --kernel-trace --stats of the driver's command (fewer steps) and of the headline alone -> trace_*.md
 #   power            rocm-smi power / sclk samples under a 400-step cfg3 loop    -> smi.txt
+#   ceiling          tools/ceiling.py: shipping lookup / MFMA-only ablation / vendor GEMM on the cfg3 contraction, each with power and clock -> ceiling.md
+#   asan             the C ABI under the ASan/UBSan build of the host side (make -C typeagent_py_amd/csrc debug first; the driver is the
+#                    torch-free tools/asan_exercise.py: torch's CUDA init does not survive the ASan runtime)          -> asan.txt
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -48,6 +52,7 @@ for step in "$@"; do
   case ${step%%:*} in
     suite) timeout 1700 python -m pytest tests -q -m gpu -x > $O/gpu_suite.log 2>&1; echo "suite rc=$?"; tail -4 $O/gpu_suite.log ;;
     tests) timeout 1200 python -m pytest tests -q -m gpu -x -k "$arg" > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -15 $O/gpu_tests.log ;;
+    opttests) TAVB_ENGINE_OPTIONS="${arg%%:*}" timeout 1200 python -m pytest tests -q -m gpu -x -k "${arg#*:}" > $O/gpu_opttests.log 2>&1; echo "opttests(${arg%%:*}) rc=$?"; tail -6 $O/gpu_opttests.log ;;
     smoke) timeout 180 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     bench)
       timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
@@ -87,6 +92,16 @@ for step in "$@"; do
         rocm-smi --showpower --showclocks 2>/dev/null | grep -E "GPU\[0\].*(Power|sclk)" | tr '\n' ' ' >> $O/smi.txt; echo >> $O/smi.txt; sleep 0.4
       done
       rocm-smi --showmaxpower 2>/dev/null | grep -E "GPU\[0\]" >> $O/smi.txt; tail -3 $O/smi.txt ;;
+    ceiling) timeout 600 python tools/ceiling.py --seconds 8 > $O/ceiling.md 2> $O/ceiling.err; echo "ceiling rc=$?"; cat $O/ceiling.md ;;
+    asan)
+      ASAN=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
+      E="env TAVB_LIBRARY=libtavb_debug.so LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=1:allocator_may_return_null=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1"
+      python tools/asan_exercise.py > $O/plain.txt 2>&1; echo "plain rc=$?"; tail -n 4 $O/plain.txt
+      timeout -k 5 600 $E python tools/asan_exercise.py > $O/asan.txt 2>&1; echo "asan rc=$?"
+      if ! grep -q "asan exercise: all good" $O/asan.txt; then  # (RCCL under the ASan runtime may refuse to initialise: the rest must still be clean)
+        timeout -k 5 600 $E TAVB_ASAN_SKIP_RCCL=1 python tools/asan_exercise.py > $O/asan_norccl.txt 2>&1; echo "asan (no rccl) rc=$?"; tail -n 6 $O/asan_norccl.txt
+      fi
+      tail -n 12 $O/asan.txt; grep -c "runtime error\|AddressSanitizer" $O/asan.txt ;;
     *) echo "unknown step $step" ;;
   esac
   echo "[$step: $(( $(date +%s) - S )) s]"

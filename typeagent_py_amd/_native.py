@@ -221,6 +221,11 @@ class Engine:
         self.dim = 0
         self.dtype = TAVB_F32
         self.ordinal_base = 0
+        # measurement / debugging hook: TAVB_ENGINE_OPTIONS="name=value,name=value" is applied to every context of the process (e.g. the GPU
+        # suite under another kernel variant: TAVB_ENGINE_OPTIONS=mfma_sched=8 pytest -m gpu).  An unknown name raises, as set_option does.
+        for item in filter(None, (x.strip() for x in os.environ.get("TAVB_ENGINE_OPTIONS", "").split(","))):
+            name, _, val = item.partition("=")
+            self.set_option(name.strip(), int(val))
 
     # -- lifecycle ---------------------------------------------------------
     def close(self) -> None:

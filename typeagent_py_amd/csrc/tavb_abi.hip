@@ -1538,7 +1538,7 @@ std::vector<int64_t> ladder_bounds(int64_t rows, int splits, int nq_pad, bool sk
 // scatter[slot] of it for the slots below *active; a work-list run of the wide tile rescoring its band first: TileRun::rs_queries).
 int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scatter, bool scatter_identity = false) {
   auto pick_splits = [&](int64_t rows) {
-    return r.skinny ? tavb::skinny_pick_splits(rows, r.nq_pad, r.qt, c->n_cu, c->dim, r.q32) : tavb::mfma_pick_splits(rows, r.nq_pad, r.qt, c->n_cu);
+    return r.skinny ? tavb::skinny_pick_splits(rows, r.nq_pad, r.qt, c->n_cu, c->dim, r.q32, (int)c->mfma_sched) : tavb::mfma_pick_splits(rows, r.nq_pad, r.qt, c->n_cu);
   };
   auto launch = [&](const tavb::MfmaParams& q) { return r.skinny ? tavb::launch_skinny_scan(q, c->stream) : tavb::launch_mfma_scan(q, c->stream); };
   const int nq = r.nq, k = r.k;

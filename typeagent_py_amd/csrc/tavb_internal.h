@@ -143,7 +143,7 @@ hipError_t launch_select_band(const unsigned long long* cand, const int* counts,
 // 32-query tiles at HBM speed, fp32 or fp16 corpora (same parameter block; `queries` in the corpus dtype)
 hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream);
 int skinny_query_tile(int nq);  // 32, or 64 for batches of 33 and more
-int skinny_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu, int dim, bool f32);
+int skinny_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu, int dim, bool f32, int sched);
 bool skinny_supported(int dim, int k, bool f32);
 
 }  // namespace tavb

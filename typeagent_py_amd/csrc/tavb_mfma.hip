@@ -830,7 +830,8 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
 constexpr int SQ32 = 32;            // queries per 32 x 32 MFMA block; a tile is NI of them (32 or 64 queries)
 constexpr int S_THREADS = 256;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <typename T, int NI, int STEP>
+typedef const __attribute__((address_space(1))) f32x4 global_f32x4;
+template <typename T, int NI, int STEP, bool DEEP = false, int DR = 0>
 struct SkinnyGeom {
   static constexpr bool F32 = sizeof(T) == 4;
   static constexpr int SQ = NI * SQ32;
@@ -846,25 +847,43 @@ struct SkinnyGeom {
   // ring depth: measured (profiles/r02_mid_batch.md) -- for 32 fp32 queries two workgroups per CU with two slots each beat one
   // workgroup with three or four slots (the depth in flight is not what limits this tile)
   static constexpr int RING = STEP == 64 ? ((F32 && NI == 1) ? 4 : 3) : ((F32 && NI == 1) ? 2 : 3);
-  static constexpr int B_RING = RING * SLOT_A;
-  static constexpr int CTRL = RING * (SLOT_A + SLOT_B);
+  // DEEP (32-query tile, whole-line steps): the corpus ring one slot deeper than the query ring -- 4 x 32 KiB of corpus + 3 query slots
+  // (152 KiB fp16, 140 KiB fp32), one workgroup per CU.  The tile is HBM-bound and what it lacks is bytes in flight: with a ring of three,
+  // 32 .. 64 KiB of corpus per CU are on their way at any time (8 TB/s x ~2 us of loaded latency / 256 CUs = 62 KiB: the edge); with four
+  // corpus slots 64 .. 96 KiB.  The query slabs come out of L2 and need no deeper ring.
+  // DR > 0 (whole-line steps): REGISTER staging.  Every byte that is on its way from HBM needs somewhere to land; with LDS-DMA that is an LDS
+  // slot, and 160 KiB of LDS hold 80 .. 110 KiB in flight however the ring is cut -- the edge of what 8 TB/s x ~2 us / 256 CUs asks for.  The
+  // register file is three times the LDS: the loads of the next DR K steps (corpus AND query pieces, the same coalesced 1 KiB pieces) land in
+  // DR x (NPA + PLANES * NPB) x 4 VGPRs per lane and are written to LDS (ds_write_b128, the layout the LDS-DMA would have produced) when
+  // their step comes up.  LDS then holds ONE corpus slot (each wave's 64 rows are its own: DS operations of a wave execute in order, nothing
+  // to synchronise) and two query slots; the compiler counts the waits (plain register dependencies).
+  static constexpr int RA = DR > 0 ? 1 : DEEP ? 4 : RING;       // corpus slots
+  static constexpr int RB = DR > 0 ? 2 : DEEP ? 3 : RING;       // query slots (RB <= RA for the LDS-DMA rings)
+  static constexpr int B_RING = RA * SLOT_A;
+  static constexpr int CTRL = RA * SLOT_A + RB * SLOT_B;
   static constexpr int LDS = CTRL + SQ * 8 + 16;
   static constexpr int WG_PER_CU = LDS <= 76 * 1024 ? 2 : 1;
   static constexpr int B_PIECES = SQ / RPP;        // query pieces per plane per step: 2 .. 8
   static constexpr int NPB = (B_PIECES + 3) / 4;   // ... per wave (waves >= B_PIECES stage none when there are fewer than 4)
+  static_assert((DR > 0 || RB <= RA) && RB >= 2 && LDS <= 160 * 1024, "ring does not fit");
+  static_assert(DR == 0 || STEP == 128, "register staging is built for whole-line steps");
 };
 
-template <typename T, int NI, int STEP, int ABL>
-__global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDeviceParams p) {
-  using G = SkinnyGeom<T, NI, STEP>;
+template <typename T, int NI, int STEP, int ABL, bool DEEP = false, int DR = 0>
+__global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) == 2)) ? 1 : 2)) skinny_scan_kernel(const MfmaDeviceParams p) {
+  using G = SkinnyGeom<T, NI, STEP, DEEP, DR>;
   constexpr int SQ = G::SQ;
   constexpr bool F32 = G::F32;
-  constexpr int S_RING = G::RING, S_SLOT_A = G::SLOT_A, S_SLOT_B = G::SLOT_B, S_B_RING = G::B_RING, S_CTRL = G::CTRL;
+  constexpr int RA = G::RA, RB = G::RB, S_SLOT_A = G::SLOT_A, S_SLOT_B = G::SLOT_B, S_B_RING = G::B_RING, S_CTRL = G::CTRL;
   constexpr int NPA = G::NPA, NPB = G::NPB, RPP = G::RPP, LPR = G::LPR, NG = G::NG;
   extern __shared__ __align__(16) unsigned char smem[];
   float* thr_lds = reinterpret_cast<float*>(smem + S_CTRL);
   int* cnt_lds = reinterpret_cast<int*>(smem + S_CTRL + SQ * 4);
-  volatile int* need_compact = reinterpret_cast<volatile int*>(smem + S_CTRL + SQ * 8);
+  // (an LDS-typed pointer: through a generic one the per-tile read below is a FLAT load, which counts in vmcnt AND lgkmcnt and cannot be waited
+  // for by count -- the compiler drained the whole staging queue behind it once per tile, and with a flat access pending anywhere in the loop
+  // it turns the first counted wait of every K-loop iteration into vmcnt(0) as well)
+  typedef __attribute__((address_space(3))) volatile int lds_flag_t;
+  lds_flag_t* need_compact = (lds_flag_t*)(smem + S_CTRL + SQ * 8);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -932,11 +951,29 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
     const int row = (wave + 4 * i) * RPP + st_row_in_piece;
     st_off_b[i] = (uint32_t)row * (uint32_t)row_bytes + (uint32_t)((((lane % LPR) ^ ((row >> G::SH) & (LPR - 1)))) * 16);
   }
-  const bool stages_b = wave < G::B_PIECES;  // (with fewer than four query pieces the last waves stage none)
-  int st_tile = 0, st_kt = 0, st_slot = 0;
+  const bool stages_b = G::B_PIECES >= 4 || wave < G::B_PIECES;  // (with fewer than four query pieces the last waves stage none)
+  // Two rings: corpus slabs run RA - 1 steps ahead of the multiply, query slabs RB - 1 (RB <= RA).  A "round" = what one K step issues:
+  // the query slab of step S + RB - 1 FIRST, then the corpus slab of step S + RA - 1 -- loads return in order, so with that order the
+  // counted wait below leaves the newest corpus slabs in flight.
+  int st_tile = 0, st_kt = 0, st_slot = 0;  // corpus slab being staged
+  int sb_kt = 0, sb_slot = 0;               // query slab being staged
   set_offsets(r_begin);
 
-  auto stage_next = [&]() {
+  auto stage_b = [&]() {
+    if (stages_b) {
+      const char* gb = sgpr_ptr(qbase + (size_t)sb_kt * STEP);
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
+        unsigned char* lb = smem + S_B_RING + sb_slot * S_SLOT_B + (wave + 4 * i) * 1024;
+        __builtin_amdgcn_global_load_lds((global_void*)(gb + (size_t)st_off_b[i]), (lds_void*)lb, 16, 0, 0);
+        if constexpr (!F32)  // the low plane of the split queries
+          __builtin_amdgcn_global_load_lds((global_void*)(gb + plane_bytes + (size_t)st_off_b[i]), (lds_void*)(lb + G::PLANE_B), 16, 0, 0);
+      }
+    }
+    if (++sb_slot == RB) sb_slot = 0;
+    if (++sb_kt == steps_per_tile) sb_kt = 0;
+  };
+  auto stage_a = [&]() {
     const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
     const int64_t src_row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM;
     const char* ga = sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * STEP);
@@ -944,28 +981,66 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
 #pragma unroll
     for (int j = 0; j < NPA; ++j)
       __builtin_amdgcn_global_load_lds((global_void*)(ga + (size_t)st_off[j]), (lds_void*)(la + j * 1024), 16, 0, 0);  // (a non-temporal policy here measured 30 % slower)
-    if (stages_b) {
-      const char* gb = sgpr_ptr(qbase + (size_t)st_kt * STEP);
-#pragma unroll
-      for (int i = 0; i < NPB; ++i) {
-        unsigned char* lb = smem + S_B_RING + st_slot * S_SLOT_B + (wave + 4 * i) * 1024;
-        __builtin_amdgcn_global_load_lds((global_void*)(gb + (size_t)st_off_b[i]), (lds_void*)lb, 16, 0, 0);
-        if constexpr (!F32)  // the low plane of the split queries
-          __builtin_amdgcn_global_load_lds((global_void*)(gb + plane_bytes + (size_t)st_off_b[i]), (lds_void*)(lb + G::PLANE_B), 16, 0, 0);
-      }
-    }
-    if (++st_slot == S_RING) st_slot = 0;
+    if (++st_slot == RA) st_slot = 0;
     if (++st_kt == steps_per_tile) {
       st_kt = 0;
       ++st_tile;
       if (st_tile < n_tiles) set_offsets(r_begin + (int64_t)st_tile * BM);
     }
   };
-  auto wait_landed = [&]() {  // all but the newest S_RING - 2 steps of this wave's loads have landed
+  auto stage_next = [&]() {
+    stage_b();
+    stage_a();
+  };
+  // this wave's loads of step S have landed.  Issue order per round: NB query loads, then NA corpus loads.  Query slab S is the first thing
+  // of round S - RB + 1: behind it come that round's corpus slab and RB - 2 whole rounds; corpus slab S is the last thing of round
+  // S - RA + 1, with RA - 2 whole rounds behind it.  Whatever is younger than BOTH may still be in flight.
+  auto wait_landed = [&]() {
+    constexpr int NB = G::PLANES * NPB;
     if (stages_b)
-      wait_vmcnt<(NPA + G::PLANES * NPB) * (S_RING - 2)>();
+      wait_vmcnt<((RA - 2) * (NPA + NB) < NPA + (RB - 2) * (NPA + NB)) ? (RA - 2) * (NPA + NB) : NPA + (RB - 2) * (NPA + NB)>();
     else
-      wait_vmcnt<NPA * (S_RING - 2)>();
+      wait_vmcnt<((RA - 2) < (RB - 1) ? (RA - 2) : (RB - 1)) * NPA>();
+  };
+
+  // ---- register staging (DR > 0): slot u of the register ring holds the pieces of the K steps congruent to u mod DR
+  constexpr int DRN = DR > 0 ? DR : 1;
+  constexpr int NBR = G::PLANES * NPB;
+  f32x4 areg[DRN][NPA];
+  f32x4 breg[DRN][NBR];
+  auto load_regs = [&](auto u_tag) {  // the pieces of the next un-issued K step -> register slot U
+    constexpr int U = decltype(u_tag)::value;
+    const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
+    const char* ga = sgpr_ptr(corpus + (size_t)(r_begin + (int64_t)tile * BM) * row_bytes + (size_t)st_kt * STEP);
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) areg[U][j] = *(global_f32x4*)(ga + (size_t)st_off[j]);  // (global, not flat: a flat load counts in lgkmcnt too and cannot be waited for by count)
+    if (stages_b) {
+      const char* gb = sgpr_ptr(qbase + (size_t)st_kt * STEP);
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
+        breg[U][G::PLANES * i] = *(global_f32x4*)(gb + (size_t)st_off_b[i]);
+        if constexpr (!F32) breg[U][G::PLANES * i + 1] = *(global_f32x4*)(gb + plane_bytes + (size_t)st_off_b[i]);
+      }
+    }
+    if (++st_kt == steps_per_tile) {
+      st_kt = 0;
+      ++st_tile;
+      if (st_tile < n_tiles) set_offsets(r_begin + (int64_t)st_tile * BM);
+    }
+  };
+  auto commit_regs = [&](auto u_tag, int bslot) {  // register slot U -> LDS, where the LDS-DMA of the other variants would have put it
+    constexpr int U = decltype(u_tag)::value;
+    unsigned char* la = smem + wave * (64 * STEP) + lane * 16;
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) *reinterpret_cast<f32x4*>(la + j * 1024) = areg[U][j];
+    if (stages_b) {
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
+        unsigned char* lb = smem + S_B_RING + bslot * S_SLOT_B + (wave + 4 * i) * 1024 + lane * 16;
+        *reinterpret_cast<f32x4*>(lb) = breg[U][G::PLANES * i];
+        if constexpr (!F32) *reinterpret_cast<f32x4*>(lb + G::PLANE_B) = breg[U][G::PLANES * i + 1];
+      }
+    }
   };
 
   // ---- fragment addresses: row (lane & 31) of a 32-row block, logical 16-byte slot 2 * g + (lane >> 5)
@@ -974,11 +1049,20 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
   const uint32_t a_lane = (uint32_t)((wave * 64 + frag_row) * STEP);  // + mi * 32 * STEP
   const uint32_t b_lane = (uint32_t)(S_B_RING + frag_row * STEP);    // + ni * 32 * STEP
 
-  // ---- prologue: S_RING - 1 steps in flight
-#pragma unroll 1
-  for (int i = 0; i < S_RING - 1; ++i) stage_next();
+  // ---- prologue: RA - 1 corpus slabs and RB - 1 query slabs in flight, in the order of the rounds that would have issued them
+  //      (register staging: the first DR steps, one per register slot)
+  if constexpr (DR > 0) {
+    [&]<int... U>(std::integer_sequence<int, U...>) { (load_regs(std::integral_constant<int, U>{}), ...); }
+    (std::make_integer_sequence<int, DRN>{});
+  } else {
+#pragma unroll
+    for (int i = 0; i < RA - 1; ++i) {
+      if (i >= RA - RB) stage_b();
+      stage_a();
+    }
+  }
 
-  int rd = 0;
+  int rd = 0, rd_b = 0;
   for (int tile = 0; tile < n_tiles; ++tile) {
     const int64_t row0 = r_begin + (int64_t)tile * BM;
     const bool tile_full = row0 + BM <= r_end;  // wave-uniform: every row of this tile belongs to the row range
@@ -990,14 +1074,23 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-#pragma unroll 1
-    for (int kt = 0; kt < steps_per_tile; ++kt) {
-      if constexpr ((ABL & 2) == 0) wait_landed();  // this wave's share of step S is in LDS
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      TAVB_BARRIER();  // the query pieces of step S are visible; everybody is done with the slot of step S - 1
-      if constexpr ((ABL & 2) == 0) stage_next();  // step S + S_RING - 1 -> the slot of step S - 1
+    auto k_step = [&](auto u_tag) {  // one K step; U = register slot (register staging only)
+      if constexpr (DR > 0) {
+        // this step's pieces out of the registers (the compiler waits for exactly these loads: whatever was issued after them -- the next
+        // DR - 1 steps -- stays in flight), the registers refilled with the step DR ahead; the query slot written here was last read two steps
+        // ago, with a barrier in between
+        commit_regs(u_tag, rd_b);
+        load_regs(u_tag);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TAVB_BARRIER();  // the query pieces of step S are visible
+      } else {
+        if constexpr ((ABL & 2) == 0) wait_landed();  // this wave's share of step S is in LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TAVB_BARRIER();  // the query pieces of step S are visible; everybody is done with the slot of step S - 1
+        if constexpr ((ABL & 2) == 0) stage_next();  // query slab S + RB - 1, corpus slab S + RA - 1 -> the slots of step S - 1
+      }
       const unsigned char* abase = smem + rd * S_SLOT_A;
-      const unsigned char* bbase = smem + rd * S_SLOT_B;
+      const unsigned char* bbase = smem + rd_b * S_SLOT_B;
 #pragma unroll
       for (int gh = 0; gh < NG / 2; ++gh) {  // two 32-byte k slices at a time
         f32x4 af[2][2], bf[2][NI], bl[2][NI];
@@ -1040,7 +1133,17 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
           if constexpr (!F32) asm volatile("" ::"v"(bl[0][0]), "v"(bl[1][NI - 1]));
         }
       }
-      if (++rd == S_RING) rd = 0;
+      if (++rd == RA) rd = 0;
+      if (++rd_b == RB) rd_b = 0;
+    };
+    if constexpr (DR > 0) {  // (the launcher checks steps_per_tile % DR == 0: a tile starts on register slot 0)
+#pragma unroll 1
+      for (int kt = 0; kt < steps_per_tile; kt += DR)
+        [&]<int... U>(std::integer_sequence<int, U...>) { (k_step(std::integral_constant<int, U>{}), ...); }
+      (std::make_integer_sequence<int, DRN>{});
+    } else {
+#pragma unroll 1
+      for (int kt = 0; kt < steps_per_tile; ++kt) k_step(std::integral_constant<int, 0>{});
     }
 
     // ---- epilogue: admission test on the raw dot products, append (as in the 256-query tile)
@@ -1080,7 +1183,15 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
                 if (pos + 1 > CAP - BM) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
                 float s1 = (sc[j] > 0.0f) ? sc[j] : 0.0f;
                 s1 = (s1 > 1.0f) ? 1.0f : s1;
-                if (pos < CAP) my_cand[(size_t)ql * CAP + pos] = make_key(s1, (uint32_t)(row_base + r_off) + p.index_base);
+                if (pos < CAP) {
+                  const u64 key = make_key(s1, (uint32_t)(row_base + r_off) + p.index_base);
+                  // issued behind the compiler's back: a store it can see among the pending staging loads makes its wait-count pass drain the
+                  // whole queue at the next loop header (on gfx9 loads and stores share vmcnt and are not ordered against each other) -- once
+                  // per tile in the LDS-DMA variants, at every K-loop iteration with register staging, whose waits the compiler counts.  An
+                  // extra entry in the queue only makes a counted wait wait longer.
+                  u64* dst = my_cand + (size_t)ql * CAP + pos;
+                  asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(key) : "memory");
+                }
               }
             }
           }
@@ -1090,7 +1201,7 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     TAVB_BARRIER();
     if (*need_compact != 0) {  // workgroup-uniform: read after the barrier
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), through the builtin: the compiler's wait-count pass sees the queue empty from here on
       TAVB_BARRIER();
       for (int q = wave; q < SQ; q += S_THREADS / 64) {
         const int n = cnt_lds[q];
@@ -1102,9 +1213,10 @@ __global__ void __launch_bounds__(S_THREADS, 2) skinny_scan_kernel(const MfmaDev
             cnt_lds[q] = kept;
             if (kept >= p.k && kth_score > thr_lds[q]) thr_lds[q] = kth_score;
           }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_waitcnt(0x0F70);
         }
       }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // (whatever the compaction left pending: the loop headers see staging loads only)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       TAVB_BARRIER();
       if (tid == 0) *need_compact = 0;
@@ -1503,11 +1615,27 @@ bool skinny_supported(int dim, int k, bool f32) {
   return (dim * (f32 ? 4 : 2)) % 64 == 0 && dim > 0 && k >= 1 && k <= 64;
 }
 
+// Staging variant of the 32/64-query tile (whole-line steps only): 0 = LDS-DMA ring (round 2), 1 = deep corpus ring (4 + 3 slots, 32-query tile),
+// 3 / 4 / 6 = register staging that many K steps deep.  `sched` (option mfma_sched, measurement): 7 = ring, 8 = deep ring, 6 / 5 / 4 = register
+// staging 3 / 4 / 6 deep; 0 = the default per corpus dtype (profiles/r05_mid_batch.md).
+constexpr int kSkinnyVariantDefault[2] = {0, 0};  // {fp16, fp32}
 // K step of the tile: whole 128-byte lines whenever a row is a multiple of that
 static bool skinny_line_steps(int dim, bool f32) { return (dim * (f32 ? 4 : 2)) % 128 == 0; }
 
-static int skinny_wg_per_cu(int dim, bool f32, int tile) {
+static int skinny_variant(int dim, bool f32, int tile, int sched) {
+  if (!skinny_line_steps(dim, f32) || sched == 9 || sched == 7) return 0;
+  int v = sched == 8 ? 1 : sched == 6 ? 3 : sched == 5 ? 4 : sched == 4 ? 6 : kSkinnyVariantDefault[f32 ? 1 : 0];
+  if (tile != 32 && v != 0) v = 0;  // (the 64-query tile keeps the ring)
+  const int steps = dim * (f32 ? 4 : 2) / 128;
+  if (v >= 3 && steps % v != 0) v = (steps % 3 == 0) ? 3 : 0;  // a tile starts on register slot 0
+  return v;
+}
+
+static int skinny_wg_per_cu(int dim, bool f32, int tile, int sched) {
   const bool line = skinny_line_steps(dim, f32);
+  const int v = skinny_variant(dim, f32, tile, sched);
+  if (v == 1 || v >= 4) return 1;
+  if (v == 3) return f32 ? 2 : 1;  // (the fp16 form keeps two query planes in flight: 256 registers do not hold it without scratch)
   if (f32) {
     if (tile == 64) return line ? SkinnyGeom<float, 2, 128>::WG_PER_CU : SkinnyGeom<float, 2, 64>::WG_PER_CU;
     return line ? SkinnyGeom<float, 1, 128>::WG_PER_CU : SkinnyGeom<float, 1, 64>::WG_PER_CU;
@@ -1516,9 +1644,9 @@ static int skinny_wg_per_cu(int dim, bool f32, int tile) {
   return line ? SkinnyGeom<_Float16, 1, 128>::WG_PER_CU : SkinnyGeom<_Float16, 1, 64>::WG_PER_CU;
 }
 
-int skinny_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu, int dim, bool f32) {
+int skinny_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu, int dim, bool f32, int sched) {
   const int n_qtiles = nq_padded / tile;
-  int splits = (skinny_wg_per_cu(dim, f32, tile) * n_cu) / (n_qtiles > 0 ? n_qtiles : 1);  // every workgroup resident at once
+  int splits = (skinny_wg_per_cu(dim, f32, tile, sched) * n_cu) / (n_qtiles > 0 ? n_qtiles : 1);  // every workgroup resident at once
   splits = (splits / 8) * 8;                                                               // whole groups of 8 (one row range per XCD)
   if (splits < 8) splits = 8;
   const int64_t tiles = (rows + BM - 1) / BM;
@@ -1562,6 +1690,21 @@ hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
     return hipGetLastError();
   };
   const bool line = skinny_line_steps(p.dim, f32) && p.sched != 9;  // (sched 9: force the 64-byte steps, measurement)
+  switch (skinny_variant(p.dim, f32, tile, p.sched)) {
+    case 1:
+      return f32 ? go(skinny_scan_kernel<float, 1, 128, 0, true>, SkinnyGeom<float, 1, 128, true>::LDS)
+                 : go(skinny_scan_kernel<_Float16, 1, 128, 0, true>, SkinnyGeom<_Float16, 1, 128, true>::LDS);
+    case 3:
+      return f32 ? go(skinny_scan_kernel<float, 1, 128, 0, false, 3>, SkinnyGeom<float, 1, 128, false, 3>::LDS)
+                 : go(skinny_scan_kernel<_Float16, 1, 128, 0, false, 3>, SkinnyGeom<_Float16, 1, 128, false, 3>::LDS);
+    case 4:
+      return f32 ? go(skinny_scan_kernel<float, 1, 128, 0, false, 4>, SkinnyGeom<float, 1, 128, false, 4>::LDS)
+                 : go(skinny_scan_kernel<_Float16, 1, 128, 0, false, 4>, SkinnyGeom<_Float16, 1, 128, false, 4>::LDS);
+    case 6:
+      return f32 ? go(skinny_scan_kernel<float, 1, 128, 0, false, 6>, SkinnyGeom<float, 1, 128, false, 6>::LDS)
+                 : go(skinny_scan_kernel<_Float16, 1, 128, 0, false, 6>, SkinnyGeom<_Float16, 1, 128, false, 6>::LDS);
+    default: break;
+  }
   if (f32) {
     if (tile == 64) return line ? go(skinny_scan_kernel<float, 2, 128, 0>, SkinnyGeom<float, 2, 128>::LDS) : go(skinny_scan_kernel<float, 2, 64, 0>, SkinnyGeom<float, 2, 64>::LDS);
     return line ? go(skinny_scan_kernel<float, 1, 128, 0>, SkinnyGeom<float, 1, 128>::LDS) : go(skinny_scan_kernel<float, 1, 64, 0>, SkinnyGeom<float, 1, 64>::LDS);

@@ -32,6 +32,7 @@ from __future__ import annotations
 
 import gc
 import os
+import time
 from collections.abc import Callable
 from dataclasses import dataclass
 
@@ -301,6 +302,8 @@ class VectorBase:
         self._view_out = False  # a view of a matrix this index owns has been handed out: fingerprint fallback on (round-3 advice)
         self._handed_out = False
         self._dev_fingerprint = None
+        self._fp_skipped = 0      # lookups since the fallback fingerprint of an owned, handed-out matrix was last compared
+        self._fp_checked = 0.0    # ... and when (time.monotonic())
         mode = (verify_host or os.environ.get("TYPEAGENT_VB_VERIFY_HOST", "sampled")).lower()
         if mode not in ("sampled", "full", "off"):
             raise ValueError("verify_host must be 'sampled', 'full' or 'off'")
@@ -370,8 +373,8 @@ class VectorBase:
             return
         if need > self._host.shape[0] or self._handed_out:
             # (an adopted matrix is the caller's: appends go to a buffer of our own, like the reference's np.append copy, :128)
-            if self._handed_out and self._dev_valid and self._dev_rows == self._count and self._dev_fingerprint != self._fingerprint():
-                self._dev_valid = False  # edited in place since the last upload: the rows already mirrored are stale too
+            if (self._handed_out or self._view_out) and self._dev_valid and self._dev_rows == self._count and self._dev_fingerprint != self._fingerprint():
+                self._dev_valid = False  # edited in place since the last upload (also through a view the tracker cannot see): the rows already mirrored are stale too
             grown = np.empty((max(need, 2 * self._host.shape[0], 4), self._embedding_size), dtype=np.float32)
             grown[: self._count] = self._host[: self._count]
             self._host = grown
@@ -475,7 +478,8 @@ class VectorBase:
         if self._watch.dirty:  # a view handed out by serialize() / _vectors / get_embedding_at() was written to
             self._watch.dirty = False
             self._dev_valid = False
-        if (self._handed_out or self._view_out) and self._dev_valid and self._dev_rows == n and n > 0 and self._dev_fingerprint != self._fingerprint():
+        if (self._handed_out or self._view_out) and self._dev_valid and self._dev_rows == n and n > 0 and self._fingerprint_due() \
+                and self._dev_fingerprint != self._fingerprint():
             self._dev_valid = False  # the caller's matrix adopted by deserialize() -- or a matrix of ours somebody holds a view of -- was edited in place
         if not self._dev_valid:
             self._dev_rows = 0
@@ -490,6 +494,22 @@ class VectorBase:
             self._dev_rows = n
             self._dev_fingerprint = self._fingerprint() if (self._handed_out or self._view_out) else None
         return eng
+
+    def _fingerprint_due(self) -> bool:
+        """A matrix the CALLER owns (deserialize(), :287) is fingerprinted before every lookup: nothing else can notice an edit.  A matrix
+        this index owns and has handed out as a write-tracking view (serialize() / _vectors / get_embedding_at()) reports its writers by
+        itself; the fingerprint there is only the fallback for writers that go around numpy's array API, and costs as much as a whole
+        lookup on a small corpus (~30 us): it is taken at most once per 64 lookups or 20 ms, whichever comes first (`mark_dirty()` is
+        the explicit, immediate form)."""
+        if self._handed_out or self._verify_host == "full":
+            return True
+        self._fp_skipped += 1
+        now = time.monotonic()
+        if self._fp_skipped >= 64 or now - self._fp_checked >= 0.02:
+            self._fp_skipped = 0
+            self._fp_checked = now
+            return True
+        return False
 
     def _fingerprint(self):
         """Watch on a matrix the CALLER owns (adopted by deserialize(), :287).  "sampled": hash of up to 32 evenly spaced rows
