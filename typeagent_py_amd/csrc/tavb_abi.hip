@@ -1516,6 +1516,13 @@ std::vector<int64_t> ladder_bounds(int64_t rows, int splits, int nq_pad, bool sk
   const int64_t one_tile_each = (int64_t)splits * 256;
   if (ladder && skinny && sample_opt == 0 && rows >= 4 * one_tile_each && rows < 2048000) {
     bounds.push_back(one_tile_each);
+  } else if (ladder && skinny && sample_opt == 0 && rows >= 2048000 && rows >= 32 * one_tile_each) {
+    // ... and on bigger corpora THREE phases: one tile per workgroup, twelve times that, the rest (10M rows: 65536 / 851968 / 9.08M).  The
+    // 32-query tile is HBM-bound and admits little (k ln(n / seen) rows per query): what its early phases cost is their launches and tails,
+    // 0.62 ms for three phases over 1.02M rows against 0.51 ms for two over 0.92M (profiles/r05_mid_batch.md; one phase fewer than the
+    // generic ladder below, +1.5 % on cfg3_b32)
+    bounds.push_back(one_tile_each);
+    if (growth > 0) bounds.push_back(13 * one_tile_each);
   } else if (ladder && sample > 0 && rows >= 8 * sample) {
     int64_t done = sample;
     bounds.push_back(done);

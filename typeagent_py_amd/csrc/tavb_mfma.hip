@@ -1615,19 +1615,20 @@ bool skinny_supported(int dim, int k, bool f32) {
   return (dim * (f32 ? 4 : 2)) % 64 == 0 && dim > 0 && k >= 1 && k <= 64;
 }
 
-// Staging variant of the 32/64-query tile (whole-line steps only): 0 = LDS-DMA ring (round 2), 1 = deep corpus ring (4 + 3 slots, 32-query tile),
-// 3 / 4 / 6 = register staging that many K steps deep.  `sched` (option mfma_sched, measurement): 7 = ring, 8 = deep ring, 6 / 5 / 4 = register
-// staging 3 / 4 / 6 deep; 0 = the default per corpus dtype (profiles/r05_mid_batch.md).
+// Staging variant of the 32/64-query tile (whole-line steps only): 0 = LDS-DMA ring (ships), 1 = deep corpus ring (4 + 3 slots), 4 = register
+// staging four K steps deep.  The two others are measurement variants behind option mfma_sched (8 / 5; 7 = ring, explicitly): with the per-tile
+// drains gone (see the kernel) the ring, the deep ring and register staging 3 / 4 / 6 steps deep all stream 10M x 1536 fp16 rows under 32 queries
+// at 6.4 .. 6.5 TB/s -- 40 .. 240 KiB in flight per CU make no difference, the tile is not short of bytes in flight (profiles/r05_mid_batch.md).
 constexpr int kSkinnyVariantDefault[2] = {0, 0};  // {fp16, fp32}
 // K step of the tile: whole 128-byte lines whenever a row is a multiple of that
 static bool skinny_line_steps(int dim, bool f32) { return (dim * (f32 ? 4 : 2)) % 128 == 0; }
 
 static int skinny_variant(int dim, bool f32, int tile, int sched) {
   if (!skinny_line_steps(dim, f32) || sched == 9 || sched == 7) return 0;
-  int v = sched == 8 ? 1 : sched == 6 ? 3 : sched == 5 ? 4 : sched == 4 ? 6 : kSkinnyVariantDefault[f32 ? 1 : 0];
+  int v = sched == 8 ? 1 : sched == 5 ? 4 : kSkinnyVariantDefault[f32 ? 1 : 0];
   if (tile != 32 && v != 0) v = 0;  // (the 64-query tile keeps the ring)
   const int steps = dim * (f32 ? 4 : 2) / 128;
-  if (v >= 3 && steps % v != 0) v = (steps % 3 == 0) ? 3 : 0;  // a tile starts on register slot 0
+  if (v >= 3 && steps % v != 0) v = 0;  // a tile starts on register slot 0
   return v;
 }
 
@@ -1635,7 +1636,6 @@ static int skinny_wg_per_cu(int dim, bool f32, int tile, int sched) {
   const bool line = skinny_line_steps(dim, f32);
   const int v = skinny_variant(dim, f32, tile, sched);
   if (v == 1 || v >= 4) return 1;
-  if (v == 3) return f32 ? 2 : 1;  // (the fp16 form keeps two query planes in flight: 256 registers do not hold it without scratch)
   if (f32) {
     if (tile == 64) return line ? SkinnyGeom<float, 2, 128>::WG_PER_CU : SkinnyGeom<float, 2, 64>::WG_PER_CU;
     return line ? SkinnyGeom<float, 1, 128>::WG_PER_CU : SkinnyGeom<float, 1, 64>::WG_PER_CU;
@@ -1694,15 +1694,9 @@ hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
     case 1:
       return f32 ? go(skinny_scan_kernel<float, 1, 128, 0, true>, SkinnyGeom<float, 1, 128, true>::LDS)
                  : go(skinny_scan_kernel<_Float16, 1, 128, 0, true>, SkinnyGeom<_Float16, 1, 128, true>::LDS);
-    case 3:
-      return f32 ? go(skinny_scan_kernel<float, 1, 128, 0, false, 3>, SkinnyGeom<float, 1, 128, false, 3>::LDS)
-                 : go(skinny_scan_kernel<_Float16, 1, 128, 0, false, 3>, SkinnyGeom<_Float16, 1, 128, false, 3>::LDS);
     case 4:
       return f32 ? go(skinny_scan_kernel<float, 1, 128, 0, false, 4>, SkinnyGeom<float, 1, 128, false, 4>::LDS)
                  : go(skinny_scan_kernel<_Float16, 1, 128, 0, false, 4>, SkinnyGeom<_Float16, 1, 128, false, 4>::LDS);
-    case 6:
-      return f32 ? go(skinny_scan_kernel<float, 1, 128, 0, false, 6>, SkinnyGeom<float, 1, 128, false, 6>::LDS)
-                 : go(skinny_scan_kernel<_Float16, 1, 128, 0, false, 6>, SkinnyGeom<_Float16, 1, 128, false, 6>::LDS);
     default: break;
   }
   if (f32) {
