@@ -983,9 +983,11 @@ def slim_sub(rec: dict) -> dict:
     the driver's record to hold every sub-record (round 3's 15 KB line lost `sub.cfg3_q1`)."""
     out = {}
     for key in ("workload", "queries_per_sec", "value", "unit", "ms_per_step", "p50_latency_us", "flagged_fraction", "vs_gaussian", "class_api",
-                "variants", "exchange", "row_queries_per_sec", "scaling"):
+                "variants", "exchange", "row_queries_per_sec"):
         if key in rec:
             out[key] = rec[key]
+    if "row_queries_per_sec" in rec and "scaling" in rec:
+        out["scaling"] = rec["scaling"]
     if "config" in rec and "workload" not in out:
         out["workload"] = rec["config"]["workload"]
     if "workload" in out:
