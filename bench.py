@@ -991,7 +991,9 @@ def slim_sub(rec: dict) -> dict:
     if "config" in rec and "workload" not in out:
         out["workload"] = rec["config"]["workload"]
     if "workload" in out:
-        out["workload"] = out["workload"].split(": ", 1)[-1].replace(", min_score 0", "")  # (the key already names the workload)
+        out["workload"] = out["workload"].split(": ", 1)[-1]  # (the key already names the workload)
+        if out["workload"].endswith(", min_score 0"):
+            out["workload"] = out["workload"][: -len(", min_score 0")]
     if rec.get("query_batches_in_rotation") or out.get("ms_per_step", 0) > 0.2:
         out.pop("p50_latency_us", None)  # a batch's latency is its ms_per_step; so is a long single lookup's (kept for the launch-bound cfg1)
     ro = rec.get("roofline") or {}

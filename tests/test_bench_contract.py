@@ -150,6 +150,39 @@ def test_pmc_summary_reads_kernel_names_in_both_forms():
     assert kb("void tavb::scan_fixed_kernel<float, 6, 1, 1, 2, true, false, 1024>(tavb::ScanParams)") == "scan_fixed_kernel"
     assert kb("tavb::(anonymous namespace)::select_band_kernel(unsigned long long const*, int const*, int)") == "select_band_kernel"
     assert kb("mfma_scan_kernel<0, 4, 8, 6, 4>") == "mfma_scan_kernel"
+    assert mod.is_split("mfma_scan_kernel<0, 4, 8, 6, 4, true, false>") and not mod.is_split("mfma_scan_kernel<0, 4, 8, 6, 4, false, false>")
+    assert not mod.is_split("mfma_scan_kernel<0, 2, 6, 4, 4, false, true>")
     assert kb("__amd_rocclr_fillBufferAligned") is None
     assert kb("void at::native::vectorized_elementwise_kernel<4, at::native::CUDAFunctor_add<float>>") is None
     assert kb("_ZN2at6native29vectorized_elementwise_kernelILi4EEEvv") is None
+
+
+def test_the_n_gpu_line_carries_the_weak_scaling_record_with_exchange_and_skew():
+    """At N > 1 the default line = the strong-scaling cfg3 headline + `sub.cfg4_weak` (BASELINE configs[3]: 12.5M rows per rank): rows x queries
+    per second, the exchange's own time (minimum over ranks of the all-gather's stream time), the skew between the ranks' scans, full parity."""
+    ctx = types.SimpleNamespace(world=8)
+    wl = dict(bench.WORKLOADS["cfg3"], rows_total=10_000_000)
+    exchange = {"scan_ms_per_rank": [3.5, 3.6, 3.5, 3.7, 3.5, 3.5, 3.6, 3.5], "rank_skew_ms": 0.2, "exchange_ms": 0.03, "exchange_ms_incl_wait": 0.25,
+                "merge_ms": 0.02, "rows_per_rank": [1_250_000] * 8}
+    weak = dict(_rec(), workload="cfg4: 100000000x1536 fp16 over 8 GPUs (12500000 rows on rank 0), 1024 q/step, top-32, min_score 0", exchange=exchange,
+                row_queries_per_sec=3.0e12, scaling="weak", query_batches_in_rotation=4,
+                parity={"ok": True, "queries_checked": 16, "rows": 100_000_000, "positions_exact": 512, "positions_permuted": 0})
+    line = bench.compact(bench.headline_line(ctx, dict(_rec(), exchange=exchange), "cfg3", wl, "strong", {"cfg4_weak": weak}))
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["exchange"]["rank_skew_ms"] == 0.2
+    sub = line["sub"]["cfg4_weak"]
+    assert sub["scaling"] == "weak" and sub["row_queries_per_sec"] == 3.0e12 and sub["parity"]["ok"] is True
+    assert sub["exchange"]["exchange_ms"] == 0.03 and len(sub["exchange"]["scan_ms_per_rank"]) == 8
+    assert "100000000x1536" in sub["workload"]
+    assert bench.WORKLOADS["cfg4"]["rows"] * 8 == 100_000_000
+
+
+def test_a_free_rendezvous_port_is_used_when_no_launcher_set_one(monkeypatch):
+    import socket
+
+    a, b = bench.free_port(), bench.free_port()
+    assert 1024 < a < 65536 and 1024 < b < 65536
+    s = socket.socket()
+    s.bind(("127.0.0.1", a))  # free at the time it was handed out
+    s.close()
+    src = open(bench.__file__).read()
+    assert '"29533"' not in src, "a fixed MASTER_PORT makes two benches on one node collide"

@@ -41,6 +41,11 @@ def kernel_base(name: str) -> str | None:
     return m.group(1) if m else None
 
 
+def is_split(name: str) -> bool:
+    """The SPLIT instantiation of the tile kernel: `mfma_scan_kernel<ABL, NI, N3, N0, N1, SPLIT = true, BD>`."""
+    return re.search(r"mfma_scan_kernel<[^>]*, true, (?:true|false)>", name) is not None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("csv", nargs="+")
@@ -48,8 +53,8 @@ def main() -> None:
     ap.add_argument("--cmd", default=None, help="the profiled command (for the header)")
     ap.add_argument("--json", default=None)
     ap.add_argument("--name", default=None)
-    ap.add_argument("--round", default="r04", help="prefix of the profiles/ file names this summary is committed under")
-    ap.add_argument("--script", default="tools/gpu_r4_pmc.sh")
+    ap.add_argument("--round", default="r05", help="prefix of the profiles/ file names this summary is committed under")
+    ap.add_argument("--script", default="tools/gpu.sh pmc")
     args = ap.parse_args()
     csv.field_size_limit(1 << 30)
     per = collections.defaultdict(lambda: collections.defaultdict(float))  # kernel -> counter -> sum
@@ -101,9 +106,9 @@ def main() -> None:
                     "kernels": lookup_kernels,
                     # launches of each lookup kernel per lookup (the tile kernel: one per ladder phase -- checked against tavb_plan_ladder() by the same test)
                     # (the SPLIT instantiation of the tile kernel -- the exact fallback, launched per ladder phase and returning at once when no query is
-                    #  flagged -- is counted apart: `..., true>` in the demangled name)
-                    "launches_per_step": {kb + suffix: round(sum(len(disp[k]) for k in per if kernel_base(k) == kb and (", true>" in k) == (suffix != "")) / args.steps, 4)
-                                          for kb in lookup_kernels for suffix in ("", "_split") if any(kernel_base(k) == kb and (", true>" in k) == (suffix != "") for k in per)},
+                    #  flagged -- is counted apart: `..., true, false>` in the demangled name)
+                    "launches_per_step": {kb + suffix: round(sum(len(disp[k]) for k in per if kernel_base(k) == kb and is_split(k) == (suffix != "")) / args.steps, 4)
+                                          for kb in lookup_kernels for suffix in ("", "_split") if any(kernel_base(k) == kb and is_split(k) == (suffix != "") for k in per)},
                 }
                 json.dump(blob, open(args.json, "w"), indent=1)
 

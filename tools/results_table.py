@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Markdown table of one bench.py line (headline + sub-records): workload, step time, value, roofline fraction, parity.
+
+    python tools/results_table.py profiles/r05_bench_default.json
+"""
+import json
+import sys
+
+
+def row(name, r, headline=False):
+    ro, pa = r.get("roofline") or {}, r.get("parity") or {}
+    val = r.get("value", r.get("queries_per_sec", 0.0))
+    unit = r.get("unit", "queries/s")
+    wl = (r.get("config") or {}).get("workload") or r.get("workload", "")
+    wl = wl.split(": ", 1)[-1]
+    par = "ok" if pa.get("ok") else ("FAILED" if pa else "–")
+    if pa.get("positions_exact") is not None:
+        par += f" ({pa['positions_exact']} exact" + (f" + {pa['positions_permuted']} permuted inside float32 ties" if pa.get("positions_permuted") else "") + ")"
+    extra = []
+    if r.get("flagged_fraction"):
+        extra.append(f"flagged {r['flagged_fraction']:g}")
+    if "vs_gaussian" in r:
+        extra.append(f"{r['vs_gaussian']:.2f}x the gaussian rate")
+    if ro.get("traffic"):
+        alg = ro.get("algorithmic_per_step")
+        extra.append(f"traffic {ro['traffic'] / 1e9:.1f} GB")
+    frac = f"**{ro.get('frac', 0):.3f}** {ro.get('bound', '')}" if ro else "–"
+    ms = r.get("ms_per_step", 0.0)
+    ms_s = f"{ms * 1e3:.1f} µs" if ms < 0.2 else f"{ms:.2f} ms"
+    v = f"{val / 1e3:.1f} k" if val >= 1e4 else f"{val:.1f}"
+    return f"| {'**' + name + '**' if headline else name} | {wl} | {ms_s} | {v} {unit} | {frac} | {par}{'; ' + ', '.join(extra) if extra else ''} |"
+
+
+def main():
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("| record | workload | per step | value | roofline `frac` | parity (whole corpus) |")
+    print("|---|---|---|---|---|---|")
+    print(row("cfg3 (headline)", d, True))
+    for name, r in (d.get("sub") or {}).items():
+        print(row(name, r))
+        for vn, v in (r.get("variants") or {}).items():
+            print(f"| {name}.{vn} | | {v['ms_per_step']:.2f} ms | {v['value']:.1f} user-queries/s | " + (f"{v['hbm_frac']:.3f} hbm" if "hbm_frac" in v else "–") + " | " + ("ok" if (v.get("parity") or {}).get("ok") else "–")
+                  + (f"; fused is {v['fused_speedup']:.2f}x these six separate calls" if "fused_speedup" in v else "") + " |")
+    ca = d.get("class_api") or {}
+    if ca:
+        print(f"\nThrough the class (`VectorBase.fuzzy_lookup_embeddings`, host queries in, Python objects out): `list[list[ScoredInt]]` "
+              f"{ca['scored_int_lists']['ms_per_step']:.2f} ms per batch, `as_arrays=True` {ca['as_arrays']['ms_per_step']:.2f} ms; engine {d['ms_per_step']:.2f} ms; "
+              f"host-buffer form of the C call {d['host_buffer_form']['ms_per_step']:.2f} ms.")
+    cb = d.get("cpu_baseline") or {}
+    if cb:
+        print(f"CPU baseline beside the headline ({cb['kind']}, {cb['host_cores']} host cores): {cb['value']:.2f} queries/s at the best thread count ({cb['cores']}), "
+              f"{cb['default_threads']['value']:.2f} at OpenBLAS's default, {cb.get('one_thread', {}).get('value', 0):.2f} on one thread.")
+    su = (d.get("roofline") or {}).get("sustained")
+    if su:
+        print(f"`roofline.sustained`: MFMA-only {su['mfma_only_tflops']:.0f} TFLOP/s, vendor GEMM {su['vendor_gemm_tflops']:.0f} TFLOP/s, shipping / MFMA-only {su['frac_of_mfma_only']:.2f}.")
+
+
+if __name__ == "__main__":
+    main()
