@@ -1590,7 +1590,15 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       if (tile != BN) return hipErrorInvalidValue;
       return go(mfma_scan_kernel<0, 4, 8, 6, 4, true>, NT6, LDS256);
     }
-    if (tile == 128) return go(mfma_scan_kernel<0, 2, 6, 4, 4>, NT6, LDS128);
+    if (tile == 128) {
+      switch (p.ablate) {  // (measurement: what bounds the 128-query width, profiles/r05_mid_batch.md)
+        case 1: return go(mfma_scan_kernel<1, 2, 6, 4, 4>, NT6, LDS128);      // no MFMAs
+        case 256: return go(mfma_scan_kernel<256, 2, 6, 4, 4>, NT6, LDS128);  // no admissions
+        case 257: return go(mfma_scan_kernel<257, 2, 6, 4, 4>, NT6, LDS128);  // neither: staging, fragment reads, barriers
+        case 264: return go(mfma_scan_kernel<264, 2, 6, 4, 4>, NT6, LDS128);  // no admissions, query operand cache resident
+        default: return go(mfma_scan_kernel<0, 2, 6, 4, 4>, NT6, LDS128);
+      }
+    }
     if (p.bdirect && p.ablate == 0) return go(mfma_scan_kernel<0, 4, 4, 3, 3, false, true>, NT6, 3 * SLOT_A6 + BN * 8 + 16);  // queries in fragment-major order (query_prepare_kernel)
     switch (p.ablate) {
       case 256: return go(mfma_scan_kernel<256, 4, 8, 6, 4>, NT6, LDS256);  // everything except admissions
