@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Drive the C ABI without torch (torch's CUDA init does not survive the ASan runtime): device buffers come from hipMalloc through
 ctypes.  Meant for `libtavb_debug.so` (host side under AddressSanitizer + UBSan, `make -C typeagent_py_amd/csrc debug`), see
-tools/gpu_asan.sh.  Checks answers against numpy on the way (test infrastructure, not product)."""
+`tools/gpu.sh LABEL asan`.  Checks answers against numpy on the way (test infrastructure, not product)."""
 import ctypes
 import os
 import sys
@@ -74,6 +74,27 @@ def main():
             o2 = np.empty((nq, k), np.int64); s2 = np.empty((nq, k), np.float32); c2 = np.empty(nq, np.int32)
             ok(lib.tavb_decode_keys(ptr(keys), nq, k, ptr(o2), ptr(s2), ptr(c2)))
             if not (o2 == o).all(): print("begin/end differs from search_batch at nq", nq, "counts", c2[:4], flush=True)
+        # round 5: per-query thresholds and k beyond 64 on the tiles (k = 100: the wide tile's split-plane fallback on fp16), a 1024-query
+        # batch (the query staging copy on several threads)
+        for nq, kk in ((40, 32), (130, 100), (1024, 32)):
+            if kk > 64 and dtype != _native.TAVB_F16:
+                continue
+            q = rng.standard_normal((nq, d)).astype(np.float32)
+            q /= np.linalg.norm(q, axis=1, keepdims=True)
+            o = np.empty((nq, kk), np.int64); s = np.empty((nq, kk), np.float32); c = np.empty(nq, np.int32)
+            thr = np.where(np.arange(nq) % 3 == 0, 0.0, 0.52).astype(np.float32)
+            thr[1] = np.nan
+            ok(lib.tavb_search_batch(h, ptr(q), nq, kk, ptr(thr), ptr(o), ptr(s), ptr(c)))
+            for qi in (0, 2, nq - 1):
+                sc = scores(vv, q[qi])
+                want = min(kk, int((sc >= thr[qi]).sum()))
+                ref = np.argsort(-sc, kind="stable")[:want]
+                if not (c[qi] == want and (want == 0 or (o[qi][:want] == ref).mean() > 0.9)):
+                    print("MISMATCH per-query thresholds", dtype, nq, kk, qi, "count", c[qi], "want", want, flush=True)
+                    bad.append((dtype, "thr", nq, qi))
+            if c[1] != 0:
+                print("MISMATCH: a NaN threshold let rows pass", flush=True); bad.append((dtype, "nan", nq))
+        print("per-query thresholds / k = 100 / 1024-query batch: ok", flush=True)
         q = v[5].copy()
         o = np.empty(k, np.int64); s = np.empty(k, np.float32); cnt = c_int32()
         ok(lib.tavb_search(h, ptr(q), k, c_float(0.0), ptr(o), ptr(s), byref(cnt)))
