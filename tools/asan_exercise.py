@@ -106,7 +106,9 @@ def main():
             o3 = np.empty(kk, np.int64); s3 = np.empty(kk, np.float32)
             ok(lib.tavb_search(h, ptr(q), kk, c_float(0.0), ptr(o3), ptr(s3), byref(cnt)))
             dflag = c_int64(); ok(lib.tavb_get_option(h, b"last_direct", byref(dflag)))
-            assert dflag.value in (1, 2) and cnt.value == kk and (o3[: min(k, kk)] == two_launch[: min(k, kk)]).all(), (kk, dflag.value, cnt.value)
+            # (k = 200: the 8192-key list budget would cut the grid to 40 of 256 workgroups for 70k rows -- less than half: the one-launch path
+            #  steps aside, round 5)
+            assert dflag.value in ((0,) if kk == 200 else (1, 2)) and cnt.value == kk and (o3[: min(k, kk)] == two_launch[: min(k, kk)]).all(), (kk, dflag.value, cnt.value)
         # ... and a FEW queries at once through it (the multi-query scan's lists merged per query on the host), every k and count, per-query thresholds
         for nq3, kk in ((2, k), (3, 1), (4, 200), (8, k)):
             q3 = v[5 : 5 + nq3].copy()

@@ -831,17 +831,22 @@ constexpr int SQ32 = 32;            // queries per 32 x 32 MFMA block; a tile is
 constexpr int S_THREADS = 256;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) f32x4 global_f32x4;
-template <typename T, int NI, int STEP, bool DEEP = false, int DR = 0>
+template <typename T, int NI, int STEP, bool DEEP = false, int DR = 0, bool HALF = false>
 struct SkinnyGeom {
+  // HALF: 128-row tiles (a wave owns 32 rows = one 32 x 32 block per 32 queries) -- half the corpus slot, so that a ring of three fits twice
+  // into a CU's LDS and TWO workgroups share a CU (one waits at its barrier, the other multiplies), as the fp32 32-query tile always did
+  static constexpr int BMT = HALF ? BM / 2 : BM;   // corpus rows per tile
+  static constexpr int RW = BMT / 4;               // ... per wave
+  static constexpr int MI = RW / 32;               // 32-row blocks per wave
   static constexpr bool F32 = sizeof(T) == 4;
   static constexpr int SQ = NI * SQ32;
   static constexpr int PLANES = F32 ? 1 : 2;
   static constexpr int LPR = STEP / 16;            // lanes (16-byte slots) per row of a staging piece
   static constexpr int RPP = 64 / LPR;             // rows per 1 KiB piece: 16 or 8
-  static constexpr int NPA = 64 / RPP;             // corpus pieces per wave per step: 4 or 8
+  static constexpr int NPA = RW / RPP;             // corpus pieces per wave per step: 4 or 8 (2 or 4 with half tiles)
   static constexpr int SH = STEP == 64 ? 2 : 1;    // swizzle term = (row >> SH) & (LPR - 1)
   static constexpr int NG = STEP / 32;             // 32-byte k slices per step: 2 or 4
-  static constexpr int SLOT_A = BM * STEP;         // 16 or 32 KiB
+  static constexpr int SLOT_A = BMT * STEP;        // 16 or 32 KiB (half tiles: 8 or 16)
   static constexpr int PLANE_B = SQ * STEP;        // one query operand plane, one step
   static constexpr int SLOT_B = PLANES * PLANE_B;
   // ring depth: measured (profiles/r02_mid_batch.md) -- for 32 fp32 queries two workgroups per CU with two slots each beat one
@@ -869,9 +874,10 @@ struct SkinnyGeom {
   static_assert(DR == 0 || STEP == 128, "register staging is built for whole-line steps");
 };
 
-template <typename T, int NI, int STEP, int ABL, bool DEEP = false, int DR = 0>
+template <typename T, int NI, int STEP, int ABL, bool DEEP = false, int DR = 0, bool HALF = false>
 __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) == 2)) ? 1 : 2)) skinny_scan_kernel(const MfmaDeviceParams p) {
-  using G = SkinnyGeom<T, NI, STEP, DEEP, DR>;
+  using G = SkinnyGeom<T, NI, STEP, DEEP, DR, HALF>;
+  constexpr int BMT = G::BMT, RW = G::RW, MI = G::MI;
   constexpr int SQ = G::SQ;
   constexpr bool F32 = G::F32;
   constexpr int RA = G::RA, RB = G::RB, S_SLOT_A = G::SLOT_A, S_SLOT_B = G::SLOT_B, S_B_RING = G::B_RING, S_CTRL = G::CTRL;
@@ -922,7 +928,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
   const char* corpus = reinterpret_cast<const char*>(p.corpus);
   const char* qbase = reinterpret_cast<const char*>(p.queries) + (size_t)qtile * SQ * row_bytes;
   const size_t plane_bytes = (size_t)p.n_qtiles * SQ * row_bytes;  // fp16: the low plane follows the high plane
-  const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BM - 1) / BM) : 0;
+  const int n_tiles = (r_end > r_begin) ? (int)((r_end - r_begin + BMT - 1) / BMT) : 0;
   if (n_tiles == 0) {
     for (int q = wave; q < SQ; q += S_THREADS / 64) {
       const int qg = qtile * SQ + q;
@@ -939,7 +945,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
   auto set_offsets = [&](int64_t row0) {
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
-      const int row = wave * 64 + j * RPP + st_row_in_piece;  // row of the tile: fixes the swizzle term
+      const int row = wave * RW + j * RPP + st_row_in_piece;  // row of the tile: fixes the swizzle term
       int64_t r = row;
       if (row0 + r >= p.rows) r = p.rows - 1 - row0;  // stay in bounds; masked in the epilogue
       st_off[j] = (uint32_t)r * (uint32_t)row_bytes + (uint32_t)((((lane % LPR) ^ ((row >> G::SH) & (LPR - 1)))) * 16);
@@ -975,9 +981,9 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
   };
   auto stage_a = [&]() {
     const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
-    const int64_t src_row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BM;
+    const int64_t src_row0 = (ABL & 4) ? 0 : r_begin + (int64_t)tile * BMT;
     const char* ga = sgpr_ptr(corpus + (size_t)src_row0 * row_bytes + (size_t)st_kt * STEP);
-    unsigned char* la = smem + st_slot * S_SLOT_A + wave * (64 * STEP);
+    unsigned char* la = smem + st_slot * S_SLOT_A + wave * (RW * STEP);
 #pragma unroll
     for (int j = 0; j < NPA; ++j)
       __builtin_amdgcn_global_load_lds((global_void*)(ga + (size_t)st_off[j]), (lds_void*)(la + j * 1024), 16, 0, 0);  // (a non-temporal policy here measured 30 % slower)
@@ -985,7 +991,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
     if (++st_kt == steps_per_tile) {
       st_kt = 0;
       ++st_tile;
-      if (st_tile < n_tiles) set_offsets(r_begin + (int64_t)st_tile * BM);
+      if (st_tile < n_tiles) set_offsets(r_begin + (int64_t)st_tile * BMT);
     }
   };
   auto stage_next = [&]() {
@@ -1011,7 +1017,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
   auto load_regs = [&](auto u_tag) {  // the pieces of the next un-issued K step -> register slot U
     constexpr int U = decltype(u_tag)::value;
     const int tile = st_tile < n_tiles ? st_tile : n_tiles - 1;  // past the end: harmless reloads of the last tile
-    const char* ga = sgpr_ptr(corpus + (size_t)(r_begin + (int64_t)tile * BM) * row_bytes + (size_t)st_kt * STEP);
+    const char* ga = sgpr_ptr(corpus + (size_t)(r_begin + (int64_t)tile * BMT) * row_bytes + (size_t)st_kt * STEP);
 #pragma unroll
     for (int j = 0; j < NPA; ++j) areg[U][j] = *(global_f32x4*)(ga + (size_t)st_off[j]);  // (global, not flat: a flat load counts in lgkmcnt too and cannot be waited for by count)
     if (stages_b) {
@@ -1025,12 +1031,12 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
     if (++st_kt == steps_per_tile) {
       st_kt = 0;
       ++st_tile;
-      if (st_tile < n_tiles) set_offsets(r_begin + (int64_t)st_tile * BM);
+      if (st_tile < n_tiles) set_offsets(r_begin + (int64_t)st_tile * BMT);
     }
   };
   auto commit_regs = [&](auto u_tag, int bslot) {  // register slot U -> LDS, where the LDS-DMA of the other variants would have put it
     constexpr int U = decltype(u_tag)::value;
-    unsigned char* la = smem + wave * (64 * STEP) + lane * 16;
+    unsigned char* la = smem + wave * (RW * STEP) + lane * 16;
 #pragma unroll
     for (int j = 0; j < NPA; ++j) *reinterpret_cast<f32x4*>(la + j * 1024) = areg[U][j];
     if (stages_b) {
@@ -1046,7 +1052,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
   // ---- fragment addresses: row (lane & 31) of a 32-row block, logical 16-byte slot 2 * g + (lane >> 5)
   const int frag_row = lane & 31;
   const uint32_t frag_x = (uint32_t)(((lane >> 5) ^ ((frag_row >> G::SH) & (LPR - 1))) << 4);
-  const uint32_t a_lane = (uint32_t)((wave * 64 + frag_row) * STEP);  // + mi * 32 * STEP
+  const uint32_t a_lane = (uint32_t)((wave * RW + frag_row) * STEP);  // + mi * 32 * STEP
   const uint32_t b_lane = (uint32_t)(S_B_RING + frag_row * STEP);    // + ni * 32 * STEP
 
   // ---- prologue: RA - 1 corpus slabs and RB - 1 query slabs in flight, in the order of the rounds that would have issued them
@@ -1064,11 +1070,11 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
 
   int rd = 0, rd_b = 0;
   for (int tile = 0; tile < n_tiles; ++tile) {
-    const int64_t row0 = r_begin + (int64_t)tile * BM;
-    const bool tile_full = row0 + BM <= r_end;  // wave-uniform: every row of this tile belongs to the row range
-    f32x16 acc[2][NI];
+    const int64_t row0 = r_begin + (int64_t)tile * BMT;
+    const bool tile_full = row0 + BMT <= r_end;  // wave-uniform: every row of this tile belongs to the row range
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -1093,7 +1099,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
       const unsigned char* bbase = smem + rd_b * S_SLOT_B;
 #pragma unroll
       for (int gh = 0; gh < NG / 2; ++gh) {  // two 32-byte k slices at a time
-        f32x4 af[2][2], bf[2][NI], bl[2][NI];
+        f32x4 af[2][MI], bf[2][NI], bl[2][NI];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           const uint32_t kx = (uint32_t)((gh * 2 + g) << 5) ^ frag_x;
@@ -1103,7 +1109,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
             if constexpr (!F32) bl[g][ni] = *reinterpret_cast<const f32x4*>(bbase + (b_lane + kx) + ni * 32 * STEP + G::PLANE_B);
           }
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) af[g][mi] = *reinterpret_cast<const f32x4*>(abase + (a_lane + kx) + mi * 32 * STEP);
+          for (int mi = 0; mi < MI; ++mi) af[g][mi] = *reinterpret_cast<const f32x4*>(abase + (a_lane + kx) + mi * 32 * STEP);
         }
         if constexpr ((ABL & 1) == 0) {
 #pragma unroll
@@ -1112,13 +1118,13 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
 #pragma unroll
               for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                   for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][mi][e], bf[g][ni][e], acc[mi][ni], 0, 0, 0);
             } else {
 #pragma unroll
-              for (int mi = 0; mi < 2; ++mi)
+              for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                   acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[g][mi]), __builtin_bit_cast(f16x8, bl[g][ni]),
@@ -1129,7 +1135,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
             }
           }
         } else {
-          asm volatile("" ::"v"(af[0][0]), "v"(af[1][1]), "v"(bf[0][0]), "v"(bf[1][NI - 1]));
+          asm volatile("" ::"v"(af[0][0]), "v"(af[1][MI - 1]), "v"(bf[0][0]), "v"(bf[1][NI - 1]));
           if constexpr (!F32) asm volatile("" ::"v"(bl[0][0]), "v"(bl[1][NI - 1]));
         }
       }
@@ -1153,7 +1159,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
       const float thr = thr_lds[ql];
       const float thr_pre = fmaf(thr, 2.0f, -1.0f) - 4.8e-7f;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < MI; ++mi) {
         float top = acc[mi][ni][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, acc[mi][ni][r]);
@@ -1161,7 +1167,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
         if constexpr (ABL != 0) asm volatile("" ::"v"(acc[mi][ni]));
         if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
           // (the admission path of the 256-query tile: wave masks in scalar registers, four rows at a time, one LDS atomic per admitted row)
-          const int64_t row_base = row0 + wave * 64 + mi * 32 + 4 * (lane >> 5);
+          const int64_t row_base = row0 + wave * RW + mi * 32 + 4 * (lane >> 5);
           const int64_t left64 = r_end - row_base;
           const int rows_left = tile_full ? 64 : (int)(left64 < 64 ? left64 : 64);
 #pragma unroll
@@ -1180,7 +1186,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
               if (m[j] == 0ull) continue;
               if (((m[j] >> lane) & 1ull) != 0ull && r_off < rows_left) {
                 const int pos = lds_add_rtn(&cnt_lds[ql], 1);
-                if (pos + 1 > CAP - BM) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
+                if (pos + 1 > CAP - BMT) lds_store_i32(need_compact, 1);  // this buffer could overflow on the next tile
                 float s1 = (sc[j] > 0.0f) ? sc[j] : 0.0f;
                 s1 = (s1 > 1.0f) ? 1.0f : s1;
                 if (pos < CAP) {
@@ -1205,7 +1211,7 @@ __global__ void __launch_bounds__(S_THREADS, ((DR >= 4 || (DR == 3 && sizeof(T) 
       TAVB_BARRIER();
       for (int q = wave; q < SQ; q += S_THREADS / 64) {
         const int n = cnt_lds[q];
-        if (n > CAP - BM) {
+        if (n > CAP - BMT) {
           u64* buf = my_cand + (size_t)q * CAP;
           float kth_score;
           const int kept = compact_to_kth<CAP>(buf, n < CAP ? n : CAP, p.k, lane, &kth_score);
@@ -1624,7 +1630,7 @@ bool skinny_supported(int dim, int k, bool f32) {
 }
 
 // Staging variant of the 32/64-query tile (whole-line steps only): 0 = LDS-DMA ring (ships), 1 = deep corpus ring (4 + 3 slots), 4 = register
-// staging four K steps deep.  The two others are measurement variants behind option mfma_sched (8 / 5; 7 = ring, explicitly): with the per-tile
+// staging four K steps deep, 2 = half tiles (128 rows, two or three workgroups per CU).  The others are measurement variants behind option mfma_sched (8 / 5 / 6; 7 = ring, explicitly): with the per-tile
 // drains gone (see the kernel) the ring, the deep ring and register staging 3 / 4 / 6 steps deep all stream 10M x 1536 fp16 rows under 32 queries
 // at 6.4 .. 6.5 TB/s -- 40 .. 240 KiB in flight per CU make no difference, the tile is not short of bytes in flight (profiles/r05_mid_batch.md).
 constexpr int kSkinnyVariantDefault[2] = {0, 0};  // {fp16, fp32}
@@ -1633,7 +1639,7 @@ static bool skinny_line_steps(int dim, bool f32) { return (dim * (f32 ? 4 : 2)) 
 
 static int skinny_variant(int dim, bool f32, int tile, int sched) {
   if (!skinny_line_steps(dim, f32) || sched == 9 || sched == 7) return 0;
-  int v = sched == 8 ? 1 : sched == 5 ? 4 : kSkinnyVariantDefault[f32 ? 1 : 0];
+  int v = sched == 8 ? 1 : sched == 5 ? 4 : sched == 6 ? 2 : kSkinnyVariantDefault[f32 ? 1 : 0];
   if (tile != 32 && v != 0) v = 0;  // (the 64-query tile keeps the ring)
   const int steps = dim * (f32 ? 4 : 2) / 128;
   if (v >= 3 && steps % v != 0) v = 0;  // a tile starts on register slot 0
@@ -1644,6 +1650,7 @@ static int skinny_wg_per_cu(int dim, bool f32, int tile, int sched) {
   const bool line = skinny_line_steps(dim, f32);
   const int v = skinny_variant(dim, f32, tile, sched);
   if (v == 1 || v >= 4) return 1;
+  if (v == 2) return f32 ? 3 : 2;  // half tiles: 72 KiB (fp16) / 40 KiB (fp32) of LDS per workgroup
   if (f32) {
     if (tile == 64) return line ? SkinnyGeom<float, 2, 128>::WG_PER_CU : SkinnyGeom<float, 2, 64>::WG_PER_CU;
     return line ? SkinnyGeom<float, 1, 128>::WG_PER_CU : SkinnyGeom<float, 1, 64>::WG_PER_CU;
@@ -1702,6 +1709,9 @@ hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
     case 1:
       return f32 ? go(skinny_scan_kernel<float, 1, 128, 0, true>, SkinnyGeom<float, 1, 128, true>::LDS)
                  : go(skinny_scan_kernel<_Float16, 1, 128, 0, true>, SkinnyGeom<_Float16, 1, 128, true>::LDS);
+    case 2:
+      return f32 ? go(skinny_scan_kernel<float, 1, 128, 0, false, 0, true>, SkinnyGeom<float, 1, 128, false, 0, true>::LDS)
+                 : go(skinny_scan_kernel<_Float16, 1, 128, 0, false, 0, true>, SkinnyGeom<_Float16, 1, 128, false, 0, true>::LDS);
     case 4:
       return f32 ? go(skinny_scan_kernel<float, 1, 128, 0, false, 4>, SkinnyGeom<float, 1, 128, false, 4>::LDS)
                  : go(skinny_scan_kernel<_Float16, 1, 128, 0, false, 4>, SkinnyGeom<_Float16, 1, 128, false, 4>::LDS);
