@@ -4,6 +4,7 @@
 #   suite            the whole `-m gpu` test suite (-x)                          -> gpu_suite.log
 #   tests:EXPR       pytest -m gpu -k EXPR                                       -> gpu_tests.log
 #   opttests:OPTS:EXPR  the same under TAVB_ENGINE_OPTIONS=OPTS (every engine of the test process gets those options)   -> gpu_opttests.log
+#   fuzz:BASES       tests/test_gpu_fuzz.py once per seed base of the comma-separated list (TAVB_FUZZ_BASE)             -> fuzz_<base>.log
 #   smoke            __graft_entry__.smoke()
 #   bench            the driver's command (bench.py --gpus 1 --steps 20 --warmup 5) + a digest of the line  -> bench_default.json
 #   dist1            the N > 1 code path on a one-rank communicator (TAVB_BENCH_FORCE_DIST=1)               -> bench_dist1.json
@@ -53,6 +54,7 @@ for step in "$@"; do
     suite) timeout 1700 python -m pytest tests -q -m gpu -x > $O/gpu_suite.log 2>&1; echo "suite rc=$?"; tail -4 $O/gpu_suite.log ;;
     tests) timeout 1200 python -m pytest tests -q -m gpu -x -k "$arg" > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -15 $O/gpu_tests.log ;;
     opttests) TAVB_ENGINE_OPTIONS="${arg%%:*}" timeout 1200 python -m pytest tests -q -m gpu -x -k "${arg#*:}" > $O/gpu_opttests.log 2>&1; echo "opttests(${arg%%:*}) rc=$?"; tail -6 $O/gpu_opttests.log ;;
+    fuzz) for b in ${arg//,/ }; do TAVB_FUZZ_BASE=$b timeout 900 python -m pytest tests/test_gpu_fuzz.py -q -m gpu > $O/fuzz_$b.log 2>&1; echo "fuzz base $b rc=$? $(tail -1 $O/fuzz_$b.log)"; done ;;
     smoke) timeout 180 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     bench)
       timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
