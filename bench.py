@@ -1096,6 +1096,7 @@ def main() -> None:
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="--gpus N > 1: split the same corpus (strong) or 12.5M rows per GPU (weak, cfg4)")
     ap.add_argument("--rows", type=int, default=None, help="override the row count (debugging)")
     ap.add_argument("--queries", type=int, default=None, help="override the queries per step (debugging)")
+    ap.add_argument("--dim", type=int, default=None, help="override the row width (debugging: widths that are not a multiple of 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="north-star suite: headline only")
@@ -1133,6 +1134,8 @@ def main() -> None:
         wl["rows"] = args.rows
     if args.queries:
         wl["nq"] = args.queries
+    if args.dim:
+        wl["dim"] = args.dim
     weak = (name == "cfg4") or (ctx.world > 1 and args.scaling == "weak")
     scaling = "weak" if weak else "strong"
     if ctx.world == 1:

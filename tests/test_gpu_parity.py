@@ -1316,10 +1316,12 @@ def test_wide_tile_row_norm_cache_follows_appends_and_rewrites():
 # rescored with the fp32 rows and fp32 queries (tavb_rescore.hip) -- same answers as the single-query fp32 kernels
 # --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
-@pytest.mark.parametrize("d,tier", [(64, 4), (768, 4), (3072, 4), (4096, 4), (1000, None), (96, None)])
-def test_wide_tile_other_dimensions(dtype, d, tier):
-    """The 128/256-query tile takes any D that is a multiple of 64 (K steps of whole 128-byte lines); other widths fall back to
-    the 32/64-query tile (D % 32 == 0 on fp16, % 16 on fp32) or the streaming tiers.  130 queries: one 256-query tile."""
+@pytest.mark.parametrize("d", [64, 768, 3072, 4096, 1000, 96, 1008, 1004])
+def test_wide_tile_other_dimensions(dtype, d):
+    """The 128/256-query tile takes any D that is a multiple of 64 (K steps of whole 128-byte lines) directly and, since round 5, other widths
+    on a zero-padded fp16 copy of the rows (the filter's operand; candidates are rescored with the corpus' own rows): multiples of 8 on fp16
+    corpora, multiples of 16 on fp32 ones (their exact fallback tile reads the fp32 rows).  What is left (1004; 1000 on fp32) falls back to the
+    32/64-query tile or the streaming tiers.  130 queries: one 256-query tile."""
     n, nq, k = 20_011, 130, 32
     v, _ = make_corpus(n, d, 9900 + d)
     qs = make_queries(nq, d, 9901 + d)
@@ -1327,12 +1329,49 @@ def test_wide_tile_other_dimensions(dtype, d, tier):
     vb = new_vb(v, dtype=dtype)
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     t = vb.engine.get_option("last_tier")
-    assert t == tier if tier else t in (1, 2, 3, 5)
+    wide = d % 64 == 0 or (d % 8 == 0 if dtype == "fp16" else d % 16 == 0)
+    assert t == 4 if wide else t in (1, 2, 3, 5), (d, dtype, t)
     ref_v = v if dtype == "fp32" else _f16(v)
     for qi in range(0, nq, 9):
         rep = vo.check_topk_parity(vo.scores_full(ref_v, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(ref_v, qs[qi]))
         assert rep.tie_permuted_positions <= 2
+        if wide:  # rescored with the streaming kernels' arithmetic: a batch is its sequential lookups, bit for bit
+            seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=0.0)
+            assert [(r.item, r.score) for r in out[qi]] == [(r.item, r.score) for r in seq], (d, dtype, qi)
     assert out[3][0].item == n - 1
+    # appended rows reach the padded copy too
+    if wide and d % 64 != 0:
+        extra, _ = make_corpus(300, d, 9950 + d)
+        vb.add_embeddings(None, extra)
+        qs2 = qs.copy()
+        qs2[7] = extra[123]
+        out2 = vb.fuzzy_lookup_embeddings(qs2, max_hits=k, min_score=0.0)
+        assert vb.engine.get_option("last_tier") == 4 and out2[7][0].item == n + 123
+        ref2 = np.concatenate([ref_v, extra if dtype == "fp32" else _f16(extra)])
+        vo.check_topk_parity(vo.scores_full(ref2, qs2[7]), *items_scores(out2[7]), k, 0.0, referee=vo.f64_referee(ref2, qs2[7]))
+
+
+@pytest.mark.parametrize("nq,k", [(130, 32), (300, 100)])
+def test_wide_tile_odd_width_with_a_band_that_does_not_fit(nq, k):
+    """D = 1000 on an fp16 corpus with 1300 near-duplicates around one query: its band overflows, the query is flagged and re-run exactly -- by the
+    64-query split-plane tile (k <= 64) or the wide split-plane form (k = 100), both over the zero-padded copy of the rows (the same fp16 values)
+    -- and rescored with the corpus' own rows: the oracle's answer."""
+    n, d = 60_000, 1000
+    v, _ = make_corpus(n, d, 8740 + k)
+    qs = make_queries(nq, d, 8741 + k)
+    rng = np.random.default_rng(8742)
+    dup = rng.choice(n, size=1300, replace=False)
+    _plant_near_duplicates(v, qs, 3, dup, rng)
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert eng.get_option("last_tier") == 4
+    assert 1 <= eng.get_option("last_flagged") <= 3
+    v16 = _f16(v)
+    for qi in sorted(set([0, 3, 4, nq // 2, nq - 1])):
+        assert len(out[qi]) == k
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
+    assert set(r.item for r in out[3]) <= set(dup.tolist())
 
 
 @pytest.mark.parametrize("nq", [65, 128, 300, 1024])

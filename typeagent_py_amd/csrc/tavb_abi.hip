@@ -125,7 +125,9 @@ struct tavb_ctx {
   Buffer d_delta, d_approx, d_flag, d_fb_queries, d_norm;  // exact rescoring of the 256-query tile (tavb_rescore.hip)
   Buffer d_minscores;      // per-query thresholds of a batch on the device: [nq_pad] min_scores, then [nq_pad] exclusive admission floors (the tile paths)
   Buffer d_fb_cand;        // what the 64-query exact tile ranked highest for the flagged queries: [slots][64] keys, rescored into the callers' rows
-  Buffer d_shadow;         // fp32 corpora: fp16 shadow copy of rows [0, norm_rows), the filter operand of the 128/256-query tile
+  Buffer d_shadow;         // fp32 corpora (and fp16 ones whose width is not a multiple of 64): fp16 copy of rows [0, norm_rows), each padded with zeros to a
+                           // multiple of 64 halves -- the filter operand of the 128/256-query tile
+  Buffer d_queries_pad;    // the queries of a batch zero-padded to that width (odd widths only)
   int64_t f32_shadow = 1;  // option: 1 = batches of mfma_min_batch+ queries on fp32 corpora go through that shadow (+50 % HBM); 2 = every lookup on
                            // fp32 corpora of f32_shadow_min_bytes and more (half the bytes per pass); 0 = never
   int64_t f32_shadow_min_bytes = (int64_t)2 << 30;  // level 2 only: fp32 corpora from this size up (below it the extra launches cost more than half a pass saves)
@@ -591,7 +593,7 @@ int tavb_set_corpus(tavb_ctx* c, const void* dev_rows, int64_t rows, int32_t dim
   if (rows >= 0x7FFFFFFFll) return fail(TAVB_E_UNSUPPORTED, "at most 2^31-2 rows per device shard (got %lld)", (long long)rows);
   if (ordinal_base < 0) return fail(TAVB_E_INVALID, "ordinal_base must be >= 0");
   if (dev_rows != c->corpus || dim != c->dim || dtype != c->dtype || rows < c->norm_rows) c->norm_rows = 0;  // cached row-norm maximum: keep it across appends only
-  if (dtype != TAVB_F32 || rows == 0) c->d_shadow.release();  // the fp16 shadow belongs to an fp32 corpus
+  if ((dtype != TAVB_F32 && dim % 64 == 0) || rows == 0) c->d_shadow.release();  // the fp16 shadow belongs to an fp32 corpus, or to an fp16 one of an odd width
   c->corpus = dev_rows;
   c->rows = rows;
   c->dim = dim;
@@ -1468,6 +1470,7 @@ struct TileRun {
   const float* floor;     // optional device [nq_pad]: per-query exclusive admission thresholds valid from the first row on
   const void* queries;    // operand in the kernel's layout
   const void* corpus;     // corpus operand (nullptr: the context's corpus; the fp16 shadow of an fp32 corpus for the filter pass)
+  int dim;                // halves / floats per row of that operand and of `queries` (0: the context's dim; the zero-padded width of a shadow whose corpus is not a multiple of 64 wide)
   const int* active;      // optional device-side live-query count (fixed-shape launch over a work list)
   int active_min, active_max;  // ... served only when active_min < *active <= active_max (0 = no upper bound): two fallbacks share one list
   bool bdirect;           // 256-query tile: `queries` are in fragment-major order (straight from L2 into registers)
@@ -1544,8 +1547,9 @@ std::vector<int64_t> ladder_bounds(int64_t rows, int splits, int nq_pad, bool sk
 // not depend on the phase boundaries.  Output: sorted key lists [nq, k] at `d_out` (or, with `scatter`, rows
 // scatter[slot] of it for the slots below *active; a work-list run of the wide tile rescoring its band first: TileRun::rs_queries).
 int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scatter, bool scatter_identity = false) {
+  const int dim = r.dim > 0 ? r.dim : c->dim;  // of the tile's operands (the candidates' ordinals are the corpus' own either way)
   auto pick_splits = [&](int64_t rows) {
-    return r.skinny ? tavb::skinny_pick_splits(rows, r.nq_pad, r.qt, c->n_cu, c->dim, r.q32, (int)c->mfma_sched) : tavb::mfma_pick_splits(rows, r.nq_pad, r.qt, c->n_cu);
+    return r.skinny ? tavb::skinny_pick_splits(rows, r.nq_pad, r.qt, c->n_cu, dim, r.q32, (int)c->mfma_sched) : tavb::mfma_pick_splits(rows, r.nq_pad, r.qt, c->n_cu);
   };
   auto launch = [&](const tavb::MfmaParams& q) { return r.skinny ? tavb::launch_skinny_scan(q, c->stream) : tavb::launch_mfma_scan(q, c->stream); };
   const int nq = r.nq, k = r.k;
@@ -1563,7 +1567,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.workspace = reinterpret_cast<u64_t*>(c->d_cand.ptr);
   p.counts = reinterpret_cast<int*>(c->d_counts.ptr);
   p.rows = c->rows;
-  p.dim = c->dim;
+  p.dim = dim;
   p.nq = nq;
   p.nq_padded = r.nq_pad;
   p.k = k;
@@ -1590,7 +1594,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.band = r.band;
   p.lost = r.lost;
   const float* floor = r.floor;  // per-query thresholds valid for every row
-  const size_t row_bytes = (size_t)c->dim * (r.q32 ? 4 : 2);  // of the corpus operand
+  const size_t row_bytes = (size_t)dim * (r.q32 ? 4 : 2);  // of the corpus operand
   for (int ph = 0; ph < n_phases; ++ph) {
     const bool last = (ph == n_phases - 1);
     tavb::MfmaParams pp = p;
@@ -1718,6 +1722,13 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
   // as the data makes it, up to kBandMax), the 32/64-query tile (`small`) the best 64 by approximate score
   const int KC = small ? 64 : tavb::kBandMax;
   const bool f32c = (c->dtype == TAVB_F32);
+  // a corpus whose width is not a multiple of 64 (the tile's K step is a whole 128-byte line): the filter -- and, on fp16 corpora, the exact
+  // fallbacks -- read a zero-padded fp16 copy of the rows (d_shadow, `fdim` halves per row; for fp32 corpora the shadow they have anyway) and a
+  // zero-padded copy of the queries: zeros add nothing to a dot product or a norm, the delta bound is unchanged.  The candidates are rescored
+  // with the corpus' own rows and the callers' own queries.
+  const bool padded = !small && (c->dim % 64 != 0);
+  const int fdim = padded ? ((c->dim + 63) / 64) * 64 : c->dim;
+  const bool shadow_ops = f32c || padded;  // the filter's corpus operand is d_shadow
   const bool big_k = k > 64;  // beyond what the 64-query exact tile ranks: every flagged query goes to the wide split-plane form (fp16 corpora only: the caller checked)
   const int qt = small ? tavb::skinny_query_tile(nq) : (c->mfma_tile > 0 ? (int)c->mfma_tile : tavb::mfma_query_tile(nq));
   const int nq_pad = ((nq + qt - 1) / qt) * qt;
@@ -1730,12 +1741,20 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
   const bool wide_fallback = !small && !f32c && c->wide_fallback && (nq >= 256 || big_k);
   if (big_k && !wide_fallback) return fail(TAVB_E_UNSUPPORTED, "k > 64 on the batched tile needs an fp16 corpus and the wide_fallback option");
   const int cap = wide_fallback ? ((nq + 255) / 256) * 256 : ((nq + 63) / 64) * 64;  // slots of the work list
-  const size_t q16_bytes = (size_t)nq_pad * c->dim * 2 * (small ? 2 : 1);  // small: high and low plane
+  const size_t q16_bytes = (size_t)nq_pad * fdim * 2 * (small ? 2 : 1);  // small: high and low plane
   if (int rc = c->d_queries_f16.reserve(q16_bytes)) return rc;
   if (int rc = c->d_delta.reserve((size_t)nq_pad * 6 * sizeof(float))) return rc;  // delta, the relaxed thresholds, the band widths; band counts, lost levels, verdicts
   if (int rc = c->d_approx.reserve((size_t)nq * KC * sizeof(u64_t))) return rc;
   if (int rc = c->d_flag.reserve((size_t)(cap + 64) * sizeof(int))) return rc;
-  if (int rc = c->d_fb_queries.reserve((size_t)2 * cap * c->dim * 2 + (size_t)2 * cap * sizeof(float))) return rc;  // + per-slot thresholds, per-slot band widths
+  if (int rc = c->d_fb_queries.reserve((size_t)2 * cap * fdim * 2 + (size_t)2 * cap * sizeof(float))) return rc;  // + per-slot thresholds, per-slot band widths
+  const float* fq = d_q;  // the queries as the filter and the padded fallbacks read them
+  if (padded) {
+    if (int rc = c->d_queries_pad.reserve((size_t)nq * fdim * sizeof(float))) return rc;
+    TAVB_HIP(hipMemsetAsync(c->d_queries_pad.ptr, 0, (size_t)nq * fdim * sizeof(float), c->stream));
+    TAVB_HIP(hipMemcpy2DAsync(c->d_queries_pad.ptr, (size_t)fdim * sizeof(float), d_q, (size_t)c->dim * sizeof(float), (size_t)c->dim * sizeof(float), (size_t)nq,
+                              hipMemcpyDeviceToDevice, c->stream));
+    fq = reinterpret_cast<const float*>(c->d_queries_pad.ptr);
+  }
   if (!big_k)
     if (int rc = c->d_fb_cand.reserve((size_t)cap * 64 * sizeof(u64_t))) return rc;
   if (int rc = c->d_norm.reserve(256)) return rc;
@@ -1759,18 +1778,27 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
     }
     if (c->norm_rows < c->rows) {  // rows appended since: extend the maxima (and the shadow)
       hipError_t e;
-      if (f32c)
-        e = tavb::launch_shadow_convert(reinterpret_cast<const float*>(c->corpus) + (size_t)c->norm_rows * c->dim, c->rows - c->norm_rows, c->dim,
-                                        reinterpret_cast<char*>(c->d_shadow.ptr) + (size_t)c->norm_rows * c->dim * 2, d_norm, c->stream);
-      else
+      const int sdim = ((c->dim + 63) / 64) * 64;  // halves per shadow row
+      char* shadow_new = c->d_shadow.ptr ? reinterpret_cast<char*>(c->d_shadow.ptr) + (size_t)c->norm_rows * sdim * 2 : nullptr;
+      if (f32c) {
+        e = tavb::launch_shadow_convert(reinterpret_cast<const float*>(c->corpus) + (size_t)c->norm_rows * c->dim, c->rows - c->norm_rows, c->dim, shadow_new, sdim,
+                                        d_norm, c->stream);
+      } else {
         e = tavb::launch_corpus_max_norm(reinterpret_cast<const char*>(c->corpus) + (size_t)c->norm_rows * c->dim * 2, c->rows - c->norm_rows, c->dim,
                                          d_norm, c->stream);
+        if (e == hipSuccess && padded) {  // fp16 rows of an odd width: the same values, rows zero-padded to whole K steps
+          const size_t n_new = (size_t)(c->rows - c->norm_rows);
+          TAVB_HIP(hipMemsetAsync(shadow_new, 0, n_new * sdim * 2, c->stream));
+          TAVB_HIP(hipMemcpy2DAsync(shadow_new, (size_t)sdim * 2, reinterpret_cast<const char*>(c->corpus) + (size_t)c->norm_rows * c->dim * 2, (size_t)c->dim * 2,
+                                    (size_t)c->dim * 2, n_new, hipMemcpyDeviceToDevice, c->stream));
+        }
+      }
       if (e != hipSuccess) return fail(TAVB_E_HIP, "corpus norm / shadow launch failed: %s", hipGetErrorString(e));
       c->norm_rows = c->rows;
     }
     TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16_bytes, c->stream));  // padding queries
     TAVB_HIP(hipMemsetAsync(d_band, 0, (size_t)nq_pad * 4 * sizeof(float), c->stream));  // band widths of the padding queries, counts, lost levels, verdicts
-    hipError_t e = tavb::launch_query_prepare(d_q, nq, c->dim, d_ms, small, d_norm, small ? nullptr : c->d_queries_f16.ptr, d_delta, d_floor,
+    hipError_t e = tavb::launch_query_prepare(fq, nq, fdim, d_ms, small, d_norm, small ? nullptr : c->d_queries_f16.ptr, d_delta, d_floor,
                                               small ? nullptr : d_band, c->stream, bdirect);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "query prepare launch failed: %s", hipGetErrorString(e));
     if (small) {
@@ -1794,7 +1822,8 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
   filt.floor = d_floor;
   filt.bdirect = bdirect;
   filt.queries = c->d_queries_f16.ptr;
-  filt.corpus = f32c ? c->d_shadow.ptr : nullptr;
+  filt.corpus = shadow_ops ? c->d_shadow.ptr : nullptr;
+  filt.dim = fdim;
   filt.ladder = true;
   // a batch MOST of whose bands are not going to fit (every query next to more near-duplicates than a band holds) is found out before the last --
   // the big -- filter phase and goes straight to the exact split-plane form: the filter's last phase, its selection and the rescoring return at once
@@ -1802,7 +1831,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
   TAVB_HIP(hipMemsetAsync(d_nflag, 0, 64 * sizeof(int), c->stream));
   filt.doomed = early ? d_nflag + 1 : nullptr;
   filt.doomed_max = nq / 2;
-  c->last_shadow = f32c ? 1 : 0;
+  c->last_shadow = shadow_ops ? 1 : 0;
   if (int rc = run_tile_ladder(c, filt, reinterpret_cast<u64_t*>(c->d_approx.ptr), nullptr)) return rc;
   char* fb = reinterpret_cast<char*>(c->d_fb_queries.ptr);
   float* fb_thr = reinterpret_cast<float*>(fb + (size_t)2 * cap * c->dim * 2);
@@ -1813,8 +1842,10 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
                                         small ? nullptr : d_band_cnt, small ? nullptr : d_verdict, d_delta, d_ms, nq, k, d_out, d_nflag, d_flagged,
                                         c->stream, filt.doomed, filt.doomed_max);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "rescore launch failed: %s", hipGetErrorString(e));
+    // (the exact tiles of an fp32 corpus read its own rows -- the dispatch admits only widths they take; those of an fp16 corpus of an odd
+    //  width read the padded copy, which holds the same values)
     e = f32c ? tavb::launch_gather_flagged_f32(d_q, c->dim, d_ms, d_nflag, d_flagged, cap, reinterpret_cast<float*>(fb), fb_thr, c->stream)
-             : tavb::launch_gather_flagged(d_q, c->dim, d_ms, d_nflag, d_flagged, cap, fb, fb + (size_t)cap * c->dim * 2, fb_thr, c->stream);
+             : tavb::launch_gather_flagged(fq, fdim, d_ms, d_nflag, d_flagged, cap, fb, fb + (size_t)cap * fdim * 2, fb_thr, c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "gather launch failed: %s", hipGetErrorString(e));
     if (wide_fallback) {
       e = tavb::launch_fill_f32(fb_band, cap, kExactBand, c->stream);
@@ -1836,6 +1867,10 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
       ex.kernel_min_score = ms_lo;
       ex.floor = fb_thr;
       ex.queries = fb;
+      if (!f32c && padded) {
+        ex.corpus = c->d_shadow.ptr;
+        ex.dim = fdim;
+      }
       ex.active = d_nflag;
       ex.active_min = 0;
       ex.active_max = wide_fallback ? 64 : 0;
@@ -1860,7 +1895,11 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
       wx.floor = fb_thr;  // (+inf for the unused slots: they admit nothing)
       wx.band = fb_band;  // kExactBand below the k-th best: what the rescoring re-orders
       wx.queries = fb;    // [2][cap][dim]: the high plane, then the low plane
-      wx.split_plane = (int64_t)cap * c->dim * 2;
+      wx.split_plane = (int64_t)cap * fdim * 2;
+      if (padded) {
+        wx.corpus = c->d_shadow.ptr;
+        wx.dim = fdim;
+      }
       wx.active = d_nflag;
       wx.active_min = big_k ? 0 : 64;
       wx.active_max = 0;
@@ -1886,14 +1925,21 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   const bool f16c = (c->dtype == TAVB_F16);
   // the wide tile keeps a band below the k-th best (any k the fused selections serve: the reference's max_matches = 50, convsettings.py:61-63,
   // included).  Its flagged queries need an exact tile: the 64-query one up to k = 64, beyond that the wide split-plane form (fp16 corpora).
-  const bool exact_tile = (k <= 64) ? tavb::skinny_supported(c->dim, k, !f16c) : (f16c && c->wide_fallback != 0);
-  bool wide = (f16c || c->f32_shadow) && c->corpus && nq >= c->mfma_min_batch && tavb::mfma_supported(c->dim, k) && c->rows > 0 && exact_tile;
+  // A width that is not a multiple of 64 (the tile's K step) rides the wide tile on a zero-padded copy of the rows (search_wide_exact): any
+  // multiple of 8 on fp16 corpora (the exact fallbacks read the padded copy too: the same values), multiples of 16 on fp32 ones (their exact
+  // tile reads the corpus' own fp32 rows).
+  const bool odd_width = c->dim % 64 != 0;
+  const int wide_dim = ((c->dim + 63) / 64) * 64;
+  const bool width_ok = !odd_width || (c->dim % 8 == 0 && (f16c || c->dim % 16 == 0));
+  const bool exact_tile = (k <= 64) ? ((f16c && odd_width) ? tavb::skinny_supported(wide_dim, k, false) : tavb::skinny_supported(c->dim, k, !f16c))
+                                    : (f16c && c->wide_fallback != 0);
+  bool wide = (f16c || c->f32_shadow) && c->corpus && nq >= c->mfma_min_batch && width_ok && tavb::mfma_supported(wide_dim, k) && c->rows > 0 && exact_tile;
   // f32_shadow = 2: smaller batches (and single queries) on big fp32 corpora filter on the shadow too, with the 32/64-query tile
   // (it keeps the best 64 candidates per query: k up to 48 leaves the slack the completeness test needs)
   bool shadow_small = !wide && !f16c && c->f32_shadow >= 2 && c->corpus && nq <= 64 && tavb::mfma_supported(c->dim, 64) && k <= 48 &&
                       tavb::skinny_supported(c->dim, k, false) && (int64_t)c->rows * c->dim * 4 >= c->f32_shadow_min_bytes;
-  if ((wide || shadow_small) && !f16c) {  // fp32 corpus: the filter needs the fp16 shadow; without the memory for it the fp32 kernels serve the batch
-    const size_t need = (size_t)c->rows * c->dim * 2;
+  if ((wide || shadow_small) && (!f16c || odd_width)) {  // the filter needs the fp16 shadow / padded copy; without the memory for it the other kernels serve the batch
+    const size_t need = (size_t)c->rows * wide_dim * 2;
     if (c->d_shadow.cap < need) {
       c->norm_rows = 0;  // reserve() does not keep the old contents
       if (c->d_shadow.reserve(need) != TAVB_OK) wide = shadow_small = false;

@@ -82,7 +82,7 @@ hipError_t launch_rescore_slots(const void* corpus, bool f32_rows, int dim, uint
                                 int stride, const int* cand_cnt, const float* min_scores, int n_slots, int k, unsigned long long* out,
                                 const int* slot_query, const int* slot_active, int slot_min, int slot_max, hipStream_t stream);
 // (gate: device-side counter; when *gate > gate_max there are no candidates -- the last filter phase was skipped -- and EVERY query is flagged)
-hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, float* stats /*[2]*/, hipStream_t stream);
+hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, int out_pitch /*halves per shadow row*/, float* stats /*[2]*/, hipStream_t stream);
 hipError_t launch_gather_flagged_f32(const float* queries, int dim, const float* min_scores, const int* n_flagged, const int* flagged, int cap, float* out,
                                      float* thr, hipStream_t stream);
 hipError_t launch_gather_flagged(const float* queries, int dim, const float* min_scores, const int* n_flagged, const int* flagged, int cap, void* hi, void* lo,

@@ -72,16 +72,17 @@ __global__ void __launch_bounds__(256) corpus_max_norm_kernel(const _Float16* __
 
 // fp32 rows -> fp16 shadow rows, and the two maxima the bound needs: stats[0] = max sum(x16^2), stats[1] = max sum((x - x16)^2).
 // A non-finite row makes the maxima +inf (every query then takes the exact path).  One wave per row.
-__global__ void __launch_bounds__(256) shadow_convert_kernel(const float* __restrict__ rows, int64_t n, int dim, _Float16* __restrict__ out,
+__global__ void __launch_bounds__(256) shadow_convert_kernel(const float* __restrict__ rows, int64_t n, int dim, _Float16* __restrict__ out, int out_pitch,
                                                              float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  const int n4 = dim / 4;  // dim % 64 == 0 on this path
+  const int n4 = dim / 4;  // dim % 4 == 0 on this path; out_pitch (>= dim, a multiple of 64) = halves per shadow row, the tail zero
   float best16 = 0.f, best_err = 0.f;
   for (int64_t r = wave; r < n; r += n_waves) {
     const f32x4* x = reinterpret_cast<const f32x4*>(rows + r * (int64_t)dim);
-    _Float16* y = out + r * (int64_t)dim;
+    _Float16* y = out + r * (int64_t)out_pitch;
+    for (int i = dim + lane; i < out_pitch; i += 64) y[i] = (_Float16)0.0f;
     float ss = 0.f, se = 0.f;
     for (int i = lane; i < n4; i += 64) {
       const f32x4 v = __builtin_nontemporal_load(x + i);
@@ -351,11 +352,11 @@ hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, floa
   return hipGetLastError();
 }
 
-hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, float* stats, hipStream_t stream) {
+hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, int out_pitch, float* stats, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   int64_t blocks = (n + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL(shadow_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rows_f32, n, dim, reinterpret_cast<_Float16*>(out_f16), stats);
+  hipLaunchKernelGGL(shadow_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rows_f32, n, dim, reinterpret_cast<_Float16*>(out_f16), out_pitch, stats);
   return hipGetLastError();
 }
 
