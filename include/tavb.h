@@ -76,11 +76,11 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "scan_nt"       1 = non-temporal corpus loads (default 1)
  *   "scan_pipe"     1 = software-prefetch next rows before reducing current ones
  *   "force_tier"    0 = auto, 1 = fixed-D kernel, 2 = vector kernel, 3 = scalar kernel
- *   "mfma_min_batch" smallest batch routed to the 256-query MFMA tile on f16 corpora (default 65; dim % 64 == 0 directly, other widths -- multiples of 8 on
+ *   "mfma_min_batch" smallest batch routed to the 128/256-query MFMA tile (default 33; dim % 64 == 0 directly, other widths -- multiples of 8 on
  *                   fp16 corpora, of 16 on fp32 ones -- on a zero-padded fp16 copy of the rows (+ device memory: rows x pad64(dim) x 2 bytes); k up to 64 on fp32 corpora
  *                   (through their fp16 shadow), up to TAVB_MAX_FUSED_K on fp16 ones; thresholds may differ per query)
  *   "skinny_min_batch_f32" / "skinny_min_batch_f16"  smallest batch routed to the 32/64-query MFMA tile on fp32 / fp16
- *                   corpora (defaults 5 / 3, the measured break-even; fp32 corpora have no other matrix-core path, fp16 ones use it up to
+ *                   corpora (defaults 5 / 3, the measured break-even; used up to
  *                   mfma_min_batch - 1); smaller batches use the streaming tiers
  *   "mfma_sample_rows", "mfma_ladder"  phases of the MFMA paths' threshold ladder: rows of the first phase (0 = auto: one
  *                   tile per workgroup; -1 = a single phase, no seeding) and the growth factor of the following ones

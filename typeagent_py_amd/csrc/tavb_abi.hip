@@ -110,7 +110,10 @@ struct tavb_ctx {
   int64_t ordinal_base = 0;
 
   tavb::ScanGeometry geom{0, 16, 2, 1, 0, 0};
-  int64_t mfma_min_batch = 65;  // fp16 corpora: batches from this size up use the 256-query tile (3 .. 64 the 32/64-query tile)
+  // batches from this size up use the 128/256-query tile + rescoring (smaller ones the 32/64-query tile).  33 since round 5 (was 65): padded to
+  // 128 queries the wide tile serves 33 / 48 / 64 queries over 10M fp16 rows in 5.42 / 5.48 / 5.46 ms against 5.54 / 5.81 / 5.91 ms on the
+  // 64-query split-plane tile, and 64 queries over 1M fp32 rows (through the fp16 shadow) in 0.85 ms against 2.17 ms (profiles/r05_raw/b64.txt)
+  int64_t mfma_min_batch = 33;
   int64_t mfma_splits = 0;  // 0 = auto
   int64_t mfma_ablate = 0;
   int64_t mfma_sched = 0;
