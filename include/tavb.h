@@ -76,7 +76,7 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "scan_nt"       1 = non-temporal corpus loads (default 1)
  *   "scan_pipe"     1 = software-prefetch next rows before reducing current ones
  *   "force_tier"    0 = auto, 1 = fixed-D kernel, 2 = vector kernel, 3 = scalar kernel
- *   "mfma_min_batch" smallest batch routed to the 128/256-query MFMA tile (default 33; dim % 64 == 0 directly, other widths -- multiples of 8 on
+ *   "mfma_min_batch" smallest batch routed to the 128/256-query MFMA tile (default 65; on corpora of "mfma_big_bytes" (default 256 MiB) or more: "mfma_min_batch_big", default 33; dim % 64 == 0 directly, other widths -- multiples of 8 on
  *                   fp16 corpora, of 16 on fp32 ones -- on a zero-padded fp16 copy of the rows (+ device memory: rows x pad64(dim) x 2 bytes); k up to 64 on fp32 corpora
  *                   (through their fp16 shadow), up to TAVB_MAX_FUSED_K on fp16 ones; thresholds may differ per query)
  *   "skinny_min_batch_f32" / "skinny_min_batch_f16"  smallest batch routed to the 32/64-query MFMA tile on fp32 / fp16

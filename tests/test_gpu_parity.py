@@ -873,7 +873,7 @@ def test_mfma_tile_against_the_exact_tile_on_a_large_corpus():
 @pytest.mark.parametrize("nq", [64, 65, 100, 128, 129, 256, 1024])
 def test_batch_equals_sequential_for_arbitrary_fp32_queries_on_fp16_corpus(nq):
     """`fuzzy_lookup_embeddings(E) == [fuzzy_lookup_embedding(e) for e in E]` at every batch size, for queries that are NOT
-    fp16-representable: 33 .. 128 queries ride the 128-query tile and 129+ the 256-query
+    fp16-representable: 64 rides the 64-query tile (split hi/lo planes), 65 .. 128 the 128-query tile and 129+ the 256-query
     tile, both + fp32 rescoring.  The
     sequential answers come from the streaming kernel (fp32 query x fp16 row), both are checked against the oracle."""
     v, _ = make_corpus(30_011, 1536, 7200)
@@ -881,7 +881,7 @@ def test_batch_equals_sequential_for_arbitrary_fp32_queries_on_fp16_corpus(nq):
     assert np.any(_f16(qs) != qs)
     vb = new_vb(v, dtype="fp16")
     batch = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
-    assert vb.engine.get_option("last_tier") == (4 if nq >= 33 else 5)
+    assert vb.engine.get_option("last_tier") == (4 if nq >= 65 else 5)
     v16 = _f16(v)
     sample = sorted(set(np.linspace(0, nq - 1, 24).astype(int).tolist()))
     for qi in sample:
@@ -1208,7 +1208,7 @@ def test_unused_slots_of_the_wide_fallback_admit_nothing():
 @pytest.mark.parametrize("nq", [24, 40, 130, 1024])
 def test_per_query_thresholds_ride_the_tiles(nq):
     """A batch whose `min_score`s differ per query (Q calls of the reference have Q of them, vectorbase.py:163-173) takes the same kernels as a
-    uniform one -- the 32-query tile at 24 queries, the 128/256-query tile + rescoring from 33 on -- and returns, query by query, what the
+    uniform one -- the 32/64-query tile at 24 and 40 queries, the 128/256-query tile + rescoring beyond -- and returns, query by query, what the
     single-query kernel returns with that query's threshold (NaN and > 1 thresholds included: nothing passes)."""
     n, d, k = 60_000, 1536, 32
     v, _ = make_corpus(n, d, 8710)
@@ -1226,13 +1226,13 @@ def test_per_query_thresholds_ride_the_tiles(nq):
     thr[6] = 1.5
     thr[7] = float(levels[0])  # exactly the best score of query 0 (for query 7: usually nothing)
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=thr.tolist())
-    assert eng.get_option("last_tier") == (4 if nq >= 33 else 5)
+    assert eng.get_option("last_tier") == (4 if nq >= 65 else 5)
     assert len(out[5]) == 0 and len(out[6]) == 0
     for qi in sorted(set([0, 1, 2, 3, 4, 5, 6, 7, 9, nq // 2, nq - 1])):
         t = thr[qi]
         seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=None if t != t else float(t)) if t == t else []
         assert eng.get_option("last_tier") in (1, 2, 3) or t != t
-        if nq >= 33:  # rescored with the streaming kernels' arithmetic: the same float32 values, so the same order
+        if nq >= 65:  # rescored with the streaming kernels' arithmetic: the same float32 values, so the same order
             assert [r.item for r in out[qi]] == [r.item for r in seq], qi
             assert [r.score for r in out[qi]] == [r.score for r in seq], qi
         else:
@@ -1248,12 +1248,12 @@ def test_per_query_thresholds_ride_the_tiles(nq):
     # the uniform form of the same call still means the same thing
     uni = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.4)
     assert [(r.item, r.score) for r in uni[3]] == [(r.item, r.score) for r in out[3]]
-    assert eng.get_option("last_tier") == (4 if nq >= 33 else 5)
+    assert eng.get_option("last_tier") == (4 if nq >= 65 else 5)
     # through the C ABI with a float32 array, on an fp32 corpus (32/64-query fp32 tile; the fp16 shadow + fp32 rescoring from 65 queries on)
     vb32 = new_vb(v[:20_000], dtype="fp32")
     t32 = np.where(np.arange(nq) % 2 == 0, np.float32(0.0), np.float32(0.5)).astype(np.float32)
     o, s_, c_ = vb32.engine.search_batch(qs, k, t32)
-    assert vb32.engine.get_option("last_tier") == (4 if nq >= 33 else 5)
+    assert vb32.engine.get_option("last_tier") == (4 if nq >= 65 else 5)
     for qi in (0, 1, nq - 2, nq - 1):
         seq = vb32.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=float(t32[qi]))
         assert o[qi, : c_[qi]].tolist() == [r.item for r in seq]
@@ -1349,6 +1349,35 @@ def test_wide_tile_other_dimensions(dtype, d):
         assert vb.engine.get_option("last_tier") == 4 and out2[7][0].item == n + 123
         ref2 = np.concatenate([ref_v, extra if dtype == "fp32" else _f16(extra)])
         vo.check_topk_parity(vo.scores_full(ref2, qs2[7]), *items_scores(out2[7]), k, 0.0, referee=vo.f64_referee(ref2, qs2[7]))
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_batches_of_33_to_64_take_the_wide_tile_on_big_corpora(dtype):
+    """On corpora of 256 MiB and more a batch of 33 .. 64 queries rides the 128-query tile (padded) + rescoring instead of the 64-query tile
+    (10M fp16 rows, 64 queries: 5.46 against 5.91 ms; 1M fp32 rows through the shadow: 0.85 against 2.17 ms); smaller corpora and smaller
+    batches keep the 32/64-query tile.  Same answers either way: a batch is its sequential lookups."""
+    n = 100_000 if dtype == "fp16" else 50_000  # 307 MB either way
+    v, _ = make_corpus(n, 1536, 8760)
+    qs = make_queries(64, 1536, 8761)
+    qs[5] = v[n - 3]
+    vb = new_vb(v, dtype=dtype)
+    eng = vb.engine
+    ref_v = v if dtype == "fp32" else _f16(v)
+    for nq, tier in ((64, 4), (33, 4), (32, 5)):
+        out = vb.fuzzy_lookup_embeddings(qs[:nq], max_hits=32, min_score=0.0)
+        assert eng.get_option("last_tier") == tier, (nq, eng.get_option("last_tier"))
+        for qi in (0, 5, nq - 1):
+            vo.check_topk_parity(vo.scores_full(ref_v, qs[qi]), *items_scores(out[qi]), 32, 0.0, referee=vo.f64_referee(ref_v, qs[qi]))
+            if tier == 4:
+                seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=32, min_score=0.0)
+                assert [(r.item, r.score) for r in out[qi]] == [(r.item, r.score) for r in seq], (nq, qi)
+        assert out[5][0].item == n - 3
+    eng.set_option("mfma_big_bytes", 1 << 40)  # "no corpus is big": the 64-query tile again
+    vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert eng.get_option("last_tier") == 5
+    small = new_vb(v[:20_000], dtype=dtype)
+    small.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert small.engine.get_option("last_tier") == 5
 
 
 @pytest.mark.parametrize("nq,k", [(130, 32), (300, 100)])
@@ -1579,7 +1608,6 @@ def test_skinny_64_query_tile_on_fp16_corpora(nq):
     qs = make_queries(nq, 1536, 9801 + nq)
     qs[1] = v[n - 5]
     vb = new_vb(v, dtype="fp16")
-    vb.engine.set_option("mfma_min_batch", 65)  # (since round 5 batches of 33+ take the 128-query tile by default: this test is about the 64-query one)
     got = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     assert vb.engine.get_option("last_tier") == 5
     v16 = _f16(v)

@@ -93,7 +93,7 @@ def _addr(arr: np.ndarray):
 
 
 def plan_ladder(rows: int, nq: int, n_cu: int = 256) -> list[int]:
-    """Phase boundaries of the threshold ladder the library runs for a batch of `nq` (>= 33) queries over `rows` rows with default options
+    """Phase boundaries of the threshold ladder the library runs for a batch of `nq` (>= 65; >= 33 on corpora of 256 MiB and more) queries over `rows` rows with default options
     (tavb_plan_ladder): len(result) - 1 = tile-kernel launches per lookup.  Needs no GPU."""
     lib = load_library(preload_torch=False)
     buf = (c_int64 * 16)()

@@ -110,10 +110,13 @@ struct tavb_ctx {
   int64_t ordinal_base = 0;
 
   tavb::ScanGeometry geom{0, 16, 2, 1, 0, 0};
-  // batches from this size up use the 128/256-query tile + rescoring (smaller ones the 32/64-query tile).  33 since round 5 (was 65): padded to
-  // 128 queries the wide tile serves 33 / 48 / 64 queries over 10M fp16 rows in 5.42 / 5.48 / 5.46 ms against 5.54 / 5.81 / 5.91 ms on the
-  // 64-query split-plane tile, and 64 queries over 1M fp32 rows (through the fp16 shadow) in 0.85 ms against 2.17 ms (profiles/r05_raw/b64.txt)
-  int64_t mfma_min_batch = 33;
+  int64_t mfma_min_batch = 65;  // batches from this size up use the 128/256-query tile + rescoring (smaller ones the 32/64-query tile) ...
+  // ... and on corpora of `mfma_big_bytes` (256 MiB) or more already from `mfma_min_batch_big` = 33 queries (round 5): padded to 128 queries the wide
+  // tile serves 33 / 48 / 64 queries over 10M fp16 rows in 5.42 / 5.48 / 5.46 ms against 5.54 / 5.81 / 5.91 ms on the 64-query split-plane tile,
+  // and 64 queries over 1M fp32 rows (through the fp16 shadow) in 0.85 ms against 2.17 ms (profiles/r05_raw/b64.txt).  On small corpora its ~40
+  // launches per batch cost more than the 64-query tile's pass.
+  int64_t mfma_min_batch_big = 33;
+  int64_t mfma_big_bytes = (int64_t)256 << 20;
   int64_t mfma_splits = 0;  // 0 = auto
   int64_t mfma_ablate = 0;
   int64_t mfma_sched = 0;
@@ -466,6 +469,12 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_min_batch") {
     if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch must be >= 1");
     c->mfma_min_batch = v;
+  } else if (n == "mfma_min_batch_big") {
+    if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch_big must be >= 1");
+    c->mfma_min_batch_big = v;
+  } else if (n == "mfma_big_bytes") {
+    if (v < 0) return fail(TAVB_E_INVALID, "mfma_big_bytes must be >= 0");
+    c->mfma_big_bytes = v;
   } else if (n == "mfma_sample_rows") {
     if (v < -1) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= -1");
     c->mfma_sample_rows = v;
@@ -539,6 +548,8 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "scan_pipe") *out = c->geom.pipe;
   else if (n == "force_tier") *out = c->geom.tier;
   else if (n == "mfma_min_batch") *out = c->mfma_min_batch;
+  else if (n == "mfma_min_batch_big") *out = c->mfma_min_batch_big;
+  else if (n == "mfma_big_bytes") *out = c->mfma_big_bytes;
   else if (n == "mfma_splits") *out = c->mfma_splits;
   else if (n == "mfma_tile") *out = c->mfma_tile;
   else if (n == "f32_shadow") *out = c->f32_shadow;
@@ -1936,7 +1947,8 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   const bool width_ok = !odd_width || (c->dim % 8 == 0 && (f16c || c->dim % 16 == 0));
   const bool exact_tile = (k <= 64) ? ((f16c && odd_width) ? tavb::skinny_supported(wide_dim, k, false) : tavb::skinny_supported(c->dim, k, !f16c))
                                     : (f16c && c->wide_fallback != 0);
-  bool wide = (f16c || c->f32_shadow) && c->corpus && nq >= c->mfma_min_batch && width_ok && tavb::mfma_supported(wide_dim, k) && c->rows > 0 && exact_tile;
+  const bool wide_batch = nq >= c->mfma_min_batch || (nq >= c->mfma_min_batch_big && (int64_t)c->rows * c->dim * (f16c ? 2 : 4) >= c->mfma_big_bytes);
+  bool wide = (f16c || c->f32_shadow) && c->corpus && wide_batch && width_ok && tavb::mfma_supported(wide_dim, k) && c->rows > 0 && exact_tile;
   // f32_shadow = 2: smaller batches (and single queries) on big fp32 corpora filter on the shadow too, with the 32/64-query tile
   // (it keeps the best 64 candidates per query: k up to 48 leaves the slack the completeness test needs)
   bool shadow_small = !wide && !f16c && c->f32_shadow >= 2 && c->corpus && nq <= 64 && tavb::mfma_supported(c->dim, 64) && k <= 48 &&
