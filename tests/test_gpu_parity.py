@@ -855,6 +855,7 @@ def test_mfma_tile_against_the_exact_tile_on_a_large_corpus():
     assert eng.get_option("last_tier") == 4 and eng.get_option("last_flagged") == 0
     o_w, s_w, c_w = _native.decode_keys(out.cpu().numpy())
     eng.set_option("mfma_min_batch", 1 << 30)  # the same batch on the 64-query tile (16 query tiles per row range)
+    eng.set_option("mfma_min_batch_big", 1 << 30)  # (this corpus is 2.4 GB: the big-corpus threshold too)
     out = eng.search_device(dq, k, 0.0)
     eng.synchronize()
     assert eng.get_option("last_tier") == 5
