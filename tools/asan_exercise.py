@@ -187,6 +187,35 @@ def main():
         ok(lib.tavb_set_corpus(h, dev, 0, d, dtype, 0))
         hip.hipFree(dev); hip.hipFree(dmap)
         print("dtype", dtype, "ok", flush=True)
+    # round 5: a width that is not a multiple of 64 on the wide tile (zero-padded copy of the rows, padded queries), with an append in between
+    d2, n2 = 1000, 30_000
+    v2 = rng.standard_normal((n2 + 500, d2)).astype(np.float32)
+    v2 /= np.linalg.norm(v2, axis=1, keepdims=True)
+    for dtype, esz in ((_native.TAVB_F16, 2), (_native.TAVB_F32, 4)):
+        dd = d2 if dtype == _native.TAVB_F16 else 1008  # (fp32: multiples of 16)
+        rows = np.ascontiguousarray(v2 if dd == d2 else np.pad(v2, ((0, 0), (0, dd - d2))))
+        seen = rows.astype(np.float16).astype(np.float32) if dtype == _native.TAVB_F16 else rows
+        dev2 = dmalloc((n2 + 500) * dd * esz)
+        for upto in (n2, n2 + 500):  # the second round: 500 appended rows extend the padded copy
+            ok(lib.tavb_upload_rows(h, ptr(rows), upto, dd, dev2, dtype))
+            ok(lib.tavb_set_corpus(h, dev2, upto, dd, dtype, 0))
+            nq = 70
+            q = rng.standard_normal((nq, dd)).astype(np.float32)
+            q /= np.linalg.norm(q, axis=1, keepdims=True)
+            q[4] = rows[upto - 1]
+            o = np.empty((nq, k), np.int64); s = np.empty((nq, k), np.float32); c = np.empty(nq, np.int32)
+            thr = np.zeros(nq, np.float32)
+            ok(lib.tavb_search_batch(h, ptr(q), nq, k, ptr(thr), ptr(o), ptr(s), ptr(c)))
+            tier = c_int64(); ok(lib.tavb_get_option(h, b"last_tier", byref(tier)))
+            for qi in (0, 4, nq - 1):
+                ref = np.argsort(-scores(seen[:upto], q[qi]), kind="stable")[:k]
+                if not (tier.value == 4 and c[qi] == k and (o[qi] == ref).mean() > 0.9):
+                    print("MISMATCH odd width", dtype, dd, upto, qi, "tier", tier.value, "count", c[qi], flush=True); bad.append((dtype, "odd", upto, qi))
+            if o[4][0] != upto - 1:
+                print("MISMATCH odd width: appended row not found", dtype, upto, o[4][:3], flush=True); bad.append((dtype, "odd-append", upto))
+        ok(lib.tavb_set_corpus(h, dev2, 0, dd, dtype, 0))
+        hip.hipFree(dev2)
+    print("odd widths on the wide tile: ok", flush=True)
     ok(lib.tavb_destroy(h))
     print("asan exercise:", "all good" if not bad else f"MISMATCHES {bad}")
     sys.exit(1 if bad else 0)
