@@ -2122,3 +2122,46 @@ def test_profile_counters_count_launches():
     ms2, n2 = eng.profile_read(_native.KERNEL_MERGE)
     assert n2 == 3 and ms2 > 0
     eng.profile_enable(False)
+
+
+def test_device_memory_does_not_grow_over_many_lookups_of_the_same_shapes():
+    """Workspaces of the library grow to the largest shape asked for and stay there: a few hundred lookups of a fixed set of shapes (single
+    query, 40 / 70 / 300-query batches, subsets, message re-rank, appends in between) leave the free device memory where the first round put it."""
+    import torch
+
+    v, _ = make_corpus(40_000, 1536, 8800)
+    qs = make_queries(300, 1536, 8801)
+    vb = new_vb(v[:30_000], dtype="fp16")
+    vb.set_row_messages(np.arange(40_000) // 3)
+    sub = list(range(0, 30_000, 7))
+
+    def one_round(i):
+        vb.fuzzy_lookup_embedding(qs[i % 300], max_hits=10, min_score=0.0)
+        vb.fuzzy_lookup_embeddings(qs[:40], max_hits=32, min_score=0.0)
+        vb.fuzzy_lookup_embeddings(qs[:70], max_hits=50, min_score=0.5)
+        vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0, as_arrays=True)
+        vb.fuzzy_lookup_embedding_in_subset(qs[(i + 1) % 300], sub, max_hits=25, min_score=0.0)
+        vb.lookup_messages_by_embedding(qs[(i + 2) % 300], 25, 0.0)
+
+    for i in range(3):
+        one_round(i)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(60):
+        one_round(i)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), (free0, free1)
+    # appends: the first one moves the corpus to a buffer of twice the size (+ staging ring, conversion scratch: one-off); the following ones
+    # fill it -- no growth per append
+    marks = []
+    for j in range(20):
+        vb.add_embeddings(None, v[30_000 + 500 * j : 30_000 + 500 * (j + 1)])
+        one_round(j)
+        if j in (4, 19):
+            torch.cuda.synchronize()
+            marks.append(torch.cuda.mem_get_info()[0])
+    assert free1 - marks[0] < (2 << 30), (free1, marks)  # one-off, bounded
+    assert marks[0] - marks[1] < (64 << 20), marks       # 15 more appends: nothing more
+    res = vb.fuzzy_lookup_embedding(v[39_999], max_hits=1)
+    assert res[0].item == 39_999
