@@ -2165,3 +2165,34 @@ def test_device_memory_does_not_grow_over_many_lookups_of_the_same_shapes():
     assert marks[0] - marks[1] < (64 << 20), marks       # 15 more appends: nothing more
     res = vb.fuzzy_lookup_embedding(v[39_999], max_hits=1)
     assert res[0].item == 39_999
+
+
+def test_destroying_a_context_returns_its_workspaces_and_the_shadow():
+    """Every workspace of a context -- the fp16 shadow of an fp32 corpus (half the corpus' bytes) and the padded query copy included -- goes
+    back to the device when the context is destroyed: engines created, used with wide batches and closed in a loop do not eat the device."""
+    import torch
+
+    v, _ = make_corpus(60_000, 1536, 8810)  # 369 MB of fp32 rows: a 184 MB shadow per context
+    v8, _ = make_corpus(20_000, 1000, 8812)
+    qs = make_queries(70, 1536, 8811)
+    qs8 = make_queries(70, 1000, 8813)
+
+    def use_and_close():
+        vb = new_vb(v)
+        vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+        assert vb.engine.get_option("last_tier") == 4 and vb.engine.get_option("last_shadow") == 1
+        vb.engine.close()
+        odd = new_vb(v8, dtype="fp16")
+        odd.fuzzy_lookup_embeddings(qs8, max_hits=32, min_score=0.0)
+        assert odd.engine.get_option("last_tier") == 4
+        odd.engine.close()
+        del vb, odd
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    use_and_close()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(4):
+        use_and_close()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (96 << 20), (free0, free1)  # four more shadows would be 740 MB

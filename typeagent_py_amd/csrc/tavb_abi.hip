@@ -418,6 +418,8 @@ int tavb_destroy(tavb_ctx* c) {
   c->d_norm.release();
   c->d_minscores.release();
   c->d_fb_cand.release();
+  c->d_shadow.release();       // (was missing until round 5: a context that had served a 65+-query batch on an fp32 corpus left its shadow -- half the corpus' size -- behind)
+  c->d_queries_pad.release();
   c->d_accept.release();
   c->d_bits.release();
   c->d_emit.release();
