@@ -1404,6 +1404,38 @@ def test_wide_tile_odd_width_with_a_band_that_does_not_fit(nq, k):
     assert set(r.item for r in out[3]) <= set(dup.tolist())
 
 
+@pytest.mark.parametrize("d", [200, 72])
+@pytest.mark.parametrize("nq,k,planted", [(130, 32, 60), (256, 32, 100), (300, 100, 50)])
+def test_odd_width_with_many_flagged_queries(d, nq, k, planted):
+    """An fp16 corpus whose width is not a multiple of 64 with MANY flagged queries: the work list's per-slot thresholds and band widths sit
+    behind the two PADDED query planes.  (Round 5 placed them behind planes of the unpadded width, i.e. inside the low plane from slot
+    cap·dim/fdim on -- row 36 of 64 at D = 200: wrong or empty answers for the slots behind it; one to three flagged queries never reached
+    those rows.)  130 queries: the 64-query exact tile over 192 slots; 256 queries: the first 64 flagged on it, the rest on the wide
+    split-plane form; k = 100: every flagged query on the wide form."""
+    n = 150_000
+    v, _ = make_corpus(n, d, 8770 + d)
+    qs = make_queries(nq, d, 8771 + d)
+    rng = np.random.default_rng(8772)
+    ids = list(range(1, 2 * planted, 2))
+    rows = _plant_clusters(v, qs, ids, 1100, rng)
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert eng.get_option("last_tier") == 4
+    assert planted <= eng.get_option("last_flagged") <= nq
+    v16 = _f16(v)
+    for j, qi in enumerate(ids):  # every flagged slot, the last ones above all
+        assert len(out[qi]) == k, (qi, len(out[qi]))
+        assert set(r.item for r in out[qi]) <= set(rows[j].tolist()), qi
+    for qi in sorted(set([0, 1, 2, ids[planted // 2], ids[-2], ids[-1], nq - 1])):
+        assert len(out[qi]) == k
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
+    # with a threshold only the planted queries clear
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.9)
+    assert len(out[0]) == 0 and len(out[ids[-1]]) == k
+    vo.check_topk_parity(vo.scores_full(v16, qs[ids[-1]]), *items_scores(out[ids[-1]]), k, 0.9, referee=vo.f64_referee(v16, qs[ids[-1]]))
+
+
 @pytest.mark.parametrize("nq", [65, 128, 300, 1024])
 def test_f32_corpus_large_batches_ride_the_fp16_shadow(nq):
     v, _ = make_corpus(60_007, 1536, 7600)

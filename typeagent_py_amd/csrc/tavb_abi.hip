@@ -1850,7 +1850,8 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
   c->last_shadow = shadow_ops ? 1 : 0;
   if (int rc = run_tile_ladder(c, filt, reinterpret_cast<u64_t*>(c->d_approx.ptr), nullptr)) return rc;
   char* fb = reinterpret_cast<char*>(c->d_fb_queries.ptr);
-  float* fb_thr = reinterpret_cast<float*>(fb + (size_t)2 * cap * c->dim * 2);
+  // behind the gathered operand: fp32 [cap][dim] on fp32 corpora, two fp16 planes of [cap][fdim] otherwise (fdim, not dim: an odd width's planes are padded)
+  float* fb_thr = reinterpret_cast<float*>(fb + (size_t)2 * cap * (f32c ? c->dim : fdim) * 2);
   float* fb_band = fb_thr + cap;
   {
     Timed t(c, TAVB_KERNEL_RESCORE);
