@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 /* bumped whenever an entry point, a signature, an option or a kernel id changes incompatibly; the binding refuses a library of another version */
-#define TAVB_ABI_VERSION 5
+#define TAVB_ABI_VERSION 6
 
 #define TAVB_OK 0
 #define TAVB_E_INVALID (-1)     /* bad argument */
@@ -45,6 +45,7 @@ extern "C" {
 #define TAVB_E_NO_CORPUS (-3)   /* search before tavb_set_corpus */
 #define TAVB_E_UNSUPPORTED (-4) /* shape outside what the kernels cover (see message) */
 #define TAVB_E_NOMEM (-5)
+#define TAVB_E_TIMEOUT (-7)     /* tavb_synchronize: an exchange did not complete within "comm_timeout_ms"; the communicator was aborted */
 #define TAVB_E_PEER (-6)        /* tavb_decode_keys: the lists come from a collective lookup in which a rank's local search failed (they lead with TAVB_KEY_PEER_FAILED) */
 
 #define TAVB_F32 0
@@ -103,6 +104,14 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "comm_fail_rank"        fault injection (default -1 = off): on the rank of the communicator with this number the local search of
  *                           tavb_search_allgather fails as a launch or an allocation inside it would -- that rank still joins the all-gather
  *                           (with TAVB_KEY_PEER_FAILED lists) and returns its error, every other rank's lists decode to TAVB_E_PEER
+ *   "comm_reserve_keys"     keys per rank of the exchange buffers tavb_comm_init reserves (default 2^20 = 8 MiB + world x 8 MiB; set BEFORE tavb_comm_init):
+ *                           an exchange of up to that many keys (nq x k) allocates nothing between entering tavb_search_allgather and ncclAllGather;
+ *                           bigger ones travel through the same buffers in chunks of whole queries (every rank cuts the same chunks)
+ *   "comm_timeout_ms"       0 (default) = tavb_synchronize waits for an exchange for ever; > 0: after that many milliseconds the communicator is
+ *                           aborted (ncclCommAbort: the stream drains), the context is left without one and tavb_synchronize returns TAVB_E_TIMEOUT
+ *   "comm_fail_alloc"       fault injection: 1 = the per-call list allocation of tavb_search_allgather (lists beyond comm_reserve_keys) fails; the rank
+ *                           still joins every chunk of the exchange with TAVB_KEY_PEER_FAILED lists
+ *   "comm_stall_ms"         fault injection (one shot, 0..5000): the next exchange is held up on the stream for that long, as by a late peer
  *   "comm_world", "comm_rank" (read only) shape of the context's communicator (0 / -1 without one)
  *   "last_tier" (read only) the kernel family of the last lookup: 1-3 streaming tiers, 4 = 256-query MFMA tile (exact
  *                   filter + fp32-query rescoring of its candidates), 5 = 32/64-query MFMA tile
@@ -250,6 +259,13 @@ int tavb_search_device(tavb_ctx* ctx, const float* dev_queries, int32_t nq, int3
  * subset POSITIONS.  Asynchronous.  Used by the fused multi-index submission. */
 int tavb_search_subset_device(tavb_ctx* ctx, const float* dev_query, const int32_t* dev_rows, int64_t n_subset,
                               int32_t k, float min_score, tavb_key* dev_out_keys);
+/* Host-synchronous tavb_search_subset (vectorbase.py:203-230) over a subset whose row list is ALREADY on the device: callers that search the
+ * same subset again and again (the memory provider hands `lookup_in_subset_by_embedding` the same scope list per query term,
+ * storage/memory/messageindex.py:173-183; tools/benchmark_vectorbase.py:133-163 passes one list for every round) upload and range-check it
+ * once.  query_host float32 [dim]; dev_rows device int32 [n_subset], wrapped and range-checked by the caller; positions / scores / count as
+ * tavb_search_subset. */
+int tavb_search_subset_resident(tavb_ctx* ctx, const float* query_host, const int32_t* dev_rows, int64_t n_subset, int32_t k, float min_score,
+                                int64_t* out_positions, float* out_scores, int32_t* out_count);
 
 /* Merge `n_lists` sorted key lists per query (dev_lists [n_lists, nq, k], e.g. the
  * all-gathered per-shard results) into one list per query: dev_out_keys [nq, k]. */
@@ -267,7 +283,11 @@ int tavb_decode_keys(const tavb_key* keys_host, int32_t nq, int32_t k, int64_t* 
  * answer of vectorbase.py:163-190 (keys carry global ordinals and order by (score desc, ordinal asc): the merged answer is the
  * single-device one, ties included).  A rank whose local search fails still joins the all-gather -- the peers are never left waiting -- with
  * TAVB_KEY_PEER_FAILED lists, returns its own error, and every other rank's merged lists decode to TAVB_E_PEER (tavb_decode_keys): a lookup
- * either returns the whole-corpus answer on a rank or an error, never an answer that silently misses a shard.
+ * either returns the whole-corpus answer on a rank or an error, never an answer that silently misses a shard.  That covers every failure
+ * local to a rank between entering the call and the all-gather: the state of its shard, its launches, its allocations (the exchange buffers
+ * themselves are reserved by tavb_comm_init, option "comm_reserve_keys", so the exchange path allocates nothing).  What it cannot cover -- a
+ * peer that never makes the call, or dies inside it -- is bounded by "comm_timeout_ms": tavb_synchronize aborts the communicator and returns
+ * TAVB_E_TIMEOUT instead of waiting for ever.
  * The collective is issued by the library itself, on the context's stream, behind the scan and
  * in front of the merge -- RCCL (librccl.so.1, resolved with dlopen at tavb_comm_init: no link-time dependency) is the only
  * communication layer; torch.distributed is not needed on the lookup path.

@@ -95,6 +95,13 @@ class FakeEngine:
             ok &= (sc < np.float32(after[0])) | ((sc == np.float32(after[0])) & (pos > after[1]))
         return _order(sc[ok], pos[ok], k)
 
+    def rows_to_device(self, rows):  # the "device" copy of a subset's row list: a private int32 array, counted
+        self.subset_uploads = getattr(self, "subset_uploads", 0) + 1
+        return np.array(rows, dtype=np.int32)
+
+    def search_subset_resident(self, q, dev_rows, k, thr):
+        return self.search_subset(q, dev_rows.astype(np.int64), k, thr)
+
     # -- split form (device groups) ----------------------------------------------------------------------------------
     def _keys(self, q, k, thr, bound=None):
         sc = self._scores(q)

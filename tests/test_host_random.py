@@ -230,16 +230,32 @@ def test_a_serialized_matrix_adopted_by_another_index_is_watched_by_both(monkeyp
 
 def test_fallback_fingerprint_of_an_owned_matrix_is_amortised(monkeypatch):
     """A matrix this index owns reports writes through its tracking view; the fingerprint behind it (writers that go around numpy) costs as
-    much as a small lookup, so after a serialize() it is compared at most once per 64 lookups / 20 ms -- not on every lookup for the rest
-    of the index' life.  A matrix the CALLER owns keeps the per-lookup check."""
+    much as a small lookup.  Default: compared before every lookup once a view is out (a write that bypasses the tracker is seen by the very
+    next lookup, as in the reference, which scores the live matrix).  `verify_host="lazy"` (opt-in): at most once per 64 lookups / 20 ms.
+    A matrix the CALLER owns keeps the per-lookup check in every mode."""
     import time
 
+    calls = []
+    orig = VectorBase._fingerprint
+    vb0, rows0, _ = _fresh(monkeypatch, n=400)
+    q0 = rows0[5].copy()
+    vb0.serialize()
+    vb0.fuzzy_lookup_embedding(q0, max_hits=1)
+    monkeypatch.setattr(VectorBase, "_fingerprint", lambda self: (calls.append(1), orig(self))[1])
+    for _ in range(10):
+        vb0.fuzzy_lookup_embedding(q0, max_hits=1)
+    assert len(calls) == 10  # the default: every lookup
+    raw0 = np.asarray(vb0.serialize())
+    raw0 *= np.float32(-1.0)  # invisible to the tracker: seen by the next lookup all the same
+    assert _answers_for_current_rows(vb0, q0)[0].item != 5
+    monkeypatch.setattr(VectorBase, "_fingerprint", orig)
+
     vb, rows, rng = _fresh(monkeypatch, n=400)
+    vb._verify_host = "lazy"
     q = rows[5].copy()
     vb.serialize()  # a view is out: the fallback watch is on
     vb.fuzzy_lookup_embedding(q, max_hits=1)
-    calls = []
-    orig = VectorBase._fingerprint
+    calls.clear()
     monkeypatch.setattr(VectorBase, "_fingerprint", lambda self: (calls.append(1), orig(self))[1])
     t0 = time.monotonic()
     for _ in range(256):
@@ -253,6 +269,7 @@ def test_fallback_fingerprint_of_an_owned_matrix_is_amortised(monkeypatch):
     assert _answers_for_current_rows(vb, q)[0].item != 5
     # ... and is not lost when an append regrows the buffer before the next check (the fingerprint is compared before the flag is dropped)
     vb2, rows2, _ = _fresh(monkeypatch, n=64)
+    vb2._verify_host = "lazy"
     q2 = rows2[9].copy()
     vb2.serialize()
     vb2.fuzzy_lookup_embedding(q2, max_hits=1)
@@ -269,3 +286,56 @@ def test_fallback_fingerprint_of_an_owned_matrix_is_amortised(monkeypatch):
     for _ in range(10):
         other.fuzzy_lookup_embedding(q, max_hits=1)
     assert len(calls) == 10
+
+
+def test_a_repeated_subset_keeps_its_row_list_on_the_device(monkeypatch):
+    """`fuzzy_lookup_embedding_in_subset` (vectorbase.py:203-230) with the SAME list object again (the memory provider's scope list per query
+    term, storage/memory/messageindex.py:173-183; tools/benchmark_vectorbase.py:133-163): the wrapped, range-checked row list is uploaded
+    once.  Recognised by identity and content: a list edited in place, another list with the same content, or an index that has grown
+    (negative ordinals wrap differently, the range check moves) is a new subset.  Answers are the oracle's every time."""
+    vb, rows, rng = _fresh(monkeypatch, n=300)
+    eng = None
+    q = rows[11].copy()
+
+    def check(subset, k=5):
+        got = vb.fuzzy_lookup_embedding_in_subset(q, subset, max_hits=k, min_score=0.0)
+        live = np.asarray(vb.serialize())
+        ref = vo.lookup_in_subset(live, q, list(subset), k, 0.0)
+        assert [r.item for r in got] == [i for i, _ in ref], subset[:8]
+        return got
+
+    subset = [5, 11, 250, -1, 11, 7]  # a duplicate and a negative (wrapping) ordinal, as numpy indexing takes them
+    check(subset)
+    eng = FakeEngine.instances[-1]
+    assert eng.subset_uploads == 1
+    for _ in range(5):
+        check(subset)
+    assert eng.subset_uploads == 1  # the same object with the same content: nothing re-uploaded
+    subset[1] = 12  # edited in place: a new subset
+    got = check(subset)
+    assert eng.subset_uploads == 2 and 11 in [r.item for r in got] and got[0].item == 11  # (the duplicate at position 4 is still there)
+    subset[4] = 13
+    assert 11 not in [r.item for r in check(subset)] and eng.subset_uploads == 3
+    check(list(subset))  # an equal list that is another object: uploaded again (identity is part of the key)
+    assert eng.subset_uploads == 4
+    arr = np.array([3, 11, 299, -300], dtype=np.int64)
+    check(arr)
+    check(arr)
+    assert eng.subset_uploads == 5
+    arr[0] = 4  # the caller's array edited in place
+    check(arr)
+    assert eng.subset_uploads == 6
+    # the index grows: -1 is another row now
+    sub2 = [-1, 0]
+    before = check(sub2)
+    vb.add_embedding(None, q)  # the new last row IS the query
+    after = check(sub2)
+    assert after[0].item == -1 and after[0].score > before[0].score and eng.subset_uploads == 8
+    with pytest.raises(IndexError):
+        vb.fuzzy_lookup_embedding_in_subset(q, [0, 301])
+    # inputs that cannot be cached (a tuple) and the paged / all-survivors forms keep the plain path
+    assert [r.item for r in vb.fuzzy_lookup_embedding_in_subset(q, (5, 11), max_hits=1)] == [11]
+    assert len(vb.fuzzy_lookup_embedding_in_subset(q, sub2, max_hits=0, min_score=0.0)) == 2
+    assert eng.subset_uploads == 8
+    vb.clear()
+    assert vb._subset_cache is None

@@ -57,6 +57,9 @@ class HostStandInBackend:
     def empty_gather(self, world, nq, k):
         return torch.empty((world, nq, k), dtype=torch.int64)
 
+    def failed_lists(self, nq, k):
+        return torch.full((nq, k), -1, dtype=torch.int64)  # PEER_FAILED_KEY in every slot
+
     # the forms beside the plain lookup (same contracts as DeviceShardBackend's)
     def local_search_subset(self, query, local_rows, positions, k, thr):
         from oracle import vectorbase_oracle as vo

@@ -16,7 +16,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 
 import numpy as np
 
-ABI_VERSION = 5  # include/tavb.h TAVB_ABI_VERSION this binding was written against
+ABI_VERSION = 6  # include/tavb.h TAVB_ABI_VERSION this binding was written against
 TAVB_F32 = 0
 TAVB_F16 = 1
 MAX_FUSED_K = 256
@@ -64,6 +64,7 @@ _SIGNATURES = [
      [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_int64, c_void_p, c_void_p, POINTER(c_int32)]),
     ("tavb_search_device", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     ("tavb_search_subset_device", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    ("tavb_search_subset_resident", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     ("tavb_merge_device", c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     ("tavb_decode_keys", c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     ("tavb_comm_unique_id", c_int, [c_void_p]),
@@ -151,12 +152,19 @@ class TavbError(RuntimeError):
     """A libtavb call failed (HIP/RCCL failures surface here, never as abort())."""
 
 
+class TavbTimeout(TavbError):
+    """`synchronize()`: an exchange of a collective lookup did not complete within the `comm_timeout_ms` option -- a peer never joined.  The
+    library has aborted its communicator; `comm_init` again to rejoin."""
+
+
 def _check(lib, rc: int) -> None:
     if rc != 0:
         msg = lib.tavb_last_error()
         text = msg.decode("utf-8", "replace") if msg else "unknown error"
         if rc == -1:
             raise ValueError(f"libtavb: {text}")
+        if rc == -7:
+            raise TavbTimeout(f"libtavb error {rc}: {text}")
         raise TavbError(f"libtavb error {rc}: {text}")
 
 
@@ -409,6 +417,24 @@ class Engine:
                 rc = self.lib.tavb_search_subset_after(self._h, _addr(a), _addr(r), r.shape[0], k,
                                                        c_float(float(thr)), c_float(after[0]), int(after[1]),
                                                        _addr(pos), _addr(scs), byref(cnt))
+        _check(self.lib, rc)
+        m = int(cnt.value)
+        return pos[:m], scs[:m]
+
+    def rows_to_device(self, rows: np.ndarray):
+        """int64 corpus rows (already wrapped and range-checked) -> torch int32 [S] on this engine's device."""
+        torch = self._torch
+        return torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(torch.device("cuda", self.device))
+
+    def search_subset_resident(self, q, dev_rows, k: int, thr: np.float32):
+        """`search_subset` over a row list that is already on the device (torch int32 [S], wrapped and range-checked by the caller)."""
+        a = self._query(q)
+        pos = np.empty(k, dtype=np.int64)
+        scs = np.empty(k, dtype=np.float32)
+        cnt = c_int32(0)
+        with self._lock:
+            rc = self.lib.tavb_search_subset_resident(self._h, _addr(a), c_void_p(dev_rows.data_ptr()), int(dev_rows.shape[0]), k,
+                                                      c_float(float(thr)), _addr(pos), _addr(scs), byref(cnt))
         _check(self.lib, rc)
         m = int(cnt.value)
         return pos[:m], scs[:m]

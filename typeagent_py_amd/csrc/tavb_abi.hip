@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <mutex>
 #include <cmath>
@@ -191,7 +192,16 @@ struct tavb_ctx {
   int comm_rank = 0, comm_world = 1;
   int64_t comm_force = 0;  // option: run the all-gather + merge even in a world of one (tests, dry runs of the N > 1 path)
   int64_t comm_fail_rank = -1;  // option (fault injection): the local search of tavb_search_allgather "fails" on this rank of the communicator
-  Buffer d_local, d_gather;  // this shard's [nq, k] lists; the all-gathered [world, nq, k]
+  int64_t comm_fail_alloc = 0;  // option (fault injection): the per-call allocations of tavb_search_allgather "fail" (lists beyond comm_reserve_keys)
+  int64_t comm_stall_ms = 0;    // option (fault injection): the next exchange is held up on the stream for this long, as by a peer that is late
+  int64_t comm_timeout_ms = 0;  // option: tavb_synchronize gives an exchange in flight this long before it aborts the communicator (0 = wait for ever)
+  // keys of the exchange buffers reserved by tavb_comm_init (d_xlocal: that many, d_gather: x world): an exchange of up to that many keys per
+  // rank allocates NOTHING between entering the call and ncclAllGather; a bigger one goes through the same buffers in chunks of whole queries
+  int64_t comm_reserve_keys = (int64_t)1 << 20;
+  bool comm_inflight = false;   // an exchange was enqueued since the last successful tavb_synchronize
+  Buffer d_local;   // this shard's [nq, k] lists when they do not fit d_xlocal
+  Buffer d_xlocal;  // this shard's lists of an exchange up to comm_reserve_keys keys; the TAVB_KEY_PEER_FAILED lists of a rank that failed
+  Buffer d_gather;  // the all-gathered [world][chunk queries][k]
 };
 
 namespace {
@@ -343,8 +353,11 @@ void decode(const u64_t* keys, int nq, int k, int64_t base, int64_t* ordinals, f
 
 int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores,
                                 uint32_t index_base, u64_t* d_out);
-
 extern "C" {
+
+namespace {
+int comm_wait_or_abort(tavb_ctx* c);  // (defined next to the RCCL bindings)
+}
 
 int tavb_version(void) { return TAVB_ABI_VERSION; }
 
@@ -435,6 +448,7 @@ int tavb_destroy(tavb_ctx* c) {
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
   (void)tavb_comm_destroy(c);
   c->d_local.release();
+  c->d_xlocal.release();
   c->d_gather.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -444,7 +458,9 @@ int tavb_destroy(tavb_ctx* c) {
 int tavb_synchronize(tavb_ctx* c) {
   if (int rc = check_ctx(c)) return rc;
   DeviceGuard guard(c->device);
+  if (c->comm && c->comm_inflight && c->comm_timeout_ms > 0) return comm_wait_or_abort(c);
   TAVB_HIP(hipStreamSynchronize(c->stream));
+  c->comm_inflight = false;
   return TAVB_OK;
 }
 
@@ -530,6 +546,18 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "comm_fail_rank") {
     if (v < -1) return fail(TAVB_E_INVALID, "comm_fail_rank must be >= -1");
     c->comm_fail_rank = v;
+  } else if (n == "comm_fail_alloc") {
+    c->comm_fail_alloc = v ? 1 : 0;
+  } else if (n == "comm_stall_ms") {
+    if (v < 0 || v > 5000) return fail(TAVB_E_INVALID, "comm_stall_ms must be 0..5000");
+    c->comm_stall_ms = v;
+  } else if (n == "comm_timeout_ms") {
+    if (v < 0) return fail(TAVB_E_INVALID, "comm_timeout_ms must be >= 0");
+    c->comm_timeout_ms = v;
+  } else if (n == "comm_reserve_keys") {
+    if (c->comm) return fail(TAVB_E_INVALID, "comm_reserve_keys is read by tavb_comm_init: set it before");
+    if (v < TAVB_MAX_FUSED_K || v > ((int64_t)1 << 28)) return fail(TAVB_E_INVALID, "comm_reserve_keys must be %d .. 2^28", TAVB_MAX_FUSED_K);
+    c->comm_reserve_keys = v;
   } else if (n == "graph_max_bytes") {
     if (v < 0) return fail(TAVB_E_INVALID, "graph_max_bytes must be >= 0");
     c->graph_max_bytes = v;
@@ -564,6 +592,10 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "compute_units") *out = c->n_cu;
   else if (n == "comm_force") *out = c->comm_force;
   else if (n == "comm_fail_rank") *out = c->comm_fail_rank;
+  else if (n == "comm_fail_alloc") *out = c->comm_fail_alloc;
+  else if (n == "comm_stall_ms") *out = c->comm_stall_ms;
+  else if (n == "comm_timeout_ms") *out = c->comm_timeout_ms;
+  else if (n == "comm_reserve_keys") *out = c->comm_reserve_keys;
   else if (n == "small_direct_bytes") *out = c->small_direct_bytes;
   else if (n == "wide_fallback") *out = c->wide_fallback;
   else if (n == "early_exact") *out = c->early_exact;
@@ -1221,6 +1253,31 @@ int tavb_search_subset_device(tavb_ctx* c, const float* dev_query, const int32_t
                             reinterpret_cast<u64_t*>(dev_out_keys));
 }
 
+int tavb_search_subset_resident(tavb_ctx* c, const float* query_host, const int32_t* dev_rows, int64_t n_subset, int32_t k, float min_score,
+                                int64_t* out_positions, float* out_scores, int32_t* out_count) {
+  if (int rc = check_search_args(c, k)) return rc;
+  if (n_subset < 0 || n_subset >= 0x7FFFFFFFll) return fail(TAVB_E_INVALID, "bad subset length");
+  if (!query_host || !out_positions || !out_scores || !out_count) return fail(TAVB_E_INVALID, "null argument");
+  if (n_subset == 0 || c->rows == 0) {
+    *out_count = 0;
+    return TAVB_OK;
+  }
+  if (!dev_rows) return fail(TAVB_E_INVALID, "null dev_rows");
+  DeviceGuard guard(c->device);
+  const size_t qbytes = (size_t)c->dim * sizeof(float);
+  if (int rc = c->h_stage.reserve(qbytes)) return rc;
+  if (int rc = c->h_out.reserve((size_t)k * sizeof(u64_t))) return rc;
+  if (int rc = c->d_queries.reserve(qbytes)) return rc;
+  memcpy(c->h_stage.ptr, query_host, qbytes);
+  TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
+  if (int rc = search_device_impl(c, reinterpret_cast<const float*>(c->d_queries.ptr), 1, k, &min_score, dev_rows, n_subset, 0u,
+                                  reinterpret_cast<u64_t*>(c->h_out.ptr)))
+    return rc;
+  TAVB_HIP(hipStreamSynchronize(c->stream));
+  decode(reinterpret_cast<const u64_t*>(c->h_out.ptr), 1, k, 0, out_positions, out_scores, out_count);
+  return TAVB_OK;
+}
+
 int tavb_merge_device(tavb_ctx* c, const tavb_key* dev_lists, int32_t n_lists, int32_t nq, int32_t k,
                       tavb_key* dev_out_keys) {
   if (int rc = check_ctx(c)) return rc;
@@ -1283,6 +1340,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;  // (optional: only the timeout path needs it)
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
@@ -1306,6 +1364,7 @@ int load_rccl() {
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(g_rccl.handle, "ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(g_rccl.handle, "ncclCommInitRank"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.handle, "ncclCommDestroy"));
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(g_rccl.handle, "ncclCommAbort"));
     g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.handle, "ncclAllGather"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.handle, "ncclGetErrorString"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
@@ -1321,6 +1380,35 @@ static_assert(TAVB_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the rendezvous id is 
     ncclResult_t r__ = (expr);                                                                                      \
     if (r__ != ncclSuccess) return fail(TAVB_E_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r__), __FILE__, __LINE__); \
   } while (0)
+
+// tavb_synchronize with an exchange in flight and "comm_timeout_ms" set: polls the stream; when the deadline passes (a peer never joined the
+// all-gather, or died in it) the communicator is ABORTED -- ncclCommAbort makes the collective's kernel return, so the stream drains -- and the
+// context is left without one (tavb_comm_init again to rejoin): TAVB_E_TIMEOUT, never a process stuck in a collective for ever.
+int comm_wait_or_abort(tavb_ctx* c) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const auto deadline = t0 + std::chrono::milliseconds(c->comm_timeout_ms);
+  int polls = 0;
+  for (;;) {
+    const hipError_t e = hipStreamQuery(c->stream);
+    if (e == hipSuccess) {
+      c->comm_inflight = false;
+      return TAVB_OK;
+    }
+    if (e != hipErrorNotReady) return fail(TAVB_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+    if (std::chrono::steady_clock::now() >= deadline) break;
+    if (++polls > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));  // (the first polls spin: a lookup of a small shard is that short)
+  }
+  ncclComm_t comm = c->comm;
+  c->comm = nullptr;
+  c->comm_rank = 0;
+  c->comm_world = 1;
+  c->comm_inflight = false;
+  const long long waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+  if (g_rccl.CommAbort) (void)g_rccl.CommAbort(comm);
+  (void)hipStreamSynchronize(c->stream);  // (drains once the aborted collective has let go of the stream)
+  return fail(TAVB_E_TIMEOUT, "the exchange did not complete within %lld ms (option comm_timeout_ms): a peer never joined the all-gather; "
+              "the communicator was aborted -- tavb_comm_init to rejoin", waited);
+}
 }  // namespace
 
 int tavb_comm_unique_id(void* out_id) {
@@ -1341,11 +1429,16 @@ int tavb_comm_init(tavb_ctx* c, const void* id_bytes, int32_t rank, int32_t worl
   DeviceGuard guard(c->device);
   ncclUniqueId id;
   memcpy(id.internal, id_bytes, TAVB_COMM_ID_BYTES);
+  // the exchange buffers come first: a rank that cannot have them fails HERE, in a collective every rank is still free to fail in, and no
+  // exchange of up to comm_reserve_keys keys allocates anything afterwards (8 MiB + world x 8 MiB at the default)
+  if (int rc = c->d_xlocal.reserve((size_t)c->comm_reserve_keys * sizeof(u64_t))) return rc;
+  if (int rc = c->d_gather.reserve((size_t)c->comm_reserve_keys * sizeof(u64_t) * world)) return rc;
   ncclComm_t comm = nullptr;
   TAVB_RCCL(g_rccl.CommInitRank(&comm, world, id, rank));
   c->comm = comm;
   c->comm_rank = rank;
   c->comm_world = world;
+  c->comm_inflight = false;
   return TAVB_OK;
 }
 
@@ -1361,52 +1454,72 @@ int tavb_comm_destroy(tavb_ctx* c) {
   return TAVB_OK;
 }
 
-// local [nq, k] lists (device) -> ncclAllGather on the context's stream -> merge kernel -> out_keys [nq, k]
+// local [nq, k] lists (device; nullptr = this rank FAILED: it sends TAVB_KEY_PEER_FAILED in every slot) -> ncclAllGather on the context's
+// stream -> merge kernel -> out_keys [nq, k].  Nothing here allocates: the lists travel through the buffers tavb_comm_init reserved, in chunks
+// of whole queries when they hold more than comm_reserve_keys keys (every rank makes the same call, so every rank cuts the same chunks).
 static int exchange_and_merge(tavb_ctx* c, const u64_t* local, int32_t nq, int32_t k, tavb_key* out_keys) {
-  const size_t list_keys = (size_t)nq * k;
-  if (int rc = c->d_gather.reserve(list_keys * sizeof(u64_t) * c->comm_world)) return rc;
+  const int64_t reserve_keys = (int64_t)(c->d_xlocal.cap / sizeof(u64_t));
+  const int qc = (int)std::min<int64_t>(nq, std::max<int64_t>(1, reserve_keys / k));  // queries per chunk
+  if ((size_t)qc * k * sizeof(u64_t) * c->comm_world > c->d_gather.cap || (size_t)qc * k * sizeof(u64_t) > c->d_xlocal.cap)
+    return fail(TAVB_E_INVALID, "the exchange buffers of this communicator are gone (tavb_comm_init reserves them)");
   u64_t* gathered = reinterpret_cast<u64_t*>(c->d_gather.ptr);
-  {
-    Timed t(c, TAVB_KERNEL_EXCHANGE);
-    TAVB_RCCL(g_rccl.AllGather(local, gathered, list_keys, ncclUint64, c->comm, c->stream));
+  if (!local) (void)hipMemsetAsync(c->d_xlocal.ptr, 0xFF, (size_t)qc * k * sizeof(u64_t), c->stream);
+  if (c->comm_stall_ms > 0) {  // fault injection: one shot
+    (void)tavb::launch_stall((int)c->comm_stall_ms, c->stream);
+    c->comm_stall_ms = 0;
   }
-  Timed t(c, TAVB_KERNEL_MERGE);
-  hipError_t e = tavb::launch_merge(gathered, c->comm_world, nq, k, /*query_major=*/false, reinterpret_cast<u64_t*>(out_keys), c->stream);
-  if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
+  c->comm_inflight = true;
+  for (int q0 = 0; q0 < nq; q0 += qc) {
+    const int qn = std::min(qc, nq - q0);
+    const u64_t* src = local ? local + (size_t)q0 * k : reinterpret_cast<const u64_t*>(c->d_xlocal.ptr);
+    {
+      Timed t(c, TAVB_KERNEL_EXCHANGE);
+      TAVB_RCCL(g_rccl.AllGather(src, gathered, (size_t)qn * k, ncclUint64, c->comm, c->stream));
+    }
+    Timed t(c, TAVB_KERNEL_MERGE);
+    hipError_t e = tavb::launch_merge(gathered, c->comm_world, qn, k, /*query_major=*/false, reinterpret_cast<u64_t*>(out_keys) + (size_t)q0 * k, c->stream);
+    if (e != hipSuccess) return fail(TAVB_E_HIP, "merge launch failed: %s", hipGetErrorString(e));
+  }
   return TAVB_OK;
 }
 
 int tavb_search_allgather(tavb_ctx* c, const float* dev_queries, int32_t nq, int32_t k, float min_score, tavb_key* out_keys) {
-  if (int rc = check_search_args(c, k)) return rc;
+  // argument errors every rank makes alike (the ranks make the same call) return at once ...
+  if (int rc = check_ctx(c)) return rc;
+  if (k < 1) return fail(TAVB_E_INVALID, "k must be >= 1 (got %d)", k);
+  if (k > TAVB_MAX_FUSED_K)
+    return fail(TAVB_E_UNSUPPORTED, "k=%d exceeds the fused-select limit %d; page with tavb_search_after / tavb_search_subset_after", k, TAVB_MAX_FUSED_K);
   if (nq < 1) return fail(TAVB_E_INVALID, "nq must be >= 1");
   if (!dev_queries || !out_keys) return fail(TAVB_E_INVALID, "null argument");
   if (!c->comm || (c->comm_world == 1 && !c->comm_force)) return tavb_search_device(c, dev_queries, nq, k, min_score, out_keys);
-  if (c->ordinal_base + c->rows >= 0xFFFFFFFFll)
-    return fail(TAVB_E_UNSUPPORTED, "device-resident keys hold 32-bit ordinals: ordinal_base + rows must be < 2^32 - 1");
   DeviceGuard guard(c->device);
-  // everything that can fail locally comes BEFORE the collectives, and a local failure still joins them (with an empty list), so that the
-  // peers are never left waiting in ncclAllGather for a rank that has returned an error to its caller
+  // ... everything that can fail on ONE rank -- the state of its shard, an allocation, a launch -- still joins the collectives, with
+  // TAVB_KEY_PEER_FAILED lists, so that the peers are never left waiting in ncclAllGather for a rank that has returned an error to its caller.
+  // Lists of up to comm_reserve_keys keys live in the buffer tavb_comm_init reserved: no allocation between here and the all-gather.
   const size_t list_keys = (size_t)nq * k;
-  if (int rc = c->d_local.reserve(list_keys * sizeof(u64_t))) return rc;
-  if (int rc = c->d_gather.reserve(list_keys * sizeof(u64_t) * c->comm_world)) return rc;
-  u64_t* local = reinterpret_cast<u64_t*>(c->d_local.ptr);
-  std::vector<float> ms((size_t)nq, min_score);
   int rc_local = TAVB_OK;
-  std::string local_error;
-  if (c->comm_fail_rank >= 0 && c->comm_fail_rank == c->comm_rank) {  // fault injection (option "comm_fail_rank"): what a failed launch / allocation inside the local search looks like
+  u64_t* local = nullptr;
+  if (!c->corpus && c->rows != 0) rc_local = fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
+  else if (c->dim <= 0) rc_local = fail(TAVB_E_NO_CORPUS, "no corpus set (call tavb_set_corpus first)");
+  else if (c->ordinal_base + c->rows >= 0xFFFFFFFFll)
+    rc_local = fail(TAVB_E_UNSUPPORTED, "device-resident keys hold 32-bit ordinals: ordinal_base + rows must be < 2^32 - 1");
+  else if (list_keys * sizeof(u64_t) <= c->d_xlocal.cap) local = reinterpret_cast<u64_t*>(c->d_xlocal.ptr);
+  else if (c->comm_fail_alloc) rc_local = fail(TAVB_E_NOMEM, "injected failure of the list allocation (option comm_fail_alloc)");
+  else if ((rc_local = c->d_local.reserve(list_keys * sizeof(u64_t))) == TAVB_OK) local = reinterpret_cast<u64_t*>(c->d_local.ptr);
+  std::vector<float> ms((size_t)nq, min_score);
+  if (rc_local != TAVB_OK) {
+  } else if (c->comm_fail_rank >= 0 && c->comm_fail_rank == c->comm_rank) {  // fault injection (option "comm_fail_rank"): what a failed launch / allocation inside the local search looks like
     rc_local = fail(TAVB_E_HIP, "injected failure of the local search on rank %d (option comm_fail_rank)", c->comm_rank);
   } else if (c->rows == 0) {  // an empty shard still takes part in the collectives
-    TAVB_HIP(hipMemsetAsync(local, 0, list_keys * sizeof(u64_t), c->stream));
+    const hipError_t e = hipMemsetAsync(local, 0, list_keys * sizeof(u64_t), c->stream);
+    if (e != hipSuccess) rc_local = fail(TAVB_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
   } else {
     rc_local = tavb_search_device_dispatch(c, dev_queries, nq, k, ms.data(), (uint32_t)c->ordinal_base, local);
   }
-  if (rc_local != TAVB_OK) {
-    local_error = g_last_error;
-    // this shard's lists = TAVB_KEY_PEER_FAILED (all bits set) in every slot: it sorts above every real key, so it leads every merged list on
-    // EVERY rank -- the peers' answers would silently miss this shard otherwise; tavb_decode_keys turns it into TAVB_E_PEER
-    (void)hipMemsetAsync(local, 0xFF, list_keys * sizeof(u64_t), c->stream);
-  }
-  const int rc_x = exchange_and_merge(c, local, nq, k, out_keys);
+  // a failed rank's lists = TAVB_KEY_PEER_FAILED (all bits set) in every slot: it sorts above every real key, so it leads every merged list on
+  // EVERY rank -- the peers' answers would silently miss this shard otherwise; tavb_decode_keys turns it into TAVB_E_PEER
+  const std::string local_error = rc_local != TAVB_OK ? g_last_error : std::string();
+  const int rc_x = exchange_and_merge(c, rc_local == TAVB_OK ? local : nullptr, nq, k, out_keys);
   if (rc_local != TAVB_OK) {
     g_last_error = local_error;
     return rc_local;

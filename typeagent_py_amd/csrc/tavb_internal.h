@@ -54,6 +54,9 @@ hipError_t launch_merge_scatter(const unsigned long long* lists, int n_lists, in
 // keys carrying list positions -> keys carrying map[position] (tavb_misc.hip)
 hipError_t launch_remap_positions(unsigned long long* keys, int64_t n, const int32_t* map, int64_t map_len, hipStream_t stream);
 
+// fault injection: holds the stream for `ms` milliseconds (tavb_misc.hip)
+hipError_t launch_stall(int ms, hipStream_t stream);
+
 // chunk-row hits -> message hits (tavb_misc.hip)
 hipError_t launch_accept_bitmap(const int32_t* msgs, int64_t n, uint32_t* bits, int64_t n_bits, hipStream_t stream);
 hipError_t launch_message_rerank(const unsigned long long* hits, int nq, int k, uint32_t index_base, const int32_t* pos_to_row, const int32_t* row_to_msg,

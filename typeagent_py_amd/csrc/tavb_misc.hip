@@ -289,6 +289,18 @@ __global__ void __launch_bounds__(256) remap_positions_kernel(u64* __restrict__ 
   }
 }
 
+// fault injection (option "comm_stall_ms"): one wave that keeps the stream busy for `ticks` of the 100 MHz wall clock, as a peer that is late
+// for the exchange would; bounded by the option's range (5 s)
+__global__ void __launch_bounds__(64) stall_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+hipError_t launch_stall(int ms, hipStream_t stream) {
+  hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long)ms * 100000ull);
+  return hipGetLastError();
+}
+
 hipError_t launch_remap_positions(unsigned long long* keys, int64_t n, const int32_t* map, int64_t map_len, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   int64_t blocks = (n + 255) / 256;

@@ -58,6 +58,9 @@ class ShardBackend(Protocol):
     def empty_gather(self, world: int, nq: int, k: int):  # tensor int64 [world, nq, k] on the backend's device
         ...
 
+    def failed_lists(self, nq: int, k: int):  # tensor int64 [nq, k] of PEER_FAILED_KEY, ordered in front of the exchange that follows
+        ...
+
     # the forms beside the plain lookup (ShardedVectorBase: subset, predicate) -------------------------------------------------------
     def local_search_subset(self, query: np.ndarray, local_rows: np.ndarray, positions: np.ndarray, k: int, thr: float):  # -> tensor int64 [1, k], keys carrying `positions`
         ...
@@ -101,10 +104,36 @@ class DeviceShardBackend:
             self.engine = _native.Engine(self.device, use_torch_stream=True)
         self._pinned: dict = {}
         self._gather: dict = {}
+        self._failed: dict = {}
+        self._qstage: dict = {}
+        self._dtype_name = "fp32"
         self.native_comm = False  # True once init_comm() has joined the library's own RCCL communicator
 
     def set_shard(self, tensor, row_offset: int, rows: int | None = None) -> None:
         self.engine.set_corpus_tensor(tensor, rows=rows, ordinal_base=row_offset)
+        self._dtype_name = "fp16" if tensor.dtype == self.torch.float16 else "fp32"
+
+    def storage_dtype(self) -> str:
+        """"fp16" / "fp32": what this rank's shard is stored as (what `rebalance()` keeps)."""
+        return self._dtype_name
+
+    def stage_queries(self, q: np.ndarray):
+        """host float32 [nq, dim] -> device tensor, through a reused pinned buffer on the backend's stream (no pageable staging copy per call)."""
+        torch = self.torch
+        shape = tuple(q.shape)
+        slot = self._qstage.get(shape)
+        if slot is None:
+            if len(self._qstage) >= 8:
+                self._qstage.clear()
+            with torch.cuda.stream(self.stream):
+                slot = self._qstage[shape] = (torch.empty(shape, dtype=torch.float32).pin_memory(),
+                                              torch.empty(shape, dtype=torch.float32, device=torch.device("cuda", self.device)))
+        pinned, dev = slot
+        self.stream.synchronize()  # (the previous lookup that read `dev` is long done in practice; cheap)
+        pinned.numpy()[...] = q
+        with torch.cuda.stream(self.stream):
+            dev.copy_(pinned, non_blocking=True)
+        return dev
 
     def init_comm(self, rank: int, world: int, exchange_id=None) -> None:
         """Collective: join libtavb's own RCCL communicator (tavb_comm_init).  Rank 0 creates the rendezvous id; `exchange_id(id or None)
@@ -128,6 +157,7 @@ class DeviceShardBackend:
         """Replace this rank's shard by host rows (float32 [n, dim]); uploaded through the pinned ring (tavb_upload_rows)."""
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         self._dtype_code = _native.TAVB_F16 if dtype == "fp16" else _native.TAVB_F32
+        self._dtype_name = "fp16" if dtype == "fp16" else "fp32"
         with self.torch.cuda.stream(self.stream):
             self.engine.ordinal_base = int(row_offset)
             if rows.ndim == 2 and rows.shape[1] > 0:
@@ -166,6 +196,30 @@ class DeviceShardBackend:
             keys = self.engine.search_subset_device(dq, rows, k, thr)
             self.engine.remap_key_positions(keys, pmap)
             self._keep = (dq, rows, pmap)  # alive until the next call (the kernels run asynchronously)
+            return keys
+
+    def subset_to_device(self, local_rows: np.ndarray, positions: np.ndarray):
+        """This shard's part of a caller's subset as device tensors (rows int32 [S], positions int32 [S]) -- a handle for
+        `local_search_subset_resident`; None when no row of the subset lies in this shard."""
+        torch = self.torch
+        if len(local_rows) == 0:
+            return None
+        dev = torch.device("cuda", self.device)
+        with torch.cuda.stream(self.stream):
+            return (torch.from_numpy(np.ascontiguousarray(local_rows, dtype=np.int32)).to(dev),
+                    torch.from_numpy(np.ascontiguousarray(positions, dtype=np.int32)).to(dev))
+
+    def local_search_subset_resident(self, query: np.ndarray, handle, k: int, thr: float):
+        """`local_search_subset` over a handle of `subset_to_device`: only the query travels."""
+        torch = self.torch
+        dev = torch.device("cuda", self.device)
+        with torch.cuda.stream(self.stream):
+            if handle is None:
+                return torch.zeros((1, k), dtype=torch.int64, device=dev)
+            dq = torch.from_numpy(np.ascontiguousarray(query, dtype=np.float32)).to(dev)
+            keys = self.engine.search_subset_device(dq, handle[0], k, thr)
+            self.engine.remap_key_positions(keys, handle[1])
+            self._keep = (dq, handle)  # alive until the next call (the kernels run asynchronously)
             return keys
 
     def local_survivors(self, query: np.ndarray, thr: float):
@@ -207,6 +261,17 @@ class DeviceShardBackend:
             pinned.copy_(keys, non_blocking=True)
         self.stream.synchronize()
         return pinned.numpy().copy()
+
+    def failed_lists(self, nq: int, k: int):
+        """[nq, k] lists of PEER_FAILED_KEY: what a rank whose local search failed sends into the exchange.  A buffer of their own (never the
+        gather buffer: with one rank that IS the collective's output), filled on the backend's stream -- the stream the exchange and the merge
+        run on, so the fill is ordered in front of them."""
+        buf = self._failed.get((nq, k))
+        with self.torch.cuda.stream(self.stream):
+            if buf is None:
+                buf = self._failed[(nq, k)] = self.torch.empty((nq, k), dtype=self.torch.int64, device=self.torch.device("cuda", self.device))
+            buf.fill_(PEER_FAILED_KEY)
+        return buf
 
     def empty_gather(self, world: int, nq: int, k: int):
         shape = (world, nq, k)
@@ -256,9 +321,7 @@ class ShardedSearcher:
             # the protocol of tavb_search_allgather (include/tavb.h): this rank joins the exchange with TAVB_KEY_PEER_FAILED in every slot -- it
             # sorts above every real key, so it leads every merged list on every rank -- and raises its own error afterwards
             failure = exc
-            nq = int(queries.shape[0])
-            local = self.backend.empty_gather(1, nq, k)[0]
-            local.fill_(PEER_FAILED_KEY)
+            local = self.backend.failed_lists(int(queries.shape[0]), k)
         if not collective:
             return local
         nq = local.shape[0]
@@ -317,6 +380,8 @@ class ShardedVectorBase:
         self.local_rows = int(local_rows)
         self.total_rows = int(total_rows)
         self.searcher = ShardedSearcher(backend, group=group)
+        self._storage_dtype = backend.storage_dtype() if hasattr(backend, "storage_dtype") else "fp32"
+        self._subset_cache = None  # (caller's subset object, private copy, total rows, ordinals int64, the backend's handle) of the last subset lookup
 
     def __len__(self) -> int:
         return self.total_rows
@@ -348,6 +413,7 @@ class ShardedVectorBase:
             self.backend.append_rows(rows)
             self.local_rows += len(rows)
         self.total_rows += len(rows)
+        self._subset_cache = None
         # Appends always land on the last rank: contiguous ranges stay contiguous and nothing already placed moves -- but every collective
         # lookup waits for the largest shard, so an index GROWN by appends drifts towards single-GPU speed.  `imbalance()` says how far it has
         # drifted; `rebalance()` re-deals the rows (a collective: every rank hands its rows to `deserialize` of the balanced layout).
@@ -360,11 +426,14 @@ class ShardedVectorBase:
         self.searcher.dist.all_gather_object(counts, self.local_rows, group=self.searcher.group)
         return max(counts) / (self.total_rows / self._world)
 
-    def rebalance(self, dtype: str = "fp32") -> None:
-        """Collective: re-deal the rows into balanced contiguous shards (`shard_range`).  Every rank serialises its rows, the ranks exchange
+    def rebalance(self, dtype: str | None = None) -> None:
+        """Collective: re-deal the rows into balanced contiguous shards (`shard_range`), stored as they are now (`dtype` None: the dtype handed
+        to `deserialize` / of the adopted shard tensor -- an fp16 index stays fp16: twice the HBM and other kernels otherwise).  Every rank serialises its rows, the ranks exchange
         them over torch.distributed (host side, every rank sees the whole matrix for a moment: a maintenance step for corpora that fit host memory,
         not the lookup path -- bigger ones are re-sharded from their source with `deserialize`) and each keeps its new range."""
         mine = self.serialize()
+        if dtype is None:
+            dtype = self._storage_dtype
         if self._world == 1:
             return
         parts = [None] * self._world
@@ -403,6 +472,8 @@ class ShardedVectorBase:
         self.row_offset = int(sum(counts[: self._rank]))
         self.local_rows = len(rows)
         self.total_rows = int(sum(counts))
+        self._storage_dtype = "fp16" if dtype == "fp16" else "fp32"
+        self._subset_cache = None
         self.backend.set_rows(rows, self.row_offset, dtype)  # (no rows: the backend drops its shard)
 
     def clear(self) -> None:
@@ -421,6 +492,8 @@ class ShardedVectorBase:
 
     def _queries(self, q):
         a = np.ascontiguousarray(q, dtype=np.float32)
+        if hasattr(self.backend, "stage_queries"):
+            return self.backend.stage_queries(a)
         torch = getattr(self.backend, "torch", None)
         if torch is None:
             import torch as _t
@@ -429,8 +502,6 @@ class ShardedVectorBase:
         return torch.from_numpy(a).to(torch.device("cuda", self.backend.device))
 
     def fuzzy_lookup_embeddings(self, embeddings, max_hits: int | None = None, min_score: float | None = None):
-        from .vectorbase import ScoredInt
-
         if max_hits is None:
             max_hits = 10
         if min_score is None:
@@ -441,11 +512,9 @@ class ShardedVectorBase:
         if self.total_rows == 0 or len(q) == 0:
             return [[] for _ in range(len(q))]
         res = self.searcher.search(self._queries(q), max_hits, min_score)
-        out = []
-        for i in range(len(q)):
-            m = int(res.counts[i])
-            out.append([ScoredInt(int(o), float(s)) for o, s in zip(res.ordinals[i, :m].tolist(), res.scores[i, :m].tolist())])
-        return out
+        from .vectorbase import _scored_lists  # (the lists are built in C: csrc/tavb_pyhits.c)
+
+        return _scored_lists(res.ordinals, res.scores, res.counts, int(max_hits))
 
     def fuzzy_lookup_embedding(self, embedding, max_hits: int | None = None, min_score: float | None = None, predicate=None):
         """vectorbase.py:163-201.  With a predicate (:191-201): every rank applies it to the survivors of ITS shard, in ascending
@@ -486,18 +555,35 @@ class ShardedVectorBase:
         thr = float(_native.f32_threshold(0.0 if min_score is None else min_score))
         if len(ordinals_of_subset) == 0 or self.total_rows == 0:
             return []
-        subset = np.asarray(ordinals_of_subset)
-        if subset.dtype.kind not in "iu":
-            raise IndexError("arrays used as indices must be of integer (or boolean) type")
-        subset = subset.astype(np.int64, copy=False).reshape(-1)
-        n = self.total_rows
-        rows = np.where(subset < 0, subset + n, subset)  # numpy index wrap (:218)
-        bad = (rows < 0) | (rows >= n)
-        if bad.any():
-            raise IndexError(f"index {int(subset[np.argmax(bad)])} is out of bounds for axis 0 with size {n}")
-        mine = np.flatnonzero((rows >= self.row_offset) & (rows < self.row_offset + self.local_rows))  # ascending positions: lists stay sorted among ties
         q = np.ascontiguousarray(embedding, dtype=np.float32)
-        local = self.backend.local_search_subset(q, rows[mine] - self.row_offset, mine, k, thr)
+        # the same subset object with the same content again (the memory provider's scope list per query term,
+        # storage/memory/messageindex.py:173-183): this shard's part of it stays on the device (as VectorBase does it)
+        layout = (self.total_rows, self.row_offset, self.local_rows)
+        cached = self._subset_cache
+        resident = hasattr(self.backend, "subset_to_device") and isinstance(ordinals_of_subset, (list, np.ndarray))
+        if (resident and cached is not None and cached[0] is ordinals_of_subset and cached[2] == layout and len(cached[1]) == len(ordinals_of_subset)
+                and (np.array_equal(cached[1], ordinals_of_subset) if isinstance(ordinals_of_subset, np.ndarray) else cached[1] == ordinals_of_subset)):
+            subset = cached[3]
+            local = self.backend.local_search_subset_resident(q, cached[4], k, thr)
+        else:
+            subset = np.asarray(ordinals_of_subset)
+            if subset.dtype.kind not in "iu":
+                raise IndexError("arrays used as indices must be of integer (or boolean) type")
+            subset = subset.astype(np.int64, copy=False).reshape(-1)
+            n = self.total_rows
+            rows = np.where(subset < 0, subset + n, subset)  # numpy index wrap (:218)
+            bad = (rows < 0) | (rows >= n)
+            if bad.any():
+                raise IndexError(f"index {int(subset[np.argmax(bad)])} is out of bounds for axis 0 with size {n}")
+            mine = np.flatnonzero((rows >= self.row_offset) & (rows < self.row_offset + self.local_rows))  # ascending positions: lists stay sorted among ties
+            if resident:
+                handle = self.backend.subset_to_device(rows[mine] - self.row_offset, mine)
+                is_array = isinstance(ordinals_of_subset, np.ndarray)
+                subset = subset.copy() if is_array else subset
+                self._subset_cache = (ordinals_of_subset, ordinals_of_subset.copy() if is_array else list(ordinals_of_subset), layout, subset, handle)
+                local = self.backend.local_search_subset_resident(q, handle, k, thr)
+            else:
+                local = self.backend.local_search_subset(q, rows[mine] - self.row_offset, mine, k, thr)
         merged = self.backend.to_host(self.searcher.exchange(local))
         pos, sc, cnt = _native.decode_keys(merged)
         return [ScoredInt(int(subset[p]), float(s_)) for p, s_ in zip(pos[0, : cnt[0]].tolist(), sc[0, : cnt[0]].tolist())]

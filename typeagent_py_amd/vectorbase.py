@@ -305,10 +305,11 @@ class VectorBase:
         self._fp_skipped = 0      # lookups since the fallback fingerprint of an owned, handed-out matrix was last compared
         self._fp_checked = 0.0    # ... and when (time.monotonic())
         mode = (verify_host or os.environ.get("TYPEAGENT_VB_VERIFY_HOST", "sampled")).lower()
-        if mode not in ("sampled", "full", "off"):
-            raise ValueError("verify_host must be 'sampled', 'full' or 'off'")
+        if mode not in ("sampled", "lazy", "full", "off"):
+            raise ValueError("verify_host must be 'sampled', 'lazy', 'full' or 'off'")
         self._verify_host = mode
         self._device_only = None  # torch tensor when the corpus lives only on the device
+        self._subset_cache = None  # (caller's subset object, private copy, row count, ordinals int64, device int32 rows) of the last subset lookup
         self._row_messages: np.ndarray | None = None  # chunk row -> message ordinal (message re-rank on the device)
         self._row_messages_rows = -1  # rows of the map already on the device
         self.clear()
@@ -496,12 +497,13 @@ class VectorBase:
         return eng
 
     def _fingerprint_due(self) -> bool:
-        """A matrix the CALLER owns (deserialize(), :287) is fingerprinted before every lookup: nothing else can notice an edit.  A matrix
-        this index owns and has handed out as a write-tracking view (serialize() / _vectors / get_embedding_at()) reports its writers by
-        itself; the fingerprint there is only the fallback for writers that go around numpy's array API, and costs as much as a whole
-        lookup on a small corpus (~30 us): it is taken at most once per 64 lookups or 20 ms, whichever comes first (`mark_dirty()` is
-        the explicit, immediate form)."""
-        if self._handed_out or self._verify_host == "full":
+        """A matrix somebody else can write to -- the CALLER's own (deserialize(), :287), or one of ours that has been handed out as a view
+        (serialize() / _vectors / get_embedding_at()) -- is fingerprinted before EVERY lookup (the reference always scores the live matrix,
+        :176).  The view reports writers that use numpy's array API by itself; the fingerprint is what notices the others
+        (torch.from_numpy on the view, ctypes, a C extension).  It costs as much as a whole lookup on a small corpus (~30 us), so
+        `verify_host="lazy"` (opt-in) takes it for a matrix of ours at most once per 64 lookups or 20 ms, whichever comes first --
+        such a writer may then be served stale answers for that long; `mark_dirty()` is the explicit, immediate form."""
+        if self._handed_out or self._verify_host != "lazy":
             return True
         self._fp_skipped += 1
         now = time.monotonic()
@@ -519,7 +521,7 @@ class VectorBase:
         n = self._count
         if n == 0 or self._host.ndim != 2 or self._verify_host == "off":
             return None
-        if self._verify_host == "full":
+        if self._verify_host == "full":  # ("lazy" fingerprints like "sampled", less often: _fingerprint_due)
             data = memoryview(np.ascontiguousarray(self._host[:n])).cast("B")
             return (n, self._host.shape[1], _digest(data))
         idx = np.unique(np.linspace(0, n - 1, num=min(n, 32)).astype(np.int64))
@@ -604,21 +606,43 @@ class VectorBase:
         max_hits, thr = self._limits(max_hits, min_score)
         if len(ordinals_of_subset) == 0 or self._count == 0:
             return []
-        subset = np.asarray(ordinals_of_subset)
-        if subset.dtype.kind not in "iu":
-            raise IndexError("arrays used as indices must be of integer (or boolean) type")
-        subset = subset.astype(np.int64, copy=False).reshape(-1)
         n = self._count
-        rows = np.where(subset < 0, subset + n, subset)  # numpy index wrap (:218)
-        bad = (rows < 0) | (rows >= n)
-        if bad.any():
-            first = int(subset[np.argmax(bad)])
-            raise IndexError(f"index {first} is out of bounds for axis 0 with size {n}")
-        eng = self._sync_device()
-        if 1 <= max_hits <= _PAGE:
-            pos, scs = eng.search_subset(embedding, rows, max_hits, thr)
+        # The same subset again (the memory provider hands in one scope list per query term, storage/memory/messageindex.py:173-183;
+        # tools/benchmark_vectorbase.py:133-163 one list for every round): its wrapped, range-checked row list stays on the device.
+        # Recognised by identity AND content -- `==` on the caller's list against a private copy (identical int objects compare by
+        # pointer: ~3 ns per ordinal, against ~30 ns to convert one), so a list edited in place since is simply a new subset.
+        cached = self._subset_cache
+        hit = (cached is not None and cached[0] is ordinals_of_subset and cached[2] == n and len(cached[1]) == len(ordinals_of_subset)
+               and (np.array_equal(cached[1], ordinals_of_subset) if isinstance(ordinals_of_subset, np.ndarray) else cached[1] == ordinals_of_subset))
+        if hit:
+            subset, rows, dev_rows = cached[3], None, cached[4]
         else:
-            pos, scs = eng.search_all(embedding, thr, None if max_hits == 0 else max_hits, subset_rows=rows)
+            subset = np.asarray(ordinals_of_subset)
+            if subset.dtype.kind not in "iu":
+                raise IndexError("arrays used as indices must be of integer (or boolean) type")
+            subset = subset.astype(np.int64, copy=False).reshape(-1)
+            rows = np.where(subset < 0, subset + n, subset)  # numpy index wrap (:218)
+            bad = (rows < 0) | (rows >= n)
+            if bad.any():
+                first = int(subset[np.argmax(bad)])
+                raise IndexError(f"index {first} is out of bounds for axis 0 with size {n}")
+            dev_rows = None
+        eng = self._sync_device()
+        if 1 <= max_hits <= _PAGE and isinstance(eng, _native.Engine) and isinstance(ordinals_of_subset, (list, np.ndarray)):
+            if dev_rows is None:
+                dev_rows = eng.rows_to_device(rows)
+                is_array = isinstance(ordinals_of_subset, np.ndarray)  # (then `subset` may be a view of the caller's array: keep a copy)
+                keep = ordinals_of_subset.copy() if is_array else list(ordinals_of_subset)
+                subset = subset.copy() if is_array else subset
+                self._subset_cache = (ordinals_of_subset, keep, n, subset, dev_rows)
+            pos, scs = eng.search_subset_resident(embedding, dev_rows, max_hits, thr)
+        else:
+            if rows is None:
+                rows = np.where(subset < 0, subset + n, subset)
+            if 1 <= max_hits <= _PAGE:
+                pos, scs = eng.search_subset(embedding, rows, max_hits, thr)
+            else:
+                pos, scs = eng.search_all(embedding, thr, None if max_hits == 0 else max_hits, subset_rows=rows)
         return [ScoredInt(int(subset[p]), float(s)) for p, s in zip(pos.tolist(), scs.tolist())]
 
     def fuzzy_lookup_embeddings(
@@ -773,6 +797,7 @@ class VectorBase:
 
     def clear(self) -> None:
         self._device_only = None
+        self._subset_cache = None
         self._handed_out = False
         self._count = 0
         self._dev_rows = 0
