@@ -6,11 +6,15 @@
 One JSON line on stdout (rank 0).  Without --workload this is the north-star suite:
 
   headline   cfg3 = BASELINE.json configs[2]: 10M x 1536 fp16 corpus, ONE 1024-query batch per step, top-32,
-             through the synchronous C-ABI call `tavb_search_batch` (query H2D, MFMA scan over the whole corpus,
-             candidate rescoring, merges, result D2H, one sync) -- what `VectorBase.fuzzy_lookup_embeddings` costs.
-             `value` = queries/s over exactly K timed steps; `roofline` = 2*Q*N*D flops per batch / the summed
-             duration of the MFMA scan launches of one batch (HIP events on the library's stream) against the
-             2.5 PFLOP/s dense fp16 MFMA peak.
+             through the C-ABI call `tavb_search_device` + `tavb_synchronize`: the query batches (four in rotation) are RESIDENT
+             in HBM when the timed region starts, the step is the MFMA scan over the whole corpus, candidate selection and
+             rescoring, and the last kernel writing the result keys into pinned host memory.  `value` = queries/s over exactly
+             K timed steps.  The same batch handed over as a HOST buffer (`tavb_search_batch`: query H2D included -- what
+             `VectorBase.fuzzy_lookup_embeddings` costs) is reported beside it as `host_buffer_form`, never as `value`.
+             `roofline` = 2*Q*N*D flops per batch / the summed duration of the MFMA scan launches of one batch (HIP events on
+             the library's stream) against the 2.5 PFLOP/s dense fp16 MFMA peak; `roofline.sclk_mhz` / `power_w` = the
+             board's clock and power sampled in-process (amdgpu hwmon) while those launches ran, `frac_at_clock` = the same
+             fraction against the peak at THAT clock (2500 x sclk / 2400).
   sub.cfg3_q1  the same corpus, ONE query per step (north star's single-query target: HBM-bound, 30.72 GB/query)
   sub.cfg2     configs[1]: 1M x 1536 fp32 corpus, one query per step (HBM-bound, 6.144 GB/query)
 
@@ -78,7 +82,23 @@ WORKLOADS = {
     "cfg3_b128": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=128, k=32, bound="hbm", seed=10043),  # 128-query tile: one HBM pass (3.9 PFLOP would take 3.2 ms at 0.49 of the matrix peak)
     # fused multi-index user query
     "cfg5": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=6, k=50, bound="hbm", seed=50043),
+    # the other widths of the reference's model table (vectorbase.py:31-35: text-embedding-3-large = 3072) and of its benchmark script
+    # (tools/benchmark_vectorbase.py:55-76: --dim 384), same bytes per corpus as cfg2 / cfg3 x 2 / x 1
+    "cfg2_d3072": dict(rows=1_000_000, dim=3072, dtype="fp32", nq=1, k=32, bound="hbm", seed=2043),
+    "cfg3_d3072_q1": dict(rows=5_000_000, dim=3072, dtype="fp16", nq=1, k=32, bound="hbm", seed=30043),
+    "cfg3_d3072": dict(rows=5_000_000, dim=3072, dtype="fp16", nq=1024, k=32, bound="mfma", seed=30043),
+    "cfg1_d384": dict(rows=10_000, dim=384, dtype="fp32", nq=1, k=10, bound="latency", seed=43),
+    # fuzzy_lookup_embedding_in_subset (vectorbase.py:203-230): the reference script's third row (1000 of 10k, subset seed 99,
+    # tools/benchmark_vectorbase.py:133-163) and a subset at bench scale (1M random ordinals of the cfg3 corpus: S * D * 2 + S * 4 bytes)
+    "cfg1_subset": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="latency", seed=43, subset=1000),
+    "cfg3_subset": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm", seed=10043, subset=1_000_000),
+    # a real-embedding-like corpus: rows = normalise(g + c * mu), mean pairwise cosine 0.75 (scores 0.875 +- 0.013), at the reference's
+    # related-terms threshold 0.85 (knowpro/convsettings.py:61-63; vectorbase.py:16-35) -- MOST rows survive min_score, the regime the
+    # reference's defaults live in (gaussian rows at 0.85: none does)
+    "cfg3_aniso": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma", seed=10343, kind="aniso", min_score=0.85),
+    "cfg3_aniso_q1": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm", seed=10343, kind="aniso", min_score=0.85),
 }
+ANISO_C = float(np.sqrt(3.0))  # |c * mu| over |g|: cosine between two rows = c^2 / (1 + c^2) = 0.75
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -103,19 +123,43 @@ def cluster_centres(eng, rows_total: int, dim: int, seed: int, cluster_rows: int
     return c
 
 
+def aniso_direction(eng, dim: int, seed: int):
+    """the common direction mu of the anisotropic corpus `seed`: a unit vector [dim] on the device (same on every rank)"""
+    import torch
+
+    dev = torch.device("cuda", eng.device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed * 1_000_003 + 999_979)
+    mu = torch.empty((1, dim), dtype=torch.float32, device=dev)
+    mu.normal_(generator=gen)
+    eng.normalize_rows_(mu)
+    return mu
+
+
+def aniso_queries(eng, count: int, dim: int, seed: int) -> np.ndarray:
+    """`count` unit queries from the distribution of the anisotropic corpus' rows (what a model that embeds queries and rows alike gives)"""
+    mu = aniso_direction(eng, dim, seed).cpu().numpy()
+    rng = np.random.default_rng(seed + 23)
+    q = rng.standard_normal((count, dim)).astype(np.float32) + np.float32(ANISO_C * np.sqrt(dim)) * mu
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q.astype(np.float32)
+
+
 def gen_rows(eng, lo: int, hi: int, dim: int, seed: int, dtype: str, kind: str = "gaussian", rows_total: int | None = None, cluster_rows: int = CLUSTER_ROWS):
     """Rows [lo, hi) of the synthetic corpus `seed` as a device tensor (fp32 or fp16).  Chunk c (CHUNK_ROWS rows) is
     torch.randn with generator seed `seed * 1000003 + c`, L2-normalised by our K1 kernel and (fp16) rounded by our
     convert kernel, so every rank / the parity checker reproduce the same bytes for any row range.
     kind = "clustered": row i belongs to cluster (i * CLUSTER_MULT) % n_clusters and is centre + CLUSTER_SPREAD * noise / sqrt(dim),
     normalised; every row with i % 8 == 5 takes the NEXT cluster's centre as its noise instead -- all such rows of a cluster are
-    exact duplicates of one another (about a dozen per cluster)."""
+    exact duplicates of one another (about a dozen per cluster).
+    kind = "aniso": row = normalise(g + ANISO_C * |g| * mu), one direction mu for the whole corpus (mean pairwise cosine 0.75)."""
     import torch
 
     dev = torch.device("cuda", eng.device)
     out = torch.empty((hi - lo, dim), dtype=torch.float16 if dtype == "fp16" else torch.float32, device=dev)
     gen = torch.Generator(device=dev)
     centres = cluster_centres(eng, rows_total if rows_total is not None else hi, dim, seed, cluster_rows) if kind == "clustered" else None
+    mu = aniso_direction(eng, dim, seed) * float(ANISO_C * np.sqrt(dim)) if kind == "aniso" else None
     c = lo // CHUNK_ROWS
     while c * CHUNK_ROWS < hi:
         c_lo = c * CHUNK_ROWS
@@ -131,6 +175,8 @@ def gen_rows(eng, lo: int, hi: int, dim: int, seed: int, dtype: str, kind: str =
             tmp[dup] = centres[(cl[dup] + 1) % n_c] * CLUSTER_SPREAD
             tmp.add_(centres[cl])
             del ids, cl, dup
+        if mu is not None:
+            tmp.add_(mu)
         a, b = max(lo, c_lo), min(hi, c_lo + CHUNK_ROWS)
         part = tmp[a - c_lo : b - c_lo]
         eng.normalize_rows_(part)
@@ -216,7 +262,7 @@ class ParityTally:
         }
 
 
-def parity_check(eng, resident, resident_lo, wl, queries: np.ndarray, sample: list[int], got: dict, min_score: float) -> dict:
+def parity_check(eng, resident, resident_lo, wl, queries: np.ndarray, sample: list[int], got: dict, min_score: float, subset=None) -> dict:
     """got[qi] = (ordinals, scores) from the GPU path.  Oracle = numpy restatement of vectorbase.py:163-190 over the
     whole corpus (oracle/vectorbase_oracle.py) in ORACLE_CHUNK-row chunks; near-ties are decided by a float64 referee computed in the
     same pass (the reference's best k + 256 rows of every chunk and the returned rows)."""
@@ -225,12 +271,21 @@ def parity_check(eng, resident, resident_lo, wl, queries: np.ndarray, sample: li
     t0 = time.perf_counter()
     ref, referee = vo.scores_full_chunked_refereed(
         oracle_chunks(eng, resident, resident_lo, wl["rows_total"], wl["dim"], wl["seed"], wl["dtype"], wl.get("kind", "gaussian"), wl.get("cluster_rows", CLUSTER_ROWS)),
-        queries[sample], [got[qi][0] for qi in sample], keep=wl["k"] + 256)
+        queries[sample], [got[qi][0] for qi in sample], keep=wl["k"] + 256, restrict=subset)
     tally = ParityTally()
+    pos_of = {int(o): i for i, o in enumerate(subset)} if subset is not None else None
     try:
         for j, qi in enumerate(sample):
             o, s = got[qi]
-            rep, n_near = vo.check_topk_parity_large(ref[j], o.tolist(), s.tolist(), wl["k"], min_score, referee=referee.for_query(j))
+            if subset is not None:  # vectorbase.py:217-227: the scores of the subset's rows, ranked among themselves
+                truth = referee.for_query(j)
+
+                def sub_truth(p_, t=truth):
+                    return t(subset[np.asarray(p_)])
+                sub_truth.dim = wl["dim"]
+                rep, n_near = vo.check_topk_parity_large(ref[j][subset], [pos_of[int(x)] for x in o], s.tolist(), wl["k"], min_score, referee=sub_truth)
+            else:
+                rep, n_near = vo.check_topk_parity_large(ref[j], o.tolist(), s.tolist(), wl["k"], min_score, referee=referee.for_query(j))
             tally.add(rep, n_near)
             tally.worst = max(tally.worst, float(np.max(np.abs(ref[j][o] - s))) if len(o) else 0.0)
     except AssertionError as exc:
@@ -238,22 +293,28 @@ def parity_check(eng, resident, resident_lo, wl, queries: np.ndarray, sample: li
     return {"ok": True, "queries_checked": len(sample), "rows": wl["rows_total"], **tally.fields(), "seconds": round(time.perf_counter() - t0, 1)}
 
 
-def cpu_baseline(host: np.ndarray, queries: np.ndarray, k: int, rows_total: int, nq: int, budget_s: float) -> dict:
-    """The reference's VectorBase.fuzzy_lookup_embedding on this host's cores, same corpus bytes (first rows of it),
-    sequential single-query calls (the reference has no batch entry point: storage/memory/reltermsindex.py:320-332).
-    Verbatim class when /root/reference is present (build container), else its numpy port (oracle/)."""
+def cpu_baseline(host: np.ndarray, queries: np.ndarray, k: int, rows_total: int, nq: int, budget_s: float, subset=None) -> dict:
+    """The reference's VectorBase.fuzzy_lookup_embedding (`subset`: fuzzy_lookup_embedding_in_subset with that list) on this host's cores,
+    same corpus bytes (first rows of it), sequential single-query calls (the reference has no batch entry point:
+    storage/memory/reltermsindex.py:320-332).  Verbatim class when /root/reference is present (build container), else its numpy port
+    (oracle/vectorbase_oracle.py -- pinned to the verbatim class by tests/test_oracle_vs_reference.py and the committed goldens)."""
     from oracle import ref_loader
     from oracle import vectorbase_oracle as vo
 
     kind = "port"
+    sub_list = None if subset is None else [int(x) for x in subset]  # a Python list, as tools/benchmark_vectorbase.py:136 passes it
     if ref_loader.reference_available():
         vb = ref_loader.make_reference_vectorbase(host)
         kind = "reference"
 
         def one(q):
+            if sub_list is not None:
+                return vb.fuzzy_lookup_embedding_in_subset(q, sub_list, max_hits=k, min_score=0.0)
             return vb.fuzzy_lookup_embedding(q, max_hits=k, min_score=0.0)
     else:
         def one(q):
+            if sub_list is not None:
+                return vo.lookup_in_subset(host, q, sub_list, k, 0.0)
             return vo.lookup(host, q, k, 0.0)
 
     cores = len(os.sched_getaffinity(0))
@@ -307,7 +368,9 @@ def cpu_baseline(host: np.ndarray, queries: np.ndarray, k: int, rows_total: int,
         "kind": kind,
         # (what the fields mean, the warm-up and the sweep: profiles/README.md "bench line")
         "sample": f"{len(times)} calls on {host.shape[0]}x{host.shape[1]} fp32 rows of the corpus, median {med * 1e3:.2f} ms"
-                  + (f", x{scale:g} to {rows_total} rows" if scale != 1 else ""),
+                  + (f", x{scale:g} to {rows_total} rows" if scale != 1 else "")
+                  + (f"; subset of {len(sub_list)} ordinals" if sub_list is not None else "")
+                  + ("; numpy port of the reference class (no /root/reference on this box), pinned to the verbatim class by the committed goldens" if kind == "port" else ""),
         "p50_ms_per_query_on_sample": med * 1e3,
         # `value` = the CPU's best: the thread count (`cores`) that won a BLAS thread sweep.  What the reference gets out of the box --
         # OpenBLAS's default of one thread per host core, SURVEY 8d's stated baseline -- is `default_threads` (oversubscribed on a 256-core host)
@@ -338,6 +401,12 @@ class Ctx:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.distributed = self.world > 1 or os.environ.get("TAVB_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank dry run of the N>1 code
+        # TAVB_BENCH_DIST_BACKEND=gloo: the DRY RUN of this script's N > 1 branches on a box with ONE GPU -- every rank on cuda:0, torch.distributed
+        # over gloo, the exchange of the lookups through the searcher's `gather_fn` hook (RCCL refuses two ranks on one device).  Exercises
+        # what the first real N > 1 run executes for the first time otherwise: `rank != 0`, the per-rank timing gather, rank 0 regenerating the
+        # other ranks' rows for the whole-corpus parity check, `sub.cfg4_weak`.  Its rates mean nothing (two ranks share one GPU).
+        self.dist_backend = os.environ.get("TAVB_BENCH_DIST_BACKEND", "nccl")
+        self.dry_run = self.dist_backend != "nccl"
         self.dist = None
         if self.distributed:
             import torch.distributed as dist
@@ -351,11 +420,16 @@ class Ctx:
                 os.environ["MASTER_PORT"] = str(free_port())
             for var, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):  # (TAVB_BENCH_FORCE_DIST=1 without a launcher)
                 os.environ.setdefault(var, val)
+            if self.dry_run:
+                self.local_rank = self.local_rank % max(1, torch.cuda.device_count())
             torch.cuda.set_device(self.local_rank)
             import datetime
 
             # (rank 0 checks parity against the CPU oracle over the WHOLE corpus -- 100M rows at N = 8 take minutes -- while the others wait in a barrier)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank), timeout=datetime.timedelta(minutes=45))
+            if self.dry_run:
+                dist.init_process_group(self.dist_backend, timeout=datetime.timedelta(minutes=45))
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank), timeout=datetime.timedelta(minutes=45))
             self.dist = dist
             if dist.get_world_size() != args.gpus:
                 raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
@@ -371,9 +445,10 @@ class Ctx:
             self.eng = self.backend.engine
             # the exchange of the lookup path is libtavb's own RCCL communicator (tavb_search_allgather); torch.distributed only carries
             # the rendezvous id, the barriers and the max-over-ranks of the timing
-            self.backend.init_comm(dist.get_rank(), dist.get_world_size())
-            if dist.get_world_size() == 1:
-                self.eng.set_option("comm_force", 1)  # 1-rank dry run of the N > 1 code
+            if not self.dry_run:
+                self.backend.init_comm(dist.get_rank(), dist.get_world_size())
+                if dist.get_world_size() == 1:
+                    self.eng.set_option("comm_force", 1)  # 1-rank dry run of the N > 1 code
         else:
             self.backend = None
             self.eng = _native.Engine(self.dev)
@@ -386,12 +461,88 @@ class Ctx:
             self.dist.barrier()
         self.torch.cuda.synchronize(self.dev)
 
+    def coll_device(self):
+        """where the tensors of this script's own collectives (timings, not lookups) live: the GPU under RCCL, the host under gloo"""
+        return self.torch.device("cpu") if self.dry_run else self.torch.device("cuda", self.dev)
+
     def max_over_ranks(self, x: float) -> float:
         if self.dist is None:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.torch.device("cuda", self.dev))
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.coll_device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather_fn(self):
+        """dry run only: the exchange of a lookup by other means than RCCL -- this rank's [nq, k] keys -> host -> gloo all-gather -> device
+        [world, nq, k] (ShardedSearcher's test hook; the merge kernel and everything around it are the product's)."""
+        if not self.dry_run:
+            return None
+        torch, dist, backend = self.torch, self.dist, self.backend
+
+        def gather(local):
+            backend.stream.synchronize()
+            mine = local.cpu().contiguous()
+            parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, mine)
+            with torch.cuda.stream(backend.stream):
+                return torch.stack(parts).to(local.device)
+        return gather
+
+
+class HwmonSampler:
+    """Board clock and power while a leg runs, read in-process from the amdgpu hwmon files of THIS device (freq1_input = sclk in Hz,
+    power1_input = package power in uW; matched to the HIP device by PCI address) every 10 ms on a thread.  Used around the event pass of a
+    record -- the same K steps as the timed region, outside it -- so the driver's own line carries the clock the roofline's kernel ran at."""
+
+    def __init__(self, torch, dev: int):
+        import glob
+        import threading
+
+        self.freq = self.power = None
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            pass
+        found = []
+        for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+            hw = glob.glob(os.path.join(card, "hwmon", "hwmon*", "freq1_input"))
+            if hw:
+                found.append((os.path.basename(os.path.realpath(card)), os.path.dirname(hw[0])))
+        pick = [h for addr, h in found if want and addr.lower() == want.lower()] or ([found[0][1]] if len(found) == 1 else [])
+        if pick:
+            self.freq, self.power = os.path.join(pick[0], "freq1_input"), os.path.join(pick[0], "power1_input")
+        self.sclk, self.watts = [], []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                with open(self.freq) as f:
+                    self.sclk.append(int(f.read()) / 1e6)
+                with open(self.power) as f:
+                    self.watts.append(int(f.read()) / 1e6)
+            except Exception:
+                return
+            self._stop.wait(0.01)
+
+    def __enter__(self):
+        if self.freq:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self.freq:
+            self._thread.join()
+
+    def summary(self) -> dict | None:
+        if len(self.sclk) < 3:
+            return None
+        tail = lambda a: a[len(a) // 4:]  # (the first quarter: the clock is still settling from the barrier's idle moment)
+        return {"sclk_mhz": float(np.median(tail(self.sclk))), "power_w": float(np.median(tail(self.watts))), "samples": len(self.sclk)}
 
 
 def kernel_times(ctx: Ctx) -> dict:
@@ -413,6 +564,8 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     if wl.get("kind") == "clustered":
         queries = clustered_queries(eng, max(64, nq * n_rot), rows_total, dim, wl["seed"], wl.get("cluster_rows", CLUSTER_ROWS))
         queries = queries[np.random.default_rng(7).permutation(len(queries))]  # (neighbouring clusters do not share a query tile)
+    elif wl.get("kind") == "aniso":
+        queries = aniso_queries(eng, max(64, nq * n_rot), dim, wl["seed"])
     else:
         queries = host_queries(max(64, nq * n_rot), dim, 4242)
 
@@ -421,7 +574,7 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         from typeagent_py_amd.sharded import ShardedSearcher
 
         ctx.backend.set_shard(corpus, row_offset=shard_lo)
-        searcher = ShardedSearcher(ctx.backend)
+        searcher = ShardedSearcher(ctx.backend, gather_fn=ctx.gather_fn())
         dq_all = torch.from_numpy(queries).to(torch.device("cuda", ctx.dev))
     else:
         eng.set_corpus_tensor(corpus)
@@ -431,12 +584,23 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
             keys_np = keys_buf.numpy()
             torch.cuda.synchronize()
 
+    # the subset form (vectorbase.py:203-230): `subset` random ordinals (seed 99, without replacement: tools/benchmark_vectorbase.py:133-136),
+    # their row list resident on the device -- uploaded once, as the class does for a subset it is handed again (tavb_search_subset_resident)
+    subset = dev_subset = None
+    if wl.get("subset") and searcher is None:
+        subset = np.random.default_rng(99).choice(rows_total, size=min(int(wl["subset"]), rows_total), replace=False).astype(np.int64)
+        dev_subset = eng.rows_to_device(subset)
+        torch.cuda.synchronize()
+
     n_lookups = [0]
 
     def one_step(i: int, host_queries_form: bool = False):
         n_lookups[0] += 1
         if nq == 1:
             qi = i % len(queries)
+            if subset is not None:
+                pos, scs = eng.search_subset_resident(queries[qi], dev_subset, k, np.float32(thr))
+                return subset[pos], scs
             if searcher is None:
                 # C ABI as the drop-in class calls it: 6 KiB host query in, host results out (the kernel writes them into pinned memory)
                 return eng.search(queries[qi], k, np.float32(thr))
@@ -485,9 +649,10 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     eng.profile_reset()
     ctx.barrier()
     e0 = time.perf_counter()
-    for i in range(steps):
-        one_step(warmup + i)
-    ctx.barrier()
+    with HwmonSampler(torch, ctx.dev) as hw:
+        for i in range(steps):
+            one_step(warmup + i)
+        ctx.barrier()
     elapsed_with_events = ctx.max_over_ranks(time.perf_counter() - e0)
     kt = kernel_times(ctx)
     eng.profile_enable(False)
@@ -497,7 +662,7 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         # stream: a rank that finishes its scan early waits there for the slowest one, so the MINIMUM over ranks is the cost of the exchange
         # itself and max - min of the scan times is the skew)
         scan_ms = sum(kt[p][0] for p in ("scan", "mfma_last_phase", "mfma_earlier_phases", "skinny_last_phase")) / steps
-        mine = torch.tensor([scan_ms, kt["exchange"][0] / steps, kt["merge"][0] / steps, float(rows_local)], dtype=torch.float64, device=torch.device("cuda", ctx.dev))
+        mine = torch.tensor([scan_ms, kt["exchange"][0] / steps, kt["merge"][0] / steps, float(rows_local)], dtype=torch.float64, device=ctx.coll_device())
         every = [torch.zeros_like(mine) for _ in range(ctx.dist.get_world_size())]
         ctx.dist.all_gather(every, mine)
         per = torch.stack(every).cpu().numpy()
@@ -509,6 +674,8 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
             "merge_ms": float(per[:, 2].max()),
             "rows_per_rank": [int(x) for x in per[:, 3]],
         }
+        if ctx.dry_run:  # (no RCCL all-gather ran: the keys went through the host; exchange_ms is 0 and the rates are two ranks sharing one GPU)
+            dist_extra["backend"] = f"{ctx.dist_backend} dry run on one GPU: keys exchanged through the host, rates not meaningful"
     host_form = None
     if searcher is None and nq > 1:  # the same batch handed over as a host buffer (what VectorBase.fuzzy_lookup_embeddings does): PCIe-inclusive
         one_step(0, True)
@@ -561,10 +728,17 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
     kern_ms_per_step = sum(kt[p][0] for p in parts) / steps
     launches_per_step = sum(kt[p][1] for p in parts) / steps
     passes = kt[parts[0]][1] / steps  # corpus passes per step (a batch bigger than one pass serves is split)
-    if wl["bound"] == "hbm":
+    if wl["bound"] in ("hbm", "latency"):
         alg = rows_local * dim * esize * passes  # bytes the scan must read per step: this rank's shard once per pass
+        if subset is not None:
+            alg = len(subset) * (dim * esize + 4) * passes  # the subset's rows + its int32 row list
         achieved = alg / (kern_ms_per_step * 1e-3) / 1e9 if kern_ms_per_step > 0 else 0.0
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+        if wl["bound"] == "latency":
+            # a corpus of a few MB (the reference's own scale) sits in the 256 MiB Infinity Cache and a lookup is two or three submissions: the
+            # record is bound by launch + synchronise latency, not by HBM -- no fraction of the HBM peak is claimed for it
+            roof = {"bound": "latency", "kernel_us_per_step": kern_ms_per_step * 1e3, "bytes_per_step": alg, "traffic": None,
+                    "note": "launch-bound: the corpus is cache-resident; p50_latency_us is the figure of merit"}
     else:
         alg = 2.0 * nq * rows_local * dim
         achieved = alg / (kern_ms_per_step * 1e-3) / 1e12 if kern_ms_per_step > 0 else 0.0
@@ -583,6 +757,13 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         pass
     if shadow:
         roof["scanned"] = "fp16 shadow"  # of the fp32 corpus, as an exact filter; the band of candidates is rescored with the fp32 rows
+    hwm = hw.summary()
+    if hwm:
+        # board clock / power sampled in-process while the event pass ran (amdgpu hwmon, 10 ms): dense MFMA work holds this board well below
+        # the 2.4 GHz the peak is quoted at -- `frac_at_clock` prices the kernel against the peak at the clock it actually ran at
+        roof.update(hwm)
+        if roof["bound"] == "mfma" and hwm["sclk_mhz"] > 0:
+            roof["frac_at_clock"] = roof["achieved"] / (roof["peak"] * hwm["sclk_mhz"] / 2400.0)
     roof.update({
         "kernel": kern_name,
         "kernel_ms_per_step": kern_ms_per_step,          # HIP event pairs around every launch, over a second pass of the same steps
@@ -623,12 +804,14 @@ def run_record(ctx: Ctx, name: str, wl: dict, corpus, shard_lo: int, steps: int,
         rec["host_buffer_form"] = host_form
     if dist_extra:
         rec["exchange"] = dist_extra
+    if subset is not None:
+        rec["workload"] += f", subset of {len(subset)} ordinals (row list resident)"
     if not args.no_parity:
-        rec["parity"] = parity_check(eng, corpus, shard_lo, wl, queries, sample, got, min_score)
+        rec["parity"] = parity_check(eng, corpus, shard_lo, wl, queries, sample, got, min_score, subset)
     if with_cpu and not args.no_cpu_baseline:
         n_host = min(rows_local, ORACLE_CHUNK)
         host = corpus[:n_host].float().cpu().numpy()
-        rec["cpu_baseline"] = cpu_baseline(host, queries, k, rows_total, nq, args.cpu_seconds)
+        rec["cpu_baseline"] = cpu_baseline(host, queries, k, rows_total, nq, wl.get("cpu_seconds", args.cpu_seconds), subset)
     return rec
 
 
@@ -698,10 +881,14 @@ def class_api_rates(ctx: Ctx, wl: dict, corpus, min_score: float, steps: int) ->
     vb = VectorBase(TextEmbeddingIndexSettings(_Null()), device=ctx.dev)
     vb.adopt_device_corpus(corpus)
     queries = host_queries(max(64, nq * BATCH_ROTATION), dim, 4242)
+    # the subset form: ONE Python list handed in again and again, as tools/benchmark_vectorbase.py:133-163 and the memory provider do
+    sub_list = np.random.default_rng(99).choice(int(corpus.shape[0]), size=int(wl["subset"]), replace=False).tolist() if wl.get("subset") else None
     out = {}
     for label, kw in (("scored_int_lists", {}), ("as_arrays", {"as_arrays": True})):
         def call(i):
             b0 = (i % BATCH_ROTATION) * nq if nq > 1 else i % len(queries)
+            if sub_list is not None:
+                return vb.fuzzy_lookup_embedding_in_subset(queries[b0], sub_list, max_hits=k, min_score=min_score)
             if nq == 1:
                 return vb.fuzzy_lookup_embedding(queries[b0], max_hits=k, min_score=min_score)
             return vb.fuzzy_lookup_embeddings(queries[b0 : b0 + nq], max_hits=k, min_score=min_score, **kw)
@@ -716,6 +903,13 @@ def class_api_rates(ctx: Ctx, wl: dict, corpus, min_score: float, steps: int) ->
             call(1 + i)
         ms = (time.perf_counter() - t0) / steps * 1e3
         out[label] = {"ms_per_step": ms, "queries_per_sec": nq / (ms * 1e-3)}
+    if sub_list is not None:  # ... and handed a FRESH list every call (nothing to recognise: list -> ndarray, range check, upload, every time)
+        call(0)
+        n_fresh = max(3, min(steps, 20))
+        t0 = time.perf_counter()
+        for i in range(n_fresh):
+            vb.fuzzy_lookup_embedding_in_subset(queries[i % len(queries)], list(sub_list), max_hits=k, min_score=min_score)
+        out["fresh_list_every_call"] = {"ms_per_step": (time.perf_counter() - t0) / n_fresh * 1e3}
     del vb
     return out
 
@@ -753,8 +947,11 @@ def headline_line(ctx: Ctx, rec: dict, name: str, wl: dict, scaling: str, sub: d
         "roofline": {k: v for k, v in rec["roofline"].items() if k not in ("pipe", "ms_per_step_with_events")},
         "cpu_baseline": rec.get("cpu_baseline"),
     }
+    if getattr(ctx, "dry_run", False):
+        out["dry_run"] = (f"{ctx.world} ranks sharing ONE GPU over {ctx.dist_backend}: this line proves that bench.py's N > 1 branches run "
+                          "(rank != 0, per-rank timing gather, whole-corpus parity over every rank's rows, cfg4_weak); its rates are not measurements")
     if "parity" in rec:
-        out["parity"] = {k: v for k, v in rec["parity"].items() if k not in ("rows", "seconds", "max_inverted_gap_gpu", "max_inverted_gap_ref")}
+        out["parity"] = {k: v for k, v in rec["parity"].items() if k not in ("rows", "max_inverted_gap_gpu", "max_inverted_gap_ref")}
     if "host_buffer_form" in rec:
         out["host_buffer_form"] = rec["host_buffer_form"]  # PCIe-inclusive rate of the same batch (never `value`)
     for key in ("query_batches_in_rotation", "flagged_fraction", "class_api", "exchange"):
@@ -765,7 +962,8 @@ def headline_line(ctx: Ctx, rec: dict, name: str, wl: dict, scaling: str, sub: d
     if sub:
         # the driver's record keeps the top-level contract fields and the last 2000 characters of the line: the records a reader is most likely
         # to look for there (this round's: the mid-batch tiles, cfg5's variants) go last
-        last = [k for k in ("cfg5", "cfg2_b32", "cfg3_b32", "cfg3_b128", "cfg4_weak") if k in sub]
+        last = [k for k in ("cfg5", "cfg3_dup", "cfg1_d384", "cfg1_subset", "cfg3_subset", "cfg2_d3072", "cfg3_d3072_q1", "cfg3_d3072", "cfg3_aniso_q1", "cfg3_aniso",
+                            "cfg4_weak") if k in sub]
         out["sub"] = {k: slim_sub(sub[k]) for k in [k for k in sub if k not in last] + last}
     return out
 
@@ -998,7 +1196,11 @@ def slim_sub(rec: dict) -> dict:
         out.pop("p50_latency_us", None)  # a batch's latency is its ms_per_step; so is a long single lookup's (kept for the launch-bound cfg1)
     ro = rec.get("roofline") or {}
     # (`peak` is the headline's for the same `bound`: 8000 GB/s hbm, 2500 TFLOP/s fp16 mfma)
-    keep = {k: ro[k] for k in ("bound", "achieved", "frac", "traffic", "kernel", "kernel_ms_per_step", "scan_kernel_ms_per_user_query", "scanned") if k in ro}
+    keep = {k: ro[k] for k in ("bound", "achieved", "frac", "traffic", "kernel", "kernel_ms_per_step", "scan_kernel_ms_per_user_query", "scanned",
+                               "kernel_us_per_step", "frac_at_clock", "sclk_mhz", "power_w") if k in ro}
+    if keep.get("bound") != "mfma":
+        for key in ("sclk_mhz", "power_w"):
+            keep.pop(key, None)
     if keep.get("traffic") is None:
         keep.pop("traffic", None)
     if "exact" not in str(keep.get("kernel", "exact")):
@@ -1009,7 +1211,10 @@ def slim_sub(rec: dict) -> dict:
     pa = rec.get("parity")
     if pa:
         out["parity"] = {k: pa[k] for k in ("ok", "error", "lookups_checked", "positions_exact", "positions_permuted", "max_permuted_gap",
-                                            "gpu_inversions_vs_f64", "reference_inversions_vs_f64", "noise_gpu", "noise_ref") if k in pa}
+                                            "gpu_inversions_vs_f64", "reference_inversions_vs_f64", "noise_gpu", "noise_ref", "rows", "seconds") if k in pa}
+        if out["parity"].get("rows", 0) <= 12_500_000:  # (how long the oracle's pass took matters where it is long: the N > 1 records)
+            out["parity"].pop("rows", None)
+            out["parity"].pop("seconds", None)
         if out["parity"].get("positions_permuted") == 0:  # every position exact: nothing permuted, nothing inverted (on either side)
             for key in ("max_permuted_gap", "gpu_inversions_vs_f64", "reference_inversions_vs_f64"):
                 out["parity"].pop(key, None)
@@ -1171,6 +1376,11 @@ def main() -> None:
         for mid in ("cfg3_b32", "cfg3_b128"):
             wm = dict(WORKLOADS[mid], rows_total=wl["rows_total"], rows=wl["rows"])
             sub[mid] = run_record(ctx, mid, wm, corpus, 0, 20, 3, with_cpu=False)
+        # the subset form at bench scale on the same corpus: 1M random ordinals of the 10M rows, the row list resident (+ through the class)
+        ws = dict(WORKLOADS["cfg3_subset"], rows_total=wl["rows_total"], rows=wl["rows"])
+        ws["subset"] = min(ws["subset"], max(1, wl["rows"] // 10))
+        sub["cfg3_subset"] = run_record(ctx, "cfg3_subset", ws, corpus, 0, 40, 5, with_cpu=False)
+        sub["cfg3_subset"]["class_api"] = class_api_rates(ctx, ws, corpus, args.min_score, 20)
         del corpus
         torch.cuda.empty_cache()
         # (the two small corpora next: measured right after big ones have come and gone, cfg2 reads 6 % slower -- where its 6 GB land in HBM)
@@ -1190,7 +1400,40 @@ def main() -> None:
         c1 = gen_rows(ctx.eng, 0, w1["rows"], w1["dim"], w1["seed"], w1["dtype"])
         sub["cfg1"] = run_record(ctx, "cfg1", w1, c1, 0, 500, 50, with_cpu=True)
         sub["cfg1"]["class_api"] = class_api_rates(ctx, w1, c1, args.min_score, 500)
+        # the reference script's third row on the same corpus: fuzzy_lookup_embedding_in_subset, 1000 of 10k (tools/benchmark_vectorbase.py:133-163)
+        w1s = dict(WORKLOADS["cfg1_subset"], rows_total=w1["rows"], cpu_seconds=6.0)
+        sub["cfg1_subset"] = run_record(ctx, "cfg1_subset", w1s, c1, 0, 500, 50, with_cpu=True)
+        sub["cfg1_subset"]["class_api"] = class_api_rates(ctx, w1s, c1, args.min_score, 500)
         del c1
+        # ... and the width that script defaults to (--dim 384, :55-76)
+        w1d = dict(WORKLOADS["cfg1_d384"])
+        w1d.update(rows_total=w1d["rows"], cpu_seconds=6.0)
+        c1d = gen_rows(ctx.eng, 0, w1d["rows"], w1d["dim"], w1d["seed"], w1d["dtype"])
+        sub["cfg1_d384"] = run_record(ctx, "cfg1_d384", w1d, c1d, 0, 500, 50, with_cpu=True)
+        del c1d
+        torch.cuda.empty_cache()
+        # the 3072-wide model of the reference's table (text-embedding-3-large, vectorbase.py:31-35): cfg2's and cfg3's shapes at that width
+        wd = dict(WORKLOADS["cfg2_d3072"])
+        wd["rows_total"] = wd["rows"]
+        cw = gen_rows(ctx.eng, 0, wd["rows"], wd["dim"], wd["seed"], wd["dtype"])
+        sub["cfg2_d3072"] = run_record(ctx, "cfg2_d3072", wd, cw, 0, 60, 8, with_cpu=False)
+        del cw
+        torch.cuda.empty_cache()
+        wd = dict(WORKLOADS["cfg3_d3072"])
+        wd["rows_total"] = wd["rows"]
+        cw = gen_rows(ctx.eng, 0, wd["rows"], wd["dim"], wd["seed"], wd["dtype"])
+        sub["cfg3_d3072"] = run_record(ctx, "cfg3_d3072", wd, cw, 0, 10, 2, with_cpu=False)
+        sub["cfg3_d3072_q1"] = run_record(ctx, "cfg3_d3072_q1", dict(WORKLOADS["cfg3_d3072_q1"], rows_total=wd["rows"]), cw, 0, 40, 5, with_cpu=False)
+        del cw
+        torch.cuda.empty_cache()
+        # a real-embedding-like corpus (one common direction, mean pairwise cosine 0.75) at the reference's threshold 0.85: most rows survive
+        wa = dict(WORKLOADS["cfg3_aniso"])
+        wa["rows_total"] = wa["rows"]
+        ca = gen_rows(ctx.eng, 0, wa["rows"], wa["dim"], wa["seed"], wa["dtype"], "aniso", wa["rows"])
+        sub["cfg3_aniso"] = run_record(ctx, "cfg3_aniso", wa, ca, 0, 10, 2, with_cpu=False)
+        sub["cfg3_aniso"]["vs_gaussian"] = sub["cfg3_aniso"]["queries_per_sec"] / rec["queries_per_sec"]
+        sub["cfg3_aniso_q1"] = run_record(ctx, "cfg3_aniso_q1", dict(WORKLOADS["cfg3_aniso_q1"], rows_total=wa["rows"]), ca, 0, 40, 5, with_cpu=False)
+        del ca
         torch.cuda.empty_cache()
 
         # the headline shape on a clustered corpus (near-duplicate clusters + exact duplicates, queries next to cluster centres): what the

@@ -492,19 +492,29 @@ class ChunkedReferee:
     computed for the rows that can matter -- the chunk's best `keep` rows per query by the float32 reference score, plus the ordinals the
     device returned -- and remembered per query.  The whole corpus' best `keep` rows are among the chunks' best `keep` rows."""
 
-    def __init__(self, queries: np.ndarray, returned: Sequence[Sequence[int]], keep: int):
+    def __init__(self, queries: np.ndarray, returned: Sequence[Sequence[int]], keep: int, restrict: np.ndarray | None = None):
+        """restrict (optional): the ordinals of a SUBSET search (vectorbase.py:203-230) -- the rows that can matter are the best `keep` of the
+        subset's rows in each chunk, not of the chunk."""
         self.queries = np.ascontiguousarray(queries, dtype=np.float32)
         self.returned = [np.unique(np.asarray(r, dtype=np.int64)) for r in returned]
         self.keep = int(keep)
+        self.restrict = None if restrict is None else np.unique(np.asarray(restrict, dtype=np.int64))
         self.truth: list[dict[int, float]] = [dict() for _ in range(len(self.queries))]
 
     def see_chunk(self, base: int, chunk: np.ndarray, scores32: np.ndarray) -> None:
         """scores32: float32 [rows of the chunk, nq] reference scores of this chunk."""
         rows = chunk.shape[0]
+        cand = None
+        if self.restrict is not None:
+            cand = self.restrict[(self.restrict >= base) & (self.restrict < base + rows)] - base
         for j in range(len(self.queries)):
             col = np.where(np.isnan(scores32[:, j]), np.float32(-1.0), scores32[:, j])
-            keep = min(self.keep, rows)
-            best = np.argpartition(-col, keep - 1)[:keep] if keep < rows else np.arange(rows)
+            if cand is not None:
+                keep = min(self.keep, len(cand))
+                best = cand[np.argpartition(-col[cand], keep - 1)[:keep]] if 0 < keep < len(cand) else cand
+            else:
+                keep = min(self.keep, rows)
+                best = np.argpartition(-col, keep - 1)[:keep] if keep < rows else np.arange(rows)
             mine = self.returned[j]
             mine = mine[(mine >= base) & (mine < base + rows)] - base
             pos = np.unique(np.concatenate([best, mine]))
@@ -520,10 +530,11 @@ class ChunkedReferee:
         return referee
 
 
-def scores_full_chunked_refereed(chunks: Iterable[np.ndarray], queries: np.ndarray, returned: Sequence[Sequence[int]], keep: int):
-    """`scores_full_chunked` + a `ChunkedReferee` filled in the same pass over the chunks."""
+def scores_full_chunked_refereed(chunks: Iterable[np.ndarray], queries: np.ndarray, returned: Sequence[Sequence[int]], keep: int,
+                                 restrict: np.ndarray | None = None):
+    """`scores_full_chunked` + a `ChunkedReferee` filled in the same pass over the chunks (`restrict`: the ordinals of a subset search)."""
     queries = np.ascontiguousarray(queries, dtype=np.float32)
-    ref = ChunkedReferee(queries, returned, keep)
+    ref = ChunkedReferee(queries, returned, keep, restrict)
     parts = []
     base = 0
     for chunk in chunks:

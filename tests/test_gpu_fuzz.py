@@ -15,7 +15,7 @@ from typeagent_py_amd import TextEmbeddingIndexSettings, VectorBase
 
 pytestmark = pytest.mark.gpu
 
-DIMS = [1, 2, 3, 7, 16, 33, 64, 96, 100, 128, 384, 768, 1000, 1024, 1536]
+DIMS = [1, 2, 3, 7, 16, 33, 64, 96, 100, 128, 384, 768, 1000, 1024, 1536, 2048, 3072]  # (2048 / 3072 since round 6: the case list of a seed base changed with them)
 BATCHES = [1, 1, 2, 3, 5, 8, 9, 31, 32, 33, 64, 65, 100, 129, 257]
 KS = [1, 2, 5, 10, 32, 48, 49, 64, 65, 100, 300]
 THRESHOLDS = [None, 0.0, 0.3, 0.5, 0.52, 0.6, 0.85, 1.0, 1.5, -0.2]

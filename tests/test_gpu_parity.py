@@ -308,6 +308,43 @@ def test_subset_search_differential():
         vb.fuzzy_lookup_embedding_in_subset(q, [-5001])
 
 
+def test_a_repeated_subset_keeps_its_row_list_on_the_device():
+    """`fuzzy_lookup_embedding_in_subset` with the same list again (tools/benchmark_vectorbase.py:133-163: 1000 of 10k, seed 99, one list for
+    every round; the memory provider's scope list, storage/memory/messageindex.py:173-183): the wrapped, range-checked row list is uploaded
+    once (`tavb_search_subset_resident`); a list edited in place is a new subset.  Same answers as the plain path and the oracle."""
+    v, q = make_corpus(10_000, 1536, 43)
+    vb = new_vb(v)
+    subset = np.random.default_rng(99).choice(10_000, size=1000, replace=False).tolist()
+    first = vb.fuzzy_lookup_embedding_in_subset(q, subset, max_hits=10, min_score=0.0)
+    cache = vb._subset_cache
+    assert cache is not None and cache[0] is subset and tuple(cache[4].shape) == (1000,)
+    ptr = cache[4].data_ptr()
+    again = vb.fuzzy_lookup_embedding_in_subset(q, subset, max_hits=10, min_score=0.0)
+    assert vb._subset_cache is cache and cache[4].data_ptr() == ptr
+    assert [(r.item, r.score) for r in first] == [(r.item, r.score) for r in again]
+    sub = np.asarray(subset, dtype=np.int64)
+    vo.check_topk_parity(vo.scores_full(v, q)[sub], [r.item for r in first], [r.score for r in first], 10, 0.0, candidate_ordinals=sub,
+                         referee=vo.f64_referee(v[sub], q))
+    plain = vb.fuzzy_lookup_embedding_in_subset(q, tuple(subset), max_hits=10, min_score=0.0)  # (a tuple: the per-call upload path)
+    assert [(r.item, r.score) for r in plain] == [(r.item, r.score) for r in first]
+    best = first[0].item
+    subset[subset.index(best)] = subset[0]  # the best row leaves the subset (in place): seen
+    edited = vb.fuzzy_lookup_embedding_in_subset(q, subset, max_hits=10, min_score=0.0)
+    assert best not in [r.item for r in edited] and vb._subset_cache is not cache
+    sub = np.asarray(subset, dtype=np.int64)
+    vo.check_topk_parity(vo.scores_full(v, q)[sub], [r.item for r in edited], [r.score for r in edited], 10, 0.0, candidate_ordinals=sub,
+                         referee=vo.f64_referee(v[sub], q))
+    # negative ordinals, duplicates, an ndarray; then the index grows and the same array means other rows
+    arr = np.array([-1, 5, 5, 9_999, 17, -10_000], dtype=np.int64)
+    a1 = vb.fuzzy_lookup_embedding_in_subset(v[9_999], arr, max_hits=3, min_score=0.0)
+    assert [r.item for r in a1][:2] == [-1, 9_999] and abs(a1[0].score - 1.0) < 1e-6
+    vb.add_embedding(None, q)
+    a2 = vb.fuzzy_lookup_embedding_in_subset(q, arr, max_hits=3, min_score=0.0)
+    assert a2[0].item == -1 and abs(a2[0].score - 1.0) < 1e-6  # -1 is the appended row now
+    with pytest.raises(IndexError):
+        vb.fuzzy_lookup_embedding_in_subset(q, [10_001], max_hits=3)
+
+
 @pytest.mark.parametrize("nq", [1, 2, 3, 5, 8, 9, 20])
 @pytest.mark.parametrize("d,k", [(1536, 32), (384, 50), (1536, 200), (10, 7)])
 def test_batch_equals_sequential(nq, d, k):
@@ -1862,6 +1899,108 @@ def test_sharded_searcher_on_one_rank_rccl():
         check(ShardedSearcher(backend, always_collective=True).search(dq, 32, 0.0))
     finally:
         dist.destroy_process_group()
+
+
+def test_exchange_allocates_nothing_chunks_big_lists_and_times_out():
+    """`tavb_comm_init` reserves the exchange buffers (option comm_reserve_keys): an exchange of up to that many keys allocates nothing between
+    entering `tavb_search_allgather` and ncclAllGather; a bigger one travels through the same buffers in chunks of whole queries -- same
+    answer; when its per-call list allocation fails (injected: comm_fail_alloc) the rank still joins EVERY chunk with TAVB_KEY_PEER_FAILED
+    lists.  A rank without a usable shard joins too.  `comm_timeout_ms`: an exchange that does not complete in time (injected: the stream
+    held up for 400 ms, as by a late peer) aborts the communicator and `synchronize()` raises TavbTimeout instead of waiting for ever."""
+    import torch
+
+    from typeagent_py_amd.sharded import DeviceShardBackend
+
+    v, _ = make_corpus(20_000, 256, 8150)
+    qs = make_queries(100, 256, 8151)
+    backend = DeviceShardBackend(0)
+    eng = backend.engine
+    with torch.cuda.stream(backend.stream):
+        shard = torch.from_numpy(v).cuda()
+        dq = torch.from_numpy(qs).cuda()
+    backend.stream.synchronize()
+    backend.set_shard(shard, row_offset=1000)
+    with pytest.raises(ValueError):
+        eng.set_option("comm_reserve_keys", 16)  # below one list of TAVB_MAX_FUSED_K keys
+    eng.set_option("comm_reserve_keys", 1024)  # 32 queries of k = 32 per chunk: 100 queries = 4 chunks
+    backend.init_comm(0, 1)
+    eng.set_option("comm_force", 1)
+    with pytest.raises(ValueError):
+        eng.set_option("comm_reserve_keys", 4096)  # read by tavb_comm_init: too late
+    plain = eng.search_device(dq, 32, 0.0)
+    eng.synchronize()
+    plain = plain.cpu().numpy().copy()
+    pinned = torch.empty((100, 32), dtype=torch.int64).pin_memory()
+    eng.profile_enable(True)
+    eng.profile_reset()
+    eng.search_allgather(dq, 32, 0.0, out_keys=pinned)
+    eng.synchronize()
+    assert eng.profile_read(_native.KERNEL_EXCHANGE)[1] == 4  # four chunks
+    np.testing.assert_array_equal(pinned.numpy(), plain)
+    o, s_, c_ = _native.decode_keys(pinned.numpy())
+    vo.check_topk_parity(vo.scores_full(v, qs[99]), (o[99, : c_[99]] - 1000).tolist(), s_[99, : c_[99]].tolist(), 32, 0.0, referee=vo.f64_referee(v, qs[99]))
+    # a list that fits the reserved buffer: one all-gather, nothing allocated on the way (the injected allocation failure is never reached)
+    plain32 = eng.search_device(dq[:32], 32, 0.0)  # (a 32-query batch rides another tile than a 100-query one: its own float32 sums)
+    eng.synchronize()
+    eng.set_option("comm_fail_alloc", 1)
+    eng.profile_reset()
+    small = torch.empty((32, 32), dtype=torch.int64).pin_memory()
+    eng.search_allgather(dq[:32], 32, 0.0, out_keys=small)
+    eng.synchronize()
+    assert eng.profile_read(_native.KERNEL_EXCHANGE)[1] == 1
+    np.testing.assert_array_equal(small.numpy(), plain32.cpu().numpy())
+    # the big one with its list allocation failing: the rank's own error, AND all four chunks of the exchange ran with the failure key
+    eng.profile_reset()
+    pinned.zero_()
+    with pytest.raises(_native.TavbError, match="injected failure of the list allocation"):
+        eng.search_allgather(dq, 32, 0.0, out_keys=pinned)
+    eng.synchronize()
+    assert eng.profile_read(_native.KERNEL_EXCHANGE)[1] == 4
+    assert (pinned.numpy().view(np.uint64) == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    with pytest.raises(_native.TavbError, match="rank of the collective lookup failed"):
+        _native.decode_keys(pinned.numpy())
+    eng.set_option("comm_fail_alloc", 0)
+    eng.search_allgather(dq, 32, 0.0, out_keys=pinned)
+    eng.synchronize()
+    np.testing.assert_array_equal(pinned.numpy(), plain)  # and the next lookup lines up
+    # a shard whose ordinals do not fit the keys: a local failure like any other -- the rank joins the exchange, then reports it
+    backend.set_shard(shard, row_offset=0xFFFFFFFF - 100)
+    eng.profile_reset()
+    with pytest.raises(_native.TavbError, match="32-bit ordinals"):
+        eng.search_allgather(dq, 32, 0.0, out_keys=pinned)
+    eng.synchronize()
+    assert eng.profile_read(_native.KERNEL_EXCHANGE)[1] == 4
+    assert (pinned.numpy().view(np.uint64) == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    backend.set_shard(shard, row_offset=1000)
+    eng.profile_enable(False)
+    # the timeout: a generous one changes nothing ...
+    eng.set_option("comm_timeout_ms", 5000)
+    eng.search_allgather(dq, 32, 0.0, out_keys=pinned)
+    eng.synchronize()
+    np.testing.assert_array_equal(pinned.numpy(), plain)
+    # ... an exchange held up for 400 ms against a 50 ms limit: TavbTimeout, the communicator is gone, the stream drains, the context works on
+    import time
+
+    eng.set_option("comm_timeout_ms", 50)
+    eng.set_option("comm_stall_ms", 400)
+    eng.search_allgather(dq, 32, 0.0, out_keys=pinned)
+    t0 = time.perf_counter()
+    with pytest.raises(_native.TavbTimeout, match="did not complete within"):
+        eng.synchronize()
+    assert time.perf_counter() - t0 < 5.0
+    assert eng.get_option("comm_world") == 0 and eng.get_option("comm_stall_ms") == 0
+    eng.synchronize()  # nothing in flight any more
+    again = eng.search_device(dq, 32, 0.0)
+    eng.synchronize()
+    np.testing.assert_array_equal(again.cpu().numpy(), plain)
+    # rejoin
+    backend.init_comm(0, 1)
+    eng.set_option("comm_force", 1)
+    eng.set_option("comm_timeout_ms", 0)
+    eng.search_allgather(dq, 32, 0.0, out_keys=pinned)
+    eng.synchronize()
+    np.testing.assert_array_equal(pinned.numpy(), plain)
+    eng.comm_destroy()
 
 
 def test_sharded_vectorbase_storage_methods_on_the_device():

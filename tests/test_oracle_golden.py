@@ -222,6 +222,28 @@ def test_float64_referee_detects_an_omitted_row_and_handles_subsets_and_chunks()
     rep_w = vo.check_topk_parity(ref2[1], items32, scores32, 32, 0.0, referee=vo.f64_referee(v, q))  # (the same float32 reference scores: sgemm's)
     assert (rep_c.tie_permuted_positions, rep_c.gpu_inversions_vs_f64) == (rep_w.tie_permuted_positions, rep_w.gpu_inversions_vs_f64)
     assert near >= rep_c.tie_permuted_positions // 2
+    # chunked form of a SUBSET search (bench.py cfg3_subset): the rows that can matter are the best of the subset in each chunk, which the
+    # chunk's own best rows need not contain -- `restrict` keeps the truth for them; same verdict as the whole-matrix referee on the subset
+    rng = np.random.default_rng(5)
+    sub = np.sort(rng.choice(len(v), size=len(v) // 10, replace=False))
+    got = vo.lookup_in_subset(v, q, sub.tolist(), 10, 0.0)
+    pos_of = {int(o): i for i, o in enumerate(sub)}
+    ref3, cr3 = vo.scores_full_chunked_refereed([v[:1500], v[1500:2600], v[2600:]], qs, [[i for i, _ in got]] * 2, keep=10 + 64, restrict=sub)
+    truth = cr3.for_query(0)
+
+    def sub_truth(p_):
+        return truth(sub[np.asarray(p_)])
+    sub_truth.dim = v.shape[1]
+    rep_s, _ = vo.check_topk_parity_large(ref3[0][sub], [pos_of[i] for i, _ in got], [s for _, s in got], 10, 0.0, margin=64, referee=sub_truth)
+    assert rep_s.refereed and rep_s.exact_positions + rep_s.tie_permuted_positions == 10
+    with pytest.raises(KeyError):  # without `restrict` the subset's best rows of a chunk are not in the table
+        _, cr4 = vo.scores_full_chunked_refereed([v[:1500], v[1500:2600], v[2600:]], qs, [[i for i, _ in got]] * 2, keep=10 + 64)
+        t4 = cr4.for_query(0)
+
+        def sub_t4(p_):
+            return t4(sub[np.asarray(p_)])
+        sub_t4.dim = v.shape[1]
+        vo.check_topk_parity_large(ref3[0][sub], [pos_of[i] for i, _ in got], [s for _, s in got], 10, 0.0, margin=64, referee=sub_t4)
 
 
 def test_f32_threshold_rule():
