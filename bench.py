@@ -73,7 +73,7 @@ WORKLOADS = {
     # the north star's single-query target on the cfg3 corpus: HBM-bound, 30.72 GB per query
     "cfg3_q1": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm", seed=10043),
     "cfg4": dict(rows=12_500_000, dim=1536, dtype="fp16", nq=1024, k=32, bound="mfma", seed=100043),  # PER GPU (weak scaling)
-    "cfg1": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="hbm", seed=43),
+    "cfg1": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="latency", seed=43),
     # batches on the reference's own dtype (fp32): 32 queries ride one HBM pass; 1024 are bound by the fp32 matrix rate
     "cfg2_b32": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=32, k=32, bound="hbm", seed=1043),
     "cfg2_b1024": dict(rows=1_000_000, dim=1536, dtype="fp32", nq=1024, k=32, bound="mfma", seed=1043),  # fp16 shadow + exact fp32 rescoring (--opt f32_shadow=0: fp32 MFMAs)

@@ -190,3 +190,24 @@ def test_a_free_rendezvous_port_is_used_when_no_launcher_set_one(monkeypatch):
     s.close()
     src = open(bench.__file__).read()
     assert '"29533"' not in src, "a fixed MASTER_PORT makes two benches on one node collide"
+
+
+def test_the_two_rank_dry_run_line_has_the_shape_of_an_n_gt_1_record():
+    """`tools/gpu.sh LABEL dist2`: bench.py's N > 1 branches executed by two ranks on one GPU (gloo; the lookups' exchange through the host).
+    The committed line must show every branch the first real multi-GPU run depends on: n_gpus 2 from rank 0, the per-rank timing gather
+    (`exchange.*` with one entry per rank), whole-corpus parity over BOTH ranks' rows for the strong-scaling headline and for
+    `sub.cfg4_weak` (rows_total = 2 x rows per rank), and the dry-run marker that keeps anyone from reading its rates as measurements."""
+    path = os.path.join(ROOT, "profiles", "r06_bench_dist2_gloo_dry_run.json")
+    line = json.loads(open(path).read().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "dry_run" in line and "gloo" in line["dry_run"]
+    assert line["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert "row-sharded x2" in line["config"]["parallelism"]
+    ex = line["exchange"]
+    assert len(ex["scan_ms_per_rank"]) == 2 and len(ex["rows_per_rank"]) == 2 and sum(ex["rows_per_rank"]) == line["config"]["total_rows"]
+    assert "backend" in ex and ex["rank_skew_ms"] >= 0
+    assert line["parity"]["ok"] and line["parity"]["queries_checked"] == 16 and line["parity"]["positions_exact"] + line["parity"]["positions_permuted"] == 512
+    weak = line["sub"]["cfg4_weak"]
+    assert weak["scaling"] == "weak" and weak["parity"]["ok"] and len(weak["exchange"]["rows_per_rank"]) == 2
+    assert weak["row_queries_per_sec"] == bench.compact(weak["queries_per_sec"] * sum(weak["exchange"]["rows_per_rank"]), 4) or \
+        abs(weak["row_queries_per_sec"] / (weak["queries_per_sec"] * sum(weak["exchange"]["rows_per_rank"])) - 1) < 1e-3
+    assert line["cpu_baseline"] is None  # (rank 0 at N = 1 only)
