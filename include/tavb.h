@@ -117,6 +117,10 @@ int tavb_synchronize(tavb_ctx* ctx);
  *                   filter + fp32-query rescoring of its candidates), 5 = 32/64-query MFMA tile
  *   "last_flagged" (read only; synchronises) queries of the last 256-query-tile lookup whose candidate set could not be
  *                   proven complete and were re-run exactly (0 on ordinary data)
+ *   "band_max"      256 .. 2048 (default 2048; 1024 until ABI 6): the most candidates per query the 128/256-query tile's selection hands to the exact
+ *                   rescoring -- every row within 2 delta of the approximate k-th best.  A query with MORE rows than that inside its band (next to a
+ *                   bigger cluster of near-duplicates) is flagged and re-run exactly; a band of 1500 near-duplicates per query (bench.py cfg3_dup) used
+ *                   to cost the whole batch an exact pass of twice the MFMAs and now costs 1500 gathered rows per query in the rescoring
  *   "wide_fallback" 1 (default): when MORE than 64 queries of a batch of 256+ are flagged, they are re-run on the 256-query tile in its
  *                   exact split-plane form (fp32 queries as two fp16 planes) instead of 64 at a time on the 64-query exact tile; 0 = never
  *   "early_exact"   1 (default): with wide_fallback, a batch MOST of whose queries (> nq / 2) already hold, before the last and biggest filter phase, a band that

@@ -1024,6 +1024,7 @@ def test_wide_tile_falls_back_to_the_exact_tile_when_the_band_overflows():
     best = qs[9] + 0.2 * rng.standard_normal(1536).astype(np.float32) / np.sqrt(1536)
     v[rows[1300:]] = best / np.linalg.norm(best)
     vb = new_vb(v, dtype="fp16")
+    vb.engine.set_option("band_max", 1024)  # (the band buffer of rounds 3-5: this test's clusters are sized to overflow THAT; the default is 2048 since round 6)
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     assert vb.engine.get_option("last_tier") == 4
     flagged = vb.engine.get_option("last_flagged")
@@ -1037,6 +1038,47 @@ def test_wide_tile_falls_back_to_the_exact_tile_when_the_band_overflows():
     for qi in [2, 3, 9]:
         vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out2[qi]), k, 0.6, referee=vo.f64_referee(v16, qs[qi]))
     assert len(out2[3]) == k and len(out2[2]) == 0
+
+
+def test_a_band_of_1500_near_duplicates_per_query_fits_the_default_band_buffer():
+    """Round 6: the band buffer holds 2048 candidates per query (option band_max; 1024 before).  The duplication cliff of bench.py's cfg3_dup --
+    EVERY query next to 1500 near-duplicates -- no longer flags anybody: the filter runs once, the rescoring gathers 1500 rows per query
+    (the whole batch used to take the exact split-plane form: twice the MFMAs of a filter pass on top of it).  2300 near-duplicates
+    still overflow: those queries are flagged and re-run exactly.  A batch is its sequential lookups either way."""
+    n, nq, k = 260_000, 130, 32
+    v, _ = make_corpus(n, 512, 8790)
+    qs = make_queries(nq, 512, 8791)
+    rng = np.random.default_rng(8792)
+    ids = list(range(0, 100))
+    rows = _plant_clusters(v, qs, ids, 1500, rng)
+    big = rng.permutation(np.setdiff1d(np.arange(n), rows.reshape(-1)))[:2300]
+    _plant_near_duplicates(v, qs, 120, big, rng)
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    assert eng.get_option("band_max") == 2048
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert eng.get_option("last_tier") == 4
+    assert 1 <= eng.get_option("last_flagged") <= 3, eng.get_option("last_flagged")  # query 120 (+ at most a neighbour or two), none of the hundred
+    v16 = _f16(v)
+    for j in (0, 1, 50, 99):
+        assert set(r.item for r in out[j]) <= set(rows[j].tolist())
+    assert set(r.item for r in out[120]) <= set(big.tolist())
+    for qi in (0, 1, 50, 99, 100, 120, 129):
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
+        seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=0.0)
+        if qi != 120:  # rescored with the streaming kernels' arithmetic over the WHOLE band: the sequential lookup bit for bit
+            assert [(r.item, r.score) for r in out[qi]] == [(r.item, r.score) for r in seq], qi
+        else:  # (flagged, on the 64-query exact tile: 64 - k ranks of slack below the k-th, not a score band -- near-ties packed inside 1e-5 may permute)
+            np.testing.assert_allclose([r.score for r in out[qi]], [r.score for r in seq], atol=3e-7, rtol=0)
+    # the old buffer: the hundred are flagged too; the oracle's answers again
+    eng.set_option("band_max", 1024)
+    out2 = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert eng.get_option("last_flagged") >= 101
+    for qi in (0, 50, 99, 100, 120):
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(out2[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
+        np.testing.assert_allclose([r.score for r in out2[qi]], [r.score for r in out[qi]], atol=3e-7, rtol=0)
+    with pytest.raises(ValueError):
+        eng.set_option("band_max", 4096)
 
 
 def test_wide_tile_with_the_query_operand_straight_from_l2():
@@ -1076,6 +1118,7 @@ def test_many_flagged_queries_take_the_wide_exact_fallback():
     for j in range(100):
         _plant_near_duplicates(v, qs, 2 * j + 1, rows[j], rng)
     vb = new_vb(v, dtype="fp16")
+    vb.engine.set_option("band_max", 1024)  # (the band buffer of rounds 3-5: this test's clusters are sized to overflow THAT; the default is 2048 since round 6)
     eng = vb.engine
     v16 = _f16(v)
     probe = [0, 1, 3, 77, 101, 199, 200, 255]
@@ -1132,6 +1175,7 @@ def test_a_batch_of_mostly_doomed_bands_skips_the_last_filter_phase(cluster):
     early_rows = int((rows < bounds[-2]).sum())  # of the cluster, in the phases before the last (~240): every one of the 200 queries holds them all in its band
     assert early_rows > 1.25 * 1024 * seen + 40 and early_rows > k + 15 + 40  # the extrapolation rule of run_tile_ladder fires with room to spare
     vb = new_vb(v, dtype="fp16")
+    vb.engine.set_option("band_max", 1024)  # (the band buffer of rounds 3-5: this test's clusters are sized to overflow THAT; the default is 2048 since round 6)
     eng = vb.engine
     v16 = _f16(v)
     probe = [0, 1, 57, 199, 200, 255]
@@ -1207,6 +1251,7 @@ def test_unused_slots_of_the_wide_fallback_admit_nothing():
     rng = np.random.default_rng(8702)
     rows = _plant_clusters(v, qs, list(range(480)), 1100, rng)
     vb = new_vb(v, dtype="fp16")
+    vb.engine.set_option("band_max", 1024)  # (the band buffer of rounds 3-5: this test's clusters are sized to overflow THAT; the default is 2048 since round 6)
     eng = vb.engine
     eng.set_option("early_exact", 0)  # (the filter runs to its end in both batches: the fallback's cost is what is compared)
     plain = make_queries(nq, d, 8703)
@@ -1310,6 +1355,7 @@ def test_wide_tile_serves_k_beyond_64(nq, k):
     dup = rng.choice(n, size=1300, replace=False)
     _plant_near_duplicates(v, qs, 3, dup, rng)
     vb = new_vb(v, dtype="fp16")
+    vb.engine.set_option("band_max", 1024)  # (the band buffer of rounds 3-5: this test's clusters are sized to overflow THAT; the default is 2048 since round 6)
     eng = vb.engine
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     assert eng.get_option("last_tier") == 4
@@ -1430,6 +1476,7 @@ def test_wide_tile_odd_width_with_a_band_that_does_not_fit(nq, k):
     dup = rng.choice(n, size=1300, replace=False)
     _plant_near_duplicates(v, qs, 3, dup, rng)
     vb = new_vb(v, dtype="fp16")
+    vb.engine.set_option("band_max", 1024)  # (the band buffer of rounds 3-5: this test's clusters are sized to overflow THAT; the default is 2048 since round 6)
     eng = vb.engine
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     assert eng.get_option("last_tier") == 4
@@ -1456,6 +1503,7 @@ def test_odd_width_with_many_flagged_queries(d, nq, k, planted):
     ids = list(range(1, 2 * planted, 2))
     rows = _plant_clusters(v, qs, ids, 1100, rng)
     vb = new_vb(v, dtype="fp16")
+    vb.engine.set_option("band_max", 1024)  # (the band buffer of rounds 3-5: this test's clusters are sized to overflow THAT; the default is 2048 since round 6)
     eng = vb.engine
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     assert eng.get_option("last_tier") == 4

@@ -152,6 +152,7 @@ struct tavb_ctx {
   Buffer h_out{nullptr, 0, true};  // pinned + device-visible: the last kernel of a synchronous lookup writes its keys straight here
   Buffer h_lists{nullptr, 0, true};  // pinned + device-visible: per-workgroup lists of a small single-query lookup (merged on the host)
   int64_t mfma_bdirect = 0;  // option (measurement for now): the 256-query tile takes its query operand straight from L2 (fragment-major layout), not through LDS
+  int64_t band_max = tavb::kBandMax;  // option: keys of a query's band the wide tile's selection hands to the rescoring (256 .. kBandMax); a band that does not fit flags the query
   int64_t early_exact = 1;    // option: ... and a batch found to be mostly such queries BEFORE the last filter phase skips that phase (needs wide_fallback)
   int64_t wide_fallback = 1;  // option: batches of 256+ queries re-run MANY (> 64) flagged queries on the 256-query tile's exact (split-plane) form
   int64_t small_direct_bytes = (int64_t)128 << 20;  // option: single-query lookups on corpora up to this size take the one-launch path (0 = never)
@@ -527,6 +528,9 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_splits") {
     if (v < 0 || v > 4096) return fail(TAVB_E_INVALID, "mfma_splits out of range");
     c->mfma_splits = v;
+  } else if (n == "band_max") {
+    if (v < TAVB_MAX_FUSED_K || v > tavb::kBandMax) return fail(TAVB_E_INVALID, "band_max must be %d .. %d", TAVB_MAX_FUSED_K, tavb::kBandMax);
+    c->band_max = v;
   } else if (n == "early_exact") {
     c->early_exact = v ? 1 : 0;
   } else if (n == "wide_fallback") {
@@ -599,6 +603,7 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "small_direct_bytes") *out = c->small_direct_bytes;
   else if (n == "wide_fallback") *out = c->wide_fallback;
   else if (n == "early_exact") *out = c->early_exact;
+  else if (n == "band_max") *out = c->band_max;
   else if (n == "last_doomed") {  // queries of the last 256-query-tile lookup counted by the early verdict (synchronises); above nq / 2 the last filter phase was skipped
     *out = 0;
     if (c->d_flag.ptr) {
@@ -1715,7 +1720,7 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   p.bdirect = r.bdirect ? 1 : 0;
   const std::vector<int64_t> bounds = ladder_bounds(c->rows, splits, r.nq_pad, r.skinny, r.ladder, c->mfma_sample_rows, c->mfma_ladder);  // phase i scans rows [bounds[i], bounds[i+1])
   const int n_phases = (int)bounds.size() - 1;
-  const int kc = wide ? tavb::kBandMax : k;  // keys per query of the running selection between phases
+  const int kc = wide ? (int)c->band_max : k;  // keys per query of the running selection between phases
   if (n_phases > 1 || (wide && r.active)) {
     if (int rc = c->d_thr.reserve((size_t)r.nq_pad * sizeof(float))) return rc;
     if (int rc = c->d_sample_keys.reserve((size_t)2 * nq * kc * sizeof(u64_t) + (size_t)2 * nq * sizeof(int))) return rc;  // running selection: two copies (ping-pong) + counts
@@ -1849,7 +1854,7 @@ int upload_min_scores(tavb_ctx* c, const float* min_scores, int nq, int nq_pad, 
 int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores, uint32_t index_base, u64_t* d_out, bool small = false) {
   // candidates per query handed to the rescoring: the wide tile selects a BAND (every row within 2 delta of the approximate k-th best: as many
   // as the data makes it, up to kBandMax), the 32/64-query tile (`small`) the best 64 by approximate score
-  const int KC = small ? 64 : tavb::kBandMax;
+  const int KC = small ? 64 : (int)c->band_max;
   const bool f32c = (c->dtype == TAVB_F32);
   // a corpus whose width is not a multiple of 64 (the tile's K step is a whole 128-byte line): the filter -- and, on fp16 corpora, the exact
   // fallbacks -- read a zero-padded fp16 copy of the rows (d_shadow, `fdim` halves per row; for fp32 corpora the shadow they have anyway) and a

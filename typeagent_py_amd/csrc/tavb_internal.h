@@ -137,7 +137,8 @@ size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide);
 // candidate buffers (+ an optional carried-over band [nq, kc_max] / carried_cnt [nq]) -> out [nq, kc_max] unsorted, out_cnt [nq];
 // thr_out[q] = just below the band's cut (or floor[q]); lost [nq]: highest score level (bits) at which band rows were dropped so far
 // (in/out); verdict (optional, last phase) [nq]: 1 = the band handed over is not provably complete; tavb_mfma.hip
-constexpr int kBandMax = 1024;  // candidates per query the rescoring accepts (kc_max; also the most the select kernel's cache keeps when it cuts mid-stream)
+constexpr int kBandMax = 2048;  // most candidates per query the rescoring accepts (kc_max <= kBandMax: the context's "band_max" option; also the most the select
+                                // kernel's cache keeps when it cuts mid-stream).  1024 until round 6: a band of 1500 near-duplicates cost a 2x exact pass
 hipError_t launch_select_band(const unsigned long long* cand, const int* counts, int n_splits, int nq, int nq_padded, int k, int kc_max,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
                               int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream, const int* active = nullptr,

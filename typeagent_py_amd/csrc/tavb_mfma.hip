@@ -1416,7 +1416,9 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
       const int n = n_cached;
       __syncthreads();
       bool mid_strict;
-      have_filter = cut_of_cache(n, SEL_CACHE / 4, &f_hi, &f_lo, &mid_strict);  // n >= k here
+      // (room for the band a cut keeps: a quarter of the cache, or the whole band buffer when that is wider -- what is left of the cache still
+      //  takes the 2048 keys of the next round)
+      have_filter = cut_of_cache(n, kc_max > SEL_CACHE / 4 ? kc_max : SEL_CACHE / 4, &f_hi, &f_lo, &mid_strict);  // n >= k here
       if (tid == 0) n_cached = 0;
       __syncthreads();
 #pragma unroll
@@ -1539,7 +1541,7 @@ hipError_t launch_select_band(const unsigned long long* cand, const int* counts,
                               const unsigned long long* carried, const int* carried_cnt, const float* floor, const float* band, unsigned long long* out,
                               int* out_cnt, float* thr_out, unsigned* lost, int* verdict, hipStream_t stream, const int* active, int active_min,
                               int active_max, const int* gate, int gate_max, int* doomed, int doom_limit) {
-  if (nq < 1 || k < 1 || k > TAVB_MAX_FUSED_K || n_splits < 1 || n_splits > 256 || nq_padded < nq || kc_max < k || kc_max > SEL_CACHE / 4) return hipErrorInvalidValue;
+  if (nq < 1 || k < 1 || k > TAVB_MAX_FUSED_K || n_splits < 1 || n_splits > 256 || nq_padded < nq || kc_max < k || kc_max > SEL_CACHE / 2 || kc_max > kBandMax) return hipErrorInvalidValue;
   constexpr int lds = SEL_CACHE * (int)sizeof(u64);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
