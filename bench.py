@@ -914,6 +914,35 @@ def class_api_rates(ctx: Ctx, wl: dict, corpus, min_score: float, steps: int) ->
     return out
 
 
+def sharded_class_api_rates(ctx: Ctx, wl: dict, corpus, shard_lo: int, min_score: float, steps: int) -> dict:
+    """COLLECTIVE (every rank calls it): the same batch through the class-shaped front end of the row-sharded path,
+    `ShardedVectorBase.fuzzy_lookup_embeddings` -- host queries in (staged through a reused pinned buffer), one `tavb_search_allgather`,
+    `list[list[ScoredInt]]` out (built in C) -- what a consumer of the sharded class pays on top of the engine step of the headline."""
+    from typeagent_py_amd.sharded import ShardedSearcher, ShardedVectorBase
+
+    nq, k, dim = wl["nq"], wl["k"], wl["dim"]
+    svb = ShardedVectorBase(ctx.backend, shard_lo, int(corpus.shape[0]), wl["rows_total"])
+    if ctx.dry_run:
+        svb.searcher = ShardedSearcher(ctx.backend, gather_fn=ctx.gather_fn())
+    queries = host_queries(max(64, nq * BATCH_ROTATION), dim, 4242)
+
+    def call(i):
+        b0 = (i % BATCH_ROTATION) * nq
+        return svb.fuzzy_lookup_embeddings(queries[b0 : b0 + nq], max_hits=k, min_score=min_score)
+
+    call(0)
+    import gc
+
+    gc.collect()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        call(1 + i)
+    ctx.barrier()
+    ms = ctx.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
+    return {"sharded_scored_int_lists": {"ms_per_step": ms, "queries_per_sec": nq / (ms * 1e-3)}}
+
+
 def shard_bounds(total: int, world: int, rank: int) -> tuple[int, int]:
     from typeagent_py_amd.sharded import shard_range
 
@@ -1364,6 +1393,11 @@ def main() -> None:
             rec["roofline"]["sustained"] = sustained_calibration(ctx, wl, corpus, rec["roofline"]["kernel_ms_per_step"])
         if suite or args.class_api:
             rec["class_api"] = class_api_rates(ctx, wl, corpus, args.min_score, 5 if wl["nq"] > 1 else 50)
+
+    if ctx.distributed and wl["nq"] > 1 and (suite or args.class_api):
+        api = sharded_class_api_rates(ctx, wl, corpus, lo, args.min_score, 5)
+        if ctx.rank == 0:
+            rec["class_api"] = api
 
     sub = None
     if suite and not ctx.distributed and not args.no_sub:

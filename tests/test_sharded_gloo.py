@@ -282,7 +282,37 @@ def _failing_worker(rank: int, world: int, port: int, fail_rank: int, ret):
         before = svb.fuzzy_lookup_embedding(qs[1], max_hits=8)
         svb.rebalance()
         after = svb.fuzzy_lookup_embedding(qs[1], max_hits=8)
-        ret[rank] = (outcome, imb, svb.imbalance(), svb.local_rows, [(r.item, r.score) for r in before] == [(r.item, r.score) for r in after], len(svb))
+        # the forms beside the plain lookup follow the same protocol: a predicate (the caller's code) that raises on ONE rank, a subset search
+        # whose local part fails there -- that rank joins the exchange with the failure key and raises its own error, the others PeerFailedError
+        def outcome_of(call):
+            try:
+                call()
+                return "answer"
+            except PeerFailedError:
+                return "peer"
+            except RuntimeError as exc:
+                return "own" if "injected failure" in str(exc) else f"other: {exc}"
+
+        def pred(i):
+            if rank == fail_rank:
+                raise RuntimeError("injected failure inside the predicate")
+            return i % 2 == 0
+
+        o_pred = outcome_of(lambda: svb.fuzzy_lookup_embedding(qs[2], max_hits=8, predicate=pred))
+        good = svb.fuzzy_lookup_embedding(qs[2], max_hits=8, predicate=lambda i: i % 2 == 0)  # the next collective lines up
+        orig = svb.backend.local_search_subset
+
+        def flaky_subset(*a, **kw):
+            if rank == fail_rank:
+                raise RuntimeError("injected failure of the subset search")
+            return orig(*a, **kw)
+        svb.backend.local_search_subset = flaky_subset
+        sub = list(range(0, 1500, 7))
+        o_sub = outcome_of(lambda: svb.fuzzy_lookup_embedding_in_subset(qs[3], sub, max_hits=8))
+        svb.backend.local_search_subset = orig
+        good_sub = svb.fuzzy_lookup_embedding_in_subset(qs[3], sub, max_hits=8)
+        ret[rank] = (outcome, imb, svb.imbalance(), svb.local_rows, [(r.item, r.score) for r in before] == [(r.item, r.score) for r in after], len(svb),
+                     o_pred, o_sub, all(r.item % 2 == 0 for r in good) and len(good) == 8, all(r.item in sub for r in good_sub) and len(good_sub) == 8)
     finally:
         dist.destroy_process_group()
 
@@ -297,8 +327,11 @@ def test_a_rank_whose_local_search_fails_still_joins_the_exchange_and_every_rank
     mp.spawn(_failing_worker, args=(world, _free_port(), 1, ret), nprocs=world, join=True)
     assert [ret[r][0] for r in range(world)] == ["peer", "own", "peer"]
     for r in range(world):
-        _, imb, imb_after, local_rows, same, total = ret[r]
+        _, imb, imb_after, local_rows, same, total, o_pred, o_sub, good_pred, good_sub = ret[r]
         assert abs(imb - 900 / 500) < 1e-9 and imb_after == 1.0 and local_rows == 500 and same and total == 1500
+        assert good_pred and good_sub
+    assert [ret[r][6] for r in range(world)] == ["peer", "own", "peer"]  # the predicate form
+    assert [ret[r][7] for r in range(world)] == ["peer", "own", "peer"]  # the subset form
 
 
 def test_shard_ranges_partition_the_rows():

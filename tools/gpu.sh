@@ -11,6 +11,8 @@
 #   dist2[:ROWS]     the N = 2 branches of bench.py on ONE GPU: two ranks under torch.distributed.run share cuda:0, gloo, the lookups' exchange
 #                    through the host (TAVB_BENCH_DIST_BACKEND=gloo); ROWS rows in the strong-scaling corpus and per rank of cfg4_weak (default 2000000)  -> bench_dist2.json
 #   parity100m       how long rank 0's whole-corpus parity pass takes at N = 8 (100M rows: 100 chunks generated on the device, 16 queries): tools/parity_leg_time.py -> parity100m.txt
+#   toolcheck        every measurement script under tools/ once, with small shapes, against the library that ships: rc per script -> toolcheck.txt
+#                    (tools/README.md's "runs against ABI 6" column comes from here)
 #   variants:FILE    bench.py variants listed one per line ("name: args") in FILE, one child process each   -> bench_<name>.json, variants.txt
 #   ab:ARGS          interleaved A/B on this box: A = cfg3 as shipped, B = the same + ARGS (3 rounds)
 #   pmc              FETCH_SIZE passes for every workload of profiles/pmc_traffic.json + the MFMA counters of cfg3 -> pmc_*.md, pmc_traffic.json
@@ -73,6 +75,24 @@ for step in "$@"; do
       echo "dist2 rc=$? line bytes: $(wc -c < $O/bench_dist2.json)"; grep -v "^W0\|^\*\*\*\|OMP_NUM" $O/bench_dist2.err | tail -5; digest $O/bench_dist2.json
       python -c "import json; d=json.loads(open('$O/bench_dist2.json').read().strip().splitlines()[-1]); print('exchange', d.get('exchange')); print('weak', d['sub']['cfg4_weak'].get('exchange'), d['sub']['cfg4_weak'].get('parity')); print(d.get('dry_run'))" ;;
     parity100m) timeout 1700 python tools/parity_leg_time.py > $O/parity100m.txt 2>&1; echo "parity100m rc=$?"; tail -5 $O/parity100m.txt ;;
+    toolcheck)
+      : > $O/toolcheck.txt
+      tc() { local name=$1; shift; local t0=$(date +%s); timeout 300 "$@" > $O/tool_$name.log 2>&1; echo "$name rc=$? $(( $(date +%s) - t0 )) s" | tee -a $O/toolcheck.txt; }
+      tc batch_sweep python tools/batch_sweep.py --rows 200000 --sizes 1,8,32,128
+      tc gemm_rate python tools/gemm_rate.py
+      tc host_submit_time python tools/host_submit_time.py 200000 1536 fp16 32
+      tc inline_query_probe python tools/inline_query_probe.py
+      tc latency_breakdown python tools/latency_breakdown.py 10000 10 0.0
+      tc load_bench python tools/load_bench.py
+      tc oracle_noise python tools/oracle_noise.py
+      tc small_batch_latency python tools/small_batch_latency.py
+      tc small_scan_forms python tools/small_scan_forms.py
+      tc sweep_scan python tools/sweep_scan.py --rows 200000 --quick --tag toolcheck
+      tc ceiling python tools/ceiling.py --seconds 2 --rows 2000000
+      tc parity_leg_time python tools/parity_leg_time.py --world 2 --rows-per-rank 1000000
+      for mb in load_paths issue_cost kernarg_query flag_completion; do
+        tc mb_$mb bash -c "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mb_$mb tools/microbench/$mb.hip && /tmp/mb_$mb"
+      done ;;
     variants) mapfile -t specs < <(grep -v '^#' "$arg" | grep .); timeout 1700 python tools/bench_variants.py $O "${specs[@]}" 2>&1 | tee -a $O/variants.txt ;;
     ab)
       specs=(); for i in 1 2 3; do specs+=("A$i: $Q --workload cfg3 --steps 20 --warmup 5" "B$i: $Q --workload cfg3 --steps 20 --warmup 5 $arg"); done
@@ -88,6 +108,11 @@ for step in "$@"; do
       pmc cfg3_b128_fetch cfg3_b128 "--workload cfg3_b128 --steps 2 --warmup 1" FETCH_SIZE
       pmc cfg2_b32_fetch cfg2_b32 "--workload cfg2_b32 --steps 5 --warmup 1" FETCH_SIZE
       pmc cfg3_b32_fetch cfg3_b32 "--workload cfg3_b32 --steps 2 --warmup 1" FETCH_SIZE
+      pmc cfg3_subset_fetch cfg3_subset "--workload cfg3_subset --steps 10 --warmup 2" FETCH_SIZE
+      pmc cfg2_d3072_fetch cfg2_d3072 "--workload cfg2_d3072 --steps 10 --warmup 2" FETCH_SIZE
+      pmc cfg3_d3072_q1_fetch cfg3_d3072_q1 "--workload cfg3_d3072_q1 --steps 5 --warmup 1" FETCH_SIZE
+      pmc cfg3_d3072_fetch cfg3_d3072 "--workload cfg3_d3072 --steps 2 --warmup 1" FETCH_SIZE
+      pmc cfg3_aniso_fetch cfg3_aniso "--workload cfg3_aniso --steps 2 --warmup 1" FETCH_SIZE
       python -c "import json; d=json.load(open('$O/pmc_traffic.json')); print({k:(round(v['traffic_bytes_per_step']/1e9,3), v['launches_per_step']) for k,v in d.items()})" ;;
     pmcw) pmc cfg3_write "" "--workload cfg3 --steps 2 --warmup 1" WRITE_SIZE; tail -12 $O/pmc_cfg3_write.md ;;
     trace)

@@ -531,17 +531,40 @@ class ShardedVectorBase:
         if self.total_rows == 0:
             return []
         q = np.ascontiguousarray(embedding, dtype=np.float32)
-        ids, scs = (np.zeros(0, np.int64), np.zeros(0, np.float32)) if self.local_rows == 0 else self.backend.local_survivors(q, thr)
-        order = np.lexsort((ids,))  # ascending ordinal: the order of np.flatnonzero (:193)
-        keep = np.fromiter((bool(predicate(int(i))) for i in ids[order]), dtype=bool, count=len(order))
-        ids, scs = ids[order][keep], scs[order][keep]
-        keys = (scs.astype(np.float32).view(np.uint32).astype(np.uint64) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - ids.astype(np.uint64))
-        local = np.zeros((1, k), dtype=np.uint64)
-        best = np.sort(keys)[::-1][:k]
-        local[0, : len(best)] = best
-        merged = self.backend.to_host(self.searcher.exchange(self.backend.keys_to_device(local)))
-        ords, sc, cnt = _native.decode_keys(merged)
+
+        def local_lists():
+            ids, scs = (np.zeros(0, np.int64), np.zeros(0, np.float32)) if self.local_rows == 0 else self.backend.local_survivors(q, thr)
+            order = np.lexsort((ids,))  # ascending ordinal: the order of np.flatnonzero (:193)
+            keep = np.fromiter((bool(predicate(int(i))) for i in ids[order]), dtype=bool, count=len(order))
+            ids, scs = ids[order][keep], scs[order][keep]
+            keys = (scs.astype(np.float32).view(np.uint32).astype(np.uint64) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - ids.astype(np.uint64))
+            local = np.zeros((1, k), dtype=np.uint64)
+            best = np.sort(keys)[::-1][:k]
+            local[0, : len(best)] = best
+            return self.backend.keys_to_device(local)
+
+        ords, sc, cnt = self._exchange_or_fail(local_lists, 1, k)
         return [ScoredInt(int(o), float(s_)) for o, s_ in zip(ords[0, : cnt[0]].tolist(), sc[0, : cnt[0]].tolist())]
+
+    def _exchange_or_fail(self, local_lists, nq: int, k: int):
+        """The collective forms beside the plain lookup (subset, predicate): `local_lists()` -> this rank's [nq, k] keys -> exchange -> decoded
+        merged lists.  The failure protocol of `ShardedSearcher.search_keys` / tavb_search_allgather: a rank whose local part raises -- the
+        caller's predicate included -- still joins the exchange, with PEER_FAILED_KEY lists, then raises ITS error; the others raise
+        `PeerFailedError` instead of waiting for ever or returning an answer that misses a shard."""
+        failure = None
+        try:
+            local = local_lists()
+        except Exception as exc:  # noqa: BLE001
+            if self._world == 1 and not getattr(self.backend, "native_comm", False):
+                raise
+            failure = exc
+            local = self.backend.failed_lists(nq, k)
+        merged = self.backend.to_host(self.searcher.exchange(local))
+        if failure is not None:
+            raise failure
+        if merged.size and (np.asarray(merged).reshape(merged.shape[0], -1)[:, 0].view(np.int64) == PEER_FAILED_KEY).any():
+            raise PeerFailedError("a rank of the collective lookup failed in its local part: the merged lists are missing its shard")
+        return _native.decode_keys(merged)
 
     def fuzzy_lookup_embedding_in_subset(self, embedding, ordinals_of_subset, max_hits: int | None = None, min_score: float | None = None):
         """vectorbase.py:203-230 over the row-sharded corpus: every rank gathers the rows of the caller's subset that lie in its shard,
@@ -564,7 +587,10 @@ class ShardedVectorBase:
         if (resident and cached is not None and cached[0] is ordinals_of_subset and cached[2] == layout and len(cached[1]) == len(ordinals_of_subset)
                 and (np.array_equal(cached[1], ordinals_of_subset) if isinstance(ordinals_of_subset, np.ndarray) else cached[1] == ordinals_of_subset)):
             subset = cached[3]
-            local = self.backend.local_search_subset_resident(q, cached[4], k, thr)
+            handle = cached[4]
+
+            def local_lists():
+                return self.backend.local_search_subset_resident(q, handle, k, thr)
         else:
             subset = np.asarray(ordinals_of_subset)
             if subset.dtype.kind not in "iu":
@@ -576,16 +602,18 @@ class ShardedVectorBase:
             if bad.any():
                 raise IndexError(f"index {int(subset[np.argmax(bad)])} is out of bounds for axis 0 with size {n}")
             mine = np.flatnonzero((rows >= self.row_offset) & (rows < self.row_offset + self.local_rows))  # ascending positions: lists stay sorted among ties
+            # (argument errors above are the same on every rank -- every rank holds the same list -- and raise before anything collective)
             if resident:
-                handle = self.backend.subset_to_device(rows[mine] - self.row_offset, mine)
-                is_array = isinstance(ordinals_of_subset, np.ndarray)
-                subset = subset.copy() if is_array else subset
-                self._subset_cache = (ordinals_of_subset, ordinals_of_subset.copy() if is_array else list(ordinals_of_subset), layout, subset, handle)
-                local = self.backend.local_search_subset_resident(q, handle, k, thr)
+                def local_lists():
+                    handle = self.backend.subset_to_device(rows[mine] - self.row_offset, mine)
+                    is_array = isinstance(ordinals_of_subset, np.ndarray)
+                    keep = subset.copy() if is_array else subset
+                    self._subset_cache = (ordinals_of_subset, ordinals_of_subset.copy() if is_array else list(ordinals_of_subset), layout, keep, handle)
+                    return self.backend.local_search_subset_resident(q, handle, k, thr)
             else:
-                local = self.backend.local_search_subset(q, rows[mine] - self.row_offset, mine, k, thr)
-        merged = self.backend.to_host(self.searcher.exchange(local))
-        pos, sc, cnt = _native.decode_keys(merged)
+                def local_lists():
+                    return self.backend.local_search_subset(q, rows[mine] - self.row_offset, mine, k, thr)
+        pos, sc, cnt = self._exchange_or_fail(local_lists, 1, k)
         return [ScoredInt(int(subset[p]), float(s_)) for p, s_ in zip(pos[0, : cnt[0]].tolist(), sc[0, : cnt[0]].tolist())]
 
     def lookup_messages_by_embedding(self, embedding, row_to_message, max_matches: int | None = None, threshold_score: float | None = None, accept=None):
