@@ -92,12 +92,12 @@ def test_random_case_against_the_oracle(seed):
 
 
 @pytest.mark.parametrize("cluster_rows,nq,k,expect_flagged", [(40, 130, 32, False), (100, 300, 32, False), (100, 1024, 50, False), (300, 130, 10, False),
-                                                               (1500, 130, 32, True)])
+                                                               (1500, 130, 32, False), (2500, 130, 32, True)])
 def test_clustered_corpus_batches_against_the_oracle(cluster_rows, nq, k, expect_flagged):
     """The mid-size twin of bench.py's cfg3_clustered: every query sits next to a cluster of near-duplicate rows (incl. exact duplicates),
     so the scores around rank k are packed far inside the fp16 filter's error bound.  The wide tile keeps the whole BAND below the k-th
     best (a cluster, not a fixed 64 candidates) and rescoring makes the answer exact: no query may need the exact-tile fallback until a
-    cluster outgrows the band capacity (1500-row clusters: flagged, re-run exactly, same answers)."""
+    cluster outgrows the band capacity (2048 rows since round 6: 1500-row clusters fit, 2500-row clusters are flagged and re-run exactly, same answers)."""
     n = 60_000
     v, q, cl, qc = make_clustered_corpus(n, 1536, 4100 + cluster_rows, cluster_rows=cluster_rows, n_queries=nq)
     vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), corpus_dtype="fp16")

@@ -1400,12 +1400,13 @@ def test_wide_tile_row_norm_cache_follows_appends_and_rewrites():
 # rescored with the fp32 rows and fp32 queries (tavb_rescore.hip) -- same answers as the single-query fp32 kernels
 # --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
-@pytest.mark.parametrize("d", [64, 768, 3072, 4096, 1000, 96, 1008, 1004])
+@pytest.mark.parametrize("d", [64, 768, 3072, 4096, 1000, 96, 1008, 1004, 1001, 70, 33])
 def test_wide_tile_other_dimensions(dtype, d):
-    """The 128/256-query tile takes any D that is a multiple of 64 (K steps of whole 128-byte lines) directly and, since round 5, other widths
-    on a zero-padded fp16 copy of the rows (the filter's operand; candidates are rescored with the corpus' own rows): multiples of 8 on fp16
-    corpora, multiples of 16 on fp32 ones (their exact fallback tile reads the fp32 rows).  What is left (1004; 1000 on fp32) falls back to the
-    32/64-query tile or the streaming tiers.  130 queries: one 256-query tile."""
+    """The 128/256-query tile takes any D that is a multiple of 64 (K steps of whole 128-byte lines) directly and other widths on a zero-padded
+    fp16 copy of the rows (the filter's operand; candidates are rescored with the corpus' own rows): ANY width on fp16 corpora (round 6: rows
+    that are not 16-byte aligned are rescored element by element, in the scalar streaming kernel's order), multiples of 16 on fp32 ones (their
+    exact fallback tile reads the fp32 rows).  What is left (fp32: 1000, 1004, 1001, 70, 33) falls back to the 32/64-query tile or the
+    streaming tiers.  130 queries: one 256-query tile."""
     n, nq, k = 20_011, 130, 32
     v, _ = make_corpus(n, d, 9900 + d)
     qs = make_queries(nq, d, 9901 + d)
@@ -1413,7 +1414,7 @@ def test_wide_tile_other_dimensions(dtype, d):
     vb = new_vb(v, dtype=dtype)
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     t = vb.engine.get_option("last_tier")
-    wide = d % 64 == 0 or (d % 8 == 0 if dtype == "fp16" else d % 16 == 0)
+    wide = d % 64 == 0 or dtype == "fp16" or d % 16 == 0
     assert t == 4 if wide else t in (1, 2, 3, 5), (d, dtype, t)
     ref_v = v if dtype == "fp32" else _f16(v)
     for qi in range(0, nq, 9):
@@ -1488,7 +1489,7 @@ def test_wide_tile_odd_width_with_a_band_that_does_not_fit(nq, k):
     assert set(r.item for r in out[3]) <= set(dup.tolist())
 
 
-@pytest.mark.parametrize("d", [200, 72])
+@pytest.mark.parametrize("d", [200, 72, 75])
 @pytest.mark.parametrize("nq,k,planted", [(130, 32, 60), (256, 32, 100), (300, 100, 50)])
 def test_odd_width_with_many_flagged_queries(d, nq, k, planted):
     """An fp16 corpus whose width is not a multiple of 64 with MANY flagged queries: the work list's per-slot thresholds and band widths sit

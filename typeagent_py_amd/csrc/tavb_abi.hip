@@ -1918,14 +1918,17 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
         e = tavb::launch_shadow_convert(reinterpret_cast<const float*>(c->corpus) + (size_t)c->norm_rows * c->dim, c->rows - c->norm_rows, c->dim, shadow_new, sdim,
                                         d_norm, c->stream);
       } else {
-        e = tavb::launch_corpus_max_norm(reinterpret_cast<const char*>(c->corpus) + (size_t)c->norm_rows * c->dim * 2, c->rows - c->norm_rows, c->dim,
-                                         d_norm, c->stream);
-        if (e == hipSuccess && padded) {  // fp16 rows of an odd width: the same values, rows zero-padded to whole K steps
+        if (padded) {  // fp16 rows of an odd width: the same values, rows zero-padded to whole K steps
           const size_t n_new = (size_t)(c->rows - c->norm_rows);
           TAVB_HIP(hipMemsetAsync(shadow_new, 0, n_new * sdim * 2, c->stream));
           TAVB_HIP(hipMemcpy2DAsync(shadow_new, (size_t)sdim * 2, reinterpret_cast<const char*>(c->corpus) + (size_t)c->norm_rows * c->dim * 2, (size_t)c->dim * 2,
                                     (size_t)c->dim * 2, n_new, hipMemcpyDeviceToDevice, c->stream));
         }
+        // (the norm kernel loads 16 bytes at a time: widths that are no multiple of 8 are read from the padded copy -- zeros add nothing to a norm)
+        const bool norm_from_pad = padded && (c->dim % 8 != 0);
+        e = norm_from_pad ? tavb::launch_corpus_max_norm(shadow_new, c->rows - c->norm_rows, sdim, d_norm, c->stream)
+                          : tavb::launch_corpus_max_norm(reinterpret_cast<const char*>(c->corpus) + (size_t)c->norm_rows * c->dim * 2, c->rows - c->norm_rows,
+                                                         c->dim, d_norm, c->stream);
       }
       if (e != hipSuccess) return fail(TAVB_E_HIP, "corpus norm / shadow launch failed: %s", hipGetErrorString(e));
       c->norm_rows = c->rows;
@@ -2061,11 +2064,13 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   // the wide tile keeps a band below the k-th best (any k the fused selections serve: the reference's max_matches = 50, convsettings.py:61-63,
   // included).  Its flagged queries need an exact tile: the 64-query one up to k = 64, beyond that the wide split-plane form (fp16 corpora).
   // A width that is not a multiple of 64 (the tile's K step) rides the wide tile on a zero-padded copy of the rows (search_wide_exact): any
-  // multiple of 8 on fp16 corpora (the exact fallbacks read the padded copy too: the same values), multiples of 16 on fp32 ones (their exact
+  // width on fp16 corpora (the exact fallbacks read the padded copy too: the same values), multiples of 16 on fp32 ones (their exact
   // tile reads the corpus' own fp32 rows).
   const bool odd_width = c->dim % 64 != 0;
   const int wide_dim = ((c->dim + 63) / 64) * 64;
-  const bool width_ok = !odd_width || (c->dim % 8 == 0 && (f16c || c->dim % 16 == 0));
+  // (round 6: ANY width on fp16 corpora -- the rescoring reads rows that are not 16-byte aligned element by element, in the scalar streaming
+  //  kernel's order)
+  const bool width_ok = !odd_width || f16c || c->dim % 16 == 0;
   const bool exact_tile = (k <= 64) ? ((f16c && odd_width) ? tavb::skinny_supported(wide_dim, k, false) : tavb::skinny_supported(c->dim, k, !f16c))
                                     : (f16c && c->wide_fallback != 0);
   const bool wide_batch = nq >= c->mfma_min_batch || (nq >= c->mfma_min_batch_big && (int64_t)c->rows * c->dim * (f16c ? 2 : 4) >= c->mfma_big_bytes);

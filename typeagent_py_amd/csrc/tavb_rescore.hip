@@ -213,7 +213,12 @@ __global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corp
     if (key != 0ull) {
       const uint32_t ord = 0xFFFFFFFFu - (uint32_t)key;
       float dot = 0.f;
-      if constexpr (sizeof(T) == 2) {
+      if (dim % (16 / (int)sizeof(T)) != 0) {
+        // rows that are not 16-byte aligned (fp16 widths that are no multiple of 8): element loads in the order of the streaming kernel that
+        // serves such widths (scan_scalar_kernel: lane l takes elements l, l + 64, ...), so a batch still is its sequential lookups bit for bit
+        const T* x = corpus + (size_t)(ord - index_base) * dim;
+        for (int e = lane; e < dim; e += 64) dot = fmaf((float)x[e], q[e], dot);
+      } else if constexpr (sizeof(T) == 2) {
         const f16x8* x = reinterpret_cast<const f16x8*>(corpus + (size_t)(ord - index_base) * dim);
         for (int i = lane; i < n8; i += 64) {
           const f16x8 v = x[i];
