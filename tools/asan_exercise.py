@@ -125,6 +125,15 @@ def main():
         rows = rng.integers(0, n, 5000).astype(np.int64)
         ok(lib.tavb_search_subset(h, ptr(q), ptr(rows), rows.size, k, c_float(0.0), ptr(o), ptr(s), byref(cnt)))
         print("subset search: count", cnt.value, flush=True)
+        # the same subset with its row list resident on the device (round 6: tavb_search_subset_resident)
+        r32 = rows.astype(np.int32); drows = dmalloc(r32.size * 4)
+        assert hip.hipMemcpy(drows, ptr(r32), r32.size * 4, 1) == 0
+        o_r = np.empty(k, np.int64); s_r = np.empty(k, np.float32); cnt_r = c_int32()
+        ok(lib.tavb_search_subset_resident(h, ptr(q), drows, r32.size, k, c_float(0.0), ptr(o_r), ptr(s_r), byref(cnt_r)))
+        if not (cnt_r.value == cnt.value and (o_r[: cnt.value] == o[: cnt.value]).all() and (s_r[: cnt.value] == s[: cnt.value]).all()):
+            print("MISMATCH resident subset", dtype, flush=True); bad.append((dtype, "subset_resident"))
+        assert lib.tavb_search_subset_resident(h, ptr(q), None, r32.size, k, c_float(0.0), ptr(o_r), ptr(s_r), byref(cnt_r)) != 0
+        hip.hipFree(drows)
         cap = 4096
         oa = np.empty(cap, np.int64); sa = np.empty(cap, np.float32); got = c_int64(); tot = c_int64()
         ok(lib.tavb_search_all(h, ptr(q), c_float(0.52), cap, ptr(oa), ptr(sa), byref(got), byref(tot)))
@@ -154,8 +163,10 @@ def main():
         if os.environ.get("TAVB_ASAN_SKIP_RCCL") != "1":
             uid = ctypes.create_string_buffer(128)
             ok(lib.tavb_comm_unique_id(uid))
+            ok(lib.tavb_set_option(h, b"comm_reserve_keys", 2048))  # (round 6) 200 queries x k keys travel in chunks through the reserved buffers
             ok(lib.tavb_comm_init(h, uid, 0, 1))
             ok(lib.tavb_set_option(h, b"comm_force", 1))
+            ok(lib.tavb_set_option(h, b"comm_timeout_ms", 20000))  # the polling form of tavb_synchronize
             for nq in (1, 40, 200):
                 qq = rng.standard_normal((nq, d)).astype(np.float32)
                 qq /= np.linalg.norm(qq, axis=1, keepdims=True)
@@ -178,9 +189,30 @@ def main():
                 assert hip.hipMemcpy(ptr(keys2), dk2, nq * k * 8, 2) == 0
                 ok(lib.tavb_decode_keys(ptr(keys2), nq, k, ptr(oo), ptr(ss), ptr(cc)))
                 for fr in (dq, dk, dk2, dm): hip.hipFree(fr)
+            # (round 6) a list allocation that fails: the rank's own error, the exchange still runs chunk by chunk with the failure key
+            nq = 200
+            dq = dmalloc(nq * d * 4); dk = dmalloc(nq * k * 8)
+            assert hip.hipMemset(dq, 0, nq * d * 4) == 0
+            ok(lib.tavb_set_option(h, b"comm_fail_alloc", 1))
+            assert lib.tavb_search_allgather(h, dq, nq, k, c_float(0.0), dk) != 0 and b"injected failure" in lib.tavb_last_error()
+            ok(lib.tavb_synchronize(h))
+            keys = np.empty((nq, k), np.uint64)
+            assert hip.hipMemcpy(ptr(keys), dk, nq * k * 8, 2) == 0 and (keys == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+            oo = np.empty((nq, k), np.int64); ss = np.empty((nq, k), np.float32); cc = np.empty(nq, np.int32)
+            assert lib.tavb_decode_keys(ptr(keys), nq, k, ptr(oo), ptr(ss), ptr(cc)) == -6
+            ok(lib.tavb_set_option(h, b"comm_fail_alloc", 0))
+            # (round 6) the timeout: an exchange held up for 300 ms against a 30 ms limit -> TAVB_E_TIMEOUT, communicator aborted, context usable
+            ok(lib.tavb_set_option(h, b"comm_timeout_ms", 30))
+            ok(lib.tavb_set_option(h, b"comm_stall_ms", 300))
+            ok(lib.tavb_search_allgather(h, dq, nq, k, c_float(0.0), dk))
+            assert lib.tavb_synchronize(h) == -7 and b"did not complete within" in lib.tavb_last_error()
+            w = c_int64(); ok(lib.tavb_get_option(h, b"comm_world", byref(w))); assert w.value == 0
+            ok(lib.tavb_synchronize(h))
+            for fr in (dq, dk): hip.hipFree(fr)
             ok(lib.tavb_comm_destroy(h))
             ok(lib.tavb_set_option(h, b"comm_force", 0))
-            print("rccl exchange: ok", flush=True)
+            ok(lib.tavb_set_option(h, b"comm_timeout_ms", 0))
+            print("rccl exchange (chunks, failed allocation, timeout): ok", flush=True)
         # bad arguments must come back as error codes, not as crashes
         assert lib.tavb_search(h, ptr(q), 100000, c_float(0.0), ptr(o), ptr(s), byref(cnt)) != 0
         assert lib.tavb_set_option(h, b"no_such_option", 1) != 0

@@ -25,6 +25,20 @@ def row(name, r, headline=False):
         alg = ro.get("algorithmic_per_step")
         extra.append(f"traffic {ro['traffic'] / 1e9:.1f} GB")
     frac = f"**{ro.get('frac', 0):.3f}** {ro.get('bound', '')}" if ro else "–"
+    if ro.get("bound") == "latency":
+        frac = f"launch-bound (kernel {ro.get('kernel_us_per_step', 0):.1f} µs)"
+    if ro.get("frac_at_clock"):
+        frac += f" ({ro['frac_at_clock']:.2f} at {ro.get('sclk_mhz', 0):.0f} MHz)"
+    ca = r.get("class_api") or {}
+    if not headline and ca.get("scored_int_lists"):
+        extra.append(f"class {ca['scored_int_lists']['ms_per_step'] * 1e3:.1f} µs" if ca['scored_int_lists']['ms_per_step'] < 0.2 else f"class {ca['scored_int_lists']['ms_per_step']:.2f} ms")
+    if ca.get("fresh_list_every_call"):
+        f_ms = ca["fresh_list_every_call"]["ms_per_step"]
+        extra.append(f"a fresh list every call {f_ms * 1e3:.0f} µs" if f_ms < 0.2 else f"a fresh list every call {f_ms:.1f} ms")
+    cb = r.get("cpu_baseline") or {}
+    if not headline and cb.get("p50_ms_per_query_on_sample"):
+        c_ms = cb["p50_ms_per_query_on_sample"]
+        extra.append(f"CPU {cb.get('kind', '')} {c_ms * 1e3:.0f} µs" if c_ms < 0.2 else f"CPU {cb.get('kind', '')} {c_ms:.1f} ms per query")
     ms = r.get("ms_per_step", 0.0)
     ms_s = f"{ms * 1e3:.1f} µs" if ms < 0.2 else f"{ms:.2f} ms"
     v = f"{val / 1e3:.1f} k" if val >= 1e4 else f"{val:.1f}"
