@@ -137,6 +137,8 @@ def test_committed_pmc_traffic_belongs_to_the_kernels_that_ship():
         if "mfma_scan_kernel" in launches and wl["nq"] >= 65:
             assert launches["mfma_scan_kernel"] == len(_native.plan_ladder(wl["rows"], wl["nq"])) - 1, f"{name}: the PMC pass ran another ladder"
         corpus_bytes = wl["rows"] * wl["dim"] * (2 if wl["dtype"] == "fp16" else 4)
+        if wl.get("subset"):  # the subset form reads the subset's rows and its int32 row list
+            corpus_bytes = wl["subset"] * (wl["dim"] * (2 if wl["dtype"] == "fp16" else 4) + 4)
         assert 0.9 <= entry["traffic_bytes_per_step"] / corpus_bytes <= 3.0, f"{name}: traffic is not of the order of this workload's corpus"
 
 
