@@ -1070,6 +1070,14 @@ def test_a_band_of_1500_near_duplicates_per_query_fits_the_default_band_buffer()
             assert [(r.item, r.score) for r in out[qi]] == [(r.item, r.score) for r in seq], qi
         else:  # (flagged, on the 64-query exact tile: 64 - k ranks of slack below the k-th, not a score band -- near-ties packed inside 1e-5 may permute)
             np.testing.assert_allclose([r.score for r in out[qi]], [r.score for r in seq], atol=3e-7, rtol=0)
+    # ONE un-seeded phase (every row of the corpus admitted: 260k keys per query stream through the select kernel's 4096-key cache, which is cut
+    # to its band again and again while the band grows to 1500 keys -- the cut keeps up to band_max keys, not a quarter of the cache): same answers
+    eng.set_option("mfma_sample_rows", -1)
+    out1 = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert 1 <= eng.get_option("last_flagged") <= 3
+    for qi in (0, 1, 50, 99, 100, 129):
+        assert [(r.item, r.score) for r in out1[qi]] == [(r.item, r.score) for r in out[qi]], qi
+    eng.set_option("mfma_sample_rows", 0)
     # the old buffer: the hundred are flagged too; the oracle's answers again
     eng.set_option("band_max", 1024)
     out2 = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
