@@ -8,7 +8,7 @@
 #   smoke            __graft_entry__.smoke()
 #   bench            the driver's command (bench.py --gpus 1 --steps 20 --warmup 5) + a digest of the line  -> bench_default.json
 #   dist1            the N > 1 code path on a one-rank communicator (TAVB_BENCH_FORCE_DIST=1)               -> bench_dist1.json
-#   dist2[:ROWS]     the N = 2 branches of bench.py on ONE GPU: two ranks under torch.distributed.run share cuda:0, gloo, the lookups' exchange
+#   dist2[:ROWS], dist8[:ROWS]  the N = 2 (N = 8) branches of bench.py on ONE GPU: the ranks under torch.distributed.run share cuda:0, gloo, the lookups' exchange
 #                    through the host (TAVB_BENCH_DIST_BACKEND=gloo); ROWS rows in the strong-scaling corpus and per rank of cfg4_weak (default 2000000)  -> bench_dist2.json
 #   parity100m       how long rank 0's whole-corpus parity pass takes at N = 8 (100M rows: 100 chunks generated on the device, 16 queries): tools/parity_leg_time.py -> parity100m.txt
 #   toolcheck        every measurement script under tools/ once, with small shapes, against the library that ships: rc per script -> toolcheck.txt
@@ -67,13 +67,14 @@ for step in "$@"; do
     dist1)
       TAVB_BENCH_FORCE_DIST=1 timeout 900 python bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_dist1.json 2> $O/bench_dist1.err
       echo "dist1 rc=$? line bytes: $(wc -c < $O/bench_dist1.json)"; tail -3 $O/bench_dist1.err; digest $O/bench_dist1.json ;;
-    dist2)
-      ROWS=2000000; [ "$arg" != "dist2" ] && ROWS=$arg
+    dist2|dist8)
+      NP=${step%%:*}; NP=${NP#dist}
+      ROWS=2000000; [ "$arg" != "dist$NP" ] && ROWS=$arg
       PORT=$(python -c "import socket; s=socket.socket(); s.bind(('127.0.0.1',0)); print(s.getsockname()[1])")
-      TAVB_BENCH_DIST_BACKEND=gloo timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $PORT \
-        bench.py --gpus 2 --steps 5 --warmup 2 --rows $ROWS > $O/bench_dist2.json 2> $O/bench_dist2.err
-      echo "dist2 rc=$? line bytes: $(wc -c < $O/bench_dist2.json)"; grep -v "^W0\|^\*\*\*\|OMP_NUM" $O/bench_dist2.err | tail -5; digest $O/bench_dist2.json
-      python -c "import json; d=json.loads(open('$O/bench_dist2.json').read().strip().splitlines()[-1]); print('exchange', d.get('exchange')); print('weak', d['sub']['cfg4_weak'].get('exchange'), d['sub']['cfg4_weak'].get('parity')); print(d.get('dry_run'))" ;;
+      TAVB_BENCH_DIST_BACKEND=gloo timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $NP --master-addr 127.0.0.1 --master-port $PORT \
+        bench.py --gpus $NP --steps 5 --warmup 2 --rows $ROWS > $O/bench_dist$NP.json 2> $O/bench_dist$NP.err
+      echo "dist$NP rc=$? line bytes: $(wc -c < $O/bench_dist$NP.json)"; grep -v "^W0\|^\*\*\*\|OMP_NUM\|Gloo\|socket.cpp" $O/bench_dist$NP.err | tail -5; digest $O/bench_dist$NP.json
+      python -c "import json; d=json.loads(open('$O/bench_dist$NP.json').read().strip().splitlines()[-1]); print('exchange', d.get('exchange')); print('weak', d['sub']['cfg4_weak'].get('exchange'), d['sub']['cfg4_weak'].get('parity')); print(d.get('dry_run'))" ;;
     parity100m) timeout 1700 python tools/parity_leg_time.py > $O/parity100m.txt 2>&1; echo "parity100m rc=$?"; tail -5 $O/parity100m.txt ;;
     toolcheck)
       : > $O/toolcheck.txt
