@@ -1530,6 +1530,37 @@ def test_odd_width_with_many_flagged_queries(d, nq, k, planted):
     vo.check_topk_parity(vo.scores_full(v16, qs[ids[-1]]), *items_scores(out[ids[-1]]), k, 0.9, referee=vo.f64_referee(v16, qs[ids[-1]]))
 
 
+@pytest.mark.parametrize("nq", [5, 8, 32])
+def test_small_batches_on_big_fp32_corpora_ride_the_shadow(nq):
+    """Round 6: on fp32 corpora of `mfma_big_bytes_f32` (4 GiB) or more a batch of 5+ queries takes the wide tile over the fp16 shadow (half the
+    bytes of the fp32 rows the 32-query fp32 tile reads: 32 queries over 1M x 1536 rows 0.79 against 1.24 ms) and its candidates are rescored
+    with the fp32 rows -- the sequential fp32 lookups bit for bit.  Smaller corpora keep the fp32 tile (the wide path's fixed launches cost more
+    than half a pass saves); here the size rule is lowered instead of building a 4 GiB corpus."""
+    n = 40_000
+    v, _ = make_corpus(n, 1536, 8795)
+    qs = make_queries(nq, 1536, 8796)
+    qs[1] = v[n - 5]
+    vb = new_vb(v, dtype="fp32")
+    eng = vb.engine
+    out5 = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert eng.get_option("last_tier") == 5 and eng.get_option("last_shadow") == 0  # 246 MB: the 32-query fp32 tile
+    eng.set_option("mfma_big_bytes_f32", 100 << 20)
+    out4 = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert eng.get_option("last_tier") == 4 and eng.get_option("last_shadow") == 1 and eng.get_option("last_flagged") == 0
+    assert out4[1][0].item == n - 5
+    for qi in range(nq):
+        seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=32, min_score=0.0)
+        assert eng.get_option("last_tier") in (1, 2, 3)
+        assert [(r.item, r.score) for r in out4[qi]] == [(r.item, r.score) for r in seq], qi
+        vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(out5[qi]), 32, 0.0, referee=vo.f64_referee(v, qs[qi]))
+    # four queries stay on the streaming scan; without the shadow option the fp32 tile serves the batch
+    vb.fuzzy_lookup_embeddings(qs[:4], max_hits=32, min_score=0.0)
+    assert eng.get_option("last_tier") in (1, 2, 3)
+    eng.set_option("f32_shadow", 0)
+    vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert eng.get_option("last_tier") == 5
+
+
 @pytest.mark.parametrize("nq", [65, 128, 300, 1024])
 def test_f32_corpus_large_batches_ride_the_fp16_shadow(nq):
     v, _ = make_corpus(60_007, 1536, 7600)

@@ -118,6 +118,13 @@ struct tavb_ctx {
   // launches per batch cost more than the 64-query tile's pass.
   int64_t mfma_min_batch_big = 33;
   int64_t mfma_big_bytes = (int64_t)256 << 20;
+  // ... and on FP32 corpora of `mfma_big_bytes_f32` (4 GiB) or more from `mfma_min_batch_big_f32` = 5 queries (round 6): the wide tile streams the fp16
+  // shadow -- half the bytes of the fp32 rows the 32-query fp32 tile reads -- and its candidates are rescored with the fp32 rows: 5 / 8 / 16 / 32
+  // queries over 1M x 1536 fp32 rows in 0.76 / 0.77 / 0.78 / 0.79 ms against 1.14 / 1.16 / 1.21 / 1.24 ms (profiles/r06_raw/f32_mid.txt).  The wide
+  // path's ~0.4 ms of selection and rescoring launches cost more than half a pass saves below ~4 GB (100k rows: 0.53 against 0.22 ms).  Needs the
+  // shadow (f32_shadow >= 1: +50 % device memory, built on first use); without the memory for it the fp32 tile serves the batch.
+  int64_t mfma_min_batch_big_f32 = 5;
+  int64_t mfma_big_bytes_f32 = (int64_t)4 << 30;
   int64_t mfma_splits = 0;  // 0 = auto
   int64_t mfma_ablate = 0;
   int64_t mfma_sched = 0;
@@ -494,6 +501,12 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_big_bytes") {
     if (v < 0) return fail(TAVB_E_INVALID, "mfma_big_bytes must be >= 0");
     c->mfma_big_bytes = v;
+  } else if (n == "mfma_min_batch_big_f32") {
+    if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch_big_f32 must be >= 1");
+    c->mfma_min_batch_big_f32 = v;
+  } else if (n == "mfma_big_bytes_f32") {
+    if (v < 0) return fail(TAVB_E_INVALID, "mfma_big_bytes_f32 must be >= 0");
+    c->mfma_big_bytes_f32 = v;
   } else if (n == "mfma_sample_rows") {
     if (v < -1) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= -1");
     c->mfma_sample_rows = v;
@@ -584,6 +597,8 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "mfma_min_batch") *out = c->mfma_min_batch;
   else if (n == "mfma_min_batch_big") *out = c->mfma_min_batch_big;
   else if (n == "mfma_big_bytes") *out = c->mfma_big_bytes;
+  else if (n == "mfma_min_batch_big_f32") *out = c->mfma_min_batch_big_f32;
+  else if (n == "mfma_big_bytes_f32") *out = c->mfma_big_bytes_f32;
   else if (n == "mfma_splits") *out = c->mfma_splits;
   else if (n == "mfma_tile") *out = c->mfma_tile;
   else if (n == "f32_shadow") *out = c->f32_shadow;
@@ -2073,7 +2088,9 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   const bool width_ok = !odd_width || f16c || c->dim % 16 == 0;
   const bool exact_tile = (k <= 64) ? ((f16c && odd_width) ? tavb::skinny_supported(wide_dim, k, false) : tavb::skinny_supported(c->dim, k, !f16c))
                                     : (f16c && c->wide_fallback != 0);
-  const bool wide_batch = nq >= c->mfma_min_batch || (nq >= c->mfma_min_batch_big && (int64_t)c->rows * c->dim * (f16c ? 2 : 4) >= c->mfma_big_bytes);
+  const int64_t corpus_bytes = (int64_t)c->rows * c->dim * (f16c ? 2 : 4);
+  const bool wide_batch = nq >= c->mfma_min_batch || (nq >= c->mfma_min_batch_big && corpus_bytes >= c->mfma_big_bytes) ||
+                          (!f16c && nq >= c->mfma_min_batch_big_f32 && corpus_bytes >= c->mfma_big_bytes_f32);
   bool wide = (f16c || c->f32_shadow) && c->corpus && wide_batch && width_ok && tavb::mfma_supported(wide_dim, k) && c->rows > 0 && exact_tile;
   // f32_shadow = 2: smaller batches (and single queries) on big fp32 corpora filter on the shadow too, with the 32/64-query tile
   // (it keeps the best 64 candidates per query: k up to 48 leaves the slack the completeness test needs)
