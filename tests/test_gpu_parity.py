@@ -1532,10 +1532,10 @@ def test_odd_width_with_many_flagged_queries(d, nq, k, planted):
 
 @pytest.mark.parametrize("nq", [5, 8, 32])
 def test_small_batches_on_big_fp32_corpora_ride_the_shadow(nq):
-    """Round 6: on fp32 corpora of `mfma_big_bytes_f32` (4 GiB) or more a batch of 5+ queries takes the wide tile over the fp16 shadow (half the
+    """Round 6: on fp32 corpora of `mfma_big_bytes_f32` (2 GiB) or more a batch of 5+ queries takes the wide tile over the fp16 shadow (half the
     bytes of the fp32 rows the 32-query fp32 tile reads: 32 queries over 1M x 1536 rows 0.79 against 1.24 ms) and its candidates are rescored
     with the fp32 rows -- the sequential fp32 lookups bit for bit.  Smaller corpora keep the fp32 tile (the wide path's fixed launches cost more
-    than half a pass saves); here the size rule is lowered instead of building a 4 GiB corpus."""
+    than half a pass saves); here the size rule is lowered instead of building a 2 GiB corpus."""
     n = 40_000
     v, _ = make_corpus(n, 1536, 8795)
     qs = make_queries(nq, 1536, 8796)
@@ -1544,7 +1544,7 @@ def test_small_batches_on_big_fp32_corpora_ride_the_shadow(nq):
     eng = vb.engine
     out5 = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
     assert eng.get_option("last_tier") == 5 and eng.get_option("last_shadow") == 0  # 246 MB: the 32-query fp32 tile
-    eng.set_option("mfma_big_bytes_f32", 100 << 20)
+    eng.set_option("mfma_big_bytes_f32", 150 << 20)  # (246 MB >= 150 MB: batches of 5+; 2 .. 4 queries need twice that)
     out4 = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
     assert eng.get_option("last_tier") == 4 and eng.get_option("last_shadow") == 1 and eng.get_option("last_flagged") == 0
     assert out4[1][0].item == n - 5
@@ -1553,9 +1553,19 @@ def test_small_batches_on_big_fp32_corpora_ride_the_shadow(nq):
         assert eng.get_option("last_tier") in (1, 2, 3)
         assert [(r.item, r.score) for r in out4[qi]] == [(r.item, r.score) for r in seq], qi
         vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(out5[qi]), 32, 0.0, referee=vo.f64_referee(v, qs[qi]))
-    # four queries stay on the streaming scan; without the shadow option the fp32 tile serves the batch
+    # two to four queries stay on the streaming scan until the corpus is twice that size; one query always does
+    few = vb.fuzzy_lookup_embeddings(qs[:4], max_hits=32, min_score=0.0)
+    assert eng.get_option("last_tier") in (1, 2, 3)
+    eng.set_option("mfma_big_bytes_f32", 50 << 20)
+    few4 = vb.fuzzy_lookup_embeddings(qs[:4], max_hits=32, min_score=0.0)
+    assert eng.get_option("last_tier") == 4 and eng.get_option("last_shadow") == 1
+    assert [[(r.item, r.score) for r in a] for a in few4] == [[(r.item, r.score) for r in a] for a in few]
+    vb.fuzzy_lookup_embeddings(qs[:1], max_hits=32, min_score=0.0)
+    assert eng.get_option("last_tier") in (1, 2, 3)
+    eng.set_option("mfma_min_batch_big_f32", 65)  # both rules off
     vb.fuzzy_lookup_embeddings(qs[:4], max_hits=32, min_score=0.0)
     assert eng.get_option("last_tier") in (1, 2, 3)
+    eng.set_option("mfma_min_batch_big_f32", 5)
     eng.set_option("f32_shadow", 0)
     vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
     assert eng.get_option("last_tier") == 5

@@ -118,13 +118,16 @@ struct tavb_ctx {
   // launches per batch cost more than the 64-query tile's pass.
   int64_t mfma_min_batch_big = 33;
   int64_t mfma_big_bytes = (int64_t)256 << 20;
-  // ... and on FP32 corpora of `mfma_big_bytes_f32` (4 GiB) or more from `mfma_min_batch_big_f32` = 5 queries (round 6): the wide tile streams the fp16
+  // ... and on FP32 corpora of `mfma_big_bytes_f32` (2 GiB) or more from `mfma_min_batch_big_f32` = 5 queries (round 6): the wide tile streams the fp16
   // shadow -- half the bytes of the fp32 rows the 32-query fp32 tile reads -- and its candidates are rescored with the fp32 rows: 5 / 8 / 16 / 32
-  // queries over 1M x 1536 fp32 rows in 0.76 / 0.77 / 0.78 / 0.79 ms against 1.14 / 1.16 / 1.21 / 1.24 ms (profiles/r06_raw/f32_mid.txt).  The wide
-  // path's ~0.4 ms of selection and rescoring launches cost more than half a pass saves below ~4 GB (100k rows: 0.53 against 0.22 ms).  Needs the
-  // shadow (f32_shadow >= 1: +50 % device memory, built on first use); without the memory for it the fp32 tile serves the batch.
+  // queries over 1M x 1536 fp32 rows in 0.76 / 0.77 / 0.78 / 0.79 ms against 1.14 / 1.16 / 1.21 / 1.24 ms (profiles/r06_raw/f32_mid.txt); 32 queries
+  // over 700k / 400k / 200k / 100k rows: 0.64 / 0.48 / 0.36 / 0.53 ms against 0.95 / 0.61 / 0.40 / 0.22 (f32_few.txt: the wide path's ~0.35 ms of
+  // selection and rescoring launches against half a pass).  Batches of 2 .. 4 queries (one pass of the fp32 streaming scan) from TWICE that size:
+  // 1M rows 0.77 against 0.92 .. 0.97 ms, 700k rows 0.64 against 0.68, 400k rows 0.48 against 0.39.  Single queries keep the fp32 scan (option
+  // f32_shadow = 2 moves them too).  Needs the shadow (f32_shadow >= 1: +50 % device memory, built on first use); without the memory for it the fp32
+  // kernels serve the batch.
   int64_t mfma_min_batch_big_f32 = 5;
-  int64_t mfma_big_bytes_f32 = (int64_t)4 << 30;
+  int64_t mfma_big_bytes_f32 = (int64_t)2 << 30;
   int64_t mfma_splits = 0;  // 0 = auto
   int64_t mfma_ablate = 0;
   int64_t mfma_sched = 0;
@@ -2090,7 +2093,8 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
                                     : (f16c && c->wide_fallback != 0);
   const int64_t corpus_bytes = (int64_t)c->rows * c->dim * (f16c ? 2 : 4);
   const bool wide_batch = nq >= c->mfma_min_batch || (nq >= c->mfma_min_batch_big && corpus_bytes >= c->mfma_big_bytes) ||
-                          (!f16c && nq >= c->mfma_min_batch_big_f32 && corpus_bytes >= c->mfma_big_bytes_f32);
+                          (!f16c && nq >= c->mfma_min_batch_big_f32 && corpus_bytes >= c->mfma_big_bytes_f32) ||
+                          (!f16c && nq >= 2 && c->mfma_min_batch_big_f32 <= 64 && corpus_bytes >= 2 * c->mfma_big_bytes_f32);
   bool wide = (f16c || c->f32_shadow) && c->corpus && wide_batch && width_ok && tavb::mfma_supported(wide_dim, k) && c->rows > 0 && exact_tile;
   // f32_shadow = 2: smaller batches (and single queries) on big fp32 corpora filter on the shadow too, with the 32/64-query tile
   // (it keeps the best 64 candidates per query: k up to 48 leaves the slack the completeness test needs)
