@@ -271,7 +271,8 @@ int tavb_search_subset_device(tavb_ctx* ctx, const float* dev_query, const int32
  * same subset again and again (the memory provider hands `lookup_in_subset_by_embedding` the same scope list per query term,
  * storage/memory/messageindex.py:173-183; tools/benchmark_vectorbase.py:133-163 passes one list for every round) upload and range-check it
  * once.  query_host float32 [dim]; dev_rows device int32 [n_subset], wrapped and range-checked by the caller; positions / scores / count as
- * tavb_search_subset. */
+ * tavb_search_subset.  A subset of up to "small_direct_bytes" of rows is ONE launch (per-workgroup lists into pinned memory, merged on the host;
+ * a 1536-wide query rides in the kernel arguments), like tavb_search on small corpora: 21 us against 28 for the 1000-of-10k case. */
 int tavb_search_subset_resident(tavb_ctx* ctx, const float* query_host, const int32_t* dev_rows, int64_t n_subset, int32_t k, float min_score,
                                 int64_t* out_positions, float* out_scores, int32_t* out_count);
 

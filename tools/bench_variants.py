@@ -30,7 +30,7 @@ def main():
         d = json.loads(lines[-1])
         ro = d["roofline"]
         parts = {k: round(v, 3) for k, v in {**ro.get("kernel_parts_ms_per_step", {}), **ro.get("other_kernels_ms_per_step", {})}.items()}
-        print(f"{name.strip():28s} {d['value']:10.1f} {d['unit']:10s} ms/step {d['ms_per_step']:8.3f}  kern {ro.get('kernel_ms_per_step', 0):7.3f}  frac {ro['frac']:.4f} {ro['bound']}  "
+        print(f"{name.strip():28s} {d['value']:10.1f} {d['unit']:10s} ms/step {d['ms_per_step']:8.3f}  kern {ro.get('kernel_ms_per_step', 0):7.3f}  frac {ro.get('frac', 0):.4f} {ro['bound']}  "
               f"parity {(d.get('parity') or {}).get('ok')}  {parts}", flush=True)
 
 

@@ -1292,6 +1292,52 @@ int tavb_search_subset_resident(tavb_ctx* c, const float* query_host, const int3
   if (int rc = c->h_out.reserve((size_t)k * sizeof(u64_t))) return rc;
   if (int rc = c->d_queries.reserve(qbytes)) return rc;
   memcpy(c->h_stage.ptr, query_host, qbytes);
+  c->last_direct = 0;
+  // a small subset (the reference script's 1000 of 10k; the memory provider's scope lists): ONE launch, as tavb_search does it for small corpora --
+  // the scan's per-workgroup lists land in pinned host memory and are merged here; a 1536-wide query rides in the kernel arguments
+  const int64_t subset_bytes = n_subset * c->dim * (c->dtype == TAVB_F16 ? 2 : 4);
+  if (c->small_direct_bytes > 0 && subset_bytes <= c->small_direct_bytes) {
+    tavb::ScanGeometry g = c->geom;
+    if (g.waves < 1) g.waves = 1;
+    if (g.waves > 16) g.waves = 16;
+    const int full_blocks = scan_blocks_for(c, n_subset, g.waves, g.unroll);
+    g.blocks = std::min(full_blocks, (int)std::max<int64_t>(8, c->small_direct_keys / (int64_t)k));
+    if (2 * g.blocks >= full_blocks) {
+      const size_t list_keys = (size_t)g.blocks * k;
+      if (int rc = c->h_lists.reserve((list_keys + (size_t)k) * sizeof(u64_t))) return rc;
+      tavb::ScanParams p{};
+      p.corpus = c->corpus;
+      p.row_ids = dev_rows;
+      p.queries = reinterpret_cast<const float*>(c->d_queries.ptr);
+      p.lists = reinterpret_cast<u64_t*>(c->h_lists.ptr);
+      p.n_pos = n_subset;
+      p.dim = c->dim;
+      p.dtype = c->dtype;
+      p.nq = 1;
+      p.k = k;
+      p.index_base = 0u;
+      p.key_bound = ~0ull;
+      for (int i = 0; i < TAVB_MAX_STREAM_QUERIES; ++i) p.min_score[i] = (i == 0) ? min_score : INFINITY;
+      hipError_t e = hipSuccess;
+      bool launched = false;
+      if (c->inline_query) {
+        Timed t(c, TAVB_KERNEL_SCAN);
+        launched = tavb::launch_scan_inline_query(p, g, c->stream, query_host, &c->last_tier, &e);
+      }
+      if (!launched) {
+        TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
+        Timed t(c, TAVB_KERNEL_SCAN);
+        e = tavb::launch_scan(p, g, c->stream, &c->last_tier);
+      }
+      if (e != hipSuccess) return fail(TAVB_E_HIP, "scan kernel launch failed: %s", hipGetErrorString(e));
+      c->last_direct = launched ? 2 : 1;
+      TAVB_HIP(hipStreamSynchronize(c->stream));
+      tavb_key* merged = reinterpret_cast<tavb_key*>(c->h_lists.ptr) + list_keys;
+      if (int rc = tavb_merge_keys_host(reinterpret_cast<const tavb_key*>(c->h_lists.ptr), g.blocks, 1, k, merged)) return rc;
+      decode(reinterpret_cast<const u64_t*>(merged), 1, k, 0, out_positions, out_scores, out_count);
+      return TAVB_OK;
+    }
+  }
   TAVB_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_stage.ptr, qbytes, hipMemcpyHostToDevice, c->stream));
   if (int rc = search_device_impl(c, reinterpret_cast<const float*>(c->d_queries.ptr), 1, k, &min_score, dev_rows, n_subset, 0u,
                                   reinterpret_cast<u64_t*>(c->h_out.ptr)))
