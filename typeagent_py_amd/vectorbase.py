@@ -643,7 +643,7 @@ class VectorBase:
                 pos, scs = eng.search_subset(embedding, rows, max_hits, thr)
             else:
                 pos, scs = eng.search_all(embedding, thr, None if max_hits == 0 else max_hits, subset_rows=rows)
-        return [ScoredInt(int(subset[p]), float(s)) for p, s in zip(pos.tolist(), scs.tolist())]
+        return list(map(ScoredInt, subset[pos].tolist(), scs.tolist()))  # (the caller's ordinals at the returned positions, :229)
 
     def fuzzy_lookup_embeddings(
         self,
