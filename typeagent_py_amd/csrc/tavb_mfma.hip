@@ -618,18 +618,26 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
     const unsigned char* bbase = smem + nslot * SLOT_B6 + (b_lane + kx);
     auto mfma_at = [&](auto i_tag) {
       constexpr int I = decltype(i_tag)::value;
-      constexpr int mi = I / NI, ni = I % NI;
+      // issue order of the NT MFMAs of a slice (measurement, profiles/r06_mfma_power.md): corpus fragment outermost (ships), query fragment
+      // outermost (ABL & 1024: the operand whose bits the board's power follows more closely stays put for five MFMAs), and either walked
+      // boustrophedon (ABL & 2048: exactly one operand changes between any two consecutive MFMAs)
+      constexpr bool BMAJ = (ABL & 1024) != 0, SERP = (ABL & 2048) != 0;
+      constexpr int outer = BMAJ ? I / 5 : I / NI;
+      constexpr int inner0 = BMAJ ? I % 5 : I % NI;
+      constexpr int inner = (SERP && (outer & 1)) ? (BMAJ ? 4 : NI - 1) - inner0 : inner0;
+      constexpr int mi = BMAJ ? inner : outer, ni = BMAJ ? outer : inner;
+      constexpr int J = mi * NI + ni;  // the accumulator block
       if constexpr ((ABL & 1) == 0) {
         if constexpr (FIRST) {
-          if constexpr (I < NA_TILES)
-            TAVB_MFMA6_A0(acc_a[I], fa[mi], fb[ni]);
+          if constexpr (J < NA_TILES)
+            TAVB_MFMA6_A0(acc_a[J], fa[mi], fb[ni]);
           else
-            TAVB_MFMA6_V0(acc_v[I - NA_TILES], fa[mi], fb[ni]);
+            TAVB_MFMA6_V0(acc_v[J - NA_TILES], fa[mi], fb[ni]);
         } else {
-          if constexpr (I < NA_TILES)
-            TAVB_MFMA6_A(acc_a[I], fa[mi], fb[ni]);
+          if constexpr (J < NA_TILES)
+            TAVB_MFMA6_A(acc_a[J], fa[mi], fb[ni]);
           else
-            TAVB_MFMA6_V(acc_v[I - NA_TILES], fa[mi], fb[ni]);
+            TAVB_MFMA6_V(acc_v[J - NA_TILES], fa[mi], fb[ni]);
         }
       }
       if constexpr ((ABL & 32) == 0) {
@@ -722,9 +730,9 @@ __global__ void __launch_bounds__(NT6) mfma_scan_kernel(const MfmaDeviceParams p
 #pragma unroll
           for (int r = 1; r < 16; ++r) top = __builtin_fmaxf(top, dots[r]);
           TAVB_SB();  // one block at a time
-          const bool any = (ABL == 0 || ABL == 512) && (top > thr_pre);
+          const bool any = ((ABL & ~3072) == 0 || ABL == 512) && (top > thr_pre);  // (bits 1024 / 2048: MFMA issue order, not an ablation)
           if constexpr (ABL == 512) asm volatile("" ::"s"(__builtin_amdgcn_ballot_w64(any)));
-          if constexpr (ABL != 0 && ABL != 512) asm volatile("" ::"v"(top));
+          if constexpr ((ABL & ~3072) != 0 && ABL != 512) asm volatile("" ::"v"(top));
           if (ABL != 512 && __builtin_amdgcn_ballot_w64(any) != 0ull) {
             // (rare: ~1 % of the blocks once the ladder's thresholds are in -- but each costs the workgroup ~0.3 us, and a batch has a few hundred
             //  thousand of them.)  One compare per row whose result is a WAVE mask in scalar registers (v_cmp into an SGPR pair: no per-lane
@@ -1614,11 +1622,17 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
       case 264: return go(mfma_scan_kernel<264, 4, 8, 6, 4>, NT6, LDS256);  // same as 256, query operand K step 0 re-read (cache resident)
       case 268: return go(mfma_scan_kernel<268, 4, 8, 6, 4>, NT6, LDS256);  // both operands cache resident
       case 258: return go(mfma_scan_kernel<258, 4, 8, 6, 4>, NT6, LDS256);  // no LDS-DMA, no admissions
+      case 1282: return go(mfma_scan_kernel<1282, 4, 8, 6, 4>, NT6, LDS256);  // the same in the other MFMA issue orders (sched 3 / 4 / 5)
+      case 2306: return go(mfma_scan_kernel<2306, 4, 8, 6, 4>, NT6, LDS256);
+      case 3330: return go(mfma_scan_kernel<3330, 4, 8, 6, 4>, NT6, LDS256);
       default: break;
     }
-    switch (p.sched) {  // staging pieces per quarter (q3, q0, q1): measurement
+    switch (p.sched) {  // staging pieces per quarter (q3, q0, q1), MFMA issue order: measurement
       case 1: return go(mfma_scan_kernel<0, 4, 10, 8, 0>, NT6, LDS256);
       case 2: return go(mfma_scan_kernel<0, 4, 6, 6, 6>, NT6, LDS256);
+      case 3: return go(mfma_scan_kernel<1024, 4, 8, 6, 4>, NT6, LDS256);  // query fragment outermost
+      case 4: return go(mfma_scan_kernel<2048, 4, 8, 6, 4>, NT6, LDS256);  // corpus fragment outermost, boustrophedon
+      case 5: return go(mfma_scan_kernel<3072, 4, 8, 6, 4>, NT6, LDS256);  // query fragment outermost, boustrophedon
       default: return go(mfma_scan_kernel<0, 4, 8, 6, 4>, NT6, LDS256);
     }
   }
