@@ -1785,6 +1785,8 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
   const std::vector<int64_t> bounds = ladder_bounds(c->rows, splits, r.nq_pad, r.skinny, r.ladder, c->mfma_sample_rows, c->mfma_ladder);  // phase i scans rows [bounds[i], bounds[i+1])
   const int n_phases = (int)bounds.size() - 1;
   const int kc = wide ? (int)c->band_max : k;  // keys per query of the running selection between phases
+  if (wide)  // (every phase's selection leaves its cut here -- the last one's seeds the exact fallbacks' admission thresholds, search_wide_exact)
+    if (int rc = c->d_thr.reserve((size_t)r.nq_pad * sizeof(float))) return rc;
   if (n_phases > 1 || (wide && r.active)) {
     if (int rc = c->d_thr.reserve((size_t)r.nq_pad * sizeof(float))) return rc;
     if (int rc = c->d_sample_keys.reserve((size_t)2 * nq * kc * sizeof(u64_t) + (size_t)2 * nq * sizeof(int))) return rc;  // running selection: two copies (ping-pong) + counts
@@ -1832,13 +1834,14 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
     }
     if (wide) {
       Timed t(c, r.active ? TAVB_KERNEL_RESCORE : TAVB_KERNEL_MERGE);
+      // (thresholds of the padding queries are never read: the tiles give every query past the live ones +inf themselves.  Until round 6 a
+      //  memset per phase filled them with NaNs -- one launch per phase for nothing.)
       float* d_thr = reinterpret_cast<float*>(c->d_thr.ptr);
-      if (!last) TAVB_HIP(hipMemsetAsync(d_thr, 0xFF, (size_t)r.nq_pad * sizeof(float), c->stream));  // padding queries: NaN bits, ignored by `>`
       // a work-list run (r.active: the SPLIT fallback) ends in its own band buffer; the strict best k of it is scattered to the callers' rows below
       u64_t* const last_out = r.active ? run_out : d_out;
       int* const last_cnt = r.active ? cnt_out : r.band_cnt;
       hipError_t e = tavb::launch_select_band(pp.workspace, pp.counts, pp.n_splits, nq, r.nq_pad, k, kc, carried ? run_in : nullptr, carried ? cnt_in : nullptr,
-                                              floor, r.band, last ? last_out : run_out, last ? last_cnt : cnt_out, last ? nullptr : d_thr, r.lost,
+                                              floor, r.band, last ? last_out : run_out, last ? last_cnt : cnt_out, (last && r.active) ? nullptr : d_thr, r.lost,
                                               last ? r.verdict : nullptr, c->stream, r.active, r.active_min, r.active_max > 0 ? r.active_max : 0x7fffffff,
                                               doom_gate ? r.doomed : nullptr, r.doomed_max, doom_count ? r.doomed : nullptr, doom_limit);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "select launch failed: %s", hipGetErrorString(e));
@@ -1856,7 +1859,6 @@ int run_tile_ladder(tavb_ctx* c, const TileRun& r, u64_t* d_out, const int* scat
     } else {
       hipError_t e = tavb::launch_merge(pp.lists, pp.list_stride, nq, k, /*query_major=*/true, run_out, c->stream);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "phase merge launch failed: %s", hipGetErrorString(e));
-      TAVB_HIP(hipMemsetAsync(c->d_thr.ptr, 0xFF, (size_t)r.nq_pad * sizeof(float), c->stream));  // NaN bits: ignored by `>`
       e = tavb::launch_sample_thresholds(run_out, nq, k, r.floor, reinterpret_cast<float*>(c->d_thr.ptr), c->stream);
       if (e != hipSuccess) return fail(TAVB_E_HIP, "threshold launch failed: %s", hipGetErrorString(e));
     }
@@ -1873,40 +1875,40 @@ float lowest_min_score(const float* min_scores, int nq) {
   return lo;
 }
 
+// The exclusive admission floor that goes with a threshold: `score > floor` <=> `score >= min_score` (+inf for NaN / > 1: nothing passes).
+float floor_of_min_score(float ms) {
+  if (ms != ms || ms > 1.0f) return INFINITY;
+  if (!(ms > 0.0f)) return -INFINITY;
+  uint32_t bits;
+  memcpy(&bits, &ms, sizeof bits);
+  --bits;
+  float f;
+  memcpy(&f, &bits, sizeof f);
+  return f;
+}
+
 // min_scores (host, [nq]) -> c->d_minscores: [nq_pad] the thresholds themselves (padding: +inf), then [nq_pad] the exclusive admission floors
-// that go with them (`score > floor` <=> `score >= min_score`; +inf for NaN / > 1 / padding).  A uniform batch -- every caller of the reference --
-// is filled by a kernel (no host buffer in flight: the device-resident forms stay asynchronous); a mixed one is copied from pageable memory
-// (staged by the runtime before the call returns).
-int upload_min_scores(tavb_ctx* c, const float* min_scores, int nq, int nq_pad, const float** d_ms_out, const float** d_floor_out) {
+// that go with them (+inf for NaN / > 1 / padding).  A mixed batch is copied from pageable memory (staged by the runtime before the call
+// returns).  A uniform one -- every caller of the reference -- needs no host buffer in flight (the device-resident forms stay asynchronous):
+// *uniform_out = true, NOTHING is written here, and the caller's prologue kernel fills both arrays from the one value (query_prepare_kernel).
+int upload_min_scores(tavb_ctx* c, const float* min_scores, int nq, int nq_pad, float** d_ms_out, float** d_floor_out, bool* uniform_out) {
   if (int rc = c->d_minscores.reserve((size_t)2 * nq_pad * sizeof(float))) return rc;
   float* d_ms = reinterpret_cast<float*>(c->d_minscores.ptr);
   float* d_floor = d_ms + nq_pad;
-  auto floor_of = [](float ms) {
-    if (ms != ms || ms > 1.0f) return INFINITY;
-    if (!(ms > 0.0f)) return -INFINITY;
-    uint32_t bits;
-    memcpy(&bits, &ms, sizeof bits);
-    --bits;
-    float f;
-    memcpy(&f, &bits, sizeof f);
-    return f;
-  };
   bool uniform = true;
   for (int i = 1; i < nq; ++i) uniform = uniform && (memcmp(&min_scores[i], &min_scores[0], sizeof(float)) == 0);
-  if (uniform) {
-    hipError_t e = tavb::launch_fill_thresholds(d_ms, d_floor, nq, nq_pad, min_scores[0], floor_of(min_scores[0]), c->stream);
-    if (e != hipSuccess) return fail(TAVB_E_HIP, "threshold fill launch failed: %s", hipGetErrorString(e));
-  } else {
+  if (!uniform) {
     std::vector<float> h((size_t)2 * nq_pad, INFINITY);
     for (int i = 0; i < nq; ++i) {
       h[i] = min_scores[i];
-      h[(size_t)nq_pad + i] = floor_of(min_scores[i]);
+      h[(size_t)nq_pad + i] = floor_of_min_score(min_scores[i]);
     }
     TAVB_HIP(hipMemcpyAsync(d_ms, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     TAVB_HIP(hipStreamSynchronize(c->stream));  // (pageable source: be sure the runtime is done with `h` before it goes out of scope)
   }
   *d_ms_out = d_ms;
   *d_floor_out = d_floor;
+  *uniform_out = uniform;
   return TAVB_OK;
 }
 
@@ -1956,8 +1958,9 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
   if (!big_k)
     if (int rc = c->d_fb_cand.reserve((size_t)cap * 64 * sizeof(u64_t))) return rc;
   if (int rc = c->d_norm.reserve(256)) return rc;
-  const float *d_ms = nullptr, *d_ms_floor = nullptr;
-  if (int rc = upload_min_scores(c, min_scores, nq, nq_pad, &d_ms, &d_ms_floor)) return rc;
+  float *d_ms = nullptr, *d_ms_floor = nullptr;
+  bool ms_uniform = false;
+  if (int rc = upload_min_scores(c, min_scores, nq, nq_pad, &d_ms, &d_ms_floor, &ms_uniform)) return rc;
   const float ms_lo = lowest_min_score(min_scores, nq);
   float* d_norm = reinterpret_cast<float*>(c->d_norm.ptr);
   float* d_delta = reinterpret_cast<float*>(c->d_delta.ptr);
@@ -1997,10 +2000,12 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
       if (e != hipSuccess) return fail(TAVB_E_HIP, "corpus norm / shadow launch failed: %s", hipGetErrorString(e));
       c->norm_rows = c->rows;
     }
-    TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16_bytes, c->stream));  // padding queries
-    TAVB_HIP(hipMemsetAsync(d_band, 0, (size_t)nq_pad * 4 * sizeof(float), c->stream));  // band widths of the padding queries, counts, lost levels, verdicts
-    hipError_t e = tavb::launch_query_prepare(fq, nq, fdim, d_ms, small, d_norm, small ? nullptr : c->d_queries_f16.ptr, d_delta, d_floor,
-                                              small ? nullptr : d_band, c->stream, bdirect);
+    // ONE launch: the filter's query operand (padding slots zero), delta / relaxed thresholds / band widths, the selection's counters zeroed,
+    // the work list's header zeroed, a uniform batch's thresholds filled in (round 6: a fill kernel, three memsets and this kernel until then)
+    if (small) TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, q16_bytes, c->stream));  // (the split planes' padding queries: launch_f32_split_f16 writes the live ones)
+    hipError_t e = tavb::launch_query_prepare(fq, nq, nq_pad, fdim, d_ms, small, d_norm, small ? nullptr : c->d_queries_f16.ptr, d_delta, d_floor,
+                                              small ? nullptr : d_band, c->stream, bdirect, d_band_cnt, d_nflag, ms_uniform, min_scores[0],
+                                              floor_of_min_score(min_scores[0]), d_ms, d_ms_floor);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "query prepare launch failed: %s", hipGetErrorString(e));
     if (small) {
       e = tavb::launch_f32_split_f16(d_q, c->d_queries_f16.ptr, reinterpret_cast<char*>(c->d_queries_f16.ptr) + q16_bytes / 2, (int64_t)nq * c->dim, c->stream);
@@ -2029,7 +2034,6 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
   // a batch MOST of whose bands are not going to fit (every query next to more near-duplicates than a band holds) is found out before the last --
   // the big -- filter phase and goes straight to the exact split-plane form: the filter's last phase, its selection and the rescoring return at once
   const bool early = wide_fallback && c->early_exact;
-  TAVB_HIP(hipMemsetAsync(d_nflag, 0, 64 * sizeof(int), c->stream));
   filt.doomed = early ? d_nflag + 1 : nullptr;
   filt.doomed_max = nq / 2;
   c->last_shadow = shadow_ops ? 1 : 0;
@@ -2046,13 +2050,13 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
     if (e != hipSuccess) return fail(TAVB_E_HIP, "rescore launch failed: %s", hipGetErrorString(e));
     // (the exact tiles of an fp32 corpus read its own rows -- the dispatch admits only widths they take; those of an fp16 corpus of an odd
     //  width read the padded copy, which holds the same values)
-    e = f32c ? tavb::launch_gather_flagged_f32(d_q, c->dim, d_ms, d_nflag, d_flagged, cap, reinterpret_cast<float*>(fb), fb_thr, c->stream)
-             : tavb::launch_gather_flagged(fq, fdim, d_ms, d_nflag, d_flagged, cap, fb, fb + (size_t)cap * fdim * 2, fb_thr, c->stream);
+    // the exact fallbacks start from what the filter has proven: the cut its last selection left in d_thr (the one before it when the early
+    // verdict skipped the last phase) less the filter's error bound is a valid admission threshold on exact scores, so ONE phase each
+    const float* seed = small ? nullptr : reinterpret_cast<const float*>(c->d_thr.ptr);
+    e = f32c ? tavb::launch_gather_flagged_f32(d_q, c->dim, d_ms, d_nflag, d_flagged, cap, reinterpret_cast<float*>(fb), fb_thr, seed, d_delta, c->stream)
+             : tavb::launch_gather_flagged(fq, fdim, d_ms, d_nflag, d_flagged, cap, fb, fb + (size_t)cap * fdim * 2, fb_thr, seed, d_delta,
+                                           wide_fallback ? fb_band : nullptr, kExactBand, c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "gather launch failed: %s", hipGetErrorString(e));
-    if (wide_fallback) {
-      e = tavb::launch_fill_f32(fb_band, cap, kExactBand, c->stream);
-      if (e != hipSuccess) return fail(TAVB_E_HIP, "band fill launch failed: %s", hipGetErrorString(e));
-    }
   }
   {  // (run_tile_ladder times its own launches, in the same bucket)
     if (!big_k) {
@@ -2105,7 +2109,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
       wx.active = d_nflag;
       wx.active_min = big_k ? 0 : 64;
       wx.active_max = 0;
-      wx.ladder = true;
+      wx.ladder = false;  // one phase, seeded by the filter's cut (fb_thr): three launches that return at once when the list is not this form's share
       wx.rs_queries = d_q;
       wx.rs_min_scores = d_ms;
       if (int rc = run_tile_ladder(c, wx, d_out, d_flagged)) return rc;
@@ -2172,9 +2176,11 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
     const size_t plane = (size_t)nq_pad * c->dim * (q32 ? 4 : 2);
     const size_t qbytes = plane * (q32 ? 1 : 2);
     if (int rc = c->d_queries_f16.reserve(qbytes)) return rc;
-    const float *d_ms = nullptr, *d_ms_floor = nullptr;
-    if (!uniform_thr)  // per-query thresholds: exclusive admission floors valid from the first row on
-      if (int rc = upload_min_scores(c, min_scores, nq, nq_pad, &d_ms, &d_ms_floor)) return rc;
+    float *d_ms = nullptr, *d_ms_floor = nullptr;
+    if (!uniform_thr) {  // per-query thresholds: exclusive admission floors valid from the first row on
+      bool uni = false;
+      if (int rc = upload_min_scores(c, min_scores, nq, nq_pad, &d_ms, &d_ms_floor, &uni)) return rc;
+    }
     TAVB_HIP(hipMemsetAsync(c->d_queries_f16.ptr, 0, qbytes, c->stream));
     if (q32) {
       TAVB_HIP(hipMemcpyAsync(c->d_queries_f16.ptr, d_q, (size_t)nq * c->dim * 4, hipMemcpyDeviceToDevice, c->stream));

@@ -54,6 +54,9 @@ hipError_t launch_merge_scatter(const unsigned long long* lists, int n_lists, in
 // keys carrying list positions -> keys carrying map[position] (tavb_misc.hip)
 hipError_t launch_remap_positions(unsigned long long* keys, int64_t n, const int32_t* map, int64_t map_len, hipStream_t stream);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize), once per (device, kernel) (tavb_misc.hip)
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
+
 // fault injection: holds the stream for `ms` milliseconds (tavb_misc.hip)
 hipError_t launch_stall(int ms, hipStream_t stream);
 
@@ -65,16 +68,19 @@ hipError_t launch_message_rerank(const unsigned long long* hits, int nq, int k, 
 
 // exact fp32-query semantics for the 256-query tile (tavb_rescore.hip)
 hipError_t launch_corpus_max_norm(const void* rows_f16, int64_t n, int dim, float* out_sq, hipStream_t stream);
+// The prologue of the wide path in one launch (tavb_rescore.hip::query_prepare_kernel): nq live queries, slots up to nq_pad zeroed.
 // q16 may be null (rows_only: the filter uses the exact queries, only the rows' rounding enters the bound)
-// band (optional, [nq]): 2 * delta, the width of the band selection
+// band (optional, [nq_pad]): 2 * delta, the width of the band selection
 // frag_major: q16 in MFMA-fragment-major order for 256-query tiles (tavb_mfma.hip, BD) instead of row-major
-// min_scores: device [nq], the callers' thresholds per query (float32 values, NaN allowed)
-hipError_t launch_query_prepare(const float* q, int nq, int dim, const float* min_scores, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
-                                float* thr, float* band, hipStream_t stream, bool frag_major = false);
-hipError_t launch_fill_f32(float* p, int n, float v, hipStream_t stream);
-hipError_t launch_fill_thresholds(float* a, float* b, int n, int n_pad, float va, float vb, hipStream_t stream);  // a[i] = va, b[i] = vb (i < n), +inf up to n_pad
+// min_scores: device [nq], the callers' thresholds per query (float32 values, NaN allowed) -- or, ms_fill: ONE threshold for the whole batch,
+//   written to ms_out / ms_floor_out [nq_pad] (+inf for the padding) by this launch
+// aux (optional): [3][nq_pad] ints zeroed (band counts, lost levels, verdicts); flag64 (optional): 64 ints zeroed (the work list's header)
+hipError_t launch_query_prepare(const float* q, int nq, int nq_pad, int dim, const float* min_scores, bool rows_only, const float* max_norm_sq, void* q16,
+                                float* delta, float* thr, float* band, hipStream_t stream, bool frag_major, int* aux, int* flag64, bool ms_fill, float ms_value,
+                                float ms_floor, float* ms_out, float* ms_floor_out);
 // candidates [nq, stride] (+ cand_cnt [nq]: band mode, the set is complete by construction unless incomplete[q]; cand_cnt == nullptr: the
 // sorted best `stride` = 64 by approximate score, complete when rank 63 + delta < the exact k-th best) -> exact top k [nq, k]
+// (*n_flagged must be zero when the launch starts: the prologue's flag64)
 hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t index_base, const float* queries, const unsigned long long* approx,
                           int stride, const int* cand_cnt, const int* incomplete, const float* delta, const float* min_scores, int nq, int k,
                           unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream, const int* gate = nullptr, int gate_max = 0);
@@ -86,10 +92,12 @@ hipError_t launch_rescore_slots(const void* corpus, bool f32_rows, int dim, uint
                                 const int* slot_query, const int* slot_active, int slot_min, int slot_max, hipStream_t stream);
 // (gate: device-side counter; when *gate > gate_max there are no candidates -- the last filter phase was skipped -- and EVERY query is flagged)
 hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void* out_f16, int out_pitch /*halves per shadow row*/, float* stats /*[2]*/, hipStream_t stream);
+// seed / delta (optional, [nq]): the filter's cut per query and its error bound -- the exact fallbacks' admission thresholds start from seed - 2 delta;
+// band_out (optional, [cap]) <- band_v: the band width of every slot of the wide exact form
 hipError_t launch_gather_flagged_f32(const float* queries, int dim, const float* min_scores, const int* n_flagged, const int* flagged, int cap, float* out,
-                                     float* thr, hipStream_t stream);
+                                     float* thr, const float* seed, const float* delta, hipStream_t stream);
 hipError_t launch_gather_flagged(const float* queries, int dim, const float* min_scores, const int* n_flagged, const int* flagged, int cap, void* hi, void* lo,
-                                 float* thr, hipStream_t stream);
+                                 float* thr, const float* seed, const float* delta, float* band_out, float band_v, hipStream_t stream);
 
 hipError_t launch_normalize_f32(const float* in, float* out, int64_t rows, int dim, hipStream_t stream);
 hipError_t launch_f32_to_f16(const float* in, void* out, int64_t count, hipStream_t stream);

@@ -1551,7 +1551,7 @@ hipError_t launch_select_band(const unsigned long long* cand, const int* counts,
                               int active_max, const int* gate, int gate_max, int* doomed, int doom_limit) {
   if (nq < 1 || k < 1 || k > TAVB_MAX_FUSED_K || n_splits < 1 || n_splits > 256 || nq_padded < nq || kc_max < k || kc_max > SEL_CACHE / 2 || kc_max > kBandMax) return hipErrorInvalidValue;
   constexpr int lds = SEL_CACHE * (int)sizeof(u64);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(select_band_kernel), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(select_band_kernel, dim3(nq), dim3(256), lds, stream, cand, counts, n_splits, nq_padded, k, kc_max, carried, carried_cnt, floor, band,
                      out, out_cnt, thr_out, lost, verdict, active, active_min, active_max, gate, gate_max, doomed, doom_limit);
@@ -1593,7 +1593,7 @@ hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream) {
   const int groups = (p.n_splits + 7) / 8;
   const int grid = groups * d.n_qtiles * 8;
   auto go = [&](auto kern, int threads, int lds) -> hipError_t {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, d);
     return hipGetLastError();
@@ -1715,7 +1715,7 @@ hipError_t launch_skinny_scan(const MfmaParams& p, hipStream_t stream) {
   const int groups = (p.n_splits + 7) / 8;
   const int grid = groups * d.n_qtiles * 8;
   auto go = [&](auto kern, int lds) -> hipError_t {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(S_THREADS), lds, stream, d);
     return hipGetLastError();

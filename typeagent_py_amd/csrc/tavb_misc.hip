@@ -3,6 +3,10 @@
 
 #include <hip/hip_fp16.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "tavb_device.h"
 #include "tavb_internal.h"
 
@@ -324,6 +328,22 @@ hipError_t launch_message_rerank(const unsigned long long* hits, int nq, int k, 
   hipLaunchKernelGGL(message_rerank_kernel, dim3(nq), dim3(256), 0, stream, hits, k, index_base, pos_to_row, row_to_msg, n_rows, accept_bits, n_bits,
                      max_messages, out);
   return hipGetLastError();
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of in front of every launch: a batched lookup on
+// the wide path makes ~20 launches of kernels that need it, and the call is host time the GPU waits for when the kernels are short.
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> done;  // largest size granted so far
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find({dev, kernel});
+  if (it != done.end() && it->second >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done[{dev, kernel}] = bytes;
+  return e;
 }
 
 }  // namespace tavb

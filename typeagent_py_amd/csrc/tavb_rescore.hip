@@ -111,15 +111,36 @@ __global__ void __launch_bounds__(256) shadow_convert_kernel(const float* __rest
   }
 }
 
-// One wave per query.  q16 <- fp16(q); delta <- score-units bound described above; thr <- the exclusive admission
-// threshold of the approximate pass (just below min_score - 2 delta; -inf when every row qualifies; +inf for NaN).
+// The prologue of a batched lookup on the wide path, ONE launch (until round 6: fill_thresholds + three memsets + this kernel; every launch of
+// a few microseconds of work costs about five, and a lookup of a 1.25M-row shard is 3.5 ms).  One wave per query slot, nq_pad of them:
+//   * a live query (slot < nq): q16 <- fp16(q); delta <- the score-units bound described above; thr <- the exclusive admission threshold of
+//     the approximate pass (just below min_score - 2 delta; -inf when every row qualifies; +inf for NaN); band <- 2 delta;
+//   * a padding slot: a zero query (it admits nothing: the tiles give it a threshold of +inf), band 0;
+//   * every slot: band count, lost level and verdict zeroed (aux, [3][nq_pad] ints behind `band`); with `ms_fill` the callers' uniform
+//     threshold goes into ms_out / ms_floor_out (+inf for the padding) -- a mixed batch arrives in `min_scores` instead;
+//   * the first wave zeroes the 64 ints of the work list's header (flag64: flagged count, doomed count).
 // rows_only: the filter multiplies the EXACT queries (split fp16 high + low planes) with the shadow rows: only the rows' rounding counts.
-__global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restrict__ q, int nq, int dim, const float* __restrict__ min_scores /*[nq]*/, int rows_only,
-                                                            const float* __restrict__ max_norm_sq /*[2]: max |x16|^2, max |x - x16|^2*/, _Float16* __restrict__ q16,
-                                                            float* __restrict__ delta, float* __restrict__ thr, float* __restrict__ band, int frag_major) {
+__global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restrict__ q, int nq, int nq_pad, int dim, const float* __restrict__ min_scores /*[nq] unless ms_fill*/,
+                                                            int rows_only, const float* __restrict__ max_norm_sq /*[2]: max |x16|^2, max |x - x16|^2*/,
+                                                            _Float16* __restrict__ q16, float* __restrict__ delta, float* __restrict__ thr, float* __restrict__ band,
+                                                            int frag_major, int* __restrict__ aux, int* __restrict__ flag64, int ms_fill, float ms_value, float ms_floor,
+                                                            float* __restrict__ ms_out, float* __restrict__ ms_floor_out) {
   const int lane = threadIdx.x & 63;
   const int qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (qi >= nq) return;
+  if (qi == 0 && flag64 != nullptr) flag64[lane] = 0;
+  if (qi >= nq_pad) return;
+  const bool live = qi < nq;
+  if (lane == 0) {
+    if (aux != nullptr) {
+      aux[qi] = 0;
+      aux[nq_pad + qi] = 0;
+      aux[2 * nq_pad + qi] = 0;
+    }
+    if (ms_fill) {
+      ms_out[qi] = live ? ms_value : __builtin_inff();
+      ms_floor_out[qi] = live ? ms_floor : __builtin_inff();
+    }
+  }
   const float* src = q + (size_t)qi * dim;
   _Float16* dst = q16 ? q16 + (size_t)qi * dim : nullptr;
   // fragment-major (the 256-query tile's direct query operand): 1 KiB per (query tile t, K step s of 64 halves, k16 slice c, 32-query block j);
@@ -128,7 +149,7 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
   const int qt = qi >> 8, qr = qi & 255;
   float err = 0.f, qq = 0.f;
   for (int i = lane; i < dim; i += 64) {
-    const float v = src[i];
+    const float v = live ? src[i] : 0.0f;
     const _Float16 h = (_Float16)v;
     if (dst) {
       if (frag_major) {
@@ -142,6 +163,10 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
     err = fmaf(d, d, err);
     qq = fmaf(v, v, qq);
   }
+  if (!live) {
+    if (lane == 0 && band) band[qi] = 0.0f;
+    return;
+  }
   err = wave_sum(err);
   qq = wave_sum(qq);
   if (lane == 0) {
@@ -154,7 +179,7 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
     delta[qi] = d;
     if (band) band[qi] = 2.0f * d;
     float t;
-    const float min_score = min_scores[qi];
+    const float min_score = ms_fill ? ms_value : min_scores[qi];
     if (min_score != min_score) {
       t = __builtin_inff();
     } else {
@@ -290,18 +315,37 @@ __global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corp
 
 // Compact the flagged queries into the operand of the exact 64-query tile: split hi / lo fp16 planes [2, cap, dim]
 // (unused slots zero) and per-slot exclusive thresholds (+inf for unused slots: they admit nothing).
+// seed (optional, [nq]) / delta: what the filter's selection has proven about a flagged query -- its cut, a level at least k rows reach by
+// APPROXIMATE score -- is a valid admission threshold for the exact fallbacks once the filter's error bound is taken off (k rows score
+// >= seed - delta exactly; a second delta and 1e-6 cover the exact tile's own arithmetic): the fallbacks start selective in ONE phase instead of
+// climbing their own ladder (round 6: fifteen launches per batch that did nothing whenever the work list was empty -- the normal case).
+// band_out (optional, [cap]): the band width of every slot of the wide exact form (fill_f32 until round 6: one more launch).
+__device__ __forceinline__ float slot_threshold(bool used, float min_score, const float* seed, const float* delta, int qi) {
+  if (!used || min_score != min_score) return __builtin_inff();
+  float t = (min_score > 0.0f) ? __uint_as_float(__float_as_uint(min_score) - 1u) : -__builtin_inff();
+  if (seed != nullptr) {
+    const float s = seed[qi] - 2.0f * delta[qi] - 1e-6f;  // (-inf, or NaN from inf - inf: the comparison is false, nothing is seeded)
+    if (s > t) t = s;
+  }
+  return t;
+}
+
 __global__ void __launch_bounds__(256) gather_flagged_kernel(const float* __restrict__ queries, int dim, const float* __restrict__ min_scores,
                                                              const int* __restrict__ n_flagged, const int* __restrict__ flagged, int cap,
-                                                             _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* __restrict__ thr) {
+                                                             _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* __restrict__ thr,
+                                                             const float* __restrict__ seed, const float* __restrict__ delta, float* __restrict__ band_out,
+                                                             float band_v) {
   const int n = *n_flagged;
   if (n == 0) return;  // the common case: nothing to do, nothing written
   const int slot = blockIdx.x;
   if (slot >= cap) return;
   const bool used = slot < n;
-  const float min_score = used ? min_scores[flagged[slot]] : 0.0f;
-  const float thr0 = (min_score > 0.0f) ? __uint_as_float(__float_as_uint(min_score) - 1u) : -__builtin_inff();
-  if (threadIdx.x == 0) thr[slot] = used ? ((min_score != min_score) ? __builtin_inff() : thr0) : __builtin_inff();
-  const float* src = used ? queries + (size_t)flagged[slot] * dim : nullptr;
+  const int qi = used ? flagged[slot] : 0;
+  if (threadIdx.x == 0) {
+    thr[slot] = slot_threshold(used, used ? min_scores[qi] : 0.0f, seed, delta, qi);
+    if (band_out != nullptr) band_out[slot] = band_v;
+  }
+  const float* src = used ? queries + (size_t)qi * dim : nullptr;
   for (int i = threadIdx.x; i < dim; i += blockDim.x) {
     _Float16 h = (_Float16)0.0f, l = (_Float16)0.0f;
     if (used) {
@@ -318,33 +362,17 @@ __global__ void __launch_bounds__(256) gather_flagged_kernel(const float* __rest
 // the same for the exact fp32 tile: plain fp32 queries [cap, dim]
 __global__ void __launch_bounds__(256) gather_flagged_f32_kernel(const float* __restrict__ queries, int dim, const float* __restrict__ min_scores,
                                                                  const int* __restrict__ n_flagged, const int* __restrict__ flagged, int cap,
-                                                                 float* __restrict__ out, float* __restrict__ thr) {
+                                                                 float* __restrict__ out, float* __restrict__ thr, const float* __restrict__ seed,
+                                                                 const float* __restrict__ delta) {
   const int n = *n_flagged;
   if (n == 0) return;
   const int slot = blockIdx.x;
   if (slot >= cap) return;
   const bool used = slot < n;
-  const float min_score = used ? min_scores[flagged[slot]] : 0.0f;
-  const float thr0 = (min_score > 0.0f) ? __uint_as_float(__float_as_uint(min_score) - 1u) : -__builtin_inff();
-  if (threadIdx.x == 0) thr[slot] = used ? ((min_score != min_score) ? __builtin_inff() : thr0) : __builtin_inff();
-  const float* src = used ? queries + (size_t)flagged[slot] * dim : nullptr;
+  const int qi = used ? flagged[slot] : 0;
+  if (threadIdx.x == 0) thr[slot] = slot_threshold(used, used ? min_scores[qi] : 0.0f, seed, delta, qi);
+  const float* src = used ? queries + (size_t)qi * dim : nullptr;
   for (int i = threadIdx.x; i < dim; i += blockDim.x) out[(size_t)slot * dim + i] = used ? src[i] : 0.0f;
-}
-
-__global__ void zero_int_kernel(int* p) { *p = 0; }
-
-__global__ void fill_f32_kernel(float* __restrict__ p, int n, float v) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-
-// a uniform batch's thresholds: a[i] = va, b[i] = vb for i < n, +inf for the padding up to n_pad
-__global__ void fill_thresholds_kernel(float* __restrict__ a, float* __restrict__ b, int n, int n_pad, float va, float vb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_pad) {
-    a[i] = i < n ? va : __builtin_inff();
-    b[i] = i < n ? vb : __builtin_inff();
-  }
 }
 
 }  // namespace
@@ -365,22 +393,13 @@ hipError_t launch_shadow_convert(const float* rows_f32, int64_t n, int dim, void
   return hipGetLastError();
 }
 
-hipError_t launch_fill_f32(float* p, int n, float v, hipStream_t stream) {
-  if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(fill_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, v);
-  return hipGetLastError();
-}
-
-hipError_t launch_fill_thresholds(float* a, float* b, int n, int n_pad, float va, float vb, hipStream_t stream) {
-  if (n_pad <= 0) return hipSuccess;
-  hipLaunchKernelGGL(fill_thresholds_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, stream, a, b, n, n_pad, va, vb);
-  return hipGetLastError();
-}
-
-hipError_t launch_query_prepare(const float* q, int nq, int dim, const float* min_scores, bool rows_only, const float* max_norm_sq, void* q16, float* delta,
-                                float* thr, float* band, hipStream_t stream, bool frag_major) {
-  hipLaunchKernelGGL(query_prepare_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, q, nq, dim, min_scores, rows_only ? 1 : 0, max_norm_sq,
-                     reinterpret_cast<_Float16*>(q16), delta, thr, band, frag_major ? 1 : 0);
+hipError_t launch_query_prepare(const float* q, int nq, int nq_pad, int dim, const float* min_scores, bool rows_only, const float* max_norm_sq, void* q16,
+                                float* delta, float* thr, float* band, hipStream_t stream, bool frag_major, int* aux, int* flag64, bool ms_fill, float ms_value,
+                                float ms_floor, float* ms_out, float* ms_floor_out) {
+  if (nq_pad < nq || (ms_fill && (!ms_out || !ms_floor_out)) || (!ms_fill && !min_scores)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(query_prepare_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, stream, q, nq, nq_pad, dim, min_scores, rows_only ? 1 : 0, max_norm_sq,
+                     reinterpret_cast<_Float16*>(q16), delta, thr, band, frag_major ? 1 : 0, aux, flag64, ms_fill ? 1 : 0, ms_value, ms_floor, ms_out,
+                     ms_floor_out);
   return hipGetLastError();
 }
 
@@ -404,7 +423,7 @@ hipError_t launch_rescore(const void* corpus, bool f32_rows, int dim, uint32_t i
                           unsigned long long* out, int* n_flagged, int* flagged, hipStream_t stream, const int* gate, int gate_max) {
   if (stride < 1 || stride > kBandMax || k < 1 || k > TAVB_MAX_FUSED_K || (cand_cnt != nullptr && incomplete == nullptr) || !min_scores) return hipErrorInvalidValue;
   if (cand_cnt == nullptr && k > 64) return hipErrorInvalidValue;  // cut mode hands over 64 candidates
-  hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, stream, n_flagged);
+  // (*n_flagged is zeroed by the caller: query_prepare_kernel's flag64)
   if (f32_rows)
     launch_rescore_t<float>(corpus, dim, index_base, queries, approx, stride, cand_cnt, incomplete, delta, min_scores, nq, k, out, n_flagged, flagged, stream,
                             gate, gate_max, nullptr, nullptr, 0, 0);
@@ -428,15 +447,15 @@ hipError_t launch_rescore_slots(const void* corpus, bool f32_rows, int dim, uint
 }
 
 hipError_t launch_gather_flagged_f32(const float* queries, int dim, const float* min_scores, const int* n_flagged, const int* flagged, int cap, float* out,
-                                     float* thr, hipStream_t stream) {
-  hipLaunchKernelGGL(gather_flagged_f32_kernel, dim3(cap), dim3(256), 0, stream, queries, dim, min_scores, n_flagged, flagged, cap, out, thr);
+                                     float* thr, const float* seed, const float* delta, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_flagged_f32_kernel, dim3(cap), dim3(256), 0, stream, queries, dim, min_scores, n_flagged, flagged, cap, out, thr, seed, delta);
   return hipGetLastError();
 }
 
 hipError_t launch_gather_flagged(const float* queries, int dim, const float* min_scores, const int* n_flagged, const int* flagged, int cap, void* hi, void* lo,
-                                 float* thr, hipStream_t stream) {
+                                 float* thr, const float* seed, const float* delta, float* band_out, float band_v, hipStream_t stream) {
   hipLaunchKernelGGL(gather_flagged_kernel, dim3(cap), dim3(256), 0, stream, queries, dim, min_scores, n_flagged, flagged, cap,
-                     reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo), thr);
+                     reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo), thr, seed, delta, band_out, band_v);
   return hipGetLastError();
 }
 
