@@ -148,20 +148,41 @@ __global__ void __launch_bounds__(256) query_prepare_kernel(const float* __restr
   const int steps = dim / 64;
   const int qt = qi >> 8, qr = qi & 255;
   float err = 0.f, qq = 0.f;
-  for (int i = lane; i < dim; i += 64) {
-    const float v = live ? src[i] : 0.0f;
+  auto one = [&](int i, float v, _Float16* h_out) {
     const _Float16 h = (_Float16)v;
-    if (dst) {
-      if (frag_major) {
-        const int ks = i >> 6, c = (i >> 4) & 3, hs = (i >> 3) & 1, e = i & 7;
-        q16[((((size_t)(qt * steps + ks) * 4 + c) * 8 + (qr >> 5)) * 512) + (size_t)((hs * 32 + (qr & 31)) * 8 + e)] = h;
-      } else {
-        dst[i] = h;
-      }
-    }
+    *h_out = h;
     const float d = v - (float)h;
     err = fmaf(d, d, err);
     qq = fmaf(v, v, qq);
+  };
+  if (dim % 4 == 0) {  // (always, on the routes that come here: four elements per lane per round, one 16-byte load, one 8-byte store)
+    for (int i = lane * 4; i < dim; i += 256) {
+      const f32x4 v = live ? *reinterpret_cast<const f32x4*>(src + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      _Float16 h[4];
+      one(i, v.x, &h[0]);
+      one(i + 1, v.y, &h[1]);
+      one(i + 2, v.z, &h[2]);
+      one(i + 3, v.w, &h[3]);
+      if (dst) {
+        // (fragment-major: elements i .. i + 3 share K step, slice and half-slice -- four consecutive halves there too)
+        const int ks = i >> 6, c = (i >> 4) & 3, hs = (i >> 3) & 1, e = i & 7;
+        _Float16* out = frag_major ? q16 + ((((size_t)(qt * steps + ks) * 4 + c) * 8 + (qr >> 5)) * 512) + (size_t)((hs * 32 + (qr & 31)) * 8 + e) : dst + i;
+        *reinterpret_cast<uint2*>(out) = *reinterpret_cast<const uint2*>(h);
+      }
+    }
+  } else {
+    for (int i = lane; i < dim; i += 64) {
+      _Float16 h;
+      one(i, live ? src[i] : 0.0f, &h);
+      if (dst) {
+        if (frag_major) {
+          const int ks = i >> 6, c = (i >> 4) & 3, hs = (i >> 3) & 1, e = i & 7;
+          q16[((((size_t)(qt * steps + ks) * 4 + c) * 8 + (qr >> 5)) * 512) + (size_t)((hs * 32 + (qr & 31)) * 8 + e)] = h;
+        } else {
+          dst[i] = h;
+        }
+      }
+    }
   }
   if (!live) {
     if (lane == 0 && band) band[qi] = 0.0f;
@@ -232,48 +253,77 @@ __global__ void __launch_bounds__(256) rescore_kernel(const T* __restrict__ corp
   const int n8 = dim / 8;
   int n_cand = cand_cnt ? cand_cnt[slot] : stride;
   if (n_cand > kBandMax) n_cand = kBandMax;
-  for (int c = wave; c < n_cand; c += 4) {
-    const u64 key = cand[c];  // wave-uniform
-    u64 out_key = 0ull;
-    if (key != 0ull) {
-      const uint32_t ord = 0xFFFFFFFFu - (uint32_t)key;
-      float dot = 0.f;
-      if (dim % (16 / (int)sizeof(T)) != 0) {
-        // rows that are not 16-byte aligned (fp16 widths that are no multiple of 8): element loads in the order of the streaming kernel that
-        // serves such widths (scan_scalar_kernel: lane l takes elements l, l + 64, ...), so a batch still is its sequential lookups bit for bit
-        const T* x = corpus + (size_t)(ord - index_base) * dim;
-        for (int e = lane; e < dim; e += 64) dot = fmaf((float)x[e], q[e], dot);
-      } else if constexpr (sizeof(T) == 2) {
-        const f16x8* x = reinterpret_cast<const f16x8*>(corpus + (size_t)(ord - index_base) * dim);
-        for (int i = lane; i < n8; i += 64) {
-          const f16x8 v = x[i];
-          const f32x4 qa = *reinterpret_cast<const f32x4*>(q + i * 8);
-          const f32x4 qb = *reinterpret_cast<const f32x4*>(q + i * 8 + 4);
-          dot = fmaf((float)v[0], qa.x, dot);
-          dot = fmaf((float)v[1], qa.y, dot);
-          dot = fmaf((float)v[2], qa.z, dot);
-          dot = fmaf((float)v[3], qa.w, dot);
-          dot = fmaf((float)v[4], qb.x, dot);
-          dot = fmaf((float)v[5], qb.y, dot);
-          dot = fmaf((float)v[6], qb.z, dot);
-          dot = fmaf((float)v[7], qb.w, dot);
-        }
-      } else {
-        const f32x4* x = reinterpret_cast<const f32x4*>(corpus + (size_t)(ord - index_base) * dim);
-        for (int i = lane; i < 2 * n8; i += 64) {
-          const f32x4 v = x[i];
-          const f32x4 qa = *reinterpret_cast<const f32x4*>(q + i * 4);
-          dot = fmaf(v.x, qa.x, dot);
-          dot = fmaf(v.y, qa.y, dot);
-          dot = fmaf(v.z, qa.z, dot);
-          dot = fmaf(v.w, qa.w, dot);
-        }
+  // Two candidates per wave per round (c and c + 4): their row loads are in flight together -- a wave works through ~9 rows of a band one
+  // after the other, each a dependent HBM round trip, and at a few dozen queries nothing else hides it.  Every row keeps its own fma chain in
+  // its own order: the scores are those of the one-row loop bit for bit.
+  const bool aligned = dim % (16 / (int)sizeof(T)) == 0;
+  for (int c = wave; c < n_cand; c += 8) {
+    const u64 key0 = cand[c];  // wave-uniform
+    const u64 key1 = (c + 4 < n_cand) ? cand[c + 4] : 0ull;
+    const uint32_t ord0 = 0xFFFFFFFFu - (uint32_t)key0, ord1 = 0xFFFFFFFFu - (uint32_t)key1;
+    // (an empty slot reads the row of the candidate next to it: harmless, its result is dropped)
+    const T* x0 = corpus + (size_t)((key0 != 0ull ? ord0 : ord1) - index_base) * dim;
+    const T* x1 = corpus + (size_t)((key1 != 0ull ? ord1 : ord0) - index_base) * dim;
+    float dot0 = 0.f, dot1 = 0.f;
+    if (key0 == 0ull && key1 == 0ull) {
+    } else if (!aligned) {
+      // rows that are not 16-byte aligned (fp16 widths that are no multiple of 8): element loads in the order of the streaming kernel that
+      // serves such widths (scan_scalar_kernel: lane l takes elements l, l + 64, ...), so a batch still is its sequential lookups bit for bit
+      for (int e = lane; e < dim; e += 64) {
+        const float qe = q[e];
+        dot0 = fmaf((float)x0[e], qe, dot0);
+        dot1 = fmaf((float)x1[e], qe, dot1);
       }
-      dot = wave_sum(dot);
-      const float s = cosine_to_score(dot);
-      if (s == s) out_key = make_key(s, ord);  // a NaN score ranks nowhere (numpy's >= drops it)
+    } else if constexpr (sizeof(T) == 2) {
+      const f16x8* r0 = reinterpret_cast<const f16x8*>(x0);
+      const f16x8* r1 = reinterpret_cast<const f16x8*>(x1);
+      for (int i = lane; i < n8; i += 64) {
+        const f16x8 v = r0[i];
+        const f16x8 w = r1[i];
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(q + i * 8);
+        const f32x4 qb = *reinterpret_cast<const f32x4*>(q + i * 8 + 4);
+        dot0 = fmaf((float)v[0], qa.x, dot0);
+        dot0 = fmaf((float)v[1], qa.y, dot0);
+        dot0 = fmaf((float)v[2], qa.z, dot0);
+        dot0 = fmaf((float)v[3], qa.w, dot0);
+        dot0 = fmaf((float)v[4], qb.x, dot0);
+        dot0 = fmaf((float)v[5], qb.y, dot0);
+        dot0 = fmaf((float)v[6], qb.z, dot0);
+        dot0 = fmaf((float)v[7], qb.w, dot0);
+        dot1 = fmaf((float)w[0], qa.x, dot1);
+        dot1 = fmaf((float)w[1], qa.y, dot1);
+        dot1 = fmaf((float)w[2], qa.z, dot1);
+        dot1 = fmaf((float)w[3], qa.w, dot1);
+        dot1 = fmaf((float)w[4], qb.x, dot1);
+        dot1 = fmaf((float)w[5], qb.y, dot1);
+        dot1 = fmaf((float)w[6], qb.z, dot1);
+        dot1 = fmaf((float)w[7], qb.w, dot1);
+      }
+    } else {
+      const f32x4* r0 = reinterpret_cast<const f32x4*>(x0);
+      const f32x4* r1 = reinterpret_cast<const f32x4*>(x1);
+      for (int i = lane; i < 2 * n8; i += 64) {
+        const f32x4 v = r0[i];
+        const f32x4 w = r1[i];
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(q + i * 4);
+        dot0 = fmaf(v.x, qa.x, dot0);
+        dot0 = fmaf(v.y, qa.y, dot0);
+        dot0 = fmaf(v.z, qa.z, dot0);
+        dot0 = fmaf(v.w, qa.w, dot0);
+        dot1 = fmaf(w.x, qa.x, dot1);
+        dot1 = fmaf(w.y, qa.y, dot1);
+        dot1 = fmaf(w.z, qa.z, dot1);
+        dot1 = fmaf(w.w, qa.w, dot1);
+      }
     }
-    if (lane == 0) exact[c] = out_key;
+    dot0 = wave_sum(dot0);
+    dot1 = wave_sum(dot1);
+    const float s0 = cosine_to_score(dot0), s1 = cosine_to_score(dot1);
+    // a NaN score ranks nowhere (numpy's >= drops it)
+    if (lane == 0) {
+      exact[c] = (key0 != 0ull && s0 == s0) ? make_key(s0, ord0) : 0ull;
+      if (c + 4 < n_cand) exact[c + 4] = (key1 != 0ull && s1 == s1) ? make_key(s1, ord1) : 0ull;
+    }
   }
   __syncthreads();
   if (wave != 0) return;
