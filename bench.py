@@ -44,6 +44,8 @@ import subprocess
 import sys
 import time
 
+_PROCESS_T0 = time.perf_counter()  # (the suite's time budget counts from here: --budget-seconds)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -1341,6 +1343,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="north-star suite: headline only")
+    ap.add_argument("--budget-seconds", type=float, default=420.0, help="north-star suite: sub-record groups that would START after this many seconds of process time are skipped (the whole default suite takes ~280 s on a box of the pool)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cfg5-subset", type=int, default=0, help="cfg5: message re-rank over a subset of this many ordinals (0 = full scan)")
     ap.add_argument("--cfg5-separate", action="store_true", help="cfg5: issue the six lookups as separate synchronous calls")
@@ -1407,6 +1410,7 @@ def main() -> None:
             rec["class_api"] = api
 
     sub = None
+    sub_skipped = []
     if suite and not ctx.distributed and not args.no_sub:
         sub = {}
         # the single-query target on the same 10M-row corpus
@@ -1424,96 +1428,128 @@ def main() -> None:
         sub["cfg3_subset"]["class_api"] = class_api_rates(ctx, ws, corpus, args.min_score, 20)
         del corpus
         torch.cuda.empty_cache()
-        # (the two small corpora next: measured right after big ones have come and gone, cfg2 reads 6 % slower -- where its 6 GB land in HBM)
-        w3 = dict(WORKLOADS["cfg2"])
-        w3["rows_total"] = w3["rows"]
-        c2 = gen_rows(ctx.eng, 0, w3["rows"], w3["dim"], w3["seed"], w3["dtype"])
-        sub["cfg2"] = run_record(ctx, "cfg2", w3, c2, 0, 100, 10, with_cpu=True)
-        # the same lookup at the reference's related-terms threshold (min_score 0.85, knowpro/convsettings.py:61-63): nothing of a gaussian
-        # corpus survives it -- the scan without any selection work
-        sub["cfg2_ms085"] = run_record(ctx, "cfg2", dict(w3, min_score=0.85), c2, 0, 100, 10, with_cpu=False)
-        wb = dict(WORKLOADS["cfg2_b32"], rows_total=w3["rows"])
-        sub["cfg2_b32"] = run_record(ctx, "cfg2_b32", wb, c2, 0, 40, 5, with_cpu=False)
-        del c2
-        # BASELINE config 1: the reference's own scale (10k x 1536 fp32, one query, top-10) -- launch-bound; with the class-level rate
-        w1 = dict(WORKLOADS["cfg1"])
-        w1["rows_total"] = w1["rows"]
-        c1 = gen_rows(ctx.eng, 0, w1["rows"], w1["dim"], w1["seed"], w1["dtype"])
-        sub["cfg1"] = run_record(ctx, "cfg1", w1, c1, 0, 500, 50, with_cpu=True)
-        sub["cfg1"]["class_api"] = class_api_rates(ctx, w1, c1, args.min_score, 500)
-        # the reference script's third row on the same corpus: fuzzy_lookup_embedding_in_subset, 1000 of 10k (tools/benchmark_vectorbase.py:133-163)
-        w1s = dict(WORKLOADS["cfg1_subset"], rows_total=w1["rows"], cpu_seconds=6.0)
-        sub["cfg1_subset"] = run_record(ctx, "cfg1_subset", w1s, c1, 0, 500, 50, with_cpu=True)
-        sub["cfg1_subset"]["class_api"] = class_api_rates(ctx, w1s, c1, args.min_score, 500)
-        del c1
-        # ... and the width that script defaults to (--dim 384, :55-76)
-        w1d = dict(WORKLOADS["cfg1_d384"])
-        w1d.update(rows_total=w1d["rows"], cpu_seconds=6.0)
-        c1d = gen_rows(ctx.eng, 0, w1d["rows"], w1d["dim"], w1d["seed"], w1d["dtype"])
-        sub["cfg1_d384"] = run_record(ctx, "cfg1_d384", w1d, c1d, 0, 500, 50, with_cpu=True)
-        del c1d
-        # ... and that script's first row, 1k vectors (1.5 MB): the CPU answers out of its cache in less time than a kernel launch + synchronise
-        # takes -- reported for what it is (the product has no CPU path to fall back to)
-        w1k = dict(WORKLOADS["cfg1_1k_d384"])
-        w1k.update(rows_total=w1k["rows"], cpu_seconds=4.0)
-        c1k = gen_rows(ctx.eng, 0, w1k["rows"], w1k["dim"], w1k["seed"], w1k["dtype"])
-        sub["cfg1_1k_d384"] = run_record(ctx, "cfg1_1k_d384", w1k, c1k, 0, 500, 50, with_cpu=True)
-        del c1k
-        torch.cuda.empty_cache()
-        # the 3072-wide model of the reference's table (text-embedding-3-large, vectorbase.py:31-35): cfg2's and cfg3's shapes at that width
-        wd = dict(WORKLOADS["cfg2_d3072"])
-        wd["rows_total"] = wd["rows"]
-        cw = gen_rows(ctx.eng, 0, wd["rows"], wd["dim"], wd["seed"], wd["dtype"])
-        sub["cfg2_d3072"] = run_record(ctx, "cfg2_d3072", wd, cw, 0, 60, 8, with_cpu=False)
-        del cw
-        torch.cuda.empty_cache()
-        wd = dict(WORKLOADS["cfg3_d3072"])
-        wd["rows_total"] = wd["rows"]
-        cw = gen_rows(ctx.eng, 0, wd["rows"], wd["dim"], wd["seed"], wd["dtype"])
-        sub["cfg3_d3072"] = run_record(ctx, "cfg3_d3072", wd, cw, 0, 10, 2, with_cpu=False)
-        sub["cfg3_d3072_q1"] = run_record(ctx, "cfg3_d3072_q1", dict(WORKLOADS["cfg3_d3072_q1"], rows_total=wd["rows"]), cw, 0, 40, 5, with_cpu=False)
-        del cw
-        torch.cuda.empty_cache()
-        # a real-embedding-like corpus (one common direction, mean pairwise cosine 0.75) at the reference's threshold 0.85: most rows survive
-        wa = dict(WORKLOADS["cfg3_aniso"])
-        wa["rows_total"] = wa["rows"]
-        ca = gen_rows(ctx.eng, 0, wa["rows"], wa["dim"], wa["seed"], wa["dtype"], "aniso", wa["rows"])
-        sub["cfg3_aniso"] = run_record(ctx, "cfg3_aniso", wa, ca, 0, 10, 2, with_cpu=False)
-        sub["cfg3_aniso"]["vs_gaussian"] = sub["cfg3_aniso"]["queries_per_sec"] / rec["queries_per_sec"]
-        sub["cfg3_aniso_q1"] = run_record(ctx, "cfg3_aniso_q1", dict(WORKLOADS["cfg3_aniso_q1"], rows_total=wa["rows"]), ca, 0, 40, 5, with_cpu=False)
-        del ca
-        torch.cuda.empty_cache()
 
-        # the headline shape on a clustered corpus (near-duplicate clusters + exact duplicates, queries next to cluster centres): what the
-        # wide tile's band selection is there for; `vs_gaussian` = its rate over the headline's
-        wc = dict(WORKLOADS["cfg3_clustered"])
-        wc["rows_total"] = wc["rows"]
-        cc = gen_rows(ctx.eng, 0, wc["rows"], wc["dim"], wc["seed"], wc["dtype"], "clustered", wc["rows"])
-        sub["cfg3_clustered"] = run_record(ctx, "cfg3_clustered", wc, cc, 0, 10, 2, with_cpu=False)
-        sub["cfg3_clustered"]["vs_gaussian"] = sub["cfg3_clustered"]["queries_per_sec"] / rec["queries_per_sec"]
-        del cc
-        torch.cuda.empty_cache()
-        # the duplication cliff: 1500-row clusters -- more near-duplicates than a band holds, EVERY query ends up on the 256-query tile's exact
-        # split-plane form (flagged_fraction 1.0).  The library finds that out before the filter's last phase and skips it (early_exact):
-        # vs_gaussian ~1/2 = the filter's first phases + an exact pass of twice the MFMAs (round 4 before that: ~1/3, round 3: 1/22)
-        wd = dict(WORKLOADS["cfg3_dup"])
-        wd["rows_total"] = wd["rows"]
-        cd = gen_rows(ctx.eng, 0, wd["rows"], wd["dim"], wd["seed"], wd["dtype"], "clustered", wd["rows"], wd["cluster_rows"])
-        sub["cfg3_dup"] = run_record(ctx, "cfg3_dup", wd, cd, 0, 4, 1, with_cpu=False)
-        sub["cfg3_dup"]["vs_gaussian"] = sub["cfg3_dup"]["queries_per_sec"] / rec["queries_per_sec"]
-        del cd
-        torch.cuda.empty_cache()
-        # one GPU's shard of cfg4 (100M rows over 8 GPUs = 12.5M rows each): the per-GPU work of the weak-scaling config, as a corpus of its own
-        w4 = dict(WORKLOADS["cfg4"])
-        w4["rows_total"] = w4["rows"]
-        c4 = gen_rows(ctx.eng, 0, w4["rows"], w4["dim"], w4["seed"], w4["dtype"])
-        sub["cfg4_shard"] = run_record(ctx, "cfg4", w4, c4, 0, 10, 2, with_cpu=False)
-        # (rank 0's 12.5M-row shard of cfg4 searched on its own: no exchange)
-        del c4
-        torch.cuda.empty_cache()
-        # cfg5: the fused multi-index user query (4 term lookups k=50@0.85 + message re-rank k=25@0.7 + thread lookup k=10@0.7; convsettings.py:61-67)
-        # + the memory provider's 1000-ordinal message subset and the six lookups as separate synchronous calls, on the same corpora
-        sub["cfg5"] = run_cfg5(args, dict(WORKLOADS["cfg5"]), emit=False, steps=20, warmup=3, variants=True)
+        def group(label, fn):
+            # the sub-records in the order of their weight (north-star targets and BASELINE configs first, then the regime checks): a box so slow that
+            # the suite would not end within --budget-seconds drops the LAST groups and says so (`sub_skipped`) instead of running into whatever
+            # limit the caller has.  The headline and the records on its corpus (above) always run.
+            spent = time.perf_counter() - _PROCESS_T0
+            if spent > args.budget_seconds:
+                sub_skipped.append(label)
+                sys.stderr.write(f"bench.py: {label}: skipped, {spent:.0f} s spent of --budget-seconds {args.budget_seconds:g}\n")
+                return
+            fn()
+            torch.cuda.empty_cache()
+            sys.stderr.write(f"bench.py: {label} done, {time.perf_counter() - _PROCESS_T0:.0f} s since start\n")
+
+        def g_cfg2():
+            # (the two small corpora next: measured right after big ones have come and gone, cfg2 reads 6 % slower -- where its 6 GB land in HBM)
+            w3 = dict(WORKLOADS["cfg2"])
+            w3["rows_total"] = w3["rows"]
+            c2 = gen_rows(ctx.eng, 0, w3["rows"], w3["dim"], w3["seed"], w3["dtype"])
+            sub["cfg2"] = run_record(ctx, "cfg2", w3, c2, 0, 100, 10, with_cpu=True)
+            # the same lookup at the reference's related-terms threshold (min_score 0.85, knowpro/convsettings.py:61-63): nothing of a gaussian
+            # corpus survives it -- the scan without any selection work
+            sub["cfg2_ms085"] = run_record(ctx, "cfg2", dict(w3, min_score=0.85), c2, 0, 100, 10, with_cpu=False)
+            wb = dict(WORKLOADS["cfg2_b32"], rows_total=w3["rows"])
+            sub["cfg2_b32"] = run_record(ctx, "cfg2_b32", wb, c2, 0, 40, 5, with_cpu=False)
+            del c2
+
+        def g_cfg1():
+            # BASELINE config 1: the reference's own scale (10k x 1536 fp32, one query, top-10) -- launch-bound; with the class-level rate
+            w1 = dict(WORKLOADS["cfg1"])
+            w1["rows_total"] = w1["rows"]
+            c1 = gen_rows(ctx.eng, 0, w1["rows"], w1["dim"], w1["seed"], w1["dtype"])
+            sub["cfg1"] = run_record(ctx, "cfg1", w1, c1, 0, 500, 50, with_cpu=True)
+            sub["cfg1"]["class_api"] = class_api_rates(ctx, w1, c1, args.min_score, 500)
+            # the reference script's third row on the same corpus: fuzzy_lookup_embedding_in_subset, 1000 of 10k (tools/benchmark_vectorbase.py:133-163)
+            w1s = dict(WORKLOADS["cfg1_subset"], rows_total=w1["rows"], cpu_seconds=6.0)
+            sub["cfg1_subset"] = run_record(ctx, "cfg1_subset", w1s, c1, 0, 500, 50, with_cpu=True)
+            sub["cfg1_subset"]["class_api"] = class_api_rates(ctx, w1s, c1, args.min_score, 500)
+            del c1
+            # ... and the width that script defaults to (--dim 384, :55-76)
+            w1d = dict(WORKLOADS["cfg1_d384"])
+            w1d.update(rows_total=w1d["rows"], cpu_seconds=6.0)
+            c1d = gen_rows(ctx.eng, 0, w1d["rows"], w1d["dim"], w1d["seed"], w1d["dtype"])
+            sub["cfg1_d384"] = run_record(ctx, "cfg1_d384", w1d, c1d, 0, 500, 50, with_cpu=True)
+            del c1d
+            # ... and that script's first row, 1k vectors (1.5 MB): the CPU answers out of its cache in less time than a kernel launch + synchronise
+            # takes -- reported for what it is (the product has no CPU path to fall back to)
+            w1k = dict(WORKLOADS["cfg1_1k_d384"])
+            w1k.update(rows_total=w1k["rows"], cpu_seconds=4.0)
+            c1k = gen_rows(ctx.eng, 0, w1k["rows"], w1k["dim"], w1k["seed"], w1k["dtype"])
+            sub["cfg1_1k_d384"] = run_record(ctx, "cfg1_1k_d384", w1k, c1k, 0, 500, 50, with_cpu=True)
+            del c1k
+            torch.cuda.empty_cache()
+
+        def g_cfg4():
+            # one GPU's shard of cfg4 (100M rows over 8 GPUs = 12.5M rows each): the per-GPU work of the weak-scaling config, as a corpus of its own
+            w4 = dict(WORKLOADS["cfg4"])
+            w4["rows_total"] = w4["rows"]
+            c4 = gen_rows(ctx.eng, 0, w4["rows"], w4["dim"], w4["seed"], w4["dtype"])
+            sub["cfg4_shard"] = run_record(ctx, "cfg4", w4, c4, 0, 10, 2, with_cpu=False)
+            # (rank 0's 12.5M-row shard of cfg4 searched on its own: no exchange)
+            del c4
+            torch.cuda.empty_cache()
+
+        def g_cfg5():
+            # cfg5: the fused multi-index user query (4 term lookups k=50@0.85 + message re-rank k=25@0.7 + thread lookup k=10@0.7; convsettings.py:61-67)
+            # + the memory provider's 1000-ordinal message subset and the six lookups as separate synchronous calls, on the same corpora
+            sub["cfg5"] = run_cfg5(args, dict(WORKLOADS["cfg5"]), emit=False, steps=20, warmup=3, variants=True)
+
+        def g_d3072():
+            # the 3072-wide model of the reference's table (text-embedding-3-large, vectorbase.py:31-35): cfg2's and cfg3's shapes at that width
+            wd = dict(WORKLOADS["cfg2_d3072"])
+            wd["rows_total"] = wd["rows"]
+            cw = gen_rows(ctx.eng, 0, wd["rows"], wd["dim"], wd["seed"], wd["dtype"])
+            sub["cfg2_d3072"] = run_record(ctx, "cfg2_d3072", wd, cw, 0, 60, 8, with_cpu=False)
+            del cw
+            torch.cuda.empty_cache()
+            wd = dict(WORKLOADS["cfg3_d3072"])
+            wd["rows_total"] = wd["rows"]
+            cw = gen_rows(ctx.eng, 0, wd["rows"], wd["dim"], wd["seed"], wd["dtype"])
+            sub["cfg3_d3072"] = run_record(ctx, "cfg3_d3072", wd, cw, 0, 10, 2, with_cpu=False)
+            sub["cfg3_d3072_q1"] = run_record(ctx, "cfg3_d3072_q1", dict(WORKLOADS["cfg3_d3072_q1"], rows_total=wd["rows"]), cw, 0, 40, 5, with_cpu=False)
+            del cw
+            torch.cuda.empty_cache()
+
+        def g_aniso():
+            # a real-embedding-like corpus (one common direction, mean pairwise cosine 0.75) at the reference's threshold 0.85: most rows survive
+            wa = dict(WORKLOADS["cfg3_aniso"])
+            wa["rows_total"] = wa["rows"]
+            ca = gen_rows(ctx.eng, 0, wa["rows"], wa["dim"], wa["seed"], wa["dtype"], "aniso", wa["rows"])
+            sub["cfg3_aniso"] = run_record(ctx, "cfg3_aniso", wa, ca, 0, 10, 2, with_cpu=False)
+            sub["cfg3_aniso"]["vs_gaussian"] = sub["cfg3_aniso"]["queries_per_sec"] / rec["queries_per_sec"]
+            sub["cfg3_aniso_q1"] = run_record(ctx, "cfg3_aniso_q1", dict(WORKLOADS["cfg3_aniso_q1"], rows_total=wa["rows"]), ca, 0, 40, 5, with_cpu=False)
+            del ca
+            torch.cuda.empty_cache()
+
+        def g_clustered():
+            # the headline shape on a clustered corpus (near-duplicate clusters + exact duplicates, queries next to cluster centres): what the
+            # wide tile's band selection is there for; `vs_gaussian` = its rate over the headline's
+            wc = dict(WORKLOADS["cfg3_clustered"])
+            wc["rows_total"] = wc["rows"]
+            cc = gen_rows(ctx.eng, 0, wc["rows"], wc["dim"], wc["seed"], wc["dtype"], "clustered", wc["rows"])
+            sub["cfg3_clustered"] = run_record(ctx, "cfg3_clustered", wc, cc, 0, 10, 2, with_cpu=False)
+            sub["cfg3_clustered"]["vs_gaussian"] = sub["cfg3_clustered"]["queries_per_sec"] / rec["queries_per_sec"]
+            del cc
+            torch.cuda.empty_cache()
+
+        def g_dup():
+            # the duplication cliff: 1500-row clusters -- more near-duplicates than a band holds, EVERY query ends up on the 256-query tile's exact
+            # split-plane form (flagged_fraction 1.0).  The library finds that out before the filter's last phase and skips it (early_exact):
+            # vs_gaussian ~1/2 = the filter's first phases + an exact pass of twice the MFMAs (round 4 before that: ~1/3, round 3: 1/22)
+            wd = dict(WORKLOADS["cfg3_dup"])
+            wd["rows_total"] = wd["rows"]
+            cd = gen_rows(ctx.eng, 0, wd["rows"], wd["dim"], wd["seed"], wd["dtype"], "clustered", wd["rows"], wd["cluster_rows"])
+            sub["cfg3_dup"] = run_record(ctx, "cfg3_dup", wd, cd, 0, 4, 1, with_cpu=False)
+            sub["cfg3_dup"]["vs_gaussian"] = sub["cfg3_dup"]["queries_per_sec"] / rec["queries_per_sec"]
+            del cd
+            torch.cuda.empty_cache()
+
+        for label, fn in (("cfg2 group", g_cfg2), ("cfg1 group", g_cfg1), ("cfg4_shard", g_cfg4), ("cfg5", g_cfg5), ("3072-wide group", g_d3072),
+                          ("cfg3_aniso group", g_aniso), ("cfg3_clustered", g_clustered), ("cfg3_dup", g_dup)):
+            group(label, fn)
     elif suite and ctx.distributed and not args.no_sub:  # (also the one-rank dry run of this code, TAVB_BENCH_FORCE_DIST=1)
         # N > 1: beside the strong-scaling headline, BASELINE configs[3] as the north star words it -- 12.5M rows PER GPU (100M rows at N = 8),
         # the same 1024-query batches; `row_queries_per_sec` is the weak-scaling figure (rows x queries per second over all ranks)
@@ -1536,6 +1572,8 @@ def main() -> None:
     ok = True
     if ctx.rank == 0:
         line = headline_line(ctx, rec, name, wl, scaling, sub)
+        if sub_skipped:
+            line["sub_skipped"] = {"groups": sub_skipped, "why": f"--budget-seconds {args.budget_seconds:g} spent before they would have started"}
         emit_result(line)
         checks = [rec.get("parity")] + [r.get("parity") for r in (sub or {}).values()]
         ok = all(c is None or c.get("ok") for c in checks)
