@@ -97,7 +97,7 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "last_shadow"           (get) 1 when the last lookup's corpus pass read the shadow
  *   "mfma_tile"             queries per workgroup tile of the wide fp16 kernel: 0 = auto (128 where that pads less: up to 128, 257..384, 513..640 queries; else 256), 128, 256
  *   "mfma_splits", "mfma_sched", "mfma_ablate"  measurement knobs: row ranges per launch; staging variant (256-query tile: 1 / 2 = other piece
- *                           schedules; 32-query tile: 7 = LDS-DMA ring (the default), 8 = deep corpus ring, 5 = register staging four K steps
+ *                           schedules, 3 / 4 / 5 = other issue orders of a slice's MFMAs -- profiles/r06_mfma_power.md; 32-query tile: 7 = LDS-DMA ring (the default), 8 = deep corpus ring, 5 = register staging four K steps
  *                           deep, 9 = 64-byte K steps -- profiles/r05_mid_batch.md); parts of a tile kernel compiled out (answers are garbage)
  *   "graph_max_bytes"       single-query lookups (tavb_search / tavb_search_batch with nq = 1) on corpora of at most this many bytes replay ONE
  *                           captured HIP graph (query H2D, scan, merge into pinned host memory) instead of three submissions; the first call
