@@ -1319,11 +1319,24 @@ __global__ void __launch_bounds__(256) select_band_kernel(const u64* __restrict_
   }
   __syncthreads();
   const int total = off[n_src];
+  // the source of flat position `flat` = the last one with off[s] <= flat.  A thread's positions only grow, so on a long stream (the all-admitted
+  // first ladder phase: thousands of keys per source) it walks forward from the source of its previous key -- one LDS read per key instead of a
+  // binary search's seven or eight dependent ones, which is what that selection's time was made of; a short stream (a few keys per source, one
+  // round) keeps the binary search.
+  const bool walk = total > 2 * SEL_CACHE;
+  int src_at = 0;
   auto key_at = [&](int flat) -> u64 {
-    int lo = 0, hi = n_src - 1;  // last source with off[s] <= flat
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (off[mid] <= flat) lo = mid; else hi = mid - 1;
+    int lo = src_at;
+    if (walk) {
+      while (lo + 1 < n_src && off[lo + 1] <= flat) ++lo;
+      src_at = lo;
+    } else {
+      int hi = n_src - 1;
+      lo = 0;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= flat) lo = mid; else hi = mid - 1;
+      }
     }
     const int i = flat - off[lo];
     if (lo == n_splits) return carried[(size_t)q * kc_max + i];
