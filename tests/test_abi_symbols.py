@@ -77,12 +77,12 @@ def test_a_library_of_another_abi_version_is_refused(tmp_path, monkeypatch):
 
 def test_plan_ladder_is_a_partition_of_the_rows():
     """tavb_plan_ladder (no GPU needed): the threshold ladder's phase boundaries start at 0, end at the row count, grow strictly, and a corpus
-    too small for a seeding phase is scanned in one phase; bad shapes come back as errors."""
+    too small for a seeding phase (below 30720 rows) is scanned in one phase; bad shapes come back as errors."""
     import pytest
 
     from typeagent_py_amd import _native
 
-    for rows in (1, 319, 10_000, 81_920, 163_840, 1_000_000, 1_250_000, 10_000_000, 100_000_000):
+    for rows in (1, 319, 10_000, 30_719, 30_720, 50_000, 81_919, 81_920, 163_840, 1_000_000, 1_250_000, 10_000_000, 100_000_000):
         for nq in (65, 128, 256, 300, 1024, 4096):
             b = _native.plan_ladder(rows, nq)
             assert b[0] == 0 and b[-1] == rows and all(x < y for x, y in zip(b, b[1:])), (rows, nq, b)
@@ -90,7 +90,10 @@ def test_plan_ladder_is_a_partition_of_the_rows():
             if len(b) > 2:
                 assert rows >= 8 * b[1]            # a seeding phase only when the corpus is at least 8 samples long
                 assert b[-1] - b[-2] >= b[-2]      # the last phase is at least as long as everything before it
-    assert len(_native.plan_ladder(50_000, 1024)) == 2
+    assert len(_native.plan_ladder(20_000, 1024)) == 2                     # one phase
+    assert _native.plan_ladder(50_000, 1024) == [0, 6080, 50_000]          # a small corpus: an eighth of the rows in whole tiles, then the rest (round 6)
+    assert _native.plan_ladder(150_000, 128) == [0, 18560, 150_000]
+    assert _native.plan_ladder(200_000, 128) == [0, 20480, 200_000]  # eight first phases' worth and more: the generic ladder
     assert _native.plan_ladder(10_000_000, 1024) == [0, 10240, 51200, 256000, 1280000, 10_000_000]
     with pytest.raises(ValueError):
         _native.plan_ladder(-1, 1024)

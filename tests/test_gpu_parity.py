@@ -865,6 +865,36 @@ def test_mfma_threshold_ladder_does_not_change_results(n, nq, k, ms, sample, lad
     assert with_pass[0][0].item == 5 and with_pass[1][0].item == n - 3 and with_pass[2][0].item == sample + 7
 
 
+@pytest.mark.parametrize("n,nq", [(30_720, 1024), (50_003, 1024), (81_919, 300), (150_001, 128), (31_000, 65)])
+def test_small_corpus_takes_two_default_phases_with_the_same_answers(n, nq):
+    """Round 6: with the DEFAULT options a corpus of 30720 rows and more, but below eight first phases' worth, is scanned in two phases (an
+    eighth of the rows in whole tiles, then the rest) instead of one un-seeded pass -- tavb_plan_ladder says so, the profile counters agree,
+    and every answer is that of the single pass and of the oracle."""
+    k = 32
+    v, _ = make_corpus(n, 1536, 9400 + n % 89)
+    qs = make_queries(nq, 1536, 9401 + nq)
+    bounds = _native.plan_ladder(n, nq)
+    assert len(bounds) == 3 and bounds[1] == n // 8 // 320 * 320
+    qs[0] = v[3]               # best hit inside the first phase
+    qs[1] = v[n - 2]           # ... in the last rows
+    qs[2] = v[bounds[1]]       # ... in the first row behind the boundary
+    vb = new_vb(v, dtype="fp16")
+    eng = vb.engine
+    eng.profile_enable(True)
+    eng.profile_reset()
+    two = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert eng.get_option("last_tier") == 4
+    assert eng.profile_read(_native.KERNEL_MFMA_SAMPLE)[1] == 1 and eng.profile_read(_native.KERNEL_MFMA)[1] == 1
+    eng.set_option("mfma_sample_rows", -1)
+    one = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    v16 = _f16(v)
+    for qi in range(nq):
+        assert [(r.item, r.score) for r in two[qi]] == [(r.item, r.score) for r in one[qi]]
+    for qi in list(range(0, nq, max(1, nq // 16))) + [1, 2]:
+        vo.check_topk_parity(vo.scores_full(v16, qs[qi]), *items_scores(two[qi]), k, 0.0, referee=vo.f64_referee(v16, qs[qi]))
+    assert two[0][0].item == 3 and two[1][0].item == n - 2 and two[2][0].item == bounds[1]
+
+
 def test_mfma_tile_against_the_exact_tile_on_a_large_corpus():
     """Two independent matrix-core kernels over 786k rows x 1024 queries: the 256-query tile (4 waves, inline-asm MFMAs with
     AGPR+VGPR accumulators, buffer-descriptor LDS-DMA of whole lines, select kernel) + fp32 rescoring, against the 64-query
