@@ -80,10 +80,12 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "mfma_min_batch" smallest batch routed to the 128/256-query MFMA tile (default 65; on corpora of "mfma_big_bytes" (default 256 MiB) or more: "mfma_min_batch_big", default 33; dim % 64 == 0 directly, other widths -- multiples of 8 on
  *                   fp16 corpora, of 16 on fp32 ones -- on a zero-padded fp16 copy of the rows (+ device memory: rows x pad64(dim) x 2 bytes); k up to 64 on fp32 corpora
  *                   (through their fp16 shadow), up to TAVB_MAX_FUSED_K on fp16 ones; thresholds may differ per query)
- *   "mfma_min_batch_big_f32" / "mfma_big_bytes_f32"  FP32 corpora of mfma_big_bytes_f32 (default 2 GiB) or more: batches from mfma_min_batch_big_f32 (default 5) queries up
- *                   -- and batches of 2 .. 4 queries on corpora of twice that size -- take the wide tile over the fp16 shadow (needs "f32_shadow" >= 1) + exact fp32
- *                   rescoring instead of the fp32 kernels: half the bytes per pass (32 queries over 1M x 1536 fp32 rows: 0.79 against 1.24 ms; 4 queries: 0.78 against 0.97);
- *                   mfma_min_batch_big_f32 > 64 switches both rules off
+ *   "mfma_min_batch_f32", "mfma_min_batch_big_f32" / "mfma_big_bytes_f32", "mfma_few_bytes_f32"  FP32 corpora: batches that take the wide tile over the fp16 shadow
+ *                   (needs "f32_shadow" >= 1) + exact fp32 rescoring instead of the fp32 kernels -- half the bytes per pass and fp16 matrix rates:
+ *                   from mfma_min_batch_f32 (default 33) queries at any corpus size (64 queries over 5000 x 1536 rows: 0.11 against 0.20 ms on the 64-query
+ *                   fp32 tile), from mfma_min_batch_big_f32 (default 5) queries on corpora of mfma_big_bytes_f32 (default 1e9 bytes) or more (32 queries over
+ *                   1M x 1536 rows: 0.73 against 1.24 ms), and batches of 2 .. 4 queries on corpora of mfma_few_bytes_f32 (default 4 GiB) or more (0.78 against
+ *                   0.97 ms at 1M rows x 1.5); mfma_min_batch_big_f32 > 64 switches the last two rules off
  *   "skinny_min_batch_f32" / "skinny_min_batch_f16"  smallest batch routed to the 32/64-query MFMA tile on fp32 / fp16
  *                   corpora (defaults 5 / 3, the measured break-even; used up to
  *                   mfma_min_batch - 1); smaller batches use the streaming tiers

@@ -139,8 +139,8 @@ def test_committed_pmc_traffic_belongs_to_the_kernels_that_ship():
         corpus_bytes = wl["rows"] * wl["dim"] * (2 if wl["dtype"] == "fp16" else 4)
         if wl.get("subset"):  # the subset form reads the subset's rows and its int32 row list
             corpus_bytes = wl["subset"] * (wl["dim"] * (2 if wl["dtype"] == "fp16" else 4) + 4)
-        elif wl["dtype"] == "fp32" and wl["nq"] >= 5 and corpus_bytes >= (2 << 30):
-            corpus_bytes //= 2  # batches of 5+ queries on fp32 corpora of 2 GiB+ stream the fp16 shadow (round 6: tavb_abi.hip mfma_min_batch_big_f32)
+        elif wl["dtype"] == "fp32" and wl["nq"] >= 5 and corpus_bytes >= 1_000_000_000:
+            corpus_bytes //= 2  # batches of 5+ queries on fp32 corpora of 1e9 bytes and more stream the fp16 shadow (round 6: tavb_abi.hip mfma_min_batch_big_f32)
         assert 0.9 <= entry["traffic_bytes_per_step"] / corpus_bytes <= 3.0, f"{name}: traffic is not of the order of this workload's corpus"
 
 

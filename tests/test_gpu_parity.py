@@ -1370,11 +1370,12 @@ def test_per_query_thresholds_ride_the_tiles(nq):
     uni = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.4)
     assert [(r.item, r.score) for r in uni[3]] == [(r.item, r.score) for r in out[3]]
     assert eng.get_option("last_tier") == (4 if nq >= 65 else 5)
-    # through the C ABI with a float32 array, on an fp32 corpus (32/64-query fp32 tile; the fp16 shadow + fp32 rescoring from 65 queries on)
+    # through the C ABI with a float32 array, on an fp32 corpus (32-query fp32 tile; the fp16 shadow + fp32 rescoring from 33 queries on -- 65 until
+    # the end of round 6)
     vb32 = new_vb(v[:20_000], dtype="fp32")
     t32 = np.where(np.arange(nq) % 2 == 0, np.float32(0.0), np.float32(0.5)).astype(np.float32)
     o, s_, c_ = vb32.engine.search_batch(qs, k, t32)
-    assert vb32.engine.get_option("last_tier") == (4 if nq >= 65 else 5)
+    assert vb32.engine.get_option("last_tier") == (4 if nq >= 33 else 5)
     for qi in (0, 1, nq - 2, nq - 1):
         seq = vb32.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=float(t32[qi]))
         assert o[qi, : c_[qi]].tolist() == [r.item for r in seq]
@@ -1495,12 +1496,19 @@ def test_batches_of_33_to_64_take_the_wide_tile_on_big_corpora(dtype):
                 seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=32, min_score=0.0)
                 assert [(r.item, r.score) for r in out[qi]] == [(r.item, r.score) for r in seq], (nq, qi)
         assert out[5][0].item == n - 3
-    eng.set_option("mfma_big_bytes", 1 << 40)  # "no corpus is big": the 64-query tile again
+    eng.set_option("mfma_big_bytes", 1 << 40)  # "no corpus is big": the 64-query tile again -- on fp16 corpora; fp32 ones send 33+ queries through
+    vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)  # the shadow at any size (mfma_min_batch_f32: one fp32 tile is 82 us of matrix work)
+    assert eng.get_option("last_tier") == (5 if dtype == "fp16" else 4)
+    eng.set_option("mfma_min_batch_f32", 65)
     vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
     assert eng.get_option("last_tier") == 5
     small = new_vb(v[:20_000], dtype=dtype)
-    small.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
-    assert small.engine.get_option("last_tier") == 5
+    out_small = small.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
+    assert small.engine.get_option("last_tier") == (5 if dtype == "fp16" else 4)
+    if dtype == "fp32":  # 64 queries over a small fp32 corpus through the shadow: the sequential fp32 lookups bit for bit
+        for qi in (0, 5, 63):
+            seq = small.fuzzy_lookup_embedding(qs[qi], max_hits=32, min_score=0.0)
+            assert [(r.item, r.score) for r in out_small[qi]] == [(r.item, r.score) for r in seq], qi
 
 
 @pytest.mark.parametrize("nq,k", [(130, 32), (300, 100)])
@@ -1562,10 +1570,11 @@ def test_odd_width_with_many_flagged_queries(d, nq, k, planted):
 
 @pytest.mark.parametrize("nq", [5, 8, 32])
 def test_small_batches_on_big_fp32_corpora_ride_the_shadow(nq):
-    """Round 6: on fp32 corpora of `mfma_big_bytes_f32` (2 GiB) or more a batch of 5+ queries takes the wide tile over the fp16 shadow (half the
+    """Round 6: on fp32 corpora of `mfma_big_bytes_f32` (1e9 bytes) or more a batch of 5+ queries takes the wide tile over the fp16 shadow (half the
     bytes of the fp32 rows the 32-query fp32 tile reads: 32 queries over 1M x 1536 rows 0.79 against 1.24 ms) and its candidates are rescored
     with the fp32 rows -- the sequential fp32 lookups bit for bit.  Smaller corpora keep the fp32 tile (the wide path's fixed launches cost more
-    than half a pass saves); here the size rule is lowered instead of building a 2 GiB corpus."""
+    than half a pass saves); here the size rule is lowered instead of building a corpus of that size.  Two to four queries (one pass of the
+    streaming scan) move from `mfma_few_bytes_f32` (4 GiB) up, a single query never does."""
     n = 40_000
     v, _ = make_corpus(n, 1536, 8795)
     qs = make_queries(nq, 1536, 8796)
@@ -1574,7 +1583,7 @@ def test_small_batches_on_big_fp32_corpora_ride_the_shadow(nq):
     eng = vb.engine
     out5 = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
     assert eng.get_option("last_tier") == 5 and eng.get_option("last_shadow") == 0  # 246 MB: the 32-query fp32 tile
-    eng.set_option("mfma_big_bytes_f32", 150 << 20)  # (246 MB >= 150 MB: batches of 5+; 2 .. 4 queries need twice that)
+    eng.set_option("mfma_big_bytes_f32", 150 << 20)  # (246 MB >= 150 MB: batches of 5+; 2 .. 4 queries have their own size rule)
     out4 = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
     assert eng.get_option("last_tier") == 4 and eng.get_option("last_shadow") == 1 and eng.get_option("last_flagged") == 0
     assert out4[1][0].item == n - 5
@@ -1583,10 +1592,10 @@ def test_small_batches_on_big_fp32_corpora_ride_the_shadow(nq):
         assert eng.get_option("last_tier") in (1, 2, 3)
         assert [(r.item, r.score) for r in out4[qi]] == [(r.item, r.score) for r in seq], qi
         vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(out5[qi]), 32, 0.0, referee=vo.f64_referee(v, qs[qi]))
-    # two to four queries stay on the streaming scan until the corpus is twice that size; one query always does
+    # two to four queries stay on the streaming scan until the corpus reaches mfma_few_bytes_f32; one query always does
     few = vb.fuzzy_lookup_embeddings(qs[:4], max_hits=32, min_score=0.0)
     assert eng.get_option("last_tier") in (1, 2, 3)
-    eng.set_option("mfma_big_bytes_f32", 50 << 20)
+    eng.set_option("mfma_few_bytes_f32", 100 << 20)
     few4 = vb.fuzzy_lookup_embeddings(qs[:4], max_hits=32, min_score=0.0)
     assert eng.get_option("last_tier") == 4 and eng.get_option("last_shadow") == 1
     assert [[(r.item, r.score) for r in a] for a in few4] == [[(r.item, r.score) for r in a] for a in few]
@@ -1659,6 +1668,7 @@ def test_f32_shadow_level_2_serves_small_batches_and_single_queries(nq):
     qs[0] = v[12_344]
     vb = new_vb(v)
     eng = vb.engine
+    eng.set_option("mfma_min_batch_f32", 65)  # (33+ queries ride the wide tile over the shadow by default: this test is about the level-2 route below it)
     plain = vb.fuzzy_lookup_embeddings(qs, max_hits=32, min_score=0.0)
     assert eng.get_option("last_shadow") == 0
     eng.set_option("f32_shadow", 2)
@@ -1678,6 +1688,7 @@ def test_f32_shadow_level_2_serves_small_batches_and_single_queries(nq):
     k50 = vb.fuzzy_lookup_embeddings(qs, max_hits=50, min_score=0.0)  # 64 candidates cannot prove a top-50: the fp32 kernels answer
     assert eng.get_option("last_shadow") == 0 and len(k50[0]) == 50
     small = new_vb(v[:1000])  # below the size where halving the pass pays for the rescoring launches
+    small.engine.set_option("mfma_min_batch_f32", 65)
     small.engine.set_option("f32_shadow", 2)
     small.fuzzy_lookup_embeddings(qs, max_hits=5, min_score=0.0)
     assert small.engine.get_option("last_shadow") == 0

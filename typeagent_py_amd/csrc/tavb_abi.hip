@@ -126,8 +126,15 @@ struct tavb_ctx {
   // 1M rows 0.77 against 0.92 .. 0.97 ms, 700k rows 0.64 against 0.68, 400k rows 0.48 against 0.39.  Single queries keep the fp32 scan (option
   // f32_shadow = 2 moves them too).  Needs the shadow (f32_shadow >= 1: +50 % device memory, built on first use); without the memory for it the fp32
   // kernels serve the batch.
+  // End of round 6 (tools/regime_sweep.py, profiles/r06_raw/regime_sweep_before.md, after the wide path's launch diet): 5+ queries from 1e9 bytes
+  // (165k x 1536 rows: 0.26 ms through the shadow against 0.27 .. 0.33 on the fp32 tile, whose workgroups start compacting with their second
+  // tile; at 120k rows the fp32 tile still wins, 0.17 .. 0.21 against 0.24), 2 .. 4 queries from 4 GiB as before (500k rows: 0.45 either way),
+  // and 33+ queries at ANY size (`mfma_min_batch_f32`): one tile of the 64-query fp32 kernel is 82 us of fp32 matrix work however small the
+  // corpus -- 64 queries over 1000 / 5000 / 20000 fp32 rows 0.189 / 0.202 / 0.204 ms against 0.087 / 0.112 / 0.140 for 65 queries on the wide tile.
   int64_t mfma_min_batch_big_f32 = 5;
-  int64_t mfma_big_bytes_f32 = (int64_t)2 << 30;
+  int64_t mfma_big_bytes_f32 = 1000000000;
+  int64_t mfma_few_bytes_f32 = (int64_t)4 << 30;
+  int64_t mfma_min_batch_f32 = 33;
   int64_t mfma_splits = 0;  // 0 = auto
   int64_t mfma_ablate = 0;
   int64_t mfma_sched = 0;
@@ -510,6 +517,12 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
   } else if (n == "mfma_big_bytes_f32") {
     if (v < 0) return fail(TAVB_E_INVALID, "mfma_big_bytes_f32 must be >= 0");
     c->mfma_big_bytes_f32 = v;
+  } else if (n == "mfma_few_bytes_f32") {
+    if (v < 0) return fail(TAVB_E_INVALID, "mfma_few_bytes_f32 must be >= 0");
+    c->mfma_few_bytes_f32 = v;
+  } else if (n == "mfma_min_batch_f32") {
+    if (v < 1) return fail(TAVB_E_INVALID, "mfma_min_batch_f32 must be >= 1");
+    c->mfma_min_batch_f32 = v;
   } else if (n == "mfma_sample_rows") {
     if (v < -1) return fail(TAVB_E_INVALID, "mfma_sample_rows must be >= -1");
     c->mfma_sample_rows = v;
@@ -602,6 +615,8 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "mfma_big_bytes") *out = c->mfma_big_bytes;
   else if (n == "mfma_min_batch_big_f32") *out = c->mfma_min_batch_big_f32;
   else if (n == "mfma_big_bytes_f32") *out = c->mfma_big_bytes_f32;
+  else if (n == "mfma_few_bytes_f32") *out = c->mfma_few_bytes_f32;
+  else if (n == "mfma_min_batch_f32") *out = c->mfma_min_batch_f32;
   else if (n == "mfma_splits") *out = c->mfma_splits;
   else if (n == "mfma_tile") *out = c->mfma_tile;
   else if (n == "f32_shadow") *out = c->f32_shadow;
@@ -1938,7 +1953,7 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
   const int fdim = padded ? ((c->dim + 63) / 64) * 64 : c->dim;
   const bool shadow_ops = f32c || padded;  // the filter's corpus operand is d_shadow
   const bool big_k = k > 64;  // beyond what the 64-query exact tile ranks: every flagged query goes to the wide split-plane form (fp16 corpora only: the caller checked)
-  const int qt = small ? tavb::skinny_query_tile(nq) : (c->mfma_tile > 0 ? (int)c->mfma_tile : tavb::mfma_query_tile(nq));
+  const int qt = small ? tavb::skinny_query_tile(nq) : (c->mfma_tile > 0 ? (int)c->mfma_tile : tavb::mfma_query_tile_for(nq, c->rows, c->n_cu));
   const int nq_pad = ((nq + qt - 1) / qt) * qt;
   const bool bdirect = !small && qt == 256 && c->mfma_bdirect && c->mfma_ablate == 0;
   // Work list of queries that need an exact pass (a band that did not fit).  Few of them (<= 64): ONE pass of the 64-query exact tile.  Many: the
@@ -2151,8 +2166,9 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
                                     : (f16c && c->wide_fallback != 0);
   const int64_t corpus_bytes = (int64_t)c->rows * c->dim * (f16c ? 2 : 4);
   const bool wide_batch = nq >= c->mfma_min_batch || (nq >= c->mfma_min_batch_big && corpus_bytes >= c->mfma_big_bytes) ||
+                          (!f16c && nq >= c->mfma_min_batch_f32) ||
                           (!f16c && nq >= c->mfma_min_batch_big_f32 && corpus_bytes >= c->mfma_big_bytes_f32) ||
-                          (!f16c && nq >= 2 && c->mfma_min_batch_big_f32 <= 64 && corpus_bytes >= 2 * c->mfma_big_bytes_f32);
+                          (!f16c && nq >= 2 && c->mfma_min_batch_big_f32 <= 64 && corpus_bytes >= c->mfma_few_bytes_f32);
   bool wide = (f16c || c->f32_shadow) && c->corpus && wide_batch && width_ok && tavb::mfma_supported(wide_dim, k) && c->rows > 0 && exact_tile;
   // f32_shadow = 2: smaller batches (and single queries) on big fp32 corpora filter on the shadow too, with the 32/64-query tile
   // (it keeps the best 64 candidates per query: k up to 48 leaves the slack the completeness test needs)
@@ -2217,7 +2233,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
 
 extern "C" int tavb_plan_ladder(int64_t rows, int32_t nq, int32_t n_cu, int64_t* out_bounds, int32_t cap) {
   if (rows < 0 || nq < 1 || n_cu < 8) return fail(TAVB_E_INVALID, "bad shape");
-  const int qt = tavb::mfma_query_tile(nq);
+  const int qt = tavb::mfma_query_tile_for(nq, rows, n_cu);
   const int nq_pad = ((nq + qt - 1) / qt) * qt;
   const int splits = tavb::mfma_pick_splits(rows, nq_pad, qt, n_cu);
   const std::vector<int64_t> b = ladder_bounds(rows, splits, nq_pad, /*skinny=*/false, /*ladder=*/true, /*sample_opt=*/0, /*growth=*/4);

@@ -138,6 +138,7 @@ struct MfmaParams {
 hipError_t launch_mfma_scan(const MfmaParams& p, hipStream_t stream);
 hipError_t launch_sample_thresholds(const unsigned long long* keys, int nq, int k, const float* floor, float* thr, hipStream_t stream);
 int mfma_query_tile(int nq);              // queries per workgroup tile: 128 where that leaves less padding (<= 128, 257..384, 513..640 queries), else 256
+int mfma_query_tile_for(int nq, int64_t rows, int n_cu);  // ... and 128 on a corpus so small that 256-query tiles leave half of the CUs idle
 int mfma_pick_splits(int64_t rows, int nq_padded, int tile, int n_cu);
 bool mfma_supported(int dim, int k);
 size_t mfma_workspace_bytes(int n_splits, int nq_padded, bool wide);

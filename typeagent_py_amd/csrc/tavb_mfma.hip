@@ -1537,6 +1537,18 @@ int mfma_query_tile(int nq) {
   return ((n128 & 1) && n128 <= 5) ? 128 : BN;
 }
 
+// ... and 128-query tiles on a corpus so small that 256-query tiles would leave half of the CUs without a workgroup (query tiles x corpus
+// tiles <= n_cu / 2): twice the workgroups, each with half the MFMAs and half the all-admitted epilogue of its one tile -- 256 queries over
+// 1000 / 5000 / 20000 / 30720 fp16 rows 0.131 / 0.157 / 0.181 / 0.226 ms against 0.093 / 0.116 / 0.147 / 0.188 for 257 queries, which took three
+// 128-query tiles all along (tools/regime_sweep.py, profiles/r06_raw/regime_sweep_before.md)
+int mfma_query_tile_for(int nq, int64_t rows, int n_cu) {
+  const int qt = mfma_query_tile(nq);
+  if (qt == 128) return qt;
+  const int64_t corpus_tiles = (rows + BM6 - 1) / BM6;
+  const int64_t wgs = (int64_t)((nq + BN - 1) / BN) * corpus_tiles;
+  return wgs * 2 <= n_cu ? 128 : qt;
+}
+
 // k: the band selection holds any k the fused selections serve (a band of k + its 2-delta neighbourhood has to fit the 640 keys a candidate
 // buffer keeps between compactions and the 1024 of the select kernel: k = 256 leaves the same slack as k = 32 on isotropic data)
 bool mfma_supported(int dim, int k) { return dim % BK == 0 && dim >= BK && dim <= 16384 && k >= 1 && k <= TAVB_MAX_FUSED_K; }
