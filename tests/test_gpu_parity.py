@@ -1253,6 +1253,7 @@ def test_wide_tile_band_overflow_inside_one_row_range(sample):
     _plant_near_duplicates(v, qs, 5, range(150_000, 150_900), rng)
     vb = new_vb(v, dtype="fp16")
     vb.engine.set_option("mfma_sample_rows", sample)
+    vb.engine.set_option("mfma_tile", 256)  # (256 row ranges of 782 rows: the geometry this test's cluster is placed for; the default at this size is 128-query tiles since round 6)
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
     assert vb.engine.get_option("last_tier") == 4
     assert vb.engine.get_option("last_flagged") in ((0, 1) if sample == 0 else (1,))  # (default ladder: whatever its geometry makes of it)

@@ -1746,13 +1746,15 @@ std::vector<int64_t> ladder_bounds(int64_t rows, int splits, int nq_pad, bool sk
       done += done * growth;
       bounds.push_back(done);
     }
-  } else if (ladder && !skinny && sample_opt == 0 && growth > 0 && rows >= 12 * 2560) {
+  } else if (ladder && !skinny && sample_opt == 0 && growth > 0 && rows >= 8 * 320 && (rows >= 12 * 2560 || rows > (int64_t)splits * 640)) {
     // the wide tile on a SMALL corpus (below eight first phases' worth: 82k rows at 1024 queries, 164k at up to 128): until the end of round 6
     // ONE un-seeded phase -- every row admitted; at 1024 queries the candidate buffers compact every other tile from the third tile of a row
     // range on (50k rows: 0.99 ms of tile kernel, twice what 100k rows took), at up to 128 queries the select kernel streams every row of the
     // corpus per query (150k rows: 0.29 ms of selection next to 0.16 ms of tile kernel).  Two phases instead: an eighth of the rows in whole
     // tiles, then the rest behind its thresholds: 1024 queries over 50k rows 1.13 -> 0.47 ms, 128 over 150k rows 0.52 -> 0.28 ms; from 30720
-    // rows up (20k rows: one phase is as fast; profiles/r06_raw/small_wide.txt).
+    // rows up (20k rows: one phase is as fast; profiles/r06_raw/small_wide.txt) -- and below that whenever a workgroup would walk more than
+    // two tiles un-seeded (many query tiles leave few row ranges: 2048 queries over 20000 rows are 16 ranges of four tiles, 0.68 ms in one
+    // phase against 0.44).
     bounds.push_back((rows / 8 / 320) * 320);
   }
   bounds.push_back(rows);

@@ -1537,16 +1537,18 @@ int mfma_query_tile(int nq) {
   return ((n128 & 1) && n128 <= 5) ? 128 : BN;
 }
 
-// ... and 128-query tiles on a corpus so small that 256-query tiles would leave half of the CUs without a workgroup (query tiles x corpus
-// tiles <= n_cu / 2): twice the workgroups, each with half the MFMAs and half the all-admitted epilogue of its one tile -- 256 queries over
-// 1000 / 5000 / 20000 / 30720 fp16 rows 0.131 / 0.157 / 0.181 / 0.226 ms against 0.093 / 0.116 / 0.147 / 0.188 for 257 queries, which took three
-// 128-query tiles all along (tools/regime_sweep.py, profiles/r06_raw/regime_sweep_before.md)
+// ... and 128-query tiles on a corpus so small that 256-query tiles would give a CU fewer than four tiles to walk (query tiles x corpus
+// tiles <= 4 n_cu): twice the workgroups or half the tile, half the all-admitted epilogue of a workgroup's first tile -- 256 queries over
+// 1000 / 5000 / 20000 / 50000 fp16 rows 0.131 / 0.157 / 0.181 / 0.238 -> 0.090 / 0.116 / 0.141 / 0.197 ms (257 queries took three 128-query
+// tiles all along and were faster than 256), 1024 queries over 30720 / 50000 rows 0.317 / 0.380 -> 0.264 / 0.342 ms, 512 over 120000 rows
+// 0.392 -> 0.367; beyond that the wider tile's operand reuse wins (1024 queries over 250k rows: 0.910 against 0.927 ms).  tools/regime_sweep.py,
+// profiles/r06_regime_sweep.md
 int mfma_query_tile_for(int nq, int64_t rows, int n_cu) {
   const int qt = mfma_query_tile(nq);
   if (qt == 128) return qt;
   const int64_t corpus_tiles = (rows + BM6 - 1) / BM6;
   const int64_t wgs = (int64_t)((nq + BN - 1) / BN) * corpus_tiles;
-  return wgs * 2 <= n_cu ? 128 : qt;
+  return wgs <= 4 * (int64_t)n_cu ? 128 : qt;
 }
 
 // k: the band selection holds any k the fused selections serve (a band of k + its 2-delta neighbourhood has to fit the 640 keys a candidate
