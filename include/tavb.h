@@ -78,8 +78,10 @@ int tavb_synchronize(tavb_ctx* ctx);
  *   "scan_pipe"     1 = software-prefetch next rows before reducing current ones
  *   "force_tier"    0 = auto, 1 = fixed-D kernel, 2 = vector kernel, 3 = scalar kernel
  *   "mfma_min_batch" smallest batch routed to the 128/256-query MFMA tile (default 65; on corpora of "mfma_big_bytes" (default 256 MiB) or more: "mfma_min_batch_big", default 33; dim % 64 == 0 directly, other widths -- multiples of 8 on
- *                   fp16 corpora, of 16 on fp32 ones -- on a zero-padded fp16 copy of the rows (+ device memory: rows x pad64(dim) x 2 bytes); k up to 64 on fp32 corpora
- *                   (through their fp16 shadow), up to TAVB_MAX_FUSED_K on fp16 ones; thresholds may differ per query)
+ *                   fp16 corpora, of 16 on fp32 ones -- on a zero-padded fp16 copy of the rows (+ device memory: rows x pad64(dim) x 2 bytes); k up to TAVB_MAX_FUSED_K on either
+ *                   (fp32 corpora through their fp16 shadow; beyond k = 64 a flagged query of an fp32 corpus is re-run on the streaming kernels after ONE
+ *                   host round trip, so such a call may block before it returns); thresholds may differ per query; k > 64 rides the tile from 9 queries,
+ *                   3 on corpora of mfma_big_bytes and more -- the streaming kernels take four such queries per corpus pass)
  *   "mfma_min_batch_f32", "mfma_min_batch_big_f32" / "mfma_big_bytes_f32", "mfma_few_bytes_f32"  FP32 corpora: batches that take the wide tile over the fp16 shadow
  *                   (needs "f32_shadow" >= 1) + exact fp32 rescoring instead of the fp32 kernels -- half the bytes per pass and fp16 matrix rates:
  *                   from mfma_min_batch_f32 (default 33) queries at any corpus size (64 queries over 5000 x 1536 rows: 0.11 against 0.20 ms on the 64-query

@@ -1412,11 +1412,69 @@ def test_wide_tile_serves_k_beyond_64(nq, k):
     thr = float(np.float32(out[0][k // 2].score))
     out2 = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=thr)
     assert len(out2[0]) == k // 2 + 1 and [r.item for r in out2[0]] == [r.item for r in out[0][: k // 2 + 1]]
-    # fp32 corpora have no exact tile beyond k = 64: the batch takes the streaming kernels, same answers
+    # fp32 corpora ride the wide tile over the shadow beyond k = 64 as well (end of round 6; the streaming kernels, four queries per pass, until then)
     vb32 = new_vb(v[:30_000], dtype="fp32")
     o32 = vb32.fuzzy_lookup_embeddings(qs[:70], max_hits=k, min_score=0.0)
-    assert vb32.engine.get_option("last_tier") in (1, 2, 3)
+    assert vb32.engine.get_option("last_tier") == 4 and vb32.engine.get_option("last_shadow") == 1
     vo.check_topk_parity(vo.scores_full(v[:30_000], qs[5]), *items_scores(o32[5]), k, 0.0, referee=vo.f64_referee(v[:30_000], qs[5]))
+
+
+@pytest.mark.parametrize("nq,k", [(130, 100), (12, 65), (1024, 256)])
+def test_k_beyond_64_on_an_fp32_corpus_rides_the_shadow_and_re_runs_flagged_queries_on_the_scan(nq, k):
+    """fp32 corpus, `max_hits` 65 .. 256, a batch: the wide tile over the fp16 shadow keeps the band, the fp32 rescoring ranks it -- any k the fused
+    selections serve.  No exact tile ranks more than 64 fp32 rows per query, so a flagged query (here: one sitting on 2500 near-duplicates, more
+    than the band buffer holds) is re-run on the streaming kernels after ONE host round trip (the work list read back).  Every answer is the
+    sequential fp32 lookup's, bit for bit; until the end of round 6 such a batch took the streaming kernels four queries per corpus pass."""
+    n, d = 60_000, 1536
+    v, _ = make_corpus(n, d, 8770 + k)
+    qs = make_queries(nq, d, 8771 + k)
+    rng = np.random.default_rng(8772)
+    dup = rng.choice(n, size=2500, replace=False)
+    _plant_near_duplicates(v, qs, 3, dup, rng)
+    vb = new_vb(v, dtype="fp32")
+    eng = vb.engine
+    out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=0.0)
+    assert eng.get_option("last_tier") == 4 and eng.get_option("last_shadow") == 1
+    assert 1 <= eng.get_option("last_flagged") <= 8  # (query 3, and at k = 256 a few queries whose 256th best reaches into its cluster)
+    for qi in sorted(set([0, 1, 2, 3, 4, nq // 2, nq - 1])):
+        assert len(out[qi]) == k
+        seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=0.0)
+        assert eng.get_option("last_tier") in (1, 2, 3)
+        assert [(r.item, r.score) for r in out[qi]] == [(r.item, r.score) for r in seq], qi
+        vo.check_topk_parity(vo.scores_full(v, qs[qi]), *items_scores(out[qi]), k, 0.0, referee=vo.f64_referee(v, qs[qi]))
+    assert set(r.item for r in out[3]) <= set(dup.tolist())
+    # per-query thresholds reach the re-run too
+    thr = np.zeros(nq)
+    thr[3] = float(np.float32(out[3][k // 2].score))
+    out2 = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=thr.tolist())
+    seq3 = vb.fuzzy_lookup_embedding(qs[3], max_hits=k, min_score=float(thr[3]))  # (near-duplicates tie at float32 scores: more than k / 2 + 1 rows reach it)
+    assert k // 2 + 1 <= len(out2[3]) <= k and [(r.item, r.score) for r in out2[3]] == [(r.item, r.score) for r in seq3]
+    assert [(r.item, r.score) for r in out2[0]] == [(r.item, r.score) for r in out[0]]
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_small_batches_with_k_beyond_64_take_the_wide_tile(dtype):
+    """k > 64 is beyond the 32/64-query tile, and the streaming kernels take four such queries per corpus pass: from 9 queries up (3 on corpora of
+    256 MiB and more) the batch rides the wide tile -- 32 queries over 2M x 1536 fp16 rows, k = 65: 12.5 ms against 1.3.  Same answers."""
+    n = 90_000 if dtype == "fp16" else 45_000  # 276 MB either way
+    v, _ = make_corpus(n, 1536, 8780)
+    qs = make_queries(32, 1536, 8781)
+    vb = new_vb(v, dtype=dtype)
+    eng = vb.engine
+    ref_v = v if dtype == "fp32" else _f16(v)
+    for nq, tier in ((32, 4), (9, 4), (3, 4), (2, None)):
+        out = vb.fuzzy_lookup_embeddings(qs[:nq], max_hits=100, min_score=0.0)
+        got = eng.get_option("last_tier")
+        assert (got == tier) if tier else (got in (1, 2, 3)), (nq, got)
+        for qi in (0, nq - 1):
+            seq = vb.fuzzy_lookup_embedding(qs[qi], max_hits=100, min_score=0.0)
+            assert [(r.item, r.score) for r in out[qi]] == [(r.item, r.score) for r in seq], (nq, qi)
+            vo.check_topk_parity(vo.scores_full(ref_v, qs[qi]), *items_scores(out[qi]), 100, 0.0, referee=vo.f64_referee(ref_v, qs[qi]))
+    small = new_vb(v[:5_000], dtype=dtype)  # below 256 MiB: 3 .. 8 queries stay on the streaming kernels (two passes at most), 9 go wide
+    small.fuzzy_lookup_embeddings(qs[:8], max_hits=100, min_score=0.0)
+    assert small.engine.get_option("last_tier") in (1, 2, 3)
+    small.fuzzy_lookup_embeddings(qs[:9], max_hits=100, min_score=0.0)
+    assert small.engine.get_option("last_tier") == 4
 
 
 def test_wide_tile_row_norm_cache_follows_appends_and_rewrites():

@@ -13,6 +13,8 @@
 #   parity100m       how long rank 0's whole-corpus parity pass takes at N = 8 (100M rows: 100 chunks generated on the device, 16 queries): tools/parity_leg_time.py -> parity100m.txt
 #   toolcheck        every measurement script under tools/ once, with small shapes, against the library that ships: rc per script -> toolcheck.txt
 #                    (tools/README.md's "runs against ABI 6" column comes from here)
+#   sweep            tools/regime_sweep.py: corpus size x batch size per dtype, every cell slower than a cell with more rows AND queries -> regime_sweep.md
+#   timeline         one steady-state lookup launch by launch (rocprofv3 kernel trace: 1.25M-row shard, cfg2_b32)    -> timeline_*.md
 #   variants:FILE    bench.py variants listed one per line ("name: args") in FILE, one child process each   -> bench_<name>.json, variants.txt
 #   ab:ARGS          interleaved A/B on this box: A = cfg3 as shipped, B = the same + ARGS (3 rounds)
 #   pmc              FETCH_SIZE passes for every workload of profiles/pmc_traffic.json + the MFMA counters of cfg3 -> pmc_*.md, pmc_traffic.json
@@ -91,9 +93,14 @@ for step in "$@"; do
       tc sweep_scan python tools/sweep_scan.py --rows 200000 --quick --tag toolcheck
       tc ceiling python tools/ceiling.py --seconds 2 --rows 2000000
       tc parity_leg_time python tools/parity_leg_time.py --world 2 --rows-per-rank 1000000
+      tc regime_sweep python tools/regime_sweep.py --dtype fp16 --rows 1000,50000 --sizes 1,32,64,65,256,1024
+      tc mantissa_power python tools/mantissa_power.py --seconds 1 --rows 1000000 --bits 10,0 --corpus-bits 0
+      tc timeline bash tools/timeline.sh
       for mb in load_paths issue_cost kernarg_query flag_completion; do
         tc mb_$mb bash -c "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mb_$mb tools/microbench/$mb.hip && /tmp/mb_$mb"
       done ;;
+    sweep) timeout 900 python tools/regime_sweep.py > $O/regime_sweep.md 2> $O/regime_sweep.err; echo "sweep rc=$?"; grep -A3 "^cells slower" $O/regime_sweep.md | cut -c1-160 ;;
+    timeline) bash tools/timeline.sh; cp $R/gpurun_out/r6z/timeline_*.md $O/ 2>/dev/null; head -6 $O/timeline_shard.md ;;
     variants) mapfile -t specs < <(grep -v '^#' "$arg" | grep .); timeout 1700 python tools/bench_variants.py $O "${specs[@]}" 2>&1 | tee -a $O/variants.txt ;;
     ab)
       specs=(); for i in 1 2 3; do specs+=("A$i: $Q --workload cfg3 --steps 20 --warmup 5" "B$i: $Q --workload cfg3 --steps 20 --warmup 5 $arg"); done

@@ -168,6 +168,7 @@ struct tavb_ctx {
   Buffer h_stage{nullptr, 0, true};
   Buffer h_out{nullptr, 0, true};  // pinned + device-visible: the last kernel of a synchronous lookup writes its keys straight here
   Buffer h_lists{nullptr, 0, true};  // pinned + device-visible: per-workgroup lists of a small single-query lookup (merged on the host)
+  Buffer h_flag{nullptr, 0, true};   // pinned: the work list of flagged queries read back by the one route that needs a host round trip (fp32 corpus, k > 64)
   int64_t mfma_bdirect = 0;  // option (measurement for now): the 256-query tile takes its query operand straight from L2 (fragment-major layout), not through LDS
   int64_t band_max = tavb::kBandMax;  // option: keys of a query's band the wide tile's selection hands to the rescoring (256 .. kBandMax); a band that does not fit flags the query
   int64_t early_exact = 1;    // option: ... and a batch found to be mostly such queries BEFORE the last filter phase skips that phase (needs wide_fallback)
@@ -462,6 +463,7 @@ int tavb_destroy(tavb_ctx* c) {
   c->h_stage.release();
   c->h_out.release();
   c->h_lists.release();
+  c->h_flag.release();
   for (auto& g : c->graphs)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
   (void)tavb_comm_destroy(c);
@@ -1964,7 +1966,12 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
   // launches over the same device-side list and return at once when it is empty or is the other one's share.  Either one hands its best rows
   // (and a small band below them) to the rescoring kernel in slot mode: a query served by a fallback gets the streaming kernels' float32 scores.
   const bool wide_fallback = !small && !f32c && c->wide_fallback && (nq >= 256 || big_k);
-  if (big_k && !wide_fallback) return fail(TAVB_E_UNSUPPORTED, "k > 64 on the batched tile needs an fp16 corpus and the wide_fallback option");
+  // k > 64 on an FP32 corpus (end of round 6): the filter, the band and the rescoring serve any k up to TAVB_MAX_FUSED_K, but no exact tile ranks
+  // more than 64 fp32 rows per query.  A flagged query -- more than band_max near-duplicates around its k-th best: rare -- is therefore re-run on
+  // the streaming kernels, which takes the one host round trip of this file (the work list is read back; nothing flagged: nothing more to do).
+  // Until then such batches took the streaming kernels four queries per corpus pass: 128 queries over 2M x 1536 fp32 rows, k = 65: 66 ms against 1.3.
+  const bool f32_big_k = !small && f32c && big_k;
+  if (big_k && !wide_fallback && !f32_big_k) return fail(TAVB_E_UNSUPPORTED, "k > 64 on the batched tile of an fp16 corpus needs the wide_fallback option");
   const int cap = wide_fallback ? ((nq + 255) / 256) * 256 : ((nq + 63) / 64) * 64;  // slots of the work list
   const size_t q16_bytes = (size_t)nq_pad * fdim * 2 * (small ? 2 : 1);  // small: high and low plane
   if (int rc = c->d_queries_f16.reserve(q16_bytes)) return rc;
@@ -1980,8 +1987,10 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
                               hipMemcpyDeviceToDevice, c->stream));
     fq = reinterpret_cast<const float*>(c->d_queries_pad.ptr);
   }
-  if (!big_k)
-    if (int rc = c->d_fb_cand.reserve((size_t)cap * 64 * sizeof(u64_t))) return rc;
+  if (!big_k || f32_big_k)
+    if (int rc = c->d_fb_cand.reserve((size_t)cap * (f32_big_k ? k : 64) * sizeof(u64_t))) return rc;
+  if (f32_big_k)
+    if (int rc = c->h_flag.reserve((size_t)(64 + cap) * sizeof(int))) return rc;
   if (int rc = c->d_norm.reserve(256)) return rc;
   float *d_ms = nullptr, *d_ms_floor = nullptr;
   bool ms_uniform = false;
@@ -2083,6 +2092,24 @@ int search_wide_exact(tavb_ctx* c, const float* d_q, int nq, int k, const float*
                                            wide_fallback ? fb_band : nullptr, kExactBand, c->stream);
     if (e != hipSuccess) return fail(TAVB_E_HIP, "gather launch failed: %s", hipGetErrorString(e));
   }
+  if (f32_big_k) {
+    int* h = reinterpret_cast<int*>(c->h_flag.ptr);
+    TAVB_HIP(hipMemcpyAsync(h, d_nflag, (size_t)(64 + cap) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    TAVB_HIP(hipStreamSynchronize(c->stream));
+    const int n_flagged = h[0] < cap ? h[0] : cap;
+    if (n_flagged > 0) {  // (gather_flagged_f32_kernel has put their fp32 queries into fb[0 .. n_flagged))
+      std::vector<float> ms_f((size_t)n_flagged);
+      for (int i = 0; i < n_flagged; ++i) ms_f[i] = min_scores[h[64 + i]];
+      u64_t* d_redo = reinterpret_cast<u64_t*>(c->d_fb_cand.ptr);
+      const int tier = c->last_tier;  // (the batch's route stays what "last_tier" reports: the re-run is a detail of it)
+      const int rc_redo = search_device_impl(c, reinterpret_cast<const float*>(fb), n_flagged, k, ms_f.data(), nullptr, c->rows, index_base, d_redo);
+      c->last_tier = tier;
+      if (rc_redo) return rc_redo;
+      for (int i = 0; i < n_flagged; ++i)
+        TAVB_HIP(hipMemcpyAsync(d_out + (size_t)h[64 + i] * k, d_redo + (size_t)i * k, (size_t)k * sizeof(u64_t), hipMemcpyDefault, c->stream));
+    }
+    return TAVB_OK;
+  }
   {  // (run_tile_ladder times its own launches, in the same bucket)
     if (!big_k) {
       // the exact tile over the work list: returns at once when the list is empty (the normal case).  It ranks 64 rows per slot whatever k: the
@@ -2165,9 +2192,12 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   //  kernel's order)
   const bool width_ok = !odd_width || f16c || c->dim % 16 == 0;
   const bool exact_tile = (k <= 64) ? ((f16c && odd_width) ? tavb::skinny_supported(wide_dim, k, false) : tavb::skinny_supported(c->dim, k, !f16c))
-                                    : (f16c && c->wide_fallback != 0);
+                                    : (f16c ? c->wide_fallback != 0 : true);  // (fp32, k > 64: flagged queries are re-run on the streaming kernels)
   const int64_t corpus_bytes = (int64_t)c->rows * c->dim * (f16c ? 2 : 4);
-  const bool wide_batch = nq >= c->mfma_min_batch || (nq >= c->mfma_min_batch_big && corpus_bytes >= c->mfma_big_bytes) ||
+  // k > 64: the 32/64-query tile does not serve it and the streaming kernels take FOUR such queries per corpus pass -- from 9 queries (more than two
+  // passes), or 3 on corpora of mfma_big_bytes and more, the wide tile (32 queries over 2M x 1536 fp16 rows, k = 65: 12.5 ms against 1.3)
+  const bool big_k_batch = k > 64 && (nq >= 9 || (nq >= 3 && corpus_bytes >= c->mfma_big_bytes));
+  const bool wide_batch = nq >= c->mfma_min_batch || big_k_batch || (nq >= c->mfma_min_batch_big && corpus_bytes >= c->mfma_big_bytes) ||
                           (!f16c && nq >= c->mfma_min_batch_f32) ||
                           (!f16c && nq >= c->mfma_min_batch_big_f32 && corpus_bytes >= c->mfma_big_bytes_f32) ||
                           (!f16c && nq >= 2 && c->mfma_min_batch_big_f32 <= 64 && corpus_bytes >= c->mfma_few_bytes_f32);
