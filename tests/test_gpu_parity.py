@@ -738,36 +738,87 @@ def test_small_corpus_lookups_take_one_launch(n, dtype):
         res = vb.fuzzy_lookup_embedding(q2, max_hits=10, min_score=-1.0)
         assert eng.get_option("last_direct") == 2
         vo.check_topk_parity(vo.scores_full(seen, q2), *items_scores(res), 10, -1.0, referee=vo.f64_referee(seen, q2))
-    # a FEW queries at once (2 .. 8: batched related-term lookups) take it too -- one launch of the multi-query scan, lists merged on the host per query --
-    # with the answers of single lookups; bigger batches go to the tiles, subset lookups are unaffected
-    qs = np.concatenate([q[None, :], make_queries(8, 1536, 77)])
+    # SEVERAL queries at once (batched related-term lookups) take it too, in its grouped form (end of round 6): ONE launch of (row workgroups) x
+    # (query groups), lists merged on the host per query -- and the answers are the single lookups' bit for bit (the same summation order); with
+    # the grouped form off, 2 .. 8 queries take the plain multi-query launch or the tiles as before and 9+ the tiles; subset lookups are unaffected
+    qs = np.concatenate([q[None, :], make_queries(63, 1536, 77)])
     if n >= 100:
         qs[3] = v[min(n - 1, 50)]
-    for nq in (2, 3, 4, 8, 9):
+    singles = {}
+
+    def single(qi, k, ms):
+        if (qi, k, ms) not in singles:
+            singles[(qi, k, ms)] = items_scores(vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=ms))
+        return singles[(qi, k, ms)]
+
+    for nq in (2, 3, 4, 8, 9, 33, 64):
         for k, ms in [(10, 0.0), (50, 0.85), (50, -1.0), (200, 0.0)]:
+            if nq > 9 and k == 200 and n == 10_000:
+                continue  # (the sequential lookups of the comparison below are the slow part)
             eng.profile_enable(True)
             eng.profile_reset()
             out = vb.fuzzy_lookup_embeddings(qs[:nq], max_hits=k, min_score=ms)
             direct = eng.get_option("last_direct")
             launches = eng.profile_read(_native.KERNEL_SCAN)[1], eng.profile_read(_native.KERNEL_MERGE)[1]
             eng.profile_enable(False)
-            if nq <= 4 and k <= 50 and n <= 1294:
-                assert direct == 1, (nq, k, direct)  # (bigger shapes: when the list budget still covers the rows in two rounds of the grid)
-            if nq == 9:
-                assert direct == 0
+            if n <= 1294 and k <= 50:
+                assert direct == 3, (nq, k, direct)  # (bigger shapes: wherever the cost model expects it to beat the tiles, plan_direct_group)
             if direct:
                 assert launches == (1, 0)
             for qi in range(nq):
-                vo.check_topk_parity(vo.scores_full(seen, qs[qi]), *items_scores(out[qi]), k, ms, referee=vo.f64_referee(seen, qs[qi]))
-                if qi in (0, nq - 1):  # the single lookup's answer (another kernel: the last bit of a score may differ)
-                    one = vb.fuzzy_lookup_embedding(qs[qi], max_hits=k, min_score=ms)
-                    np.testing.assert_allclose([r.score for r in out[qi]], [r.score for r in one], atol=1e-6, rtol=0)
+                if direct == 3:
+                    assert items_scores(out[qi]) == single(qi, k, ms), (nq, k, ms, qi)
+                if qi < 3 or qi == nq - 1:
+                    vo.check_topk_parity(vo.scores_full(seen, qs[qi]), *items_scores(out[qi]), k, ms, referee=vo.f64_referee(seen, qs[qi]))
+            if k == 200:
+                continue
+            eng.set_option("direct_group_max_nq", 0)
+            old = vb.fuzzy_lookup_embeddings(qs[:nq], max_hits=k, min_score=ms)
+            direct = eng.get_option("last_direct")
+            eng.set_option("direct_group_max_nq", 64)
+            if nq <= 4 and k <= 50 and n <= 1294:
+                assert direct == 1, (nq, k, direct)  # (bigger shapes: when the list budget still covers the rows in two rounds of the grid)
+            if nq >= 9:
+                assert direct == 0
+            for qi in (0, nq - 1):  # (the tiles: another summation order, the last bit of a score may differ)
+                np.testing.assert_allclose([r.score for r in old[qi]], [r.score for r in out[qi]], atol=1e-6, rtol=0)
+    # every group size gives the same answers (the option forces the form whatever the cost model says)
+    ref = vb.fuzzy_lookup_embeddings(qs[:13], max_hits=10, min_score=0.0)
+    for group in (1, 2, 4, 8):
+        eng.set_option("direct_group", group)
+        got = vb.fuzzy_lookup_embeddings(qs[:13], max_hits=10, min_score=0.0)
+        assert eng.get_option("last_direct") == 3
+        assert [items_scores(r) for r in got] == [items_scores(r) for r in ref], group
+    eng.set_option("direct_group", 0)
     # per-query thresholds through the C ABI's batch call
     thr = np.array([0.0, 0.9, -1.0, 0.5], dtype=np.float32)
     o, s_, c_ = eng.search_batch(qs[:4], 10, thr)
-    assert eng.get_option("last_direct") == (1 if n <= 1294 or dtype == "fp32" else eng.get_option("last_direct"))
+    assert eng.get_option("last_direct") == 3
     for qi in range(4):
         vo.check_topk_parity(vo.scores_full(seen, qs[qi]), o[qi, : c_[qi]].tolist(), s_[qi, : c_[qi]].tolist(), 10, float(thr[qi]), referee=vo.f64_referee(seen, qs[qi]))
+    thr = np.linspace(0.0, 0.9, 40).astype(np.float32)  # ... and a grouped launch of many groups reads each query's own threshold
+    o, s_, c_ = eng.search_batch(qs[:40], 10, thr)
+    assert eng.get_option("last_direct") == (3 if n <= 1294 else eng.get_option("last_direct"))
+    for qi in (0, 7, 22, 39):
+        vo.check_topk_parity(vo.scores_full(seen, qs[qi]), o[qi, : c_[qi]].tolist(), s_[qi, : c_[qi]].tolist(), 10, float(thr[qi]), referee=vo.f64_referee(seen, qs[qi]))
+    # the device-resident form (tavb_search_device: sharded and fused paths): the grouped scan + ONE merge launch, the same keys
+    import torch
+
+    dq = torch.from_numpy(qs[:24]).cuda()
+    eng.profile_enable(True)
+    eng.profile_reset()
+    keys = eng.search_device(dq, 10, 0.0)
+    eng.synchronize()
+    if n <= 1294:
+        assert eng.get_option("last_direct") == 4
+        assert (eng.profile_read(_native.KERNEL_SCAN)[1], eng.profile_read(_native.KERNEL_MERGE)[1]) == (1, 1)
+    eng.profile_enable(False)
+    ords, scs, cnts = _native.decode_keys(keys.cpu().numpy())
+    host = eng.search_batch(qs[:24], 10, np.float32(0.0))
+    if eng.get_option("last_direct") == 3 and n <= 1294:
+        for qi in range(24):
+            m = int(cnts[qi])
+            assert m == int(host[2][qi]) and ords[qi, :m].tolist() == host[0][qi, :m].tolist() and scs[qi, :m].tolist() == host[1][qi, :m].tolist()
 
 
 def test_wrong_query_size_raises_value_error():
@@ -802,6 +853,7 @@ def test_mfma_batch_against_oracle(n, nq, k, ms, splits):
     eng = vb.engine
     eng.set_option("mfma_min_batch", 32)
     eng.set_option("mfma_splits", splits)
+    eng.set_option("direct_group_max_nq", 0)  # (a batch of up to 64 queries on a corpus this small is the grouped streaming launch's otherwise)
     eng.profile_enable(True)
     eng.profile_reset()
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)

@@ -177,6 +177,11 @@ struct tavb_ctx {
   int64_t small_direct_keys = 8192;                 // option: most keys the per-workgroup lists of such a lookup may hold (the grid is cut to fit; x 2 for a batch of 2 .. 8 queries)
   int64_t last_direct = 0;                          // option "last_direct" (get): 1 when the last lookup took it, 2 = with the query inside the kernel arguments
   int inline_query = 1;                             // option: 1536-wide single queries of that path ride in the kernel arguments (no H2D copy before the launch)
+  // the GROUPED form of that path (ScanParams::group): batches of 2 .. direct_group_max_nq queries in one launch of gridDim.y query groups
+  int64_t direct_group_max_nq = TAVB_MAX_GROUPED_QUERIES;  // option: biggest batch that may take it (0 / 1 = never: batches of up to 8 keep the plain form, bigger ones the tiles)
+  int64_t direct_group = 0;                         // option: queries per group, 1 / 2 / 4 / 8, taken whatever the cost model says (0 = plan_direct_group)
+  int64_t direct_group_wgs = 0;                     // option: most workgroups of such a launch (row workgroups x groups); 0 = plan_direct_group (256 or 512)
+  int64_t direct_group_keys = 32768;                // option: most keys the lists of such a launch may hold (nq x workgroups-per-group x k; 256 KiB over PCIe)
 
   bool profiling = false;
   double total_ms[TAVB_KERNEL_COUNT] = {0};
@@ -268,12 +273,95 @@ int drain_timings(tavb_ctx* c) {
   return TAVB_OK;
 }
 
+// Shape of a grouped one-launch lookup (tavb_search_batch on a small corpus, 2 .. 64 queries; ScanParams::group) and whether it is expected to
+// beat the tiles.  Fitted to tools/group_sweep.py on MI355X (profiles/r06_group_sweep.md: rows 1000 .. 40000, D = 384 / 1536 / 3072, k = 10 at
+// min_score 0 and k = 50 at 0.85), all in us per host-synchronous call:
+//  * queries per group: ONE on fp16 corpora (1536-wide rows: the query stays in registers) and for up to ~10k (row, query) pairs, two on fp32
+//    corpora beyond -- the smaller the group, the less a workgroup does besides reading rows (query staging, one 16-wave list merge per query),
+//    and the rows are L2 / Infinity-Cache resident from the second group on;
+//  * one workgroup per CU in all (256); two (512) for groups of two when one would walk a wave over more than ~6 row pairs;
+//  * both routes pay 20 + 0.4 nq around their kernels on the host-synchronous call (staging and H2D copy of the queries, host merges / decode);
+//  * grouped: 12 (launch + synchronise) + c x (rows x nq / 1000) for the scan, c = 0.10 / 0.235 / 0.51 (fp32) and 0.10 / 0.17 / 0.40 (fp16) at
+//    D = 384 / 1536 / 3072, + 0.6 per 1000 list keys beyond 5000 (their way over PCIe and the host merge);
+//  * the tiles (32/64-query tile, wide tile over the shadow) depend on how many rows survive `min_score` (fp16, 64 queries over 1000 rows: 154 at
+//    min_score 0, 77 at 0.85) -- the estimate sits between the two: 35 + 0.035 D - 0.2 nq on fp32 corpora, 18 + 0.008 D + 0.4 nq on fp16 ones.
+//    Up to 4 queries (2 on fp16) the alternative is the plain one-launch form or the streaming passes: the grouped form is never slower there;
+//  * k <= 64 only (the 64-deep lists are what was measured).
+struct DirectGroupPlan {
+  int group;   // queries per group
+  int blocks;  // row workgroups per group
+  bool worth;  // predicted faster than the other routes (or forced by the `direct_group` option)
+};
+DirectGroupPlan plan_direct_group(const tavb_ctx* c, int nq, int k, int full_blocks, bool host) {
+  const bool f16 = c->dtype == TAVB_F16;
+  DirectGroupPlan p{};
+  p.group = (f16 || (double)c->rows * nq <= 10000.0) ? 1 : 2;
+  if (c->direct_group > 0) p.group = (int)c->direct_group;
+  const int n_groups = (nq + p.group - 1) / p.group;
+  int wgs = (p.group >= 2 && (double)c->rows * n_groups / (256.0 * 32.0) > 6.0) ? 512 : 256;
+  if (c->direct_group_wgs > 0) wgs = (int)c->direct_group_wgs;
+  // lists: nq x blocks x k keys over PCIe into pinned memory (`direct_group_keys`, 32768 = 256 KiB); blocks in whole rounds of the eight XCDs
+  // (the device-resident form keeps its lists in device memory and merges them with a second launch: no such budget)
+  int blocks = host ? (int)std::min<int64_t>(full_blocks, c->direct_group_keys / ((int64_t)k * nq)) : full_blocks;
+  blocks = std::min(blocks, std::max(8, wgs / n_groups));
+  p.blocks = blocks >= 8 ? blocks / 8 * 8 : blocks;
+  if (p.blocks < 1 || (p.blocks < 8 && p.blocks != full_blocks)) return p;  // (worth = false)
+  const double d = c->dim, wide = std::max(0.0, d - 1536.0);
+  const double per_kpair = f16 ? 0.08 + 0.00006 * d + 0.00009 * wide : 0.055 + 0.000117 * d + 0.00006 * wide;
+  const double keys = (double)nq * p.blocks * k;
+  // what both routes pay around their kernels on the host-synchronous call (staging + H2D copy of the queries, Python-free part of the call);
+  // the device-resident form pays a second launch (the merge) instead of the lists' way over PCIe
+  const double around = host ? 20.0 + 0.4 * nq : 0.0;
+  const double grouped_us = around + 12.0 + (host ? 0.0006 * std::max(0.0, keys - 5000.0) : 0.0) + per_kpair * ((double)c->rows * nq / 1000.0);
+  // (device-resident form, measured as back-to-back submissions: 32 queries over 1000 fp32 rows 109 -> 18 us, 64 over 1000 fp16 rows 112 -> 20)
+  const double tiles_us = around + (host ? (f16 ? 18.0 + 0.008 * d + 0.4 * nq : 35.0 + 0.035 * d - 0.2 * nq)
+                                         : (f16 ? 0.85 * (22.0 + 0.008 * d + 0.8 * nq) : 38.0 + 0.03 * d));
+  p.worth = c->direct_group > 0 || (host && nq <= (f16 ? 2 : 4)) || grouped_us <= tiles_us;
+  return p;
+}
+
 int scan_blocks_for(const tavb_ctx* c, int64_t n_pos, int waves, int unroll) {
   int blocks = c->geom.blocks > 0 ? c->geom.blocks : c->n_cu;
   const int64_t per_block = (int64_t)waves * unroll;
   const int64_t needed = (n_pos + per_block - 1) / per_block;
   if (needed < blocks) blocks = (int)std::max<int64_t>(needed, 1);
   return blocks;
+}
+
+// Small corpus, 2 .. 64 device-resident queries: ONE grouped scan launch (ScanParams::group; plan_direct_group) + ONE merge launch -> d_out [nq, k]
+// (async on the stream).  Bit for bit the answers of nq single-query scans.
+int search_device_grouped(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores /*host, nq*/, uint32_t index_base, u64_t* d_out,
+                          const DirectGroupPlan& plan) {
+  tavb::ScanGeometry g = c->geom;
+  if (g.waves < 1) g.waves = 1;
+  if (g.waves > 16) g.waves = 16;
+  g.blocks = plan.blocks;
+  if (int rc = c->d_lists.reserve((size_t)nq * g.blocks * k * sizeof(u64_t))) return rc;
+  tavb::ScanParams p{};
+  p.corpus = c->corpus;
+  p.row_ids = nullptr;
+  p.queries = d_q;
+  p.lists = reinterpret_cast<u64_t*>(c->d_lists.ptr);  // [nq][blocks][k]
+  p.n_pos = c->rows;
+  p.dim = c->dim;
+  p.dtype = c->dtype;
+  p.nq = nq;
+  p.k = k;
+  p.index_base = index_base;
+  p.key_bound = ~0ull;
+  p.group = plan.group;
+  for (int i = 0; i < TAVB_MAX_GROUPED_QUERIES; ++i) p.min_score[i] = (i < nq) ? min_scores[i] : INFINITY;
+  {
+    Timed t(c, TAVB_KERNEL_SCAN);
+    hipError_t e = tavb::launch_scan(p, g, c->stream, &c->last_tier);
+    if (e != hipSuccess) return fail(TAVB_E_HIP, "scan kernel launch failed: %s", hipGetErrorString(e));
+  }
+  {
+    Timed t(c, TAVB_KERNEL_MERGE);
+    hipError_t e = tavb::launch_merge(p.lists, g.blocks, nq, k, /*query_major=*/true, d_out, c->stream);
+    if (e != hipSuccess) return fail(TAVB_E_HIP, "merge kernel launch failed: %s", hipGetErrorString(e));
+  }
+  return TAVB_OK;
 }
 
 // Core: queries on device (f32 [nq, dim]) -> sorted key lists d_out [nq, k] (async on the stream).
@@ -573,6 +661,18 @@ int tavb_set_option(tavb_ctx* c, const char* name, int64_t v) {
     c->small_direct_keys = v;
   } else if (n == "inline_query") {
     c->inline_query = v ? 1 : 0;
+  } else if (n == "direct_group_max_nq") {
+    if (v < 0 || v > TAVB_MAX_GROUPED_QUERIES) return fail(TAVB_E_INVALID, "direct_group_max_nq must be 0 .. %d", TAVB_MAX_GROUPED_QUERIES);
+    c->direct_group_max_nq = v;
+  } else if (n == "direct_group") {
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 8)) return fail(TAVB_E_INVALID, "direct_group must be 0, 1, 2, 4 or 8");
+    c->direct_group = v;
+  } else if (n == "direct_group_wgs") {
+    if (v != 0 && (v < 8 || v > 65536)) return fail(TAVB_E_INVALID, "direct_group_wgs must be 0 or 8 .. 65536");
+    c->direct_group_wgs = v;
+  } else if (n == "direct_group_keys") {
+    if (v < 64 || v > (1 << 22)) return fail(TAVB_E_INVALID, "direct_group_keys must be 64 .. 4194304");
+    c->direct_group_keys = v;
   } else if (n == "small_direct_bytes") {
     if (v < 0) return fail(TAVB_E_INVALID, "small_direct_bytes must be >= 0");
     c->small_direct_bytes = v;
@@ -653,6 +753,10 @@ int tavb_get_option(tavb_ctx* c, const char* name, int64_t* out) {
   else if (n == "last_direct") *out = c->last_direct;
   else if (n == "inline_query") *out = c->inline_query;
   else if (n == "small_direct_keys") *out = c->small_direct_keys;
+  else if (n == "direct_group_max_nq") *out = c->direct_group_max_nq;
+  else if (n == "direct_group") *out = c->direct_group;
+  else if (n == "direct_group_wgs") *out = c->direct_group_wgs;
+  else if (n == "direct_group_keys") *out = c->direct_group_keys;
   else if (n == "graph_max_bytes") *out = c->graph_max_bytes;
   else if (n == "last_graph") *out = c->last_graph;
   else if (n == "comm_world") *out = c->comm ? c->comm_world : 0;
@@ -852,19 +956,35 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
   //      what keeps the lists within `small_direct_keys` keys (8192 = 64 KiB over PCIe; twice that for a batch): 163 workgroups at k = 50,
   //      all of them at k <= 32.  A batch takes this path when its share of that budget still covers the rows in two rounds of the grid, and on
   //      fp16 corpora up to 4 queries: beyond that the multi-query scan (6 us more per query) loses to the 32-query tile (measured).
+  //      Batches of up to `direct_group_max_nq` (64) queries take it in its GROUPED form (end of round 6): gridDim.y query groups of `group` queries each
+  //      (ScanParams::group), every group a pass of its own over the rows -- which sit in L2 after the first one (workgroup (x, y) runs on XCD
+  //      x % 8 for every y) -- wherever plan_direct_group expects it to beat the tiles.  Until then 9 .. 64 queries (5+ on fp16) went to
+  //      the 32/64-query tile or the wide tile, both several launches and, on a corpus of a few thousand rows, one or two busy CUs:
+  //      32 queries over 1000 fp32 rows 141 -> 52 us, 64 over 1000 fp16 rows 153 -> 62 us, the answers now the sequential lookups' bit for bit.
   const int direct_nq_max = (k > 64) ? 4 : TAVB_MAX_STREAM_QUERIES;  // queries one pass of the streaming kernels serves
-  const bool few = nq >= 2 && nq <= direct_nq_max && !(c->dtype == TAVB_F32 && c->f32_shadow >= 2 && corpus_bytes >= c->f32_shadow_min_bytes);
-  if ((streaming || few) && slot == nullptr && c->small_direct_bytes > 0 && corpus_bytes <= c->small_direct_bytes) {
+  const bool shadow2 = c->dtype == TAVB_F32 && c->f32_shadow >= 2 && corpus_bytes >= c->f32_shadow_min_bytes;
+  const bool few = nq >= 2 && nq <= direct_nq_max && !shadow2;
+  const bool many = nq >= 2 && nq <= std::min<int64_t>(c->direct_group_max_nq, TAVB_MAX_GROUPED_QUERIES) && !shadow2 && k <= 64;  // (fitted for the 64-deep lists only)
+  if ((streaming || few || many) && slot == nullptr && c->small_direct_bytes > 0 && corpus_bytes <= c->small_direct_bytes) {
     tavb::ScanGeometry g = c->geom;
     if (g.waves < 1) g.waves = 1;
     if (g.waves > 16) g.waves = 16;
-    const int64_t budget = c->small_direct_keys * (nq > 1 ? 2 : 1);
     const int full_blocks = scan_blocks_for(c, c->rows, g.waves, g.unroll);
-    g.blocks = std::min(full_blocks, (int)std::max<int64_t>(8, budget / ((int64_t)k * nq)));
-    const int64_t rounds = (c->rows + (int64_t)g.blocks * g.waves * g.unroll - 1) / ((int64_t)g.blocks * g.waves * g.unroll);
-    // one query: only while the cut grid keeps at least half of the full one (k = 256 would leave 32 workgroups to stream up to 128 MiB: slower
-    // than the full grid + the device merge; measured at k <= 50, where 163+ of 204 workgroups stay)
-    if ((nq == 1 && 2 * g.blocks >= full_blocks) || (nq > 1 && rounds <= 2 && (c->dtype == TAVB_F32 || nq <= 4))) {
+    // the grouped form (plan_direct_group): a launch of (row workgroups) x (query groups), every group a pass of its own over the rows
+    DirectGroupPlan plan{};
+    if (many) plan = plan_direct_group(c, nq, k, full_blocks, /*host=*/true);
+    const bool grouped = many && plan.worth;
+    bool take = grouped;
+    if (grouped) g.blocks = plan.blocks;
+    if (!take && (streaming || few)) {
+      const int64_t budget = c->small_direct_keys * (nq > 1 ? 2 : 1);
+      g.blocks = std::min(full_blocks, (int)std::max<int64_t>(8, budget / ((int64_t)k * nq)));
+      const int64_t rounds = (c->rows + (int64_t)g.blocks * g.waves * g.unroll - 1) / ((int64_t)g.blocks * g.waves * g.unroll);
+      // one query: only while the cut grid keeps at least half of the full one (k = 256 would leave 32 workgroups to stream up to 128 MiB: slower
+      // than the full grid + the device merge; measured at k <= 50, where 163+ of 204 workgroups stay)
+      take = (nq == 1 && 2 * g.blocks >= full_blocks) || (nq > 1 && rounds <= 2 && (c->dtype == TAVB_F32 || nq <= 4));
+    }
+    if (take) {
       const size_t list_keys = (size_t)nq * g.blocks * k;
       if (int rc = c->h_lists.reserve((list_keys + (size_t)nq * k) * sizeof(u64_t))) return rc;  // + the merged keys
       tavb::ScanParams p{};
@@ -879,7 +999,8 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
       p.k = k;
       p.index_base = 0u;
       p.key_bound = ~0ull;
-      for (int i = 0; i < TAVB_MAX_STREAM_QUERIES; ++i) p.min_score[i] = (i < nq) ? min_scores[i] : INFINITY;
+      p.group = grouped ? plan.group : 0;
+      for (int i = 0; i < TAVB_MAX_GROUPED_QUERIES; ++i) p.min_score[i] = (i < nq) ? min_scores[i] : INFINITY;
       {
         // one 1536-wide query (the embedding size typeagent runs at): it rides in the kernel arguments -- one submission, no copy in front of the launch
         hipError_t e = hipSuccess;
@@ -894,7 +1015,7 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
           e = tavb::launch_scan(p, g, c->stream, &c->last_tier);
         }
         if (e != hipSuccess) return fail(TAVB_E_HIP, "scan kernel launch failed: %s", hipGetErrorString(e));
-        c->last_direct = launched ? 2 : 1;
+        c->last_direct = launched ? 2 : (grouped ? 3 : 1);
       }
       TAVB_HIP(hipStreamSynchronize(c->stream));
       tavb_key* merged = reinterpret_cast<tavb_key*>(c->h_lists.ptr) + list_keys;
@@ -2181,6 +2302,20 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   bool uniform_thr = true;
   for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (memcmp(&min_scores[i], &min_scores[0], sizeof(float)) == 0);
   const bool f16c = (c->dtype == TAVB_F16);
+  c->last_direct = 0;
+  {  // small corpora, 2 .. 64 queries: the grouped streaming scan + one merge where it beats the tiles (plan_direct_group)
+    const int64_t bytes = (int64_t)c->rows * c->dim * (f16c ? 2 : 4);
+    const bool shadow2 = !f16c && c->f32_shadow >= 2 && bytes >= c->f32_shadow_min_bytes;
+    if (c->corpus && c->rows > 0 && nq >= 2 && nq <= std::min<int64_t>(c->direct_group_max_nq, TAVB_MAX_GROUPED_QUERIES) && !shadow2 &&
+        c->small_direct_bytes > 0 && bytes <= c->small_direct_bytes && k <= 64) {
+      int waves = c->geom.waves < 1 ? 1 : (c->geom.waves > 16 ? 16 : c->geom.waves);
+      const DirectGroupPlan plan = plan_direct_group(c, nq, k, scan_blocks_for(c, c->rows, waves, c->geom.unroll), /*host=*/false);
+      if (plan.worth) {
+        c->last_direct = 4;
+        return search_device_grouped(c, d_q, nq, k, min_scores, index_base, d_out, plan);
+      }
+    }
+  }
   // the wide tile keeps a band below the k-th best (any k the fused selections serve: the reference's max_matches = 50, convsettings.py:61-63,
   // included).  Its flagged queries need an exact tile: the 64-query one up to k = 64, beyond that the wide split-plane form (fp16 corpora).
   // A width that is not a multiple of 64 (the tile's K step) rides the wide tile on a zero-padded copy of the rows (search_wide_exact): any

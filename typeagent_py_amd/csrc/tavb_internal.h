@@ -7,6 +7,8 @@
 
 #include "../../include/tavb.h"
 
+#define TAVB_MAX_GROUPED_QUERIES 64  // most queries of one grouped streaming launch (ScanParams::group)
+
 namespace tavb {
 
 struct ScanParams {
@@ -17,11 +19,16 @@ struct ScanParams {
   int64_t n_pos;           // number of candidate positions (rows, or subset length)
   int32_t dim;
   int32_t dtype;  // TAVB_F32 / TAVB_F16
-  int32_t nq;     // 1..TAVB_MAX_STREAM_QUERIES
+  int32_t nq;     // 1..TAVB_MAX_STREAM_QUERIES; with `group` > 0: 1..TAVB_MAX_GROUPED_QUERIES
   int32_t k;      // 1..TAVB_MAX_FUSED_K
   uint32_t index_base;  // added to the position before it is packed into the key
   unsigned long long key_bound;  // exclusive upper bound on accepted keys (~0 = none): paging cursor
-  float min_score[TAVB_MAX_STREAM_QUERIES];
+  // grouped form (small corpora, 2 .. 64 queries in ONE launch): gridDim.y = ceil(nq / group) query groups, workgroup (x, y) scans the rows
+  // of workgroup x for queries y * group .. -- `group` (1, 2, 4 or 8) queries per pass of a wave over a row, as many passes over the (L2-resident)
+  // rows as there are groups.  The launch order puts workgroup (x, y) on XCD x % 8 whatever y (gridDim.x a multiple of 8): every group finds the
+  // rows of "its" x in that XCD's L2 after the first one read them.  0 = the plain form (gridDim.y = 1, nq <= TAVB_MAX_STREAM_QUERIES).
+  int32_t group;
+  float min_score[TAVB_MAX_GROUPED_QUERIES];  // one per query (the plain form reads the first TAVB_MAX_STREAM_QUERIES)
 };
 
 struct ScanGeometry {

@@ -98,14 +98,27 @@ struct Selector {
   }
 };
 
+// The queries of this workgroup: all of them (plain form), or group blockIdx.y of the grouped form (ScanParams::group).
+struct QueryGroup {
+  int q0;  // first query
+  int n;   // queries of this workgroup, 1 .. NQ
+};
+template <int NQ>
+__device__ __forceinline__ QueryGroup query_group(const ScanParams& p) {
+  QueryGroup g;
+  g.q0 = p.group > 0 ? (int)blockIdx.y * p.group : 0;
+  g.n = (p.nq - g.q0 < NQ) ? p.nq - g.q0 : NQ;
+  return g;
+}
+
 template <int NQ, int KPL>
-__device__ __forceinline__ void finish_block(Selector<NQ, KPL>& sel, const ScanParams& p, u64* scratch, int wave,
+__device__ __forceinline__ void finish_block(Selector<NQ, KPL>& sel, const ScanParams& p, const QueryGroup& qg, u64* scratch, int wave,
                                              int n_waves, int lane) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    if (q < p.nq) {  // uniform
+    if (q < qg.n) {  // uniform
       block_merge<KPL>(sel.top[q], scratch, wave, n_waves, lane);
-      if (wave == 0) sel.top[q].store(p.lists + ((size_t)q * gridDim.x + blockIdx.x) * (size_t)p.k, p.k, lane);
+      if (wave == 0) sel.top[q].store(p.lists + ((size_t)(qg.q0 + q) * gridDim.x + blockIdx.x) * (size_t)p.k, p.k, lane);
     }
   }
 }
@@ -136,6 +149,8 @@ __global__ void __launch_bounds__(MAXT) scan_fixed_kernel(const ScanParams p, co
   const int64_t n_pos = p.n_pos;
   const int64_t stride = (int64_t)gridDim.x * n_waves * U;
   const int k = p.k;
+  const QueryGroup qg = query_group<NQ>(p);
+  const float* queries = p.queries + (size_t)qg.q0 * D;
 
   float qreg[QREG ? CH : 1][EPL];
   if constexpr (QREG) {
@@ -146,19 +161,19 @@ __global__ void __launch_bounds__(MAXT) scan_fixed_kernel(const ScanParams p, co
         if constexpr (sizeof(QA) == sizeof(InlineQuery))
           qreg[c][e] = qa.v[(c * 64 + lane) * EPL + e];
         else
-          qreg[c][e] = p.queries[(c * 64 + lane) * EPL + e];
+          qreg[c][e] = queries[(c * 64 + lane) * EPL + e];
       }
   } else {
     for (int i = threadIdx.x; i < NQ * D; i += blockDim.x) {
       const int q = i / D;
-      const int src = (q < p.nq) ? q : (p.nq - 1);
-      qlds[i] = p.queries[(size_t)src * D + (i - q * D)];
+      const int src = (q < qg.n) ? q : (qg.n - 1);
+      qlds[i] = queries[(size_t)src * D + (i - q * D)];
     }
     __syncthreads();
   }
   float minsc[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) minsc[q] = (q < p.nq) ? p.min_score[q] : __builtin_inff();  // never passes
+  for (int q = 0; q < NQ; ++q) minsc[q] = (q < qg.n) ? p.min_score[qg.q0 + q] : __builtin_inff();  // never passes
 
   Selector<NQ, KPL> sel;
   sel.clear();
@@ -243,7 +258,7 @@ __global__ void __launch_bounds__(MAXT) scan_fixed_kernel(const ScanParams p, co
     }
   }
 
-  finish_block<NQ, KPL>(sel, p, scratch, wave, n_waves, lane);
+  finish_block<NQ, KPL>(sel, p, qg, scratch, wave, n_waves, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -265,16 +280,18 @@ __global__ void __launch_bounds__(1024) scan_vec_kernel(const ScanParams p) {
   const int64_t stride = (int64_t)gridDim.x * n_waves * U;
   const int k = p.k;
   const int n_slices = D / EPL;  // 16-byte slices per row
+  const QueryGroup qg = query_group<NQ>(p);
+  const float* queries = p.queries + (size_t)qg.q0 * D;
 
   for (int i = threadIdx.x; i < NQ * D; i += blockDim.x) {
     const int q = i / D;
-    const int src = (q < p.nq) ? q : (p.nq - 1);
-    qlds[i] = p.queries[(size_t)src * D + (i - q * D)];
+    const int src = (q < qg.n) ? q : (qg.n - 1);
+    qlds[i] = queries[(size_t)src * D + (i - q * D)];
   }
   __syncthreads();
   float minsc[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) minsc[q] = (q < p.nq) ? p.min_score[q] : __builtin_inff();
+  for (int q = 0; q < NQ; ++q) minsc[q] = (q < qg.n) ? p.min_score[qg.q0 + q] : __builtin_inff();
 
   Selector<NQ, KPL> sel;
   sel.clear();
@@ -325,7 +342,7 @@ __global__ void __launch_bounds__(1024) scan_vec_kernel(const ScanParams p) {
       }
     }
   }
-  finish_block<NQ, KPL>(sel, p, scratch, wave, n_waves, lane);
+  finish_block<NQ, KPL>(sel, p, qg, scratch, wave, n_waves, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -342,9 +359,11 @@ __global__ void __launch_bounds__(1024) scan_scalar_kernel(const ScanParams p) {
   const int64_t n_pos = p.n_pos;
   const int64_t stride = (int64_t)gridDim.x * n_waves;
   const int k = p.k;
+  const QueryGroup qg = query_group<NQ>(p);
+  const float* queries = p.queries + (size_t)qg.q0 * D;
   float minsc[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) minsc[q] = (q < p.nq) ? p.min_score[q] : __builtin_inff();
+  for (int q = 0; q < NQ; ++q) minsc[q] = (q < qg.n) ? p.min_score[qg.q0 + q] : __builtin_inff();
   Selector<NQ, KPL> sel;
   sel.clear();
   const T* corpus = reinterpret_cast<const T*>(p.corpus);
@@ -359,14 +378,14 @@ __global__ void __launch_bounds__(1024) scan_scalar_kernel(const ScanParams p) {
       const float x = (float)rp[e];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int src = (q < p.nq) ? q : (p.nq - 1);
-        acc[q] = fmaf(x, p.queries[(size_t)src * D + e], acc[q]);
+        const int src = (q < qg.n) ? q : (qg.n - 1);
+        acc[q] = fmaf(x, queries[(size_t)src * D + e], acc[q]);
       }
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) sel.offer(q, acc[q], (uint32_t)pos + p.index_base, minsc[q], k, lane, p.key_bound);
   }
-  finish_block<NQ, KPL>(sel, p, scratch, wave, n_waves, lane);
+  finish_block<NQ, KPL>(sel, p, qg, scratch, wave, n_waves, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -464,6 +483,9 @@ namespace {
 
 constexpr size_t scratch_bytes(int kpl, int waves) { return (size_t)((waves + 1) / 2) * 64 * kpl * sizeof(u64); }
 
+// grid of a scan launch: the row workgroups x the query groups of the grouped form (ScanParams::group)
+inline dim3 scan_grid(const ScanParams& p, const ScanGeometry& g) { return dim3(g.blocks, p.group > 0 ? (p.nq + p.group - 1) / p.group : 1); }
+
 template <typename T, int CH, int NQ, int KPL, int U, bool NT, bool PIPE>
 hipError_t go_fixed(const ScanParams& p, const ScanGeometry& g, hipStream_t s) {
   constexpr int regs_est = U * CH * 4 * (PIPE ? 2 : 1) + (NQ == 1 ? CH * Elem<T>::EPL : 8) + U * NQ + NQ * KPL * 2 + 24;
@@ -477,7 +499,7 @@ hipError_t go_fixed(const ScanParams& p, const ScanGeometry& g, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(waves * 64), lds, s, p, NoInlineQuery{});
+  hipLaunchKernelGGL(kern, scan_grid(p, g), dim3(waves * 64), lds, s, p, NoInlineQuery{});
   return hipGetLastError();
 }
 
@@ -504,12 +526,12 @@ hipError_t go_vec(const ScanParams& p, const ScanGeometry& g, hipStream_t s) {
     auto kern = scan_vec_kernel<T, NQ, KPL, true>;
     if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), lds, s, p);
+    hipLaunchKernelGGL(kern, scan_grid(p, g), dim3(g.waves * 64), lds, s, p);
   } else {
     auto kern = scan_vec_kernel<T, NQ, KPL, false>;
     if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(g.blocks), dim3(g.waves * 64), lds, s, p);
+    hipLaunchKernelGGL(kern, scan_grid(p, g), dim3(g.waves * 64), lds, s, p);
   }
   return hipGetLastError();
 }
@@ -517,7 +539,7 @@ hipError_t go_vec(const ScanParams& p, const ScanGeometry& g, hipStream_t s) {
 template <typename T, int NQ, int KPL>
 hipError_t go_scalar(const ScanParams& p, const ScanGeometry& g, hipStream_t s) {
   const size_t lds = scratch_bytes(KPL, g.waves);
-  hipLaunchKernelGGL((scan_scalar_kernel<T, NQ, KPL>), dim3(g.blocks), dim3(g.waves * 64), lds, s, p);
+  hipLaunchKernelGGL((scan_scalar_kernel<T, NQ, KPL>), scan_grid(p, g), dim3(g.waves * 64), lds, s, p);
   return hipGetLastError();
 }
 
@@ -580,10 +602,13 @@ bool launch_scan_inline_query(const ScanParams& p, const ScanGeometry& g, hipStr
 }
 
 hipError_t launch_scan(const ScanParams& p, const ScanGeometry& g, hipStream_t stream, int* tier_used) {
-  if (p.nq < 1 || p.nq > TAVB_MAX_STREAM_QUERIES || p.k < 1 || p.k > TAVB_MAX_FUSED_K || p.dim < 1)
+  const bool grouped = p.group > 0;
+  if (grouped && !(p.group == 1 || p.group == 2 || p.group == 4 || p.group == 8)) return hipErrorInvalidValue;
+  if (p.nq < 1 || p.nq > (grouped ? TAVB_MAX_GROUPED_QUERIES : TAVB_MAX_STREAM_QUERIES) || p.k < 1 || p.k > TAVB_MAX_FUSED_K || p.dim < 1)
     return hipErrorInvalidValue;
-  if (p.k > 64 && p.nq > 4) return hipErrorInvalidValue;  // 256-deep lists: at most 4 queries per pass (registers)
-  const int nqt = p.nq <= 1 ? 1 : p.nq <= 2 ? 2 : p.nq <= 4 ? 4 : 8;
+  const int per = grouped ? (p.group < p.nq ? p.group : p.nq) : p.nq;  // queries per pass of a wave over a row
+  if (p.k > 64 && per > 4) return hipErrorInvalidValue;  // 256-deep lists: at most 4 queries per pass (registers)
+  const int nqt = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 8;
   const int kpl = p.k <= 64 ? 1 : 4;
   const bool f16 = p.dtype == TAVB_F16;
   const int esize = f16 ? 2 : 4;
