@@ -181,6 +181,7 @@ struct tavb_ctx {
   int64_t direct_group_max_nq = TAVB_MAX_GROUPED_QUERIES;  // option: biggest batch that may take it (0 / 1 = never: batches of up to 8 keep the plain form, bigger ones the tiles)
   int64_t direct_group = 0;                         // option: queries per group, 1 / 2 / 4 / 8, taken whatever the cost model says (0 = plan_direct_group)
   int64_t direct_group_wgs = 0;                     // option: most workgroups of such a launch (row workgroups x groups); 0 = plan_direct_group (256 or 512)
+  bool dispatch_no_group = false;                   // set by tavb_search_batch around its fall-through: the host-synchronous cost model already said no
   int64_t direct_group_keys = 32768;                // option: most keys the lists of such a launch may hold (nq x workgroups-per-group x k; 256 KiB over PCIe)
 
   bool profiling = false;
@@ -1026,6 +1027,13 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
       return TAVB_OK;
     }
   }
+  // (a batch the host-synchronous cost model kept off the grouped form stays off it: the device-resident model below prices submissions that
+  //  are not waited for one by one)
+  struct NoGroup {
+    tavb_ctx* c;
+    explicit NoGroup(tavb_ctx* ctx) : c(ctx) { c->dispatch_no_group = true; }
+    ~NoGroup() { c->dispatch_no_group = false; }
+  } no_group(c);
   const bool capture = slot != nullptr && slot->seen >= 1;  // (the first call of a shape sizes the workspaces: no allocation may happen inside a capture)
   if (slot) ++slot->seen;
   if (capture) TAVB_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -2306,7 +2314,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   {  // small corpora, 2 .. 64 queries: the grouped streaming scan + one merge where it beats the tiles (plan_direct_group)
     const int64_t bytes = (int64_t)c->rows * c->dim * (f16c ? 2 : 4);
     const bool shadow2 = !f16c && c->f32_shadow >= 2 && bytes >= c->f32_shadow_min_bytes;
-    if (c->corpus && c->rows > 0 && nq >= 2 && nq <= std::min<int64_t>(c->direct_group_max_nq, TAVB_MAX_GROUPED_QUERIES) && !shadow2 &&
+    if (c->corpus && c->rows > 0 && !c->dispatch_no_group && nq >= 2 && nq <= std::min<int64_t>(c->direct_group_max_nq, TAVB_MAX_GROUPED_QUERIES) && !shadow2 &&
         c->small_direct_bytes > 0 && bytes <= c->small_direct_bytes && k <= 64) {
       int waves = c->geom.waves < 1 ? 1 : (c->geom.waves > 16 ? 16 : c->geom.waves);
       const DirectGroupPlan plan = plan_direct_group(c, nq, k, scan_blocks_for(c, c->rows, waves, c->geom.unroll), /*host=*/false);
