@@ -94,6 +94,10 @@ WORKLOADS = {
     # fuzzy_lookup_embedding_in_subset (vectorbase.py:203-230): the reference script's third row (1000 of 10k, subset seed 99,
     # tools/benchmark_vectorbase.py:133-163) and a subset at bench scale (1M random ordinals of the cfg3 corpus: S * D * 2 + S * 4 bytes)
     "cfg1_subset": dict(rows=10_000, dim=1536, dtype="fp32", nq=1, k=10, bound="latency", seed=43, subset=1000),
+    # the reference's batched call site at its own scale: `lookup_terms` (storage/memory/reltermsindex.py:320-332: a loop of single lookups) with 32
+    # terms over a term index of 1294 rows (the shape of its one real fixture), k = 50 @ 0.85 (knowpro/convsettings.py:61-63), on the
+    # real-embedding-like corpus (most rows survive 0.85): ONE grouped streaming launch since the end of round 6 (profiles/r06_group_sweep.md)
+    "cfg1_terms32": dict(rows=1294, dim=1536, dtype="fp32", nq=32, k=50, bound="latency", seed=44, kind="aniso", min_score=0.85),
     "cfg3_subset": dict(rows=10_000_000, dim=1536, dtype="fp16", nq=1, k=32, bound="hbm", seed=10043, subset=1_000_000),
     # a real-embedding-like corpus: rows = normalise(g + c * mu), mean pairwise cosine 0.75 (scores 0.875 +- 0.013), at the reference's
     # related-terms threshold 0.85 (knowpro/convsettings.py:61-63; vectorbase.py:16-35) -- MOST rows survive min_score, the regime the
@@ -878,6 +882,36 @@ def sustained_calibration(ctx: Ctx, wl: dict, corpus, kern_ms_per_step: float) -
     return out
 
 
+def terms_variants(ctx: Ctx, wl: dict, corpus) -> dict:
+    """cfg1_terms32 as the batched `lookup_terms` patch calls it (`tavb_search_batch`: host queries in, host results out), median us per call:
+    as shipped (the grouped one-launch form), with that form off (the tiles: the routing until the end of round 6), and as nq sequential single
+    lookups (what the reference's loop costs on this engine).  Outside every timed region."""
+    eng = ctx.eng
+    nq, k = wl["nq"], wl["k"]
+    thr = np.float32(ctx.native.f32_threshold(wl["min_score"]))
+    q = aniso_queries(eng, nq, wl["dim"], wl["seed"])
+    eng.set_corpus_tensor(corpus)
+
+    def med(fn, n=200):
+        for _ in range(20):
+            fn()
+        t = []
+        for _ in range(n):
+            t0 = time.perf_counter_ns()
+            fn()
+            t.append((time.perf_counter_ns() - t0) / 1e3)
+        return float(np.median(t))
+
+    out = {"grouped_us": med(lambda: eng.search_batch(q, k, thr)), "last_direct": int(eng.get_option("last_direct"))}
+    eng.set_option("direct_group_max_nq", 0)
+    try:
+        out["tiles_us"] = med(lambda: eng.search_batch(q, k, thr))
+    finally:
+        eng.set_option("direct_group_max_nq", 64)
+    out["sequential_us"] = med(lambda: [eng.search(q[i], k, thr) for i in range(nq)], n=50)
+    return out
+
+
 def class_api_rates(ctx: Ctx, wl: dict, corpus, min_score: float, steps: int) -> dict:
     """The same batch through the drop-in class: `VectorBase.fuzzy_lookup_embeddings` to `list[list[ScoredInt]]` (what the reference's
     callers get, vectorbase.py:188-190 per query) and with `as_arrays=True`.  Host queries in, host objects out."""
@@ -1000,7 +1034,7 @@ def headline_line(ctx: Ctx, rec: dict, name: str, wl: dict, scaling: str, sub: d
     if sub:
         # the driver's record keeps the top-level contract fields and the last 2000 characters of the line: the records a reader is most likely
         # to look for there (this round's: the mid-batch tiles, cfg5's variants) go last
-        last = [k for k in ("cfg5", "cfg3_dup", "cfg1_1k_d384", "cfg1_d384", "cfg1_subset", "cfg3_subset", "cfg2_d3072", "cfg3_d3072_q1", "cfg3_d3072", "cfg3_aniso_q1", "cfg3_aniso",
+        last = [k for k in ("cfg5", "cfg3_dup", "cfg1_1k_d384", "cfg1_d384", "cfg1_subset", "cfg1_terms32", "cfg3_subset", "cfg2_d3072", "cfg3_d3072_q1", "cfg3_d3072", "cfg3_aniso_q1", "cfg3_aniso",
                             "cfg4_weak") if k in sub]
         out["sub"] = {k: slim_sub(sub[k]) for k in [k for k in sub if k not in last] + last}
     return out
@@ -1467,6 +1501,14 @@ def main() -> None:
             sub["cfg1_subset"] = run_record(ctx, "cfg1_subset", w1s, c1, 0, 500, 50, with_cpu=True)
             sub["cfg1_subset"]["class_api"] = class_api_rates(ctx, w1s, c1, args.min_score, 500)
             del c1
+            # batched related-term lookups at the reference's scale (32 terms, 1294 rows); `variants`: the same call with the grouped form off
+            # (the 32-query tile: the routing until the end of round 6) and as 32 sequential single lookups
+            wt = dict(WORKLOADS["cfg1_terms32"])
+            wt.update(rows_total=wt["rows"], cpu_seconds=4.0)
+            ct = gen_rows(ctx.eng, 0, wt["rows"], wt["dim"], wt["seed"], wt["dtype"], "aniso", wt["rows"])
+            sub["cfg1_terms32"] = run_record(ctx, "cfg1_terms32", wt, ct, 0, 300, 30, with_cpu=True)
+            sub["cfg1_terms32"]["variants"] = terms_variants(ctx, wt, ct)
+            del ct
             # ... and the width that script defaults to (--dim 384, :55-76)
             w1d = dict(WORKLOADS["cfg1_d384"])
             w1d.update(rows_total=w1d["rows"], cpu_seconds=6.0)

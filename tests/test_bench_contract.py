@@ -76,6 +76,7 @@ def test_the_line_stays_short_enough_for_the_driver_record():
            "cfg2_b32": sub_rec("cfg2_b32", True), "cfg3_b32": sub_rec("cfg3_b32", True), "cfg3_b128": sub_rec("cfg3_b128", True),
            "cfg3_subset": sub_rec("cfg3_subset", False, with_api=True), "cfg1_subset": sub_rec("cfg1_subset", False, with_cpu=True, with_api=True),
            "cfg1_d384": sub_rec("cfg1_d384", False, with_cpu=True), "cfg2_d3072": sub_rec("cfg2_d3072", False),
+           "cfg1_terms32": dict(sub_rec("cfg1_terms32", True, with_cpu=True), variants={"grouped_us": 53.3123456, "last_direct": 3, "tiles_us": 103.8123456, "sequential_us": 690.123456}),
            "cfg3_d3072": sub_rec("cfg3_d3072", True), "cfg3_d3072_q1": sub_rec("cfg3_d3072_q1", False),
            "cfg3_aniso": sub_rec("cfg3_aniso", True), "cfg3_aniso_q1": sub_rec("cfg3_aniso_q1", False)}
     sub["cfg5"]["variants"] = {"subset1000": {"value": 186.123456, "ms_per_step": 5.3712345, "hbm_frac": 0.71234567, "parity": {"ok": True, "lookups_checked": 1, "hits_returned": 0}},

@@ -109,6 +109,8 @@ def test_merge_keys_host_random_shapes():
     plain sort: more lists than k and fewer, lists that are short or empty, exact duplicates across lists, one list, k = 1."""
     rng = np.random.default_rng(77)
     shapes = [(204, 1, 10), (40, 1, 50), (64, 1, 32), (8, 1, 256), (1, 3, 5), (300, 2, 1), (3, 2, 64), (17, 4, 17)]
+    shapes += [(8, 1, 50), (16, 1, 10), (2, 1, 64), (8, 1, 1), (16, 1, 64), (1, 1, 7)]  # a few lists, one query: the plain k-way merge (grouped one-launch lookups)
+    shapes += [(int(rng.integers(1, 17)), 1, int(rng.integers(1, 70))) for _ in range(60)]
     shapes += [(int(rng.integers(1, 260)), int(rng.integers(1, 4)), int(rng.integers(1, 70))) for _ in range(200)]
     for trial, (n_lists, nq, k) in enumerate(shapes):
         keys = rng.integers(1, (1 << 63) - 1, size=(n_lists, nq, k), dtype=np.int64).astype(np.uint64)

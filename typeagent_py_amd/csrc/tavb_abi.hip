@@ -1020,9 +1020,23 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
       }
       TAVB_HIP(hipStreamSynchronize(c->stream));
       tavb_key* merged = reinterpret_cast<tavb_key*>(c->h_lists.ptr) + list_keys;
-      for (int q = 0; q < nq; ++q)
-        if (int rc = tavb_merge_keys_host(reinterpret_cast<const tavb_key*>(c->h_lists.ptr) + (size_t)q * g.blocks * k, g.blocks, 1, k, merged + (size_t)q * k))
-          return rc;
+      // The lists were just written by the device: every cache line of them is a miss to DRAM for this core (~100 ns), and a merge hops between
+      // its lists -- 16 lines per query one after the other were 1.6 us per query, 51 us of a 32-term batch.  The heads of the NEXT query's lists
+      // are prefetched while this one is merged (two lines per list: the merge rarely reads further), so the misses overlap.
+      const tavb_key* all = reinterpret_cast<const tavb_key*>(c->h_lists.ptr);
+      auto prefetch_query = [&](int q) {
+        const tavb_key* base = all + (size_t)q * g.blocks * k;
+        const int n = std::min(g.blocks, 256);
+        for (int l = 0; l < n; ++l) {
+          __builtin_prefetch(base + (size_t)l * k);
+          if (k > 8 && g.blocks <= 64) __builtin_prefetch(base + (size_t)l * k + 8);
+        }
+      };
+      prefetch_query(0);
+      for (int q = 0; q < nq; ++q) {
+        if (q + 1 < nq) prefetch_query(q + 1);
+        if (int rc = tavb_merge_keys_host(all + (size_t)q * g.blocks * k, g.blocks, 1, k, merged + (size_t)q * k)) return rc;
+      }
       decode(reinterpret_cast<const u64_t*>(merged), nq, k, c->ordinal_base, out_ordinals, out_scores, out_counts);
       return TAVB_OK;
     }
@@ -1125,6 +1139,32 @@ int tavb_merge_keys_host(const tavb_key* lists, int32_t n_lists, int32_t nq, int
   // the lists whose head is >= t.  One pass over n_lists keys, a selection among them, a sort of a few dozen keys: 0.6 us for the 204 lists of a
   // 10k-row lookup and 0.9 us for 40 lists of 50, where picking the maximum head k times took k * n_lists steps (3.1 us of a 30 us call;
   // profiles/r04_latency_small.md).
+  // A FEW lists (the grouped one-launch form leaves 8 .. 32 per query, and there are up to 64 queries to merge): a plain k-way merge, the
+  // largest head k times -- with 8 lists of 50 the selection above keeps most of their 400 keys for the sort (~2 us per query, 64 us for
+  // a 32-term batch of a 91 us call); k * n_lists steps are ~0.3 us.
+  if (n_lists <= 16 && nq == 1) {
+    const tavb_key* head[16];
+    int left[16];
+    for (int l = 0; l < n_lists; ++l) {
+      head[l] = lists + (size_t)l * k;
+      left[l] = k;
+    }
+    for (int i = 0; i < k; ++i) {
+      int best = -1;
+      u64_t best_key = 0;
+      for (int l = 0; l < n_lists; ++l)
+        if (left[l] > 0 && *head[l] > best_key) {
+          best_key = *head[l];
+          best = l;
+        }
+      out[i] = best_key;  // 0 once every list is exhausted (an empty slot of a list is 0 too, and the lists are sorted: nothing behind it)
+      if (best >= 0) {
+        ++head[best];
+        --left[best];
+      }
+    }
+    return TAVB_OK;
+  }
   static thread_local std::vector<u64_t> pool;
   const int j = (k + n_lists - 1) / n_lists;
   const int m = (k + j - 1) / j;  // <= n_lists
