@@ -91,6 +91,50 @@ def test_random_case_against_the_oracle(seed):
         assert all(0.0 <= r.score <= 1.0 for r in got), tag
 
 
+@pytest.mark.parametrize("seed", range(80))
+def test_random_grouped_batch_is_the_sequential_lookups_bit_for_bit(seed):
+    """The grouped one-launch form (batches of 2 .. 64 queries on small corpora, end of round 6) with a FORCED group size -- every scan kernel
+    family (1536-wide register tier, 16-byte vector tier, element tier of odd widths), both dtypes, random k <= 64 and thresholds, degenerate
+    rows: each query's answer is its single lookup's, item for item and bit for bit (same per-row arithmetic and order), through the
+    host-synchronous call and through the device-resident one."""
+    import torch
+
+    from typeagent_py_amd import _native
+
+    c = _case(FUZZ_BASE + 5000 + seed)
+    rng = np.random.default_rng(FUZZ_BASE + 9000 + seed)
+    nq = int(rng.choice([2, 3, 5, 8, 9, 17, 32, 33, 64]))
+    k = int(rng.choice([1, 2, 5, 10, 32, 50, 64]))
+    group = int(rng.choice([1, 2, 4, 8]))
+    v, ms = c["v"], c["ms"]
+    q = rng.standard_normal((nq, c["d"])).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0] = c["q"][0]
+    vb = VectorBase(TextEmbeddingIndexSettings(NullModel()), corpus_dtype=c["dtype"])
+    vb.add_embeddings(None, v)
+    eng = vb.engine
+    tag = dict(d=c["d"], n=c["n"], nq=nq, k=k, ms=ms, dtype=c["dtype"], flavour=c["flavour"], group=group)
+    singles = [[(r.item, r.score) for r in vb.fuzzy_lookup_embedding(q[qi], max_hits=k, min_score=ms)] for qi in range(nq)]
+    eng.set_option("direct_group", group)
+    out = vb.fuzzy_lookup_embeddings(q, max_hits=k, min_score=ms)
+    small = v.shape[0] * v.shape[1] * (2 if c["dtype"] == "fp16" else 4) <= 128 << 20  # (`small_direct_bytes`: bigger corpora keep the tiles)
+    assert eng.get_option("last_direct") == (3 if small else 0), tag
+    for qi in range(nq):
+        assert [(r.item, r.score) for r in out[qi]] == singles[qi] or not small, (tag, qi)
+    keys = eng.search_device(torch.from_numpy(q).cuda(), k, float(_native.f32_threshold(0.0 if ms is None else ms)))
+    eng.synchronize()
+    assert eng.get_option("last_direct") == (4 if small else 0), tag
+    if not small:
+        return
+    ords, scs, cnts = _native.decode_keys(keys.cpu().numpy())
+    for qi in range(nq):
+        m = int(cnts[qi])
+        assert list(zip(ords[qi, :m].tolist(), scs[qi, :m].tolist())) == singles[qi], (tag, qi, "device-resident form")
+    seen = v.astype(np.float16).astype(np.float32) if c["dtype"] == "fp16" else v
+    vo.check_topk_parity(vo.scores_full(seen, q[0]), [r.item for r in out[0]], [r.score for r in out[0]], k, 0.0 if ms is None else ms,
+                         referee=vo.f64_referee(seen, q[0]))
+
+
 @pytest.mark.parametrize("cluster_rows,nq,k,expect_flagged", [(40, 130, 32, False), (100, 300, 32, False), (100, 1024, 50, False), (300, 130, 10, False),
                                                                (1500, 130, 32, False), (2500, 130, 32, True)])
 def test_clustered_corpus_batches_against_the_oracle(cluster_rows, nq, k, expect_flagged):
