@@ -903,11 +903,12 @@ def terms_variants(ctx: Ctx, wl: dict, corpus) -> dict:
         return float(np.median(t))
 
     out = {"grouped_us": med(lambda: eng.search_batch(q, k, thr)), "last_direct": int(eng.get_option("last_direct"))}
+    max_nq = eng.get_option("direct_group_max_nq")
     eng.set_option("direct_group_max_nq", 0)
     try:
         out["tiles_us"] = med(lambda: eng.search_batch(q, k, thr))
     finally:
-        eng.set_option("direct_group_max_nq", 64)
+        eng.set_option("direct_group_max_nq", max_nq)
     out["sequential_us"] = med(lambda: [eng.search(q[i], k, thr) for i in range(nq)], n=50)
     return out
 

@@ -141,7 +141,7 @@ int tavb_synchronize(tavb_ctx* ctx);
  *                   -- the grid is cut to fit; twice that for a batch, which goes the usual way when its share would starve the grid): the scan's per-workgroup lists go to pinned host memory and are merged
  *                   on the host; "last_direct" (read only) = 1 when the last lookup took that path, 2 when in addition the query rode
  *                   inside the kernel arguments ("inline_query", default 1: 1536-wide queries on the default scan form; no H2D copy before the launch)
- *   "direct_group_max_nq" (default 64; 0 = never) batches of 2 .. this many queries (k <= 64) on corpora up to "small_direct_bytes" take that ONE launch
+ *   "direct_group_max_nq" (default 128; 0 = never) batches of 2 .. this many queries (k <= 64) on corpora up to "small_direct_bytes" take that ONE launch
  *                   in its GROUPED form wherever a fitted cost model expects it to beat the 32/64-query and wide tiles (a corpus of a few
  *                   thousand rows is one or two busy CUs for a tile): a 2-D grid of row workgroups x query groups of one or two queries
  *                   ("direct_group": 1 / 2 / 4 / 8 forces the group size and the form, 0 = pick), "direct_group_wgs" workgroups in all (0 = pick:

@@ -772,10 +772,11 @@ def test_small_corpus_lookups_take_one_launch(n, dtype):
                     vo.check_topk_parity(vo.scores_full(seen, qs[qi]), *items_scores(out[qi]), k, ms, referee=vo.f64_referee(seen, qs[qi]))
             if k == 200:
                 continue
+            max_nq = eng.get_option("direct_group_max_nq")
             eng.set_option("direct_group_max_nq", 0)
             old = vb.fuzzy_lookup_embeddings(qs[:nq], max_hits=k, min_score=ms)
             direct = eng.get_option("last_direct")
-            eng.set_option("direct_group_max_nq", 64)
+            eng.set_option("direct_group_max_nq", max_nq)
             if nq <= 4 and k <= 50 and n <= 1294:
                 assert direct == 1, (nq, k, direct)  # (bigger shapes: when the list budget still covers the rows in two rounds of the grid)
             if nq >= 9:
@@ -853,7 +854,7 @@ def test_mfma_batch_against_oracle(n, nq, k, ms, splits):
     eng = vb.engine
     eng.set_option("mfma_min_batch", 32)
     eng.set_option("mfma_splits", splits)
-    eng.set_option("direct_group_max_nq", 0)  # (a batch of up to 64 queries on a corpus this small is the grouped streaming launch's otherwise)
+    eng.set_option("direct_group_max_nq", 0)  # (a batch of up to 128 queries on a corpus this small is the grouped streaming launch's otherwise)
     eng.profile_enable(True)
     eng.profile_reset()
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Small corpora x batches of 2 .. 64 queries, host-synchronous (`tavb_search_batch`: what `VectorBase.fuzzy_lookup_embeddings` and the batched
+"""Small corpora x batches of 2 .. 128 queries, host-synchronous (`tavb_search_batch`: what `VectorBase.fuzzy_lookup_embeddings` and the batched
 `lookup_terms` patch call): median us per call the way the library routes it by default, with the grouped one-launch form off
 (`direct_group_max_nq` = 0: the plain one-launch form up to 8 queries, the 32/64-query tile and the wide tile beyond -- the routing until the
 end of round 6) and with 1 / 2 / 4 / 8 queries per group forced.  Answers of every form are compared with the default's (bit for bit).

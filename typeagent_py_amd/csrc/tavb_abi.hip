@@ -274,7 +274,7 @@ int drain_timings(tavb_ctx* c) {
   return TAVB_OK;
 }
 
-// Shape of a grouped one-launch lookup (tavb_search_batch on a small corpus, 2 .. 64 queries; ScanParams::group) and whether it is expected to
+// Shape of a grouped one-launch lookup (tavb_search_batch on a small corpus, 2 .. 128 queries; ScanParams::group) and whether it is expected to
 // beat the tiles.  Fitted to tools/group_sweep.py on MI355X (profiles/r06_group_sweep.md: rows 1000 .. 40000, D = 384 / 1536 / 3072, k = 10 at
 // min_score 0 and k = 50 at 0.85), all in us per host-synchronous call:
 //  * queries per group: ONE on fp16 corpora (1536-wide rows: the query stays in registers) and for up to ~10k (row, query) pairs, two on fp32
@@ -304,7 +304,7 @@ DirectGroupPlan plan_direct_group(const tavb_ctx* c, int nq, int k, int full_blo
   // lists: nq x blocks x k keys over PCIe into pinned memory (`direct_group_keys`, 32768 = 256 KiB); blocks in whole rounds of the eight XCDs
   // (the device-resident form keeps its lists in device memory and merges them with a second launch: no such budget)
   int blocks = host ? (int)std::min<int64_t>(full_blocks, c->direct_group_keys / ((int64_t)k * nq)) : full_blocks;
-  blocks = std::min(blocks, std::max(8, wgs / n_groups));
+  blocks = std::min(blocks, std::max(8, (wgs / n_groups + 4) / 8 * 8));  // (to the NEAREST whole round of the XCDs: 33 groups of 15 are 16, not 8)
   p.blocks = blocks >= 8 ? blocks / 8 * 8 : blocks;
   if (p.blocks < 1 || (p.blocks < 8 && p.blocks != full_blocks)) return p;  // (worth = false)
   const double d = c->dim, wide = std::max(0.0, d - 1536.0);
@@ -329,7 +329,7 @@ int scan_blocks_for(const tavb_ctx* c, int64_t n_pos, int waves, int unroll) {
   return blocks;
 }
 
-// Small corpus, 2 .. 64 device-resident queries: ONE grouped scan launch (ScanParams::group; plan_direct_group) + ONE merge launch -> d_out [nq, k]
+// Small corpus, 2 .. 128 device-resident queries: ONE grouped scan launch (ScanParams::group; plan_direct_group) + ONE merge launch -> d_out [nq, k]
 // (async on the stream).  Bit for bit the answers of nq single-query scans.
 int search_device_grouped(tavb_ctx* c, const float* d_q, int nq, int k, const float* min_scores /*host, nq*/, uint32_t index_base, u64_t* d_out,
                           const DirectGroupPlan& plan) {
@@ -957,7 +957,7 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
   //      what keeps the lists within `small_direct_keys` keys (8192 = 64 KiB over PCIe; twice that for a batch): 163 workgroups at k = 50,
   //      all of them at k <= 32.  A batch takes this path when its share of that budget still covers the rows in two rounds of the grid, and on
   //      fp16 corpora up to 4 queries: beyond that the multi-query scan (6 us more per query) loses to the 32-query tile (measured).
-  //      Batches of up to `direct_group_max_nq` (64) queries take it in its GROUPED form (end of round 6): gridDim.y query groups of `group` queries each
+  //      Batches of up to `direct_group_max_nq` (128) queries take it in its GROUPED form (end of round 6): gridDim.y query groups of `group` queries each
   //      (ScanParams::group), every group a pass of its own over the rows -- which sit in L2 after the first one (workgroup (x, y) runs on XCD
   //      x % 8 for every y) -- wherever plan_direct_group expects it to beat the tiles.  Until then 9 .. 64 queries (5+ on fp16) went to
   //      the 32/64-query tile or the wide tile, both several launches and, on a corpus of a few thousand rows, one or two busy CUs:
@@ -2351,7 +2351,7 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   for (int i = 1; i < nq; ++i) uniform_thr = uniform_thr && (memcmp(&min_scores[i], &min_scores[0], sizeof(float)) == 0);
   const bool f16c = (c->dtype == TAVB_F16);
   c->last_direct = 0;
-  {  // small corpora, 2 .. 64 queries: the grouped streaming scan + one merge where it beats the tiles (plan_direct_group)
+  {  // small corpora, 2 .. 128 queries: the grouped streaming scan + one merge where it beats the tiles (plan_direct_group)
     const int64_t bytes = (int64_t)c->rows * c->dim * (f16c ? 2 : 4);
     const bool shadow2 = !f16c && c->f32_shadow >= 2 && bytes >= c->f32_shadow_min_bytes;
     if (c->corpus && c->rows > 0 && !c->dispatch_no_group && nq >= 2 && nq <= std::min<int64_t>(c->direct_group_max_nq, TAVB_MAX_GROUPED_QUERIES) && !shadow2 &&

@@ -7,7 +7,7 @@
 
 #include "../../include/tavb.h"
 
-#define TAVB_MAX_GROUPED_QUERIES 64  // most queries of one grouped streaming launch (ScanParams::group)
+#define TAVB_MAX_GROUPED_QUERIES 128  // most queries of one grouped streaming launch (ScanParams::group)
 
 namespace tavb {
 
@@ -23,7 +23,7 @@ struct ScanParams {
   int32_t k;      // 1..TAVB_MAX_FUSED_K
   uint32_t index_base;  // added to the position before it is packed into the key
   unsigned long long key_bound;  // exclusive upper bound on accepted keys (~0 = none): paging cursor
-  // grouped form (small corpora, 2 .. 64 queries in ONE launch): gridDim.y = ceil(nq / group) query groups, workgroup (x, y) scans the rows
+  // grouped form (small corpora, 2 .. 128 queries in ONE launch): gridDim.y = ceil(nq / group) query groups, workgroup (x, y) scans the rows
   // of workgroup x for queries y * group .. -- `group` (1, 2, 4 or 8) queries per pass of a wave over a row, as many passes over the (L2-resident)
   // rows as there are groups.  The launch order puts workgroup (x, y) on XCD x % 8 whatever y (gridDim.x a multiple of 8): every group finds the
   // rows of "its" x in that XCD's L2 after the first one read them.  0 = the plain form (gridDim.y = 1, nq <= TAVB_MAX_STREAM_QUERIES).
