@@ -2380,10 +2380,13 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   // k > 64: the 32/64-query tile does not serve it and the streaming kernels take FOUR such queries per corpus pass -- from 9 queries (more than two
   // passes), or 3 on corpora of mfma_big_bytes and more, the wide tile (32 queries over 2M x 1536 fp16 rows, k = 65: 12.5 ms against 1.3)
   const bool big_k_batch = k > 64 && (nq >= 9 || (nq >= 3 && corpus_bytes >= c->mfma_big_bytes));
+  // (narrow rows: the streaming scan's cost per row does not shrink with the row -- 3 queries over 1M x 384 fp32 rows 0.39 ms against 0.28 on the
+  //  wide tile, profiles/r06_raw/regime_sweep_d384.md -- so the byte thresholds measured at D = 1536 scale down with the width)
+  const int64_t few_bytes_f32 = c->dim < 1536 ? c->mfma_few_bytes_f32 / 1536 * c->dim : c->mfma_few_bytes_f32;
   const bool wide_batch = nq >= c->mfma_min_batch || big_k_batch || (nq >= c->mfma_min_batch_big && corpus_bytes >= c->mfma_big_bytes) ||
                           (!f16c && nq >= c->mfma_min_batch_f32) ||
                           (!f16c && nq >= c->mfma_min_batch_big_f32 && corpus_bytes >= c->mfma_big_bytes_f32) ||
-                          (!f16c && nq >= 2 && c->mfma_min_batch_big_f32 <= 64 && corpus_bytes >= c->mfma_few_bytes_f32);
+                          (!f16c && nq >= 2 && c->mfma_min_batch_big_f32 <= 64 && corpus_bytes >= few_bytes_f32);
   bool wide = (f16c || c->f32_shadow) && c->corpus && wide_batch && width_ok && tavb::mfma_supported(wide_dim, k) && c->rows > 0 && exact_tile;
   // f32_shadow = 2: smaller batches (and single queries) on big fp32 corpora filter on the shadow too, with the 32/64-query tile
   // (it keeps the best 64 candidates per query: k up to 48 leaves the slack the completeness test needs)
@@ -2403,7 +2406,8 @@ int tavb_search_device_dispatch(tavb_ctx* c, const float* d_q, int nq, int k, co
   }
   // 32/64-query tiles at HBM speed: small batches on fp16 corpora, every batch from `skinny_min_batch_f32` up on fp32 ones
   const bool skinny = !wide && c->corpus && c->rows > 0 && tavb::skinny_supported(c->dim, k, !f16c) &&
-                      nq >= (f16c ? c->skinny_min_batch_f16 : c->skinny_min_batch_f32);
+                      nq >= (f16c ? ((c->dim <= 768 && c->rows >= 200000) ? std::min<int64_t>(2, c->skinny_min_batch_f16) : c->skinny_min_batch_f16)
+                                  : c->skinny_min_batch_f32);  // (two queries over 1M x 384 fp16 rows: 0.23 ms on the streaming scan, 0.17 on the tile)
   if (wide) {
     c->last_tier = 4;  // 1-3 = streaming tiers, 4 = 256-query MFMA tile, 5 = 32/64-query MFMA tile
     return search_wide_exact(c, d_q, nq, k, min_scores, index_base, d_out);
