@@ -1764,6 +1764,7 @@ def test_f32_shadow_small_and_odd_shapes(n, nq, k, ms):
     qs = make_queries(nq, 1536, 7651 + nq)
     qs[0] = v[n - 1]
     vb = new_vb(v)
+    vb.engine.set_option("direct_group_max_nq", 0)  # (up to 128 queries on corpora this small are the grouped streaming launch's otherwise: this test is about the shadow)
     out = vb.fuzzy_lookup_embeddings(qs, max_hits=k, min_score=ms)
     assert vb.engine.get_option("last_tier") == 4
     for qi in sorted(set(np.linspace(0, nq - 1, 24).astype(int).tolist())):
