@@ -95,6 +95,10 @@ for step in "$@"; do
       tc parity_leg_time python tools/parity_leg_time.py --world 2 --rows-per-rank 1000000
       tc regime_sweep python tools/regime_sweep.py --dtype fp16 --rows 1000,50000 --sizes 1,32,64,65,256,1024
       tc mantissa_power python tools/mantissa_power.py --seconds 1 --rows 1000000 --bits 10,0 --corpus-bits 0
+      tc group_sweep python tools/group_sweep.py --rows 1000,5000 --sizes 4,32,100 --k 10 --forms default,off,2 --kernel
+      tc class_sweep python tools/class_sweep.py --rows 1000,10000 --sizes 1,16,64
+      tc terms_breakdown python tools/terms_breakdown.py
+      tc misc_sweep python tools/misc_sweep.py --rows 300000
       tc timeline bash tools/timeline.sh
       for mb in load_paths issue_cost kernarg_query flag_completion; do
         tc mb_$mb bash -c "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mb_$mb tools/microbench/$mb.hip && /tmp/mb_$mb"

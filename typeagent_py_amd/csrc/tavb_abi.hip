@@ -304,7 +304,10 @@ DirectGroupPlan plan_direct_group(const tavb_ctx* c, int nq, int k, int full_blo
   // lists: nq x blocks x k keys over PCIe into pinned memory (`direct_group_keys`, 32768 = 256 KiB); blocks in whole rounds of the eight XCDs
   // (the device-resident form keeps its lists in device memory and merges them with a second launch: no such budget)
   int blocks = host ? (int)std::min<int64_t>(full_blocks, c->direct_group_keys / ((int64_t)k * nq)) : full_blocks;
-  blocks = std::min(blocks, std::max(8, (wgs / n_groups + 4) / 8 * 8));  // (to the NEAREST whole round of the XCDs: 33 groups of 15 are 16, not 8)
+  // whole rounds of the XCDs, within `wgs` in all (3 groups of 88 = 264 workgroups leave 8 CUs with two: 39 us against 27 for 4 groups of 64) --
+  // except that 15 per group are 16, not 8 (33 groups of two at 512)
+  const int per_group = wgs / n_groups;
+  blocks = std::min(blocks, std::max(8, per_group >= 12 && per_group < 16 ? 16 : per_group / 8 * 8));
   p.blocks = blocks >= 8 ? blocks / 8 * 8 : blocks;
   if (p.blocks < 1 || (p.blocks < 8 && p.blocks != full_blocks)) return p;  // (worth = false)
   const double d = c->dim, wide = std::max(0.0, d - 1536.0);
