@@ -38,11 +38,15 @@ def main():
     ap.add_argument("--k", default="10,50")
     ap.add_argument("--forms", default="default,off,1,2,4,8")
     ap.add_argument("--min-score", type=float, default=0.0)
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value, set once (e.g. scan_nt=0)")
     ap.add_argument("--kernel", action="store_true", help="(scan kernel us) behind the grouped forms' times (HIP events)")
     args = ap.parse_args()
     sizes = [int(x) for x in args.sizes.split(",")]
     forms = args.forms.split(",")
     eng = _native.Engine(0)
+    for o in args.opt:
+        name, val = o.split("=")
+        eng.set_option(name, int(val))
     qs = bench.host_queries(max(sizes), args.dim, 7)
     thr = np.float32(args.min_score)
     dflt = {n: eng.get_option(n) for n in ("direct_group_max_nq", "direct_group", "direct_group_wgs", "scan_waves")}

@@ -340,6 +340,7 @@ int search_device_grouped(tavb_ctx* c, const float* d_q, int nq, int k, const fl
   if (g.waves < 1) g.waves = 1;
   if (g.waves > 16) g.waves = 16;
   g.blocks = plan.blocks;
+  g.nt = 0;  // (the rows are read again by every further group: no evict-first hint)
   if (int rc = c->d_lists.reserve((size_t)nq * g.blocks * k * sizeof(u64_t))) return rc;
   tavb::ScanParams p{};
   p.corpus = c->corpus;
@@ -979,7 +980,10 @@ int tavb_search_batch(tavb_ctx* c, const float* queries_host, int32_t nq, int32_
     if (many) plan = plan_direct_group(c, nq, k, full_blocks, /*host=*/true);
     const bool grouped = many && plan.worth;
     bool take = grouped;
-    if (grouped) g.blocks = plan.blocks;
+    if (grouped) {
+      g.blocks = plan.blocks;
+      g.nt = 0;  // the rows are read again by every further group: no evict-first hint (16 queries over 10k fp32 rows: scan 47 -> 41 us)
+    }
     if (!take && (streaming || few)) {
       const int64_t budget = c->small_direct_keys * (nq > 1 ? 2 : 1);
       g.blocks = std::min(full_blocks, (int)std::max<int64_t>(8, budget / ((int64_t)k * nq)));
