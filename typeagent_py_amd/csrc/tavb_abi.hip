@@ -282,8 +282,9 @@ int drain_timings(tavb_ctx* c) {
 //    and the rows are L2 / Infinity-Cache resident from the second group on;
 //  * one workgroup per CU in all (256); two (512) for groups of two when one would walk a wave over more than ~6 row pairs;
 //  * both routes pay 20 + 0.4 nq around their kernels on the host-synchronous call (staging and H2D copy of the queries, host merges / decode);
-//  * grouped: 12 (launch + synchronise) + c x (rows x nq / 1000) for the scan, c = 0.10 / 0.235 / 0.51 (fp32) and 0.10 / 0.17 / 0.40 (fp16) at
-//    D = 384 / 1536 / 3072, + 0.6 per 1000 list keys beyond 5000 (their way over PCIe and the host merge);
+//  * grouped: 12 (launch + synchronise) + c x (rows x nq / 1000) for the scan, c = 0.08 / 0.19 / 0.41 (fp32) and 0.08 / 0.14 / 0.34 (fp16) at
+//    D = 384 / 1536 / 3072 (with temporal row loads; a fifth more with the evict-first hint the single-query scan uses), + 0.6 per 1000 list
+//    keys beyond 5000 (their way over PCIe and the host merge);
 //  * the tiles (32/64-query tile, wide tile over the shadow) depend on how many rows survive `min_score` (fp16, 64 queries over 1000 rows: 154 at
 //    min_score 0, 77 at 0.85) -- the estimate sits between the two: 35 + 0.035 D - 0.2 nq on fp32 corpora, 18 + 0.008 D + 0.4 nq on fp16 ones.
 //    Up to 4 queries (2 on fp16) the alternative is the plain one-launch form or the streaming passes: the grouped form is never slower there;
@@ -311,7 +312,7 @@ DirectGroupPlan plan_direct_group(const tavb_ctx* c, int nq, int k, int full_blo
   p.blocks = blocks >= 8 ? blocks / 8 * 8 : blocks;
   if (p.blocks < 1 || (p.blocks < 8 && p.blocks != full_blocks)) return p;  // (worth = false)
   const double d = c->dim, wide = std::max(0.0, d - 1536.0);
-  const double per_kpair = f16 ? 0.08 + 0.00006 * d + 0.00009 * wide : 0.055 + 0.000117 * d + 0.00006 * wide;
+  const double per_kpair = f16 ? 0.065 + 0.00005 * d + 0.00008 * wide : 0.045 + 0.000095 * d + 0.00005 * wide;
   const double keys = (double)nq * p.blocks * k;
   // what both routes pay around their kernels on the host-synchronous call (staging + H2D copy of the queries, Python-free part of the call);
   // the device-resident form pays a second launch (the merge) instead of the lists' way over PCIe
