@@ -52,7 +52,12 @@ def main():
     print(row("cfg3 (headline)", d, True))
     for name, r in (d.get("sub") or {}).items():
         print(row(name, r))
-        for vn, v in (r.get("variants") or {}).items():
+        variants = r.get("variants") or {}
+        if variants and not any(isinstance(v, dict) for v in variants.values()):  # cfg1_terms32: the same call three ways, us per call
+            print(f"| {name}.variants | `tavb_search_batch` (host queries in, host results out) | | | – | as ONE grouped launch {variants.get('grouped_us', 0):.0f} µs, "
+                  f"on the tiles (grouped form off) {variants.get('tiles_us', 0):.0f} µs, as sequential single lookups {variants.get('sequential_us', 0):.0f} µs |")
+            continue
+        for vn, v in variants.items():
             print(f"| {name}.{vn} | | {v['ms_per_step']:.2f} ms | {v['value']:.1f} user-queries/s | " + (f"{v['hbm_frac']:.3f} hbm" if "hbm_frac" in v else "–") + " | " + ("ok" if (v.get("parity") or {}).get("ok") else "–")
                   + (f"; fused is {v['fused_speedup']:.2f}x these six separate calls" if "fused_speedup" in v else "") + " |")
     ca = d.get("class_api") or {}
