@@ -2347,6 +2347,14 @@ def test_fused_multi_index_query_equals_separate_calls():
     # missing pieces are simply skipped
     only_terms = fq.run(tq[:2])
     assert len(only_terms.terms) == 2 and only_terms.messages == [] and only_terms.threads == []
+    # ... also when the call before (same shape: the result buffer is reused, its keys written by the kernels straight into pinned memory) had them
+    fq.run(tq, mq, hq)
+    terms_again = fq.run(tq)
+    assert terms_again.messages == [] and terms_again.threads == []
+    assert [[r.item for r in t] for t in terms_again.terms] == [[r.item for r in t] for t in full.terms]
+    no_terms = fq.run(np.zeros((0, dim), np.float32), mq, hq)
+    assert no_terms.terms == [] and [r.item for r in no_terms.messages] == [r.item for r in full.messages]
+    assert [r.item for r in no_terms.threads] == [r.item for r in full.threads]
 
 
 @pytest.mark.slow
